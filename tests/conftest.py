@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_present():
+    try:
+        from mbpls_amd import _capi
+        return _capi.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu_required():
+    """GPU tests must run the HIP path: a missing library or device is a failure
+    on the GPU box, never a silent skip to some fallback."""
+    from mbpls_amd import _capi
+    lib = _capi.load()  # raises loudly if the .so is missing
+    assert _capi.device_count() > 0, "no HIP device visible"
+    return lib

@@ -1,0 +1,131 @@
+"""Pins the CPU oracle (both modes) to the reference: its own 69 golden CSVs and
+fixtures captured from the imported reference (tools/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import mbpls_oracle as orc
+from tests import util
+
+TOL = 1e-9   # oracle vs reference-generated fixtures (observed <= ~1e-12)
+
+
+def _flat_with_new(model, Xnew, Ynew, block_scores=True):
+    flat = util.model_to_flat(model)
+    flat["predict"] = orc.predict(model, Xnew)
+    if model["method"] != "SIMPLS" and block_scores:
+        Ts, T, U = orc.transform(model, Xnew, Ynew, return_block_scores=True)
+        for b, blk in enumerate(T):
+            flat[f"T_new/{b}"] = blk
+    else:
+        Ts, U = orc.transform(model, Xnew, Ynew)
+    flat["Ts_new"], flat["U_new"] = Ts, U
+    return flat
+
+
+@pytest.mark.parametrize("faithful", [False, True])
+@pytest.mark.parametrize("fixture,methods", [
+    ("ref_golden_pgtn", ["UNIPALS", "NIPALS", "KERNEL", "SIMPLS"]),
+    ("ref_golden_ngtp", ["UNIPALS", "KERNEL"]),
+])
+def test_reference_csvs(fixture, methods, faithful):
+    """The reference's own golden CSVs (mbpls/tests/test_mbpls.py:66-117):
+    absolute-value comparison with np.allclose defaults, exactly as it does."""
+    g = util.load(fixture)
+    X = [g["x1_train"], g["x2_train"]]
+    Xt = [g["x1_test"], g["x2_test"]]
+    preds = []
+    for m in methods:
+        for full in (True, False):
+            mdl = orc.fit(X, g["y_train"], n_components=2, method=m, standardize=True,
+                          full_svd=full, faithful=faithful)
+            csv = util.sub(g, f"csv/{m}")
+            got = {"Ts": mdl.Ts_, "U": mdl.U_, "V": mdl.V_, "beta": mdl.beta_,
+                   "P1": mdl.P_[0], "P2": mdl.P_[1], "Y_predict_test": orc.predict(mdl, Xt)}
+            if m != "SIMPLS":
+                Ts_t, T_t, U_t = orc.transform(mdl, Xt, g["y_test"], return_block_scores=True)
+                got.update(T=np.hstack(mdl.T_), A=mdl.A_, T_test=np.hstack(T_t))
+            else:
+                Ts_t, U_t = orc.transform(mdl, Xt, g["y_test"])
+            got.update(Ts_test=Ts_t, U_test=U_t)
+            assert set(got) == set(csv)
+            for k, ref in csv.items():
+                assert np.allclose(np.abs(got[k]), np.abs(ref)), (m, k)
+                assert util.relerr(np.abs(got[k]), np.abs(ref)) < 1e-9, (m, k)
+            # and everything the CSVs omit, against the captured reference attributes
+            ref = util.sub(g, f"ref/{m}/full{int(full)}")
+            util.compare(_flat_with_new(mdl, Xt, g["y_test"]), ref, TOL, what=f"{fixture}/{m}")
+        preds.append(got["Y_predict_test"])
+    for p in preds:  # mbpls/tests/test_mbpls.py:121-123
+        assert np.allclose(preds[0], p, atol=1e-3)
+
+
+@pytest.mark.parametrize("faithful", [False, True])
+def test_quickstart_config1(faithful):
+    g = util.load("quickstart_c1")
+    for m in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+        mdl = orc.fit(g["x"], g["y"], n_components=2, method=m, full_svd=(m == "SIMPLS"), faithful=faithful)
+        util.compare(_flat_with_new(mdl, g["x"], g["y"]), util.sub(g, f"ref/{m}"), TOL, what=m)
+        if m == "NIPALS":
+            assert mdl.nipals_iterations_ == [2, 2]
+
+
+@pytest.mark.parametrize("faithful", [False, True])
+@pytest.mark.parametrize("fixture", ["matrix_pgtn", "matrix_ngtp"])
+def test_matrix(fixture, faithful):
+    g = util.load(fixture)
+    splits = np.cumsum(g["splits"])[:-1]
+    n_cases = 0
+    for q in (1, 3):
+        X, Y = g[f"in/q{q}/X"], g[f"in/q{q}/Y"]
+        Xn, Yn = g[f"in/q{q}/Xnew"], g[f"in/q{q}/Ynew"]
+        for blocks in ("single", "multi"):
+            sp = (lambda A: A) if blocks == "single" else (lambda A: list(np.split(A, splits, axis=1)))
+            for m in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+                for std in (True, False):
+                    for ca in (True, False):
+                        pre = f"ref/q{q}/{blocks}/{m}/std{int(std)}/ca{int(ca)}"
+                        ref = util.sub(g, pre)
+                        assert ref, pre
+                        mdl = orc.fit(sp(X), Y, n_components=3, method=m, standardize=std,
+                                      calc_all=ca, full_svd=(m == "SIMPLS"), faithful=faithful)
+                        has_T_new = any(k.startswith("T_new") for k in ref)
+                        got = _flat_with_new(mdl, sp(Xn), Yn, block_scores=has_T_new)
+                        util.compare(got, ref, TOL, what=pre)
+                        n_cases += 1
+    assert n_cases == 64
+
+
+def test_edges():
+    g = util.load("edges")
+    # constant column: scale 1, zero weight
+    mdl = orc.fit(g["const/X"], g["const/Y"], n_components=3)
+    assert mdl.x_scalers_[0].scale_[5] == 1.0
+    assert mdl.beta_[5, 0] == 0.0
+    util.compare(_flat_with_new(mdl, g["const/X"], g["const/Y"]), util.sub(g, "ref/const"), TOL, what="const")
+    X, Y = g["plain/X"], g["plain/Y"]
+    m0 = orc.fit(X, Y, n_components=3)
+    m1 = orc.fit(X, Y.ravel(), n_components=3)
+    m2 = orc.fit([X], Y, n_components=3)
+    assert np.array_equal(m0.beta_, m1.beta_) and np.array_equal(m0.beta_, m2.beta_)
+    for nm, o in (("1", 1), ("inf", np.inf), ("-inf", -np.inf), ("fro", "fro"), ("nuc", "nuc"), ("-1", -1), ("-2", -2)):
+        mm = orc.fit(X, Y, n_components=3, nipals_convergence_norm=o)
+        assert util.relerr(mm.beta_, g[f"ref/norm/{nm}/beta_"]) < TOL
+    for bad in (0, 3):
+        with pytest.raises(ValueError):
+            orc.fit(X, Y, n_components=2, nipals_convergence_norm=bad)
+    with pytest.raises(NameError):
+        orc.fit(X, Y, method="nope")
+    X3, Y3 = g["q3/X"], g["q3/Y"]
+    for nm, o in (("2", 2), ("1", 1), ("inf", np.inf)):
+        mm = orc.fit([X3[:, :50], X3[:, 50:]], Y3, n_components=3, nipals_convergence_norm=o)
+        util.compare(_flat_with_new(mm, [X3[:, :50], X3[:, 50:]], Y3), util.sub(g, f"ref/q3/norm{nm}"),
+                     1e-8, what=f"q3/{nm}")
+
+
+def test_scaler_matches_fixture():
+    g = util.load("matrix_pgtn")
+    X = g["in/q1/X"]
+    s = orc.ColumnScaler().fit(X)
+    pre = "ref/q1/single/NIPALS/std1/ca1"
+    assert np.array_equal(s.mean_, g[pre + "/x_mean/0"])
+    assert util.relerr(s.scale_, g[pre + "/x_scale/0"]) < 1e-15

@@ -1,0 +1,82 @@
+"""Shared helpers for the parity tests: fixture loading and sign-aligned comparison."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# attributes whose column k flips with the sign of component k
+SIGNED = ("Ts_", "U_", "V_", "R_", "T_", "W_", "P_", "W_non_normal_", "W_concat_", "Ts_new", "T_new", "U_new")
+UNSIGNED = ("beta_", "A_", "A_corrected_", "explained_var_x_", "explained_var_y_",
+            "explained_var_xblocks_", "predict")
+
+
+def load(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def sub(store, prefix):
+    """All entries below ``prefix/`` with the prefix stripped."""
+    pre = prefix.rstrip("/") + "/"
+    return {k[len(pre):]: v for k, v in store.items() if k.startswith(pre)}
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.size == 0:
+        return 0.0
+    den = np.max(np.abs(b))
+    return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
+
+
+def model_to_flat(m, n_blocks=None):
+    """Flatten a fitted estimator / OracleModel into the fixture's key scheme."""
+    get = (lambda k: m[k]) if isinstance(m, dict) else (lambda k: getattr(m, k))
+    has = (lambda k: k in m) if isinstance(m, dict) else (lambda k: hasattr(m, k))
+    out = {}
+    for a in ("Ts_", "U_", "V_", "R_", "beta_", "A_", "A_corrected_", "explained_var_x_",
+              "explained_var_y_", "explained_var_xblocks_", "W_concat_"):
+        if has(a):
+            out[a] = np.asarray(get(a), dtype=np.float64)
+    for a in ("T_", "W_", "P_", "W_non_normal_"):
+        if has(a):
+            v = get(a)
+            if isinstance(v, list):
+                for b, blk in enumerate(v):
+                    out[f"{a}/{b}"] = np.asarray(blk)
+            else:
+                out[a] = np.asarray(v)
+    return out
+
+
+def compare(got, ref, tol, skip=(), only=None, what=""):
+    """Sign-aligned comparison of two flat attribute dicts.  Returns worst rel. error.
+
+    Every key present in ``ref`` (minus ``skip``) must be present in ``got``."""
+    s = np.sign(np.sum(ref["Ts_"] * got["Ts_"], axis=0))
+    s[s == 0] = 1.0
+    worst = 0.0
+    for k, rv in ref.items():
+        base = k.split("/")[0]
+        if base in skip or k in skip:
+            continue
+        if only is not None and base not in only:
+            continue
+        if base in ("x_mean", "x_scale", "y_mean", "y_scale"):
+            continue
+        if np.asarray(rv).size == 0 and k not in got:
+            continue  # the reference leaves empty placeholders (e.g. W_concat_ outside KERNEL)
+        assert k in got, f"{what}: missing {k}"
+        gv = np.asarray(got[k], dtype=np.float64)
+        rv = np.asarray(rv, dtype=np.float64)
+        if gv.ndim == 1 and rv.ndim == 1:
+            pass
+        if base in SIGNED and gv.ndim == 2 and gv.shape[1] == s.size:
+            gv = gv * s
+        e = relerr(gv.reshape(rv.shape), rv)
+        assert e <= tol, f"{what}: {k} rel err {e:.3e} > {tol:.1e}"
+        worst = max(worst, e)
+    return worst

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (``/root/reference`` is mounted there, read
+only).  Nothing of the reference's source is copied: the fixtures are data --
+captured input arrays, the reference's fitted attributes / predictions for them,
+and the numeric contents of the reference's own golden CSVs
+(``mbpls/tests/test_data/*.csv``, enumerated in ``mbpls/tests/load_data.py:17-86``).
+
+    python tools/make_golden.py            # writes tests/golden/*.npz and prints pin report
+
+Fixture sets follow SURVEY.md 8(c'):
+  G0 ref_golden_pgtn   the reference's p>n golden test (tests/test_mbpls.py:34-215)
+  G1 ref_golden_ngtp   the reference's n>p golden test (:220-421)
+  G2 quickstart_c1     README quick-start = BASELINE config 1
+  G3 matrix_pgtn       method x blocks x q x standardize x calc_all, p>n
+  G4 matrix_ngtp       n>=p branches
+  G5 edges             constant column, 1-D Y, list-of-one, norm variants
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+warnings.filterwarnings("ignore")
+from mbpls.mbpls import MBPLS  # noqa: E402  (the reference, imported in place)
+from oracle import mbpls_oracle as orc  # noqa: E402
+
+ATTRS = ["Ts_", "U_", "V_", "R_", "beta_", "A_", "A_corrected_", "explained_var_x_",
+         "explained_var_y_", "explained_var_xblocks_", "W_concat_"]
+LIST_ATTRS = ["T_", "W_", "P_", "W_non_normal_"]
+
+
+def capture(m, store, prefix, Xnew=None, Ynew=None):
+    """Copy every fitted attribute of a reference estimator into ``store``."""
+    for a in ATTRS:
+        if hasattr(m, a):
+            store[f"{prefix}/{a}"] = np.asarray(getattr(m, a), dtype=np.float64)
+    for a in LIST_ATTRS:
+        if hasattr(m, a):
+            v = getattr(m, a)
+            if isinstance(v, list):
+                for b, blk in enumerate(v):
+                    store[f"{prefix}/{a}/{b}"] = np.asarray(blk, dtype=np.float64)
+            else:  # SIMPLS: W_ is one array
+                store[f"{prefix}/{a}"] = np.asarray(v, dtype=np.float64)
+    if hasattr(m, "x_scalers_"):
+        for b, s in enumerate(m.x_scalers_):
+            store[f"{prefix}/x_mean/{b}"] = s.mean_.copy()
+            store[f"{prefix}/x_scale/{b}"] = s.scale_.copy()
+        store[f"{prefix}/y_mean"] = m.y_scaler_.mean_.copy()
+        store[f"{prefix}/y_scale"] = m.y_scaler_.scale_.copy()
+    if Xnew is not None:
+        store[f"{prefix}/predict"] = m.predict(Xnew)
+        if m.method != "SIMPLS":
+            try:
+                Ts, T, U = m.transform(Xnew, Ynew, return_block_scores=True)
+                for b, blk in enumerate(T):
+                    store[f"{prefix}/T_new/{b}"] = blk
+            except UnboundLocalError:
+                # reference bug (mbpls.py:1256-1286): non-standardised transform with
+                # 2-D Y never builds block scores; capture without them
+                Ts, U = m.transform(Xnew, Ynew)
+        else:
+            Ts, U = m.transform(Xnew, Ynew)
+        store[f"{prefix}/Ts_new"] = Ts
+        store[f"{prefix}/U_new"] = U
+
+
+def ref_test_inputs(num_samples, seed=25, n1=25, n2=45, noise=5):
+    """The input recipe of mbpls/tests/test_mbpls.py:36-57 with the legacy
+    ortho_group sampler (the one the CSVs were produced with)."""
+    np.random.seed(seed)
+    l1 = np.expand_dims(np.random.randint(0, 10, n1), 1)
+    l2 = np.expand_dims(np.sin(np.linspace(0, 5, n2)), 1)
+    y = orc.legacy_ortho_group(num_samples, seed)[:, :2]
+    x1 = np.dot(y[:, 0:1], l1.T)
+    x2 = np.dot(y[:, 1:2], l2.T)
+    x1 = np.random.normal(x1, 0.05 * noise)
+    x2 = np.random.normal(x2, 0.05 * noise)
+    idx = np.random.choice(np.arange(num_samples), num_samples, replace=False)
+    k = round(num_samples * 8 / 10)
+    tr, te = idx[:k], idx[k:]
+    return dict(x1_train=x1[tr], x2_train=x2[tr], y_train=y[tr],
+                x1_test=x1[te], x2_test=x2[te], y_test=y[te])
+
+
+def load_csvs(tag, methods):
+    """Numeric contents of the reference's golden CSVs for one test family."""
+    d = os.path.join(REF, "mbpls", "tests", "test_data")
+    out = {}
+    names = ["T", "A", "T_test", "Ts_test", "U_test", "P1", "P2", "Ts", "U", "V", "beta", "Y_predict_test"]
+    for m in methods:
+        for nm in names:
+            f = os.path.join(d, f"{nm}_{tag}{m}.csv")
+            if os.path.exists(f):
+                out[f"csv/{m}/{nm}"] = np.genfromtxt(f, delimiter=",")
+    return out
+
+
+def golden_ref_tests():
+    report = []
+    for fname, ns, tag, methods in (("ref_golden_pgtn", 50, "", ["UNIPALS", "NIPALS", "KERNEL", "SIMPLS"]),
+                                    ("ref_golden_ngtp", 150, "NlargerP_", ["UNIPALS", "KERNEL"])):
+        inp = ref_test_inputs(ns)
+        store = dict(inp)
+        csv = load_csvs(tag, methods)
+        store.update(csv)
+        worst = 0.0
+        for full in (True, False):
+            for m in methods:
+                mdl = MBPLS(n_components=2, method=m, standardize=True, full_svd=full)
+                mdl.fit([inp["x1_train"], inp["x2_train"]], inp["y_train"])
+                pre = f"ref/{m}/full{int(full)}"
+                capture(mdl, store, pre, [inp["x1_test"], inp["x2_test"]], inp["y_test"])
+                # pin: the current stack reproduces the CSVs with the legacy sampler
+                chk = {"Ts": store[pre + "/Ts_"], "U": store[pre + "/U_"], "V": store[pre + "/V_"],
+                       "beta": store[pre + "/beta_"], "P1": store[pre + "/P_/0"], "P2": store[pre + "/P_/1"],
+                       "Y_predict_test": store[pre + "/predict"], "Ts_test": store[pre + "/Ts_new"],
+                       "U_test": store[pre + "/U_new"]}
+                if m != "SIMPLS":
+                    chk["T"] = np.hstack([store[pre + "/T_/0"], store[pre + "/T_/1"]])
+                    chk["A"] = store[pre + "/A_"]
+                    chk["T_test"] = np.hstack([store[pre + "/T_new/0"], store[pre + "/T_new/1"]])
+                for nm, val in chk.items():
+                    ref = csv[f"csv/{m}/{nm}"]
+                    worst = max(worst, float(np.max(np.abs(np.abs(val) - np.abs(ref)))))
+        report.append((fname, len(csv), worst))
+        np.savez_compressed(os.path.join(OUT, fname + ".npz"), **store)
+    return report
+
+
+def golden_quickstart():
+    np.random.seed(0)
+    x = np.random.rand(40, 200)
+    y = np.random.rand(40, 1)
+    store = dict(x=x, y=y)
+    for m, full in (("NIPALS", False), ("UNIPALS", False), ("KERNEL", False), ("SIMPLS", True)):
+        mdl = MBPLS(n_components=2, method=m, full_svd=full)
+        mdl.fit(x, y)
+        capture(mdl, store, f"ref/{m}", x, y)
+    np.savez_compressed(os.path.join(OUT, "quickstart_c1.npz"), **store)
+
+
+def golden_matrix(fname, n, p, splits, n_new, seeds, methods, K=3):
+    store = {}
+    for q in (1, 3):
+        X, Y = orc.make_latent(n, p, q, r=6, seed=seeds[0])
+        Xn, Yn = orc.make_latent(n_new, p, q, r=6, seed=seeds[1])
+        store[f"in/q{q}/X"] = X; store[f"in/q{q}/Y"] = Y
+        store[f"in/q{q}/Xnew"] = Xn; store[f"in/q{q}/Ynew"] = Yn
+        for blocks in ("single", "multi"):
+            def split(A):
+                if blocks == "single":
+                    return A
+                return [np.ascontiguousarray(b) for b in np.split(A, np.cumsum(splits)[:-1], axis=1)]
+            for m in methods:
+                for std in (True, False):
+                    for ca in (True, False):
+                        full = (m == "SIMPLS")  # svds fails for q=1 SIMPLS in current scipy (mbpls.py:1003)
+                        mdl = MBPLS(n_components=K, method=m, standardize=std, calc_all=ca, full_svd=full)
+                        mdl.fit(split(X), Y)
+                        pre = f"ref/q{q}/{blocks}/{m}/std{int(std)}/ca{int(ca)}"
+                        capture(mdl, store, pre, split(Xn), Yn)
+    store["splits"] = np.asarray(splits)
+    np.savez_compressed(os.path.join(OUT, fname + ".npz"), **store)
+
+
+def golden_edges():
+    X, Y = orc.make_latent(48, 180, 1, r=6, seed=7)
+    store = {}
+    Xc = X.copy()
+    Xc[:, 5] = 3.25
+    store["const/X"] = Xc; store["const/Y"] = Y
+    mdl = MBPLS(n_components=3).fit(Xc, Y)
+    capture(mdl, store, "ref/const", Xc, Y)
+    # 1-D Y and list-of-one give the bare-array result
+    m1 = MBPLS(n_components=3).fit(X, Y.ravel())
+    m2 = MBPLS(n_components=3).fit([X], Y)
+    m0 = MBPLS(n_components=3).fit(X, Y)
+    store["plain/X"] = X; store["plain/Y"] = Y
+    capture(m0, store, "ref/plain", X, Y)
+    assert np.array_equal(m0.beta_, m1.beta_) and np.array_equal(m0.beta_, m2.beta_)
+    for nm, o in (("1", 1), ("inf", np.inf), ("-inf", -np.inf), ("fro", "fro"), ("nuc", "nuc"), ("-1", -1), ("-2", -2)):
+        mm = MBPLS(n_components=3, nipals_convergence_norm=o).fit(X, Y)
+        store[f"ref/norm/{nm}/beta_"] = mm.beta_
+        store[f"ref/norm/{nm}/Ts_"] = mm.Ts_
+    # multiblock q=3 NIPALS iteration-heavy case with non-default norms
+    X3, Y3 = orc.make_latent(40, 120, 3, r=6, seed=11)
+    store["q3/X"] = X3; store["q3/Y"] = Y3
+    for nm, o in (("2", 2), ("1", 1), ("inf", np.inf)):
+        mm = MBPLS(n_components=3, nipals_convergence_norm=o).fit([X3[:, :50], X3[:, 50:]], Y3)
+        capture(mm, store, f"ref/q3/norm{nm}", [X3[:, :50], X3[:, 50:]], Y3)
+    np.savez_compressed(os.path.join(OUT, "edges.npz"), **store)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    rep = golden_ref_tests()
+    for fname, ncsv, worst in rep:
+        print(f"{fname}: {ncsv} reference CSV arrays captured; reference (this stack, legacy sampler) "
+              f"vs CSV worst |abs| diff = {worst:.3e}")
+        assert worst < 1e-11
+    golden_quickstart()
+    golden_matrix("matrix_pgtn", 48, 180, [54, 54, 72], 12, (7, 8), ["NIPALS", "UNIPALS", "KERNEL", "SIMPLS"])
+    golden_matrix("matrix_ngtp", 96, 60, [18, 18, 24], 12, (9, 10), ["NIPALS", "UNIPALS", "KERNEL", "SIMPLS"])
+    golden_edges()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
