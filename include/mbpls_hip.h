@@ -1,0 +1,175 @@
+/*
+ * mbpls_hip.h -- C ABI of the MI355X (gfx950) hot path of MBPLS.fit()/predict()/transform().
+ *
+ * The reference (DTUComputeStatisticsAndDataAnalysis/MBPLS v1.0.4) is one pure-Python module
+ * that delegates every X-sized operation to numpy (mbpls/mbpls.py).  It has no FFI of its own,
+ * so this header defines the boundary a maintainer would bind with ctypes:
+ * each entry point below names the reference statement(s) it replaces.  Everything is plain C:
+ * opaque handles, raw pointers, 64-bit sizes, int status (0 = ok, <0 = error, text via
+ * mbpls_hip_last_error()).  No exceptions cross the boundary, no torch types appear in it.
+ *
+ * Data model
+ *   X lives in HBM FEATURE-MAJOR: feature (column) j of the n x p data matrix is the contiguous
+ *   run  X[j*ld .. j*ld+n)  of doubles (ld >= n, even; = numpy's asfortranarray(X) memory).
+ *   Blocks of a multiblock model are column ranges [block_offsets[b], block_offsets[b+1]) of the
+ *   one hstacked matrix (mbpls.py:351-357,379).  A matrix carries a CHUNK TABLE: contiguous
+ *   column ranges that never straddle a block; one workgroup owns one chunk, writes one partial
+ *   n-vector, and a fixed-order second stage sums the chunks of each block -- so every reduction
+ *   is deterministic and bit-identical between NIPALS iterations (the loop exit at mbpls.py:841
+ *   compares successive score vectors against 1e-14).
+ *
+ *   Pointers named d_* are DEVICE pointers (hipMalloc / mbpls_hip_malloc / torch data_ptr()).
+ *   Pointers named h_* are HOST pointers.  All floating point is float64, as in the reference
+ *   (mbpls.py:293,310,318).  All calls are asynchronous on the context's stream unless they
+ *   return data to the host; mbpls_hip_sync() drains the stream.
+ */
+#ifndef MBPLS_HIP_H
+#define MBPLS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBPLS_HIP_ABI_VERSION 1
+
+enum {
+  MBPLS_OK = 0,
+  MBPLS_ERR_ARG = -1,          /* bad argument / shape */
+  MBPLS_ERR_HIP = -2,          /* a HIP runtime call failed */
+  MBPLS_ERR_OOM = -3,          /* device allocation failed */
+  MBPLS_ERR_UNSUPPORTED = -4   /* shape outside what the kernels cover (e.g. n > 16384 fused) */
+};
+
+enum { MBPLS_ROW_MAJOR = 0,    /* host array is n x p C-order (numpy default), ld = row stride  */
+       MBPLS_COL_MAJOR = 1 };  /* host array is feature-major / Fortran order, ld = col stride */
+
+/* scaling mode of mbpls_hip_standardize_sweep */
+enum { MBPLS_SCALE_FIT = 0,    /* compute mean/scale per column (StandardScaler.fit_transform)  */
+       MBPLS_SCALE_APPLY = 1,  /* apply given mean/scale (StandardScaler.transform)             */
+       MBPLS_SCALE_NONE = 2 }; /* standardize=False: copy only, still emits column sums of squares */
+
+typedef struct mbpls_ctx mbpls_ctx;   /* device + stream + workspace */
+typedef struct mbpls_mat mbpls_mat;   /* feature-major matrix in HBM + block offsets + chunk table */
+
+/* ---- library / context ------------------------------------------------------------------ */
+int         mbpls_hip_abi_version(void);
+const char* mbpls_hip_last_error(void);
+/* Number of visible HIP devices; does not create a context. */
+int mbpls_hip_device_count(int* count);
+/* stream: a hipStream_t, or NULL for the default (null) stream -- which is also PyTorch's
+ * default stream, so RCCL collectives issued through torch.distributed order correctly
+ * against these kernels. */
+int mbpls_hip_create(int device, void* stream, mbpls_ctx** out);
+int mbpls_hip_destroy(mbpls_ctx* ctx);
+int mbpls_hip_sync(mbpls_ctx* ctx);
+int mbpls_hip_device_info(mbpls_ctx* ctx, char* name, size_t name_len, int* compute_units,
+                          size_t* total_bytes, size_t* free_bytes);
+/* Tunables (all optional): "chunks_per_cu", "rows_per_thread", "prefetch".  Returns MBPLS_ERR_ARG for unknown keys. */
+int mbpls_hip_set_tunable(mbpls_ctx* ctx, const char* key, int value);
+
+/* ---- raw device memory (so a host needs nothing but this library) ------------------------- */
+int mbpls_hip_malloc(mbpls_ctx* ctx, size_t bytes, void** d_ptr);
+int mbpls_hip_free(mbpls_ctx* ctx, void* d_ptr);
+int mbpls_hip_memcpy_h2d(mbpls_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int mbpls_hip_memcpy_d2h(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);  /* synchronous */
+int mbpls_hip_memcpy_d2d(mbpls_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+int mbpls_hip_memset(mbpls_ctx* ctx, void* d_ptr, int value, size_t bytes);
+
+/* ---- timing (HIP events on the context's stream; used by bench.py for the roofline) ------- */
+int mbpls_hip_timer_start(mbpls_ctx* ctx);
+int mbpls_hip_timer_stop(mbpls_ctx* ctx, double* elapsed_ms);   /* synchronous */
+
+/* Per-kernel profile: when enabled every hot-path launch is bracketed by HIP events on the
+ * context's stream (main kernel only, not the small chunk-reduction that follows it).
+ * kind: one of MBPLS_K_*.  profile_get drains the stream and returns launches / summed ms /
+ * summed algorithmic bytes (SURVEY 8d per-kernel figures) since the last reset. */
+enum { MBPLS_K_STANDARDIZE = 0, MBPLS_K_SWEEP = 1, MBPLS_K_DEFLATE_SWEEP = 2, MBPLS_K_DEFLATE = 3,
+       MBPLS_K_XT_V = 4, MBPLS_K_X_W = 5, MBPLS_K_GRAM = 6, MBPLS_K_COUNT = 7 };
+int mbpls_hip_profile_enable(mbpls_ctx* ctx, int on);
+int mbpls_hip_profile_reset(mbpls_ctx* ctx);
+int mbpls_hip_profile_get(mbpls_ctx* ctx, int kind, int64_t* launches, double* total_ms, double* total_bytes);
+
+/* ---- matrices -------------------------------------------------------------------------------
+ * Replaces the host-side copies of fit(): deepcopy (mbpls.py:303), check_array(copy=True) (:310),
+ * np.hstack (:379).  block_offsets has nblocks+1 entries, block_offsets[0]=0, last = p.
+ * d_storage: NULL (library allocates p*ld doubles) or caller-owned device memory of that size. */
+int mbpls_hip_mat_create(mbpls_ctx* ctx, int64_t n, int64_t p, int nblocks,
+                         const int64_t* block_offsets, void* d_storage, mbpls_mat** out);
+int mbpls_hip_mat_destroy(mbpls_mat* m);
+int mbpls_hip_mat_info(const mbpls_mat* m, int64_t* n, int64_t* p, int64_t* ld, void** d_data,
+                       int* nblocks, int* nchunks);
+/* Host -> device, columns [col0, col0+ncols) of the matrix.  h_src points at element (0, 0) of
+ * the n x ncols source; layout/ld_host describe it.  Row-major sources are transposed on the GPU. */
+int mbpls_hip_mat_upload(mbpls_mat* m, const double* h_src, int64_t ld_host, int layout,
+                         int64_t col0, int64_t ncols);
+/* Device -> host, same conventions (used for samples / debugging, not on the fit path). */
+int mbpls_hip_mat_download(const mbpls_mat* m, double* h_dst, int64_t ld_host, int layout,
+                           int64_t col0, int64_t ncols);
+int mbpls_hip_mat_copy(mbpls_mat* dst, const mbpls_mat* src);
+/* Synthetic wide matrix with planted latent structure, generated in HBM (SURVEY 8d make_latent
+ * recipe with a counter-based RNG): X[:, j] = (T * s) @ L[:, j] + noise * N(0,1), for global
+ * column index col_base + j.  d_T is n x r column-major (T already scaled by s). */
+int mbpls_hip_mat_fill_latent(mbpls_mat* m, const double* d_T, int r, double noise, uint64_t seed,
+                              int64_t col_base);
+
+/* ---- the hot path -----------------------------------------------------------------------------
+ * Common conventions: d_v / d_ts are n-vectors; d_g / d_p are p-vectors (may point into a column
+ * of a p x K device array); d_t is n*nblocks (block b at d_t + b*n); d_ssq_* are nblocks doubles.
+ * Any output pointer may be NULL to skip that output.                                            */
+
+/* fit() pre-processing, fused with the first NIPALS/UNIPALS sweep.
+ *   replaces StandardScaler().fit_transform per block (mbpls.py:314,:323), (X**2).sum() per block
+ *   (:829,:945,:431,:439,:523,:531,:756,:776) and -- when d_v is given -- the first
+ *   X_b.T.dot(u)/u.T.dot(u) (:856) and X_b.dot(w_b) (:875) of component 0.
+ *   src -> dst (may be the same matrix for in-place = copy=False).
+ *   mode FIT:   d_mean/d_scale (p each) are OUTPUTS;  APPLY: inputs;  NONE: ignored.
+ *   d_ssq_x[b] = sum of squares of the standardised block b.
+ *   sweep part as mbpls_hip_sweep (skipped when d_v == NULL).                                     */
+int mbpls_hip_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode,
+                                double* d_mean, double* d_scale, double* d_ssq_x,
+                                const double* d_v, double alpha,
+                                double* d_g, double* d_t, double* d_ssq_g);
+
+/* One NIPALS inner iteration over X in ONE read (mbpls.py:856 + :875, a2+a3 of SURVEY 8a):
+ *   g = alpha * X^T v                (w~_b = X_b^T u / (u^T u), all blocks at once)
+ *   t_b = X_b g_b                    (UN-normalised block scores; caller divides by ||g_b||)
+ *   ssq_g[b] = ||g_b||^2
+ * Also UNIPALS p>n: X (X^T y) (:489) and X^T u + X_b w_b (:503,:517).                            */
+int mbpls_hip_sweep(const mbpls_mat* m, const double* d_v, double alpha,
+                    double* d_g, double* d_t, double* d_ssq_g);
+
+/* Loadings + rank-1 deflation in ONE read + ONE write (mbpls.py:928 + :969, a5+a7), optionally
+ * fused with the next component's first sweep on the deflated matrix:
+ *   p = inv_tt * X^T ts ;  X <- X - ts p^T ;  ssq_p[b] = ||p_b||^2
+ *   if d_v: g = alpha * X_new^T v ; t_b = X_new,b g_b ; ssq_g[b]
+ * deflate = 0 computes p (and the sweep on the un-deflated X) without writing X.                   */
+int mbpls_hip_deflate_sweep(mbpls_mat* m, const double* d_ts, double inv_tt, int deflate,
+                            double* d_p, double* d_ssq_p,
+                            const double* d_v, double alpha,
+                            double* d_g, double* d_t, double* d_ssq_g);
+
+/* G = alpha * X^T V for c right-hand sides (mbpls.py:503,:731,:734,:998,:1011).
+ *   d_V: n x c column-major (leading dim ldv), d_G: p x c column-major (leading dim ldg).
+ *   d_ssq (optional): nblocks x c, d_ssq[k*nblocks + b] = ||G[block b, k]||^2.                     */
+int mbpls_hip_xt_v(const mbpls_mat* m, const double* d_V, int64_t ldv, int c, double alpha,
+                   double* d_G, int64_t ldg, double* d_ssq);
+
+/* OUT = X W for c right-hand sides (mbpls.py:413,:517,:661,:752,:1006,:1117,:1386,:1408).
+ *   d_W: p x c column-major (ldw).  per_block = 0: d_out is n x c column-major (ldo);
+ *   per_block = 1: d_out holds nblocks matrices, block b at d_out + b*ldo*c, each X_b W_b.
+ *   d_mean/d_scale (optional, p each): standardise X on the fly, x <- (x - mean_j)/scale_j
+ *   (predict/transform of new data, mbpls.py:1369,:1372,:1097,:1103) without a second pass.       */
+int mbpls_hip_x_w(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block,
+                  const double* d_mean, const double* d_scale, double* d_out, int64_t ldo);
+
+/* Association matrix of the KERNEL method: d_G (n x n, leading dim ldg) = X X^T (mbpls.py:704),
+ * f64 MFMA SYRK; both triangles are written (bitwise symmetric, like numpy's syrk dispatch).      */
+int mbpls_hip_gram(const mbpls_mat* m, double* d_G, int64_t ldg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBPLS_HIP_H */

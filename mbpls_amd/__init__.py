@@ -1,0 +1,17 @@
+"""mbpls_amd -- MI355X-native hot path of (multiblock) PLS fitting.
+
+    from mbpls_amd import MBPLS          # same API as mbpls.mbpls.MBPLS
+    MBPLS(n_components=10, method='NIPALS').fit(X, y).predict(X)
+
+The data matrix lives feature-major in HBM and is touched only by hand-written gfx950 HIP
+kernels (``csrc/``) reached through the C ABI of ``include/mbpls_hip.h``.
+"""
+from ._capi import Context, DeviceArray, DeviceMatrix, HipError, device_count
+from .comm import LocalComm, TorchDistComm, shard_columns
+from .mbpls import MBPLS
+from .runtime import column_sharded, get_comm, get_context, set_comm, set_device
+
+__all__ = ["MBPLS", "Context", "DeviceArray", "DeviceMatrix", "HipError", "device_count", "LocalComm",
+           "TorchDistComm", "shard_columns", "column_sharded", "get_comm", "get_context", "set_comm",
+           "set_device"]
+__version__ = "0.1.0"

@@ -1,0 +1,331 @@
+"""ctypes binding of ``libmbpls_hip.so`` (C ABI declared in ``include/mbpls_hip.h``).
+
+This is the only module that touches the shared library.  There is NO fallback: if the
+library is missing or a call fails, an exception is raised -- the product never computes
+on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmbpls_hip.so")
+
+ROW_MAJOR, COL_MAJOR = 0, 1
+SCALE_FIT, SCALE_APPLY, SCALE_NONE = 0, 1, 2
+ABI_VERSION = 1
+
+_vp, _i64, _dbl, _int, _sz = C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); must list every symbol of include/mbpls_hip.h
+SIGNATURES = {
+    "mbpls_hip_abi_version": (_int, []),
+    "mbpls_hip_last_error": (C.c_char_p, []),
+    "mbpls_hip_device_count": (_int, [C.POINTER(_int)]),
+    "mbpls_hip_create": (_int, [_int, _vp, _pp]),
+    "mbpls_hip_destroy": (_int, [_vp]),
+    "mbpls_hip_sync": (_int, [_vp]),
+    "mbpls_hip_device_info": (_int, [_vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_sz), C.POINTER(_sz)]),
+    "mbpls_hip_set_tunable": (_int, [_vp, C.c_char_p, _int]),
+    "mbpls_hip_malloc": (_int, [_vp, _sz, _pp]),
+    "mbpls_hip_free": (_int, [_vp, _vp]),
+    "mbpls_hip_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
+    "mbpls_hip_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz]),
+    "mbpls_hip_memcpy_d2d": (_int, [_vp, _vp, _vp, _sz]),
+    "mbpls_hip_memset": (_int, [_vp, _vp, _int, _sz]),
+    "mbpls_hip_timer_start": (_int, [_vp]),
+    "mbpls_hip_timer_stop": (_int, [_vp, C.POINTER(_dbl)]),
+    "mbpls_hip_profile_enable": (_int, [_vp, _int]),
+    "mbpls_hip_profile_reset": (_int, [_vp]),
+    "mbpls_hip_profile_get": (_int, [_vp, _int, C.POINTER(_i64), C.POINTER(_dbl), C.POINTER(_dbl)]),
+    "mbpls_hip_mat_create": (_int, [_vp, _i64, _i64, _int, C.POINTER(_i64), _vp, _pp]),
+    "mbpls_hip_mat_destroy": (_int, [_vp]),
+    "mbpls_hip_mat_info": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), _pp,
+                                  C.POINTER(_int), C.POINTER(_int)]),
+    "mbpls_hip_mat_upload": (_int, [_vp, _vp, _i64, _int, _i64, _i64]),
+    "mbpls_hip_mat_download": (_int, [_vp, _vp, _i64, _int, _i64, _i64]),
+    "mbpls_hip_mat_copy": (_int, [_vp, _vp]),
+    "mbpls_hip_mat_fill_latent": (_int, [_vp, _vp, _int, _dbl, C.c_uint64, _i64]),
+    "mbpls_hip_standardize_sweep": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
+    "mbpls_hip_sweep": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp]),
+    "mbpls_hip_deflate_sweep": (_int, [_vp, _vp, _dbl, _int, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
+    "mbpls_hip_xt_v": (_int, [_vp, _vp, _i64, _int, _dbl, _vp, _i64, _vp]),
+    "mbpls_hip_x_w": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _i64]),
+    "mbpls_hip_gram": (_int, [_vp, _vp, _i64]),
+}
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipError(
+            f"{LIB_PATH} not found: build it with `python -m mbpls_amd.build` (hipcc, gfx950). "
+            "mbpls_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.mbpls_hip_abi_version()
+    if v != ABI_VERSION:
+        raise HipError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().mbpls_hip_last_error()
+        raise HipError(f"mbpls_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def device_count():
+    n = _int(0)
+    check(load().mbpls_hip_device_count(C.byref(n)))
+    return n.value
+
+
+def _ptr(x):
+    """Device pointer of a DeviceArray / int / None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return x.ptr
+
+
+class Context:
+    """One device + stream + workspace (``mbpls_ctx``)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = _vp()
+        check(self.lib.mbpls_hip_create(int(device), stream, C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mbpls_hip_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.mbpls_hip_sync(self.handle))
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        cus, tot, free = _int(0), _sz(0), _sz(0)
+        check(self.lib.mbpls_hip_device_info(self.handle, name, 256, C.byref(cus), C.byref(tot), C.byref(free)))
+        return dict(name=name.value.decode(), compute_units=cus.value, total_bytes=tot.value, free_bytes=free.value)
+
+    def set_tunable(self, key, value):
+        check(self.lib.mbpls_hip_set_tunable(self.handle, key.encode(), int(value)))
+
+    def timer_start(self):
+        check(self.lib.mbpls_hip_timer_start(self.handle))
+
+    def timer_stop(self):
+        ms = _dbl(0)
+        check(self.lib.mbpls_hip_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    # ---- per-kernel profile (HIP events on the launch stream)
+    KERNEL_KINDS = ("standardize_sweep", "sweep", "deflate_sweep", "deflate", "xt_v", "x_w", "gram")
+
+    def profile(self, on=True):
+        check(self.lib.mbpls_hip_profile_enable(self.handle, int(bool(on))))
+
+    def profile_reset(self):
+        check(self.lib.mbpls_hip_profile_reset(self.handle))
+
+    def profile_get(self):
+        out = {}
+        for k, name in enumerate(self.KERNEL_KINDS):
+            cnt, ms, by = _i64(0), _dbl(0), _dbl(0)
+            check(self.lib.mbpls_hip_profile_get(self.handle, k, C.byref(cnt), C.byref(ms), C.byref(by)))
+            if cnt.value:
+                out[name] = dict(launches=cnt.value, total_ms=ms.value, avg_ms=ms.value / cnt.value,
+                                 bytes_per_launch=by.value / cnt.value,
+                                 GBps=by.value / 1e9 / (ms.value / 1e3) if ms.value > 0 else 0.0)
+        return out
+
+    # ---- device arrays
+    def empty(self, shape, zero=False):
+        return DeviceArray(self, shape, zero=zero)
+
+    def from_host(self, arr):
+        arr = np.asarray(arr, dtype=np.float64)
+        d = DeviceArray(self, arr.shape)
+        d.set(arr)
+        return d
+
+
+class DeviceArray:
+    """float64 device buffer; 2-D arrays are COLUMN-major (each column contiguous), matching
+    the p x K / n x c conventions of the C ABI."""
+
+    def __init__(self, ctx, shape, zero=False, ptr=None):
+        if isinstance(shape, int):
+            shape = (shape,)
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = 8 * self.size
+        self._own = ptr is None
+        if ptr is None:
+            h = _vp()
+            check(ctx.lib.mbpls_hip_malloc(ctx.handle, max(self.nbytes, 8), C.byref(h)))
+            self.ptr = h.value
+        else:
+            self.ptr = int(ptr)
+        if zero:
+            check(ctx.lib.mbpls_hip_memset(ctx.handle, self.ptr, 0, self.nbytes))
+
+    @property
+    def ld(self):
+        return self.shape[0]
+
+    def col(self, k, ncols=1):
+        """View of columns [k, k+ncols) (no copy)."""
+        rows = self.shape[0]
+        return DeviceArray(self.ctx, (rows, ncols) if ncols > 1 else (rows,), ptr=self.ptr + 8 * rows * k)
+
+    def set(self, arr):
+        a = np.asarray(arr, dtype=np.float64)
+        if a.ndim == 2:
+            a = np.asfortranarray(a)
+        else:
+            a = np.ascontiguousarray(a)
+        assert a.size == self.size, (a.shape, self.shape)
+        check(self.ctx.lib.mbpls_hip_memcpy_h2d(self.ctx.handle, self.ptr, a.ctypes.data, self.nbytes))
+        self._keep = a  # the copy is stream-ordered: keep the source alive until the next set()/free()
+        return self
+
+    def get(self):
+        if len(self.shape) == 2:
+            out = np.empty(self.shape, dtype=np.float64, order="F")
+        else:
+            out = np.empty(self.shape, dtype=np.float64)
+        if self.size:
+            check(self.ctx.lib.mbpls_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self._own and self.ptr:
+            self.ctx.lib.mbpls_hip_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self.ctx.handle:
+                self.free()
+        except Exception:
+            pass
+
+
+class DeviceMatrix:
+    """Feature-major n x p matrix in HBM with block offsets (``mbpls_mat``)."""
+
+    def __init__(self, ctx, n, p, block_offsets=None, storage=None):
+        self.ctx = ctx
+        self.n, self.p = int(n), int(p)
+        offs = [0, self.p] if block_offsets is None else [int(o) for o in block_offsets]
+        self.block_offsets = offs
+        self.nblocks = len(offs) - 1
+        arr = (_i64 * len(offs))(*offs)
+        h = _vp()
+        check(ctx.lib.mbpls_hip_mat_create(ctx.handle, self.n, self.p, self.nblocks, arr, _ptr(storage), C.byref(h)))
+        self.handle = h
+        n_, p_, ld_, d_, nb_, nc_ = _i64(), _i64(), _i64(), _vp(), _int(), _int()
+        check(ctx.lib.mbpls_hip_mat_info(h, C.byref(n_), C.byref(p_), C.byref(ld_), C.byref(d_), C.byref(nb_), C.byref(nc_)))
+        self.ld, self.data_ptr, self.nchunks = ld_.value, d_.value, nc_.value
+
+    @property
+    def nbytes(self):
+        return 8 * self.ld * self.p
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            self.ctx.lib.mbpls_hip_mat_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, host, col0=0):
+        """Copy a host n x w array into columns [col0, col0+w)."""
+        a = np.asarray(host, dtype=np.float64)
+        assert a.ndim == 2 and a.shape[0] == self.n, (a.shape, self.n)
+        if a.flags.f_contiguous and not a.flags.c_contiguous:
+            layout, ld = COL_MAJOR, a.strides[1] // 8
+        else:
+            if not a.flags.c_contiguous:
+                # a column slice of a C-ordered array keeps unit column stride: pass it through un-copied
+                if a.strides[1] == 8 and a.strides[0] % 8 == 0 and a.strides[0] >= 8 * a.shape[1]:
+                    pass
+                else:
+                    a = np.ascontiguousarray(a)
+            layout, ld = ROW_MAJOR, a.strides[0] // 8
+        check(self.ctx.lib.mbpls_hip_mat_upload(self.handle, a.ctypes.data, ld, layout, int(col0), a.shape[1]))
+        return self
+
+    def download(self, col0=0, ncols=None, order="C"):
+        ncols = self.p - col0 if ncols is None else ncols
+        out = np.empty((self.n, ncols), dtype=np.float64, order=order)
+        if order == "F":
+            layout, ld = COL_MAJOR, self.n
+        else:
+            layout, ld = ROW_MAJOR, ncols
+        check(self.ctx.lib.mbpls_hip_mat_download(self.handle, out.ctypes.data, ld, layout, int(col0), int(ncols)))
+        return out
+
+    def copy_from(self, other):
+        check(self.ctx.lib.mbpls_hip_mat_copy(self.handle, other.handle))
+
+    def fill_latent(self, Ts_dev, r, noise, seed, col_base=0):
+        check(self.ctx.lib.mbpls_hip_mat_fill_latent(self.handle, Ts_dev.ptr, int(r), float(noise), int(seed), int(col_base)))
+
+    # ---- hot path
+    def standardize_sweep(self, dst, mode, mean, scale, ssq_x, v=None, alpha=1.0, g=None, t=None, ssq_g=None):
+        check(self.ctx.lib.mbpls_hip_standardize_sweep(self.handle, dst.handle, int(mode), _ptr(mean), _ptr(scale),
+                                                       _ptr(ssq_x), _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g)))
+
+    def sweep(self, v, alpha, g, t, ssq_g):
+        check(self.ctx.lib.mbpls_hip_sweep(self.handle, _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g)))
+
+    def deflate_sweep(self, ts, inv_tt, deflate, p, ssq_p, v=None, alpha=1.0, g=None, t=None, ssq_g=None):
+        check(self.ctx.lib.mbpls_hip_deflate_sweep(self.handle, _ptr(ts), float(inv_tt), int(bool(deflate)), _ptr(p),
+                                                   _ptr(ssq_p), _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g)))
+
+    def xt_v(self, V, c, alpha, G, ssq=None, ldv=None, ldg=None):
+        check(self.ctx.lib.mbpls_hip_xt_v(self.handle, _ptr(V), int(ldv or self.n), int(c), float(alpha), _ptr(G),
+                                          int(ldg or self.p), _ptr(ssq)))
+
+    def x_w(self, W, c, out, per_block=False, mean=None, scale=None, ldw=None, ldo=None):
+        check(self.ctx.lib.mbpls_hip_x_w(self.handle, _ptr(W), int(ldw or self.p), int(c), int(bool(per_block)),
+                                         _ptr(mean), _ptr(scale), _ptr(out), int(ldo or self.n)))
+
+    def gram(self, G, ldg=None):
+        check(self.ctx.lib.mbpls_hip_gram(self.handle, _ptr(G), int(ldg or self.n)))

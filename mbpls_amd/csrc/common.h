@@ -1,0 +1,141 @@
+// Internal definitions shared by the HIP translation units of libmbpls_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mbpls_hip.h"
+
+namespace mbpls {
+
+void set_error(const char* fmt, ...);
+
+#define MB_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      ::mbpls::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                       \
+      return e_ == hipErrorOutOfMemory ? MBPLS_ERR_OOM : MBPLS_ERR_HIP;                   \
+    }                                                                                     \
+  } while (0)
+
+#define MB_ARG(cond, ...)              \
+  do {                                 \
+    if (!(cond)) {                     \
+      ::mbpls::set_error(__VA_ARGS__); \
+      return MBPLS_ERR_ARG;            \
+    }                                  \
+  } while (0)
+
+#define MB_TRY(expr)          \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != MBPLS_OK) return rc_; \
+  } while (0)
+
+// One chunk table: contiguous column ranges that never straddle a block.
+struct ChunkTable {
+  int nchunks = 0;
+  std::vector<int64_t> h_c0, h_c1;   // [nchunks]
+  std::vector<int> h_blk;            // [nchunks]
+  std::vector<int> h_blk_start;      // [nblocks+1] chunk range of each block
+  int64_t* d_c0 = nullptr;
+  int64_t* d_c1 = nullptr;
+  int* d_blk_start = nullptr;
+};
+
+}  // namespace mbpls
+
+struct mbpls_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int cus = 256;
+  // tunables
+  int chunks_per_cu = 4;
+  int rows_per_thread = 0;   // 0 = auto
+  int xw_chunks_per_cu = 1;
+  // workspace for chunk partials (grown on demand, never shrunk)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  // staging for transposing uploads
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // per-kernel profile (HIP events around the main kernel of every hot-path call)
+  bool prof = false;
+  struct Pending { hipEvent_t a, b; int kind; double bytes; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+  int64_t prof_count[MBPLS_K_COUNT] = {0};
+  double prof_ms[MBPLS_K_COUNT] = {0};
+  double prof_bytes[MBPLS_K_COUNT] = {0};
+};
+
+struct mbpls_mat {
+  mbpls_ctx* ctx = nullptr;
+  int64_t n = 0, p = 0, ld = 0;
+  int nblocks = 1;
+  std::vector<int64_t> block_offsets;
+  double* data = nullptr;
+  bool owns = false;
+  mbpls::ChunkTable fine;    // column-pass kernels (one workgroup per chunk, full columns)
+  mbpls::ChunkTable coarse;  // row-slab kernels (x_w)
+};
+
+namespace mbpls {
+int ensure_ws(mbpls_ctx* ctx, size_t bytes);
+int ensure_stage(mbpls_ctx* ctx, size_t bytes);
+int build_chunks(mbpls_ctx* ctx, const std::vector<int64_t>& offs, int target, ChunkTable* t);
+void free_chunks(ChunkTable* t);
+
+// RAII bracket: records an event pair around a kernel launch when profiling is on.
+struct ProfScope {
+  mbpls_ctx* ctx;
+  int kind;
+  double bytes;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(mbpls_ctx* c, int k, double by);
+  ~ProfScope();
+};
+
+// ---------------------------------------------------------------- device helpers
+#ifdef __HIPCC__
+// 64-lane butterfly: every lane ends with the same, order-fixed sum.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Sum NV values over the whole workgroup; every thread receives the same result.
+// red: LDS scratch double[2][16][4]; buf alternates so one barrier per call suffices.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* red, int& buf) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+  const int nw = blockDim.x >> 6;
+  if (nw == 1) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double* r = red + buf * 64;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) r[w * 4 + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double s = r[k];
+    for (int i = 1; i < nw; ++i) s += r[i * 4 + k];
+    v[k] = s;
+  }
+  buf ^= 1;
+}
+#endif
+
+}  // namespace mbpls

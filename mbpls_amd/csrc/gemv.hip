@@ -1,0 +1,254 @@
+// Multi-right-hand-side products with the feature-major X:
+//   xt_v : G = alpha * X^T V   (p x c from n x c)   -- column held by the workgroup, c dots per column
+//   x_w  : OUT = X W           (n x c from p x c)   -- row slabs x column chunks, register accumulators
+// Both are HBM-bound (<= c/4 flop per byte); right-hand sides are processed in groups so X is
+// read ceil(c/CB) times.
+#include <algorithm>
+
+#include "common.h"
+
+namespace mbpls {
+
+// ------------------------------------------------------------------------------------ xt_v
+template <int R, int TMAX, int CB>
+__global__ __launch_bounds__(TMAX) void k_xtv(const double* __restrict__ X, int64_t ld, int64_t n,
+                                              const int64_t* __restrict__ c0, const int64_t* __restrict__ c1,
+                                              const double* __restrict__ V, int64_t ldv, int cb, double alpha,
+                                              double* __restrict__ G, int64_t ldg, double* __restrict__ part_s) {
+  __shared__ double red[2 * 64];
+  int buf = 0;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int chunk = blockIdx.x;
+  const int64_t j0 = c0[chunk], j1 = c1[chunk];
+  double v[CB][R];
+#pragma unroll
+  for (int q = 0; q < CB; ++q)
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) {
+      const int64_t r0 = 2 * ((int64_t)k * T + tid);
+      v[q][2 * k] = (q < cb && r0 < n) ? V[q * ldv + r0] : 0.0;
+      v[q][2 * k + 1] = (q < cb && r0 + 1 < n) ? V[q * ldv + r0 + 1] : 0.0;
+    }
+  double ssq[CB];
+#pragma unroll
+  for (int q = 0; q < CB; ++q) ssq[q] = 0.0;
+
+  auto load = [&](double(&x)[R], int64_t j) {
+    const double* col = X + j * ld;
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) {
+      const int64_t r0 = 2 * ((int64_t)k * T + tid);
+      double2 t = make_double2(0.0, 0.0);
+      if (r0 < ld) t = *reinterpret_cast<const double2*>(col + r0);
+      x[2 * k] = (r0 < n) ? t.x : 0.0;
+      x[2 * k + 1] = (r0 + 1 < n) ? t.y : 0.0;
+    }
+  };
+  double x[2][R];
+  if (j0 < j1) load(x[0], j0);
+  if (j0 + 1 < j1) load(x[1], j0 + 1);
+  for (int64_t j = j0; j < j1; j += 2) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int64_t jj = j + d;
+      if (jj >= j1) break;
+      double dot[CB];
+#pragma unroll
+      for (int q = 0; q < CB; ++q) {
+        dot[q] = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) dot[q] = fma(x[d][k], v[q][k], dot[q]);
+      }
+      block_sum<CB>(dot, red, buf);
+      if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < CB; ++q)
+          if (q < cb) G[q * ldg + jj] = alpha * dot[q];
+      }
+#pragma unroll
+      for (int q = 0; q < CB; ++q) {
+        const double gq = alpha * dot[q];
+        ssq[q] = fma(gq, gq, ssq[q]);
+      }
+      if (jj + 2 < j1) load(x[d], jj + 2);
+    }
+  }
+  if (tid == 0 && part_s) {
+#pragma unroll
+    for (int q = 0; q < CB; ++q) part_s[(int64_t)chunk * 4 + q] = ssq[q];
+  }
+}
+
+// d_ssq[(k0+q)*nblocks + b] = sum over the chunks of block b of part_s[chunk][q]
+__global__ __launch_bounds__(64) void k_reduce_ssq(const double* __restrict__ part_s, const int* __restrict__ blk_start,
+                                                   int nblocks, int cb, double* __restrict__ out) {
+  const int b = blockIdx.x, q = blockIdx.y, lane = threadIdx.x;
+  if (q >= cb) return;
+  double s = 0.0;
+  for (int c = blk_start[b] + lane; c < blk_start[b + 1]; c += 64) s += part_s[(int64_t)c * 4 + q];
+  s = wave_sum(s);
+  if (lane == 0) out[(int64_t)q * nblocks + b] = s;
+}
+
+// ------------------------------------------------------------------------------------ x_w
+// grid (nchunks, nslabs); a workgroup owns rows [slab*512, slab*512+512) of the columns of its chunk.
+template <int CB, bool SCALE>
+__global__ __launch_bounds__(256) void k_xw(const double* __restrict__ X, int64_t ld, int64_t n,
+                                            const int64_t* __restrict__ c0, const int64_t* __restrict__ c1,
+                                            const double* __restrict__ W, int64_t ldw, int cb,
+                                            const double* __restrict__ mean, const double* __restrict__ scale,
+                                            double* __restrict__ part /* [nchunks][CB][n] */) {
+  const int chunk = blockIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * 512 + 2 * threadIdx.x;
+  const int64_t j0 = c0[chunk], j1 = c1[chunk];
+  const bool in0 = r0 < n, in1 = r0 + 1 < n, inld = r0 < ld;
+  double acc[CB][2];
+#pragma unroll
+  for (int q = 0; q < CB; ++q) acc[q][0] = acc[q][1] = 0.0;
+  const double* col = X + j0 * ld + r0;
+#pragma unroll 4
+  for (int64_t j = j0; j < j1; ++j, col += ld) {
+    double2 t = make_double2(0.0, 0.0);
+    if (inld) t = *reinterpret_cast<const double2*>(col);
+    double x0 = in0 ? t.x : 0.0, x1 = in1 ? t.y : 0.0;
+    if constexpr (SCALE) {
+      const double mu = mean[j], sc = scale[j];
+      x0 = in0 ? (x0 - mu) / sc : 0.0;
+      x1 = in1 ? (x1 - mu) / sc : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {
+      const double w = (q < cb) ? W[q * ldw + j] : 0.0;  // workgroup-uniform -> scalar load
+      acc[q][0] = fma(w, x0, acc[q][0]);
+      acc[q][1] = fma(w, x1, acc[q][1]);
+    }
+  }
+  double* out = part + (int64_t)chunk * CB * n;
+#pragma unroll
+  for (int q = 0; q < CB; ++q) {
+    if (in0) out[q * n + r0] = acc[q][0];
+    if (in1) out[q * n + r0 + 1] = acc[q][1];
+  }
+}
+
+// out[(b or 0)][q][i] = sum over chunks (of block b, or all) of part[chunk][q][i], fixed order.
+__global__ __launch_bounds__(256) void k_reduce_xw(const double* __restrict__ part, int CB, int cb, int64_t n,
+                                                   const int* __restrict__ blk_start, int nblocks, int per_block,
+                                                   double* __restrict__ out, int64_t ldo, int c_total, int k0) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int q = blockIdx.y;
+  const int b = blockIdx.z;
+  if (i >= n || q >= cb) return;
+  const int cs = per_block ? blk_start[b] : blk_start[0];
+  const int ce = per_block ? blk_start[b + 1] : blk_start[nblocks];
+  double s0 = 0.0, s1 = 0.0;
+  int c = cs;
+  for (; c + 1 < ce; c += 2) {
+    s0 += part[((int64_t)c * CB + q) * n + i];
+    s1 += part[((int64_t)(c + 1) * CB + q) * n + i];
+  }
+  if (c < ce) s0 += part[((int64_t)c * CB + q) * n + i];
+  out[(int64_t)b * ldo * c_total + (int64_t)(k0 + q) * ldo + i] = s0 + s1;
+}
+
+struct Cfg {
+  int R, TMAX;
+};
+static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T) {
+  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}};
+  for (const Cfg& c : table) {
+    int64_t need = (n + c.R - 1) / c.R;
+    need = (need + 63) / 64 * 64;
+    if (need <= c.TMAX) {
+      *cfg = c;
+      *T = (int)need;
+      return true;
+    }
+  }
+  return false;
+}
+
+}  // namespace mbpls
+
+using namespace mbpls;
+
+extern "C" {
+
+int mbpls_hip_xt_v(const mbpls_mat* m, const double* d_V, int64_t ldv, int c, double alpha, double* d_G,
+                   int64_t ldg, double* d_ssq) {
+  MB_ARG(m && d_V && d_G, "NULL argument");
+  MB_ARG(c >= 1 && ldv >= m->n && ldg >= m->p, "bad shape (c=%d ldv=%lld ldg=%lld)", c, (long long)ldv,
+         (long long)ldg);
+  mbpls_ctx* ctx = m->ctx;
+  Cfg cfg;
+  int T = 0;
+  if (!pick_cfg(ctx, m->n, &cfg, &T)) {
+    set_error("xt_v supports n <= 8192 (got n=%lld)", (long long)m->n);
+    return MBPLS_ERR_UNSUPPORTED;
+  }
+  const ChunkTable& ct = m->fine;
+  MB_TRY(ensure_ws(ctx, sizeof(double) * (size_t)ct.nchunks * 4));
+  double* part_s = (double*)ctx->ws;
+  constexpr int CB = 2;
+  for (int k0 = 0; k0 < c; k0 += CB) {
+    const int cb = std::min(CB, c - k0);
+    const double* V = d_V + (int64_t)k0 * ldv;
+    double* G = d_G + (int64_t)k0 * ldg;
+    dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
+    ProfScope prof(ctx, MBPLS_K_XT_V, 8.0 * (double)m->n * (double)m->p);
+#define MB_LAUNCH(R_, TM_)                                                                                       \
+  hipLaunchKernelGGL((k_xtv<R_, TM_, CB>), grid, block, 0, ctx->stream, (const double*)m->data, m->ld, m->n,     \
+                     (const int64_t*)ct.d_c0, (const int64_t*)ct.d_c1, V, ldv, cb, alpha, G, ldg,                \
+                     d_ssq ? part_s : (double*)nullptr)
+    if (cfg.R == 2) MB_LAUNCH(2, 256);
+    else if (cfg.R == 4) MB_LAUNCH(4, 512);
+    else if (cfg.R == 8 && cfg.TMAX == 512) MB_LAUNCH(8, 512);
+    else if (cfg.R == 8) MB_LAUNCH(8, 1024);
+    else MB_LAUNCH(16, 512);
+#undef MB_LAUNCH
+    MB_HIP(hipGetLastError());
+    if (d_ssq) {
+      hipLaunchKernelGGL(k_reduce_ssq, dim3((unsigned)m->nblocks, (unsigned)cb), dim3(64), 0, ctx->stream,
+                         (const double*)part_s, (const int*)ct.d_blk_start, m->nblocks, cb,
+                         d_ssq + (int64_t)k0 * m->nblocks);
+      MB_HIP(hipGetLastError());
+    }
+  }
+  return MBPLS_OK;
+}
+
+int mbpls_hip_x_w(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block, const double* d_mean,
+                  const double* d_scale, double* d_out, int64_t ldo) {
+  MB_ARG(m && d_W && d_out, "NULL argument");
+  MB_ARG(c >= 1 && ldw >= m->p && ldo >= m->n, "bad shape (c=%d ldw=%lld ldo=%lld)", c, (long long)ldw,
+         (long long)ldo);
+  MB_ARG((d_mean == nullptr) == (d_scale == nullptr), "mean and scale must be given together");
+  mbpls_ctx* ctx = m->ctx;
+  const ChunkTable& ct = m->coarse;
+  constexpr int CB = 8;
+  MB_TRY(ensure_ws(ctx, sizeof(double) * (size_t)ct.nchunks * CB * (size_t)m->n));
+  double* part = (double*)ctx->ws;
+  const unsigned slabs = (unsigned)((m->n + 511) / 512);
+  for (int k0 = 0; k0 < c; k0 += CB) {
+    const int cb = std::min(CB, c - k0);
+    const double* W = d_W + (int64_t)k0 * ldw;
+    dim3 grid((unsigned)ct.nchunks, slabs);
+    {
+    ProfScope prof(ctx, MBPLS_K_X_W, 8.0 * (double)m->n * (double)m->p);
+    if (d_mean)
+      hipLaunchKernelGGL((k_xw<CB, true>), grid, dim3(256), 0, ctx->stream, (const double*)m->data, m->ld, m->n,
+                         (const int64_t*)ct.d_c0, (const int64_t*)ct.d_c1, W, ldw, cb, d_mean, d_scale, part);
+    else
+      hipLaunchKernelGGL((k_xw<CB, false>), grid, dim3(256), 0, ctx->stream, (const double*)m->data, m->ld, m->n,
+                         (const int64_t*)ct.d_c0, (const int64_t*)ct.d_c1, W, ldw, cb, d_mean, d_scale, part);
+    }
+    MB_HIP(hipGetLastError());
+    dim3 rgrid((unsigned)((m->n + 255) / 256), (unsigned)cb, per_block ? (unsigned)m->nblocks : 1u);
+    hipLaunchKernelGGL(k_reduce_xw, rgrid, dim3(256), 0, ctx->stream, (const double*)part, CB, cb, m->n,
+                       (const int*)ct.d_blk_start, m->nblocks, per_block ? 1 : 0, d_out, ldo, c, k0);
+    MB_HIP(hipGetLastError());
+  }
+  return MBPLS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Synthetic wide matrix with planted latent structure, generated directly in HBM.
+//   X[:, j] = Ts @ L[:, j] + noise * N(0, 1)          (SURVEY 8d "make_latent" recipe)
+// Ts (n x r, column-major) is the score matrix already scaled by the decay; L and the noise come
+// from a counter-based generator (splitmix64 of (seed, stream, index) + Box-Muller), so any
+// column range of the same global matrix can be produced independently on any rank.
+#include "common.h"
+
+namespace mbpls {
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// two independent standard normals from one counter
+__device__ __forceinline__ void normal2(uint64_t seed, uint64_t stream, uint64_t idx, double* z0, double* z1) {
+  const uint64_t k = splitmix64(seed ^ splitmix64(stream * 0xD1B54A32D192ED03ull + idx));
+  const uint64_t a = splitmix64(k), b = splitmix64(k ^ 0xA5A5A5A5A5A5A5A5ull);
+  const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740993.0);  // (0, 1)
+  const double u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);          // [0, 1)
+  const double rad = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincos(6.283185307179586 * u2, &s, &c);
+  *z0 = rad * c;
+  *z1 = rad * s;
+}
+
+// one workgroup per column; thread t owns row pairs
+__global__ __launch_bounds__(256) void k_fill_latent(double* __restrict__ X, int64_t ld, int64_t n, int64_t p,
+                                                     const double* __restrict__ Ts, int r, double noise,
+                                                     uint64_t seed, int64_t col_base) {
+  __shared__ double L[64];
+  for (int64_t j = blockIdx.x; j < p; j += gridDim.x) {
+    const uint64_t gj = (uint64_t)(col_base + j);
+    __syncthreads();
+    if (threadIdx.x < (r + 1) / 2) {
+      double z0, z1;
+      normal2(seed, 1, gj * 32 + threadIdx.x, &z0, &z1);
+      L[2 * threadIdx.x] = z0;
+      L[2 * threadIdx.x + 1] = z1;
+    }
+    __syncthreads();
+    double* col = X + j * ld;
+    for (int64_t i2 = threadIdx.x; 2 * i2 < ld; i2 += blockDim.x) {
+      const int64_t i = 2 * i2;
+      double s0 = 0.0, s1 = 0.0;
+      const bool in0 = i < n, in1 = i + 1 < n;
+      for (int k = 0; k < r; ++k) {
+        const double l = L[k];
+        if (in0) s0 = fma(Ts[(int64_t)k * n + i], l, s0);
+        if (in1) s1 = fma(Ts[(int64_t)k * n + i + 1], l, s1);
+      }
+      double z0, z1;
+      normal2(seed, 2, gj * (uint64_t)((n + 1) / 2) + (uint64_t)i2, &z0, &z1);
+      col[i] = in0 ? fma(noise, z0, s0) : 0.0;
+      col[i + 1] = in1 ? fma(noise, z1, s1) : 0.0;
+    }
+  }
+}
+
+}  // namespace mbpls
+
+using namespace mbpls;
+
+extern "C" int mbpls_hip_mat_fill_latent(mbpls_mat* m, const double* d_T, int r, double noise, uint64_t seed,
+                                         int64_t col_base) {
+  MB_ARG(m && d_T, "NULL argument");
+  MB_ARG(r >= 1 && r <= 64, "r must be in [1, 64]");
+  mbpls_ctx* ctx = m->ctx;
+  const unsigned grid = (unsigned)std::min<int64_t>(m->p, (int64_t)ctx->cus * 16);
+  hipLaunchKernelGGL(k_fill_latent, dim3(grid), dim3(256), 0, ctx->stream, m->data, m->ld, m->n, m->p, d_T, r,
+                     noise, seed, col_base);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}

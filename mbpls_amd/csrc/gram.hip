@@ -1,0 +1,167 @@
+// Association matrix of the KERNEL method: G = X X^T (n x n) from the feature-major X (p x n).
+//
+// The only true dense GEMM on the path (n(n+1)p flop), so it runs on the f64 matrix cores:
+// v_mfma_f64_16x16x4_f64, D(16x16) += A(16x4) B(4x16) with the reduction index k running over
+// FEATURES.  In the feature-major layout both operands of one k-step are rows of X:
+//   A[i][k] = X[j+k][a0+i],  B[k][c] = X[j+k][b0+c]
+// and the MFMA lane map (lane l feeds A[l&15][l>>4], B[l>>4][l&15]) turns into four 128-byte
+// contiguous segments per wave-load -- the reduction index is the slow one, perfectly streaming.
+//
+// Work decomposition: lower-triangle 128x128 tiles (SYRK), 4 waves per tile as 2x2, each wave a
+// 64x64 sub-tile = 4x4 MFMA tiles (64 f64 accumulators per lane).  Tiles are ordered in 8x8
+// super-tiles and dealt to XCDs in contiguous runs so the workgroups that share an XCD L2 read
+// the same few 128-sample panels of each feature.  Small n: split-K over features with a
+// fixed-order slice reduction (deterministic).  A final pass mirrors the lower triangle.
+#include <algorithm>
+
+#include "common.h"
+
+namespace mbpls {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int GT = 128;  // tile edge
+
+struct GramArgs {
+  const double* X;
+  int64_t ld, n, p;
+  const int* tile_i;  // [ntiles]
+  const int* tile_j;
+  int ntiles, nslices;
+  int64_t slice_len;  // features per slice (multiple of 4)
+  double* out;        // [nslices][n*ldg]
+  int64_t ldg;
+};
+
+__global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
+  // XCD-aware remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous run of work items
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+  const int wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tile = wid % a.ntiles, slice = wid / a.ntiles;
+  const int ti = a.tile_i[tile], tj = a.tile_j[tile];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t a0 = (int64_t)ti * GT + wr * 64, b0 = (int64_t)tj * GT + wc * 64;
+  const int lk = lane >> 4, li = lane & 15;
+
+  double4_t acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int64_t jbeg = (int64_t)slice * a.slice_len;
+  const int64_t jend = std::min<int64_t>(a.p, jbeg + a.slice_len);
+  // per-lane row offsets (clamped; out-of-range samples are masked to zero)
+  int64_t ra[4], rb[4];
+  bool va[4], vb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    ra[t] = a0 + t * 16 + li;
+    rb[t] = b0 + t * 16 + li;
+    va[t] = ra[t] < a.n;
+    vb[t] = rb[t] < a.n;
+    if (!va[t]) ra[t] = 0;
+    if (!vb[t]) rb[t] = 0;
+  }
+  for (int64_t j = jbeg; j < jend; j += 4) {
+    const int64_t jf = j + lk;
+    const bool vj = jf < jend;
+    const double* row = a.X + (vj ? jf : j) * a.ld;
+    double av[4], bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double xa = row[ra[t]], xb = row[rb[t]];
+      av[t] = (vj && va[t]) ? xa : 0.0;
+      bv[t] = (vj && vb[t]) ? xb : 0.0;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+  }
+  // D layout (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
+  double* out = a.out + (int64_t)slice * a.n * a.ldg;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int64_t row = a0 + mi * 16 + lk + 4 * rg, col = b0 + ni * 16 + li;
+        if (row < a.n && col < a.n) out[row * a.ldg + col] = acc[mi][ni][rg];
+      }
+}
+
+// G[i][j] (j <= i) = sum_s part[s][i][j] in slice order; G[j][i] = G[i][j].
+__global__ __launch_bounds__(256) void k_gram_finish(const double* __restrict__ part, int nslices, int64_t n,
+                                                     int64_t ldg, double* __restrict__ G) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = blockIdx.y;
+  if (j > i || i >= n) return;
+  double s = part[i * ldg + j];
+  for (int k = 1; k < nslices; ++k) s += part[(int64_t)k * n * ldg + i * ldg + j];
+  G[i * ldg + j] = s;
+  G[j * ldg + i] = s;
+}
+
+}  // namespace mbpls
+
+using namespace mbpls;
+
+extern "C" int mbpls_hip_gram(const mbpls_mat* m, double* d_G, int64_t ldg) {
+  MB_ARG(m && d_G, "NULL argument");
+  MB_ARG(ldg >= m->n, "ldg < n");
+  mbpls_ctx* ctx = m->ctx;
+  const int64_t n = m->n, p = m->p;
+  const int nt = (int)((n + GT - 1) / GT);
+  // lower-triangle tiles in 8x8 super-tile order
+  std::vector<int> ti, tj;
+  for (int SI = 0; SI < nt; SI += 8)
+    for (int SJ = 0; SJ <= SI; SJ += 8)
+      for (int i = SI; i < std::min(nt, SI + 8); ++i)
+        for (int j = SJ; j < std::min(nt, SJ + 8); ++j)
+          if (j <= i) {
+            ti.push_back(i);
+            tj.push_back(j);
+          }
+  const int ntiles = (int)ti.size();
+  int nslices = 1;
+  const int want = ctx->cus * 4;
+  if (ntiles < want) {
+    nslices = (want + ntiles - 1) / ntiles;
+    const int64_t max_slices = std::max<int64_t>(1, p / 256);
+    nslices = (int)std::min<int64_t>(nslices, max_slices);
+    // keep the slice partials within 1 GiB
+    const int64_t cap = std::max<int64_t>(1, ((int64_t)1 << 30) / std::max<int64_t>(1, n * ldg * 8));
+    nslices = (int)std::min<int64_t>(nslices, cap);
+  }
+  int64_t slice_len = (p + nslices - 1) / nslices;
+  slice_len = (slice_len + 3) / 4 * 4;
+  nslices = (int)((p + slice_len - 1) / slice_len);
+  const size_t tile_bytes = sizeof(int) * (size_t)ntiles * 2;
+  const size_t part_bytes = sizeof(double) * (size_t)nslices * (size_t)n * (size_t)ldg;
+  MB_TRY(ensure_ws(ctx, tile_bytes + 256 + part_bytes));
+  int* d_ti = (int*)ctx->ws;
+  int* d_tj = d_ti + ntiles;
+  double* part = (double*)((char*)ctx->ws + ((tile_bytes + 255) / 256) * 256);
+  MB_HIP(hipMemcpyAsync(d_ti, ti.data(), sizeof(int) * ntiles, hipMemcpyHostToDevice, ctx->stream));
+  MB_HIP(hipMemcpyAsync(d_tj, tj.data(), sizeof(int) * ntiles, hipMemcpyHostToDevice, ctx->stream));
+  MB_HIP(hipStreamSynchronize(ctx->stream));  // ti/tj are stack-owned
+  GramArgs a{};
+  a.X = m->data; a.ld = m->ld; a.n = n; a.p = p;
+  a.tile_i = d_ti; a.tile_j = d_tj; a.ntiles = ntiles; a.nslices = nslices; a.slice_len = slice_len;
+  a.out = part; a.ldg = ldg;
+  {
+    ProfScope prof(ctx, MBPLS_K_GRAM, 8.0 * (double)n * (double)p);
+    hipLaunchKernelGGL(k_gram, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
+  }
+  MB_HIP(hipGetLastError());
+  dim3 fgrid((unsigned)((n + 255) / 256), (unsigned)n);
+  hipLaunchKernelGGL(k_gram_finish, fgrid, dim3(256), 0, ctx->stream, (const double*)part, nslices, n, ldg, d_G);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}

@@ -1,0 +1,246 @@
+"""Device engine: owns the (deflating) feature-major X in HBM and issues the HIP kernels.
+
+The solvers in ``solvers.py`` are written against this small interface; every quantity that
+is a sum over feature columns passes through ``comm`` so the same solver code runs on one
+GPU and column-sharded over several.  Small results come back as host numpy
+arrays (the tiny n x B / n x q algebra and the loop-exit decision stay on the host, as in
+the reference); p-length results stay in named device *slots* (p x K, column-major) until
+``fetch``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _capi
+from .comm import LocalComm
+
+
+class HipEngine:
+    def __init__(self, ctx=None, comm=None, device=0):
+        self.ctx = ctx if ctx is not None else _capi.Context(device)
+        self.comm = comm if comm is not None else LocalComm()
+        self.X = None            # working matrix (standardised, deflated in place)
+        self._owns_X = True
+        self.slots = {}
+        self._xchg = None
+        self._xw_buf = None
+        self.mean = None
+        self.scale = None
+        self.G = None
+        self.timings = {}
+
+    # ------------------------------------------------------------------ data
+    def load_host_blocks(self, blocks):
+        """Upload host blocks (each n x p_b) side by side into one feature-major matrix.
+        Replaces deepcopy / check_array(copy) / hstack of the reference (mbpls.py:303,310,379):
+        the caller's arrays are only ever read."""
+        n = blocks[0].shape[0]
+        offs = np.concatenate(([0], np.cumsum([b.shape[1] for b in blocks]))).astype(np.int64)
+        X = _capi.DeviceMatrix(self.ctx, n, int(offs[-1]), offs)
+        for b, o in zip(blocks, offs[:-1]):
+            X.upload(b, int(o))
+        self._set_matrix(X, owns=True)
+        return self
+
+    def load_device(self, dmat, copy=True):
+        """Adopt a matrix already resident in HBM.  copy=True keeps the caller's matrix intact
+        (the standardise pass writes into a second matrix); copy=False deflates it in place."""
+        if copy:
+            W = _capi.DeviceMatrix(self.ctx, dmat.n, dmat.p, dmat.block_offsets)
+            self._src = dmat
+            self._set_matrix(W, owns=True)
+        else:
+            self._src = None
+            self._set_matrix(dmat, owns=False)
+        return self
+
+    def _set_matrix(self, X, owns):
+        self.X = X
+        self._owns_X = owns
+        self.n, self.p, self.nblocks = X.n, X.p, X.nblocks
+        self.block_offsets = list(X.block_offsets)
+        self.block_sizes = [self.block_offsets[b + 1] - self.block_offsets[b] for b in range(self.nblocks)]
+        B, n = self.nblocks, self.n
+        self._xchg = self.comm.exchange_buffer(self.ctx, n * B + 3 * B)
+        self._vec_n = [self.ctx.empty(n), self.ctx.empty(n)]
+        if not hasattr(self, "_src"):
+            self._src = None
+
+    def close(self):
+        for s in self.slots.values():
+            s.free()
+        self.slots = {}
+        if self.X is not None and self._owns_X:
+            self.X.close()
+        self.X = None
+        if self.G is not None:
+            self.G[0].close()
+            self.G[1].free()
+            self.G = None
+
+    # ------------------------------------------------------------------ slots (p x K device arrays)
+    def slot(self, name, K):
+        s = self.slots.get(name)
+        if s is None or s.shape != (self.p, K):
+            if s is not None:
+                s.free()
+            s = self.ctx.empty((self.p, K), zero=True)
+            self.slots[name] = s
+        return s
+
+    def fetch(self, name):
+        return self.slots[name].get()
+
+    def put(self, name, arr):
+        arr = np.asarray(arr, dtype=np.float64)
+        if arr.ndim == 1:
+            arr = arr.reshape(-1, 1)
+        return self.slot(name, arr.shape[1]).set(arr)
+
+    def put_col(self, name, k, vec):
+        self.slots[name].col(k).set(np.ascontiguousarray(vec, dtype=np.float64).ravel())
+
+    def _slot_col(self, spec):
+        if spec is None:
+            return None
+        name, k = spec
+        return self.slots[name].col(k)
+
+    # ------------------------------------------------------------------ exchange helpers
+    def _xptr(self, off):
+        return self._xchg.ptr + 8 * off
+
+    def _finish_pass(self, want_t, want_g, want_p, want_x):
+        """all-reduce the exchange buffer (if sharded) and split it on the host."""
+        n, B = self.n, self.nblocks
+        self.comm.allreduce_device(self._xchg)
+        h = self._xchg.get()
+        t = h[: n * B].reshape(B, n).T.copy() if want_t else None   # n x B
+        o = n * B
+        return (t, h[o:o + B].copy() if want_g else None, h[o + B:o + 2 * B].copy() if want_p else None,
+                h[o + 2 * B:o + 3 * B].copy() if want_x else None)
+
+    def _put_vec(self, idx, v):
+        d = self._vec_n[idx]
+        d.set(np.ascontiguousarray(v, dtype=np.float64).ravel())
+        return d
+
+    # ------------------------------------------------------------------ hot path
+    def prepare(self, standardize, v=None, alpha=1.0, g_slot=None, mean=None, scale=None):
+        """a1 (+ first sweep): standardise X (or just take its sums of squares) and optionally run the
+        first sweep of component 0 in the same pass.  Returns (ssq_x[B], t[n,B] or None, ssq_g[B] or None)."""
+        n, B = self.n, self.nblocks
+        if standardize:
+            self.mean = self.ctx.empty(self.p)
+            self.scale = self.ctx.empty(self.p)
+            mode = _capi.SCALE_FIT
+            if mean is not None:
+                self.mean.set(mean)
+                self.scale.set(scale)
+                mode = _capi.SCALE_APPLY
+        else:
+            mode = _capi.SCALE_NONE
+        src = self._src if self._src is not None else self.X
+        dv = self._put_vec(0, v) if v is not None else None
+        src.standardize_sweep(self.X, mode, self.mean, self.scale, self._xptr(n * B + 2 * B), dv, alpha,
+                              self._slot_col(g_slot), self._xptr(0) if v is not None else None,
+                              self._xptr(n * B) if v is not None else None)
+        self._src = None
+        t, g, _, x = self._finish_pass(v is not None, v is not None, False, True)
+        return x, t, g
+
+    def sweep(self, v, alpha, g_slot):
+        """a2+a3: g = alpha X^T v (into the slot column), t~_b = X_b g_b, ||g_b||^2.  One read of X."""
+        n, B = self.n, self.nblocks
+        dv = self._put_vec(0, v)
+        self.X.sweep(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B))
+        t, g, _, _ = self._finish_pass(True, True, False, False)
+        return t, g
+
+    def deflate_sweep(self, ts, inv_tt, deflate, p_slot, v=None, alpha=1.0, g_slot=None):
+        """a5+a7 (+ next component's first sweep): p = inv_tt X^T ts, X -= ts p^T.  One read + one write."""
+        n, B = self.n, self.nblocks
+        dts = self._put_vec(1, ts)
+        dv = self._put_vec(0, v) if v is not None else None
+        self.X.deflate_sweep(dts, inv_tt, deflate, self._slot_col(p_slot), self._xptr(n * B + B), dv, alpha,
+                             self._slot_col(g_slot), self._xptr(0) if v is not None else None,
+                             self._xptr(n * B) if v is not None else None)
+        t, g, p, _ = self._finish_pass(v is not None, v is not None, True, False)
+        return p, t, g
+
+    def xt_v(self, V, alpha, slot, k0=0, want_ssq=False):
+        """slot[:, k0:k0+c] = alpha X^T V  (V: n x c host).  Optional per-block column norms^2 (B x c)."""
+        V = np.asarray(V, dtype=np.float64)
+        if V.ndim == 1:
+            V = V.reshape(-1, 1)
+        c = V.shape[1]
+        dV = self.ctx.from_host(V)
+        S = self.slots[slot]
+        ssq = self.ctx.empty((self.nblocks, c)) if want_ssq else None
+        self.X.xt_v(dV, c, alpha, S.col(k0, c), ssq)
+        out = None
+        if want_ssq:
+            out = self.comm.allreduce_host(ssq.get())
+            ssq.free()
+        dV.free()
+        return out
+
+    def _xw(self, Wdev, c, per_block, mean=None, scale=None, mat=None):
+        mat = mat if mat is not None else self.X
+        n = mat.n
+        nb = mat.nblocks if per_block else 1
+        buf = self.comm.exchange_buffer(self.ctx, n * c * nb)
+        mat.x_w(Wdev, c, buf, per_block=per_block, mean=mean, scale=scale, ldw=mat.p, ldo=n)
+        self.comm.allreduce_device(buf)
+        h = buf.get()
+        if hasattr(buf, "free"):
+            buf.free()
+        if per_block:
+            return [h[b * n * c:(b + 1) * n * c].reshape(c, n).T.copy() for b in range(nb)]
+        return h.reshape(c, n).T.copy()
+
+    def x_w_slot(self, slot, k0, c, per_block=False):
+        """X @ slot[:, k0:k0+c]  -> n x c (or one n x c per block)."""
+        return self._xw(self.slots[slot].col(k0, c), c, per_block)
+
+    def x_w_host(self, W, per_block=False):
+        W = np.asarray(W, dtype=np.float64)
+        if W.ndim == 1:
+            W = W.reshape(-1, 1)
+        dW = self.ctx.from_host(W)
+        out = self._xw(dW, W.shape[1], per_block)
+        dW.free()
+        return out
+
+    # ------------------------------------------------------------------ KERNEL method
+    def gram(self):
+        """A = X X^T on the matrix cores; kept in HBM as an n x n 'matrix' so A @ Z reuses x_w."""
+        n = self.n
+        ldg = n + (n & 1)
+        store = self.ctx.empty((ldg, n), zero=True)
+        self.X.gram(store, ldg)
+        if self.comm.is_distributed:
+            h = self.comm.allreduce_host(store.get())
+            store.set(h)
+        Gm = _capi.DeviceMatrix(self.ctx, n, n, [0, n], storage=store)
+        self.G = (Gm, store)
+        return self
+
+    def gram_apply(self, Z):
+        """A @ Z for a host n x c matrix (A symmetric, so the feature-major product X W is A Z)."""
+        Z = np.asarray(Z, dtype=np.float64)
+        if Z.ndim == 1:
+            Z = Z.reshape(-1, 1)
+        Gm = self.G[0]
+        dZ = self.ctx.from_host(Z)
+        n, c = Z.shape
+        buf = self.ctx.empty(n * c)
+        Gm.x_w(dZ, c, buf, ldw=n, ldo=n)
+        h = buf.get().reshape(c, n).T.copy()
+        buf.free()
+        dZ.free()
+        return h
+
+    def gram_host(self):
+        n = self.n
+        return self.G[1].get()[:n, :n]

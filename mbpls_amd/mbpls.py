@@ -1,0 +1,263 @@
+"""``MBPLS`` -- drop-in for ``mbpls.mbpls.MBPLS`` (reference mbpls/mbpls.py:22-1437) whose
+``fit`` / ``predict`` / ``transform`` run on an MI355X through ``libmbpls_hip.so``.
+
+Same constructor (verbatim, sklearn ``clone``/``get_params`` depend on it), same fitted
+attribute names, types and shapes, same errors.  There is no CPU path: without
+the HIP library or a GPU every method raises.
+
+Deliberate deviations from the reference (documented in DESIGN.md):
+* ``sparse_data=True`` (NaN-aware NIPALS, per-row/column Python loops, mbpls.py:846-909) is out of
+  scope of the accelerated path -> ``NotImplementedError``.
+* NIPALS has an iteration cap (``solvers.NIPALS_MAX_ITER``) with a warning; the reference loops
+  forever on data without latent structure (mbpls.py:841).
+* SIMPLS with one response and ``full_svd=False`` works (the reference raises inside scipy ``svds``).
+* X may also be a ``DeviceMatrix`` already resident in HBM (feature-major); ``copy`` then decides
+  whether it is deflated in place.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from . import _capi, runtime, solvers
+from .engine import HipEngine
+from .scaler import ColumnScaler
+
+try:  # sklearn is what the reference builds on; use its mixins / validators when present
+    from sklearn.base import BaseEstimator, MultiOutputMixin, RegressorMixin, TransformerMixin
+    from sklearn.exceptions import NotFittedError
+    from sklearn.utils import check_array, check_consistent_length
+    _HAVE_SKLEARN = True
+except Exception:  # pragma: no cover
+    _HAVE_SKLEARN = False
+
+    class BaseEstimator:  # minimal stand-ins
+        def get_params(self, deep=True):
+            import inspect
+            return {k: getattr(self, k) for k in inspect.signature(self.__init__).parameters}
+
+        def set_params(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+            return self
+
+    class TransformerMixin: pass
+    class RegressorMixin: pass
+    class MultiOutputMixin: pass
+
+    class NotFittedError(ValueError, AttributeError): pass
+
+    def check_array(a, dtype=np.float64, ensure_2d=True, copy=False, **kw):
+        a = np.array(a, dtype=dtype, copy=copy) if copy else np.asarray(a, dtype=dtype)
+        if ensure_2d and a.ndim != 2:
+            raise ValueError(f"Expected 2D array, got {a.ndim}D array instead")
+        if not np.all(np.isfinite(a)):
+            raise ValueError("Input contains NaN, infinity or a value too large for dtype('float64').")
+        return a
+
+    def check_consistent_length(*arrays):
+        ls = {len(a) for a in arrays}
+        if len(ls) > 1:
+            raise ValueError(f"Found input variables with inconsistent numbers of samples: {sorted(ls)}")
+
+_METHODS = ("UNIPALS", "KERNEL", "NIPALS", "SIMPLS")
+
+
+def _is_block_list(X):
+    return isinstance(X, list) and not isinstance(X[0], list)       # mbpls.py:301
+
+
+class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
+    """(Multiblock) PLS regression, MI355X-native.  See the module docstring."""
+
+    def __init__(self, n_components=2, full_svd=False, method='NIPALS', standardize=True, max_tol=1e-14,
+                 nipals_convergence_norm=2, calc_all=True, sparse_data=False, copy=True):
+        self.n_components = n_components
+        self.full_svd = full_svd
+        self.method = method
+        self.standardize = standardize
+        self.max_tol = max_tol
+        self.nipals_convergence_norm = nipals_convergence_norm
+        self.calc_all = calc_all
+        self.sparse_data = sparse_data
+        self.copy = copy
+
+    # ------------------------------------------------------------------ input handling
+    def _host_blocks(self, X, Y=None):
+        """Validate like the reference (mbpls.py:301-323); host arrays are never modified, the
+        device upload *is* the copy, so no deepcopy / check_array(copy=True) is needed."""
+        raw = X if _is_block_list(X) else [X]
+        blocks = []
+        for b in raw:
+            if Y is not None:
+                check_consistent_length(b, Y)                        # :309
+            blocks.append(check_array(b, dtype=np.float64, copy=False))   # :310 (values only read)
+        return blocks
+
+    def _engine(self):
+        return HipEngine(ctx=runtime.get_context(), comm=runtime.get_comm())
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, X, Y):
+        """Fit model to given data (reference mbpls.py:273).
+
+        X : 2-D array, list of 2-D arrays (blocks), or a ``DeviceMatrix`` resident in HBM
+        Y : 1-D or 2-D array"""
+        if self.sparse_data is True:
+            raise NotImplementedError(
+                "sparse_data=True (NaN-aware NIPALS, reference mbpls.py:846-909) is outside the HIP hot path")
+        Y = check_array(Y, dtype=np.float64, ensure_2d=False, copy=self.copy)      # :293
+        if Y.ndim == 1:
+            Y = Y.reshape(-1, 1)                                                    # :297-298
+        device_input = isinstance(X, _capi.DeviceMatrix)
+        if device_input:
+            if X.n != Y.shape[0]:
+                raise ValueError(f"Found input variables with inconsistent numbers of samples: [{X.n}, {Y.shape[0]}]")
+            blocks = None
+        else:
+            blocks = self._host_blocks(X, Y)
+        if self.method not in _METHODS:
+            raise NameError('Method you called is unknown')                         # :1050
+        if self.method == 'SIMPLS':
+            warnings.warn("Method 'SIMPLS' does not calculate A_ and T_!")          # :996
+        if self.standardize:
+            self.y_scaler_ = ColumnScaler().fit(Y)                                  # :325-326
+            Ys = self.y_scaler_.transform(Y)
+        else:
+            Ys = Y
+        eng = self._engine()
+        try:
+            if device_input:
+                eng.load_device(X, copy=self.copy)
+            else:
+                eng.load_host_blocks(blocks)
+            K = self.n_components
+            if self.method == 'NIPALS':
+                res = solvers.fit_nipals(eng, Ys, K, self.standardize, self.max_tol,
+                                         self.nipals_convergence_norm, self.calc_all)
+            elif self.method == 'UNIPALS':
+                res = solvers.fit_unipals(eng, Ys, K, self.standardize)
+            elif self.method == 'KERNEL':
+                res = solvers.fit_kernel(eng, Ys, K, self.standardize, self.calc_all)
+            else:
+                res = solvers.fit_simpls(eng, Ys, K, self.standardize)
+            self._store(eng, res)
+        finally:
+            eng.close()
+        return self
+
+    def _store(self, eng, res):
+        B = eng.nblocks
+        sizes = eng.block_sizes
+        self.num_blocks_ = B
+        self._block_offsets = list(eng.block_offsets)
+        if self.standardize:
+            mean, scale = eng.mean.get(), eng.scale.get()
+            self.x_scalers_ = [ColumnScaler(mean[s:e], scale[s:e], eng.n)
+                               for s, e in zip(eng.block_offsets[:-1], eng.block_offsets[1:])]
+        # containers exactly as the reference leaves them (mbpls.py:359-382)
+        self.W_non_normal_ = [np.empty((sz, 0)) for sz in sizes]
+        self.W_concat_ = np.empty((eng.p, 0))
+        for k, v in res.items():
+            setattr(self, k, v)
+        if self.method == 'SIMPLS':
+            self.explained_var_xblocks_ = np.empty((B, 0))
+            self.explained_var_x_ = []
+            self.explained_var_y_ = []
+
+    # ------------------------------------------------------------------ predict / transform
+    def _check_fitted(self):
+        if not hasattr(self, 'beta_'):
+            raise NotFittedError("This MBPLS instance is not fitted yet. Call 'fit' with appropriate "
+                                 "arguments before using this estimator.")
+
+    def _device_new(self, eng, X):
+        """Upload new data; returns (matrix, mean_dev, scale_dev).  Standardisation with the fitted
+        scalers (mbpls.py:1369,:1372,:1097,:1103) is applied on the fly inside the x_w kernel."""
+        if isinstance(X, _capi.DeviceMatrix):
+            mat = X
+        else:
+            blocks = self._host_blocks(X)
+            if len(blocks) != self.num_blocks_ or any(b.shape[1] != e - s for b, s, e in zip(
+                    blocks, self._block_offsets[:-1], self._block_offsets[1:])):
+                raise ValueError("X has a different block structure than the data the model was fitted on")
+            eng.load_host_blocks(blocks)
+            mat = eng.X
+        mean = scale = None
+        if self.standardize:
+            mean = eng.ctx.from_host(np.concatenate([s.mean_ for s in self.x_scalers_]))
+            scale = eng.ctx.from_host(np.concatenate([s.scale_ for s in self.x_scalers_]))
+        return mat, mean, scale
+
+    def predict(self, X, copy=True):
+        """Predict y based on the fitted model (reference mbpls.py:1337): (X_std beta) sigma_y + mu_y."""
+        self._check_fitted()
+        eng = self._engine()
+        try:
+            mat, mean, scale = self._device_new(eng, X)
+            dB = eng.ctx.from_host(self.beta_)
+            y = eng._xw(dB, self.beta_.shape[1], False, mean, scale, mat=mat)      # :1386 / :1408
+        finally:
+            eng.close()
+        if self.standardize:
+            y = self.y_scaler_.inverse_transform(y)
+        return y
+
+    def transform(self, X, Y=None, return_block_scores=False, copy=True):
+        """Scores of new data (reference mbpls.py:1052): Ts = X_std R_; block scores by the
+        deflation-free identity T_b = X_b W_b - Ts triu(P_b^T W_b, 1) (== the sequential deflation
+        of :1129-1155); Y scores U = colnorm(Y_std V_) (:1166)."""
+        self._check_fitted()
+        eng = self._engine()
+        try:
+            mat, mean, scale = self._device_new(eng, X)
+            K = self.R_.shape[1]
+            dR = eng.ctx.from_host(self.R_)
+            Ts = eng._xw(dR, K, False, mean, scale, mat=mat)                        # :1117 / :1250
+            T = None
+            if self.method != 'SIMPLS' and (return_block_scores):
+                W = np.vstack(self.W_)
+                dW = eng.ctx.from_host(W)
+                XW = eng._xw(dW, K, True, mean, scale, mat=mat)
+                T = []
+                for b in range(self.num_blocks_):
+                    PtW = eng.comm.allreduce_host(self.P_[b].T.dot(self.W_[b]))
+                    T.append(XW[b] - Ts.dot(np.triu(PtW, 1)))
+        finally:
+            eng.close()
+        out = [Ts]
+        if T is not None:
+            out.append(T)
+        if Y is not None:
+            Y = check_array(Y, dtype=np.float64, ensure_2d=False, copy=copy)       # :1120
+            if Y.ndim == 1:
+                Y = Y.reshape(-1, 1)
+            if self.standardize:
+                Y = self.y_scaler_.transform(Y)                                     # :1125
+            YV = Y.dot(self.V_)
+            out.append(YV / np.linalg.norm(YV, axis=0))                             # :1166
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def fit_transform(self, X, y=None, **fit_params):
+        """Fit the model, then transform the given data (reference mbpls.py:1412)."""
+        return self.fit(X, y, **fit_params).transform(X, y)
+
+    def fit_predict(self, X, Y, **fit_params):
+        """Fit to data, then predict it (reference mbpls.py:1418)."""
+        return self.fit(X, Y, **fit_params).predict(X)
+
+    def r2_score(self, X, Y):
+        """reference mbpls.py:1424 (variance-weighted when the data is not standardised)."""
+        from sklearn import metrics
+        if self.standardize:
+            return metrics.r2_score(Y, self.predict(X))
+        return metrics.r2_score(Y, self.predict(X), sample_weight=None, multioutput='variance_weighted')
+
+    def explained_variance_score(self, X, Y):
+        """reference mbpls.py:1431."""
+        from sklearn import metrics
+        if self.standardize:
+            return metrics.explained_variance_score(Y, self.predict(X))
+        return metrics.explained_variance_score(Y, self.predict(X), sample_weight=None,
+                                                multioutput='variance_weighted')

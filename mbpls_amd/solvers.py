@@ -1,0 +1,384 @@
+"""Host drivers of the four solver branches of ``MBPLS.fit`` (reference mbpls.py:384-1048).
+
+Control flow and the tiny n x B / n x q / K x K algebra stay on the host in numpy, exactly
+where the reference has them; every X-sized operation is a call into the engine (HIP
+kernels).  The formulations are the lean restatements of SURVEY.md Appendix A, each verified
+against the imported reference to <= 5e-15:
+
+* postponed normalisation  t_b = (X_b w~_b) / ||w~_b||      -> weights and scores in ONE read
+* loadings + deflation (+ next component's first sweep)      -> ONE read + ONE write
+* analytic explained variance (ts^T ts)(p^T p)               -> no n x p temporaries
+* rank-q thin-factor singular vectors                        -> no n x n SVD / ARPACK
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+# Guard against the reference's unbounded ``while diff_t > max_tol`` (mbpls.py:841): on data
+# without latent structure it never terminates.  Far above any converging case (q=10: ~100).
+NIPALS_MAX_ITER = 5000
+
+
+def _norm(x, order):
+    """np.linalg.norm of the n x 1 *matrix* ts_old - ts (mbpls.py:887): matrix-norm rules."""
+    return np.linalg.norm(np.asarray(x).reshape(-1, 1), ord=order)
+
+
+def _psd_factor(G):
+    lam, Q = np.linalg.eigh((G + G.T) * 0.5)
+    return Q * np.sqrt(np.clip(lam, 0.0, None))
+
+
+def _tlsv(thin):
+    """first left singular vector of a thin matrix (host LAPACK), n x 1"""
+    if thin.shape[1] == 1:
+        return thin / np.linalg.norm(thin)
+    return np.linalg.svd(thin, full_matrices=False)[0][:, 0:1]
+
+
+def _bip_corrected(a, sizes):
+    """mbpls.py:950-964: a_b (1 - p_b/p) renormalised; [1] for a single block."""
+    a = np.asarray(a, dtype=np.float64).ravel()
+    if a.size == 1:
+        return np.array([1.0])
+    sizes = np.asarray(sizes, dtype=np.float64)
+    f = a * (1.0 - sizes / sizes.sum())
+    return f / f.sum()
+
+
+def _split(arr, offsets):
+    return [arr[offsets[b]:offsets[b + 1]] for b in range(len(offsets) - 1)]
+
+
+class FitResult(dict):
+    __getattr__ = dict.__getitem__
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _global_sizes(eng):
+    """Block sizes of the WHOLE problem (summed over shards) for the BIP correction."""
+    s = np.asarray(eng.block_sizes, dtype=np.float64)
+    return eng.comm.allreduce_host(s)
+
+
+def _finalise(eng, res, Wcols, P, V):
+    """R_ = W (P^T W)^+,  beta_ = R_ V^T   (mbpls.py:988-989, :569-570, :737-738).
+    The K x K cross product is a sum over features -> all-reduced when sharded."""
+    PtW = eng.comm.allreduce_host(P.T.dot(Wcols))
+    res.R_ = Wcols.dot(np.linalg.pinv(PtW))
+    res.beta_ = res.R_.dot(V.T)
+    res.P_ = _split(P, eng.block_offsets)
+
+
+# ----------------------------------------------------------------------------------- NIPALS
+def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max_iter=None):
+    """mbpls.py:809-993.  Per component: iterate {sweep(u) -> T -> sw, ts -> v -> u} until
+    ||ts_old - ts|| <= max_tol (never on the first pass, :884), then p = X^T ts and
+    X <- X - ts p^T fused with the next component's first sweep (u = Y[:, 0], :838)."""
+    n, B = eng.n, eng.nblocks
+    q = Y.shape[1]
+    max_iter = NIPALS_MAX_ITER if max_iter is None else max_iter
+    sizes = _global_sizes(eng)
+    u0 = Y[:, 0:1]
+    alpha0 = 1.0 / u0.T.dot(u0).item()
+    eng.slot("Wn", K)
+    eng.slot("P", K)
+    varxb, t_raw, ssq = eng.prepare(standardize, v=u0, alpha=alpha0, g_slot=("Wn", 0))
+    varx = varxb.sum()
+    vary = (Y ** 2).sum()
+    Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
+    T = [np.empty((n, K)) for _ in range(B)]
+    nu_all = np.empty((B, K))
+    evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
+    for k in range(K):
+        u = u0
+        diff, run, ts_old = 1.0, 1, None
+        while diff > max_tol:
+            uu = u.T.dot(u).item()
+            if run > 1:
+                t_raw, ssq = eng.sweep(u, 1.0 / uu, ("Wn", k))
+            nu = np.sqrt(ssq)                               # ||w~_b||           (:860)
+            Tm = t_raw / nu                                 # t_b = X_b w_b      (:875-877)
+            sw = Tm.T.dot(u) / uu                           # (:879)
+            sw = sw / np.linalg.norm(sw)
+            ts = Tm.dot(sw)                                 # (:882)
+            ts = ts / np.linalg.norm(ts)
+            if run > 1:
+                diff = _norm(ts_old - ts, norm)             # (:887)
+            ts_old = ts.copy()
+            v = Y.T.dot(ts) / ts.T.dot(ts)                  # (:899)
+            u = Y.dot(v) / v.T.dot(v)                       # (:911)
+            u = u / np.linalg.norm(u)
+            run += 1
+            if run - 1 >= max_iter and diff > max_tol:
+                warnings.warn(f"NIPALS component {k}: no convergence to max_tol={max_tol} after {max_iter} "
+                              f"iterations (last diff {diff:.3e}); the reference would loop forever here.")
+                break
+        iters.append(run - 1)
+        last = (k == K - 1)
+        # loadings (:928, no division: ts is unit length) + deflation (:969) + next first sweep
+        ssq_p, t_next, ssq_next = eng.deflate_sweep(ts, 1.0, not last, ("P", k),
+                                                    None if last else u0, alpha0,
+                                                    None if last else ("Wn", k + 1))
+        Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u; V[:, k:k + 1] = v; A[:, k:k + 1] = sw ** 2
+        nu_all[:, k] = nu
+        for b in range(B):
+            T[b][:, k] = Tm[:, b]
+        if calc_all:                                        # (:932-964), analytic (ts^T ts)(p^T p)
+            tt = ts.T.dot(ts).item()
+            evx.append(tt * ssq_p.sum() / varx)
+            evy.append(tt * v.T.dot(v).item() / vary)
+            evxb[:, k] = tt * ssq_p / varxb
+            Acorr[:, k] = _bip_corrected(sw ** 2, sizes)
+        t_raw, ssq = t_next, ssq_next
+    Wn = eng.fetch("Wn")
+    P = eng.fetch("P")
+    res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, nipals_iterations_=iters)
+    res.W_non_normal_ = _split(Wn, eng.block_offsets)
+    res.W_ = [w / nu_all[b] for b, w in enumerate(res.W_non_normal_)]
+    if calc_all:
+        res.update(explained_var_x_=evx, explained_var_y_=evy, explained_var_xblocks_=evxb, A_corrected_=Acorr)
+    else:
+        res.update(explained_var_x_=[], explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)),
+                   A_corrected_=np.empty((B, 0)))
+    cn2 = eng.comm.allreduce_host((Wn ** 2).sum(axis=0))
+    _finalise(eng, res, Wn / np.sqrt(cn2), P, V)            # (:986-991)
+    return res
+
+
+# ----------------------------------------------------------------------------------- UNIPALS
+def fit_unipals(eng, Y, K, standardize):
+    """mbpls.py:384-574 (calc_all is ignored by the reference here).
+    p>n (:481-572): ts = tlsv((X (X^T Y)) F(Y^T Y));  n>=p (:388-479): w = tlsv(X^T Y)."""
+    n, B = eng.n, eng.nblocks
+    q = Y.shape[1]
+    p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
+    wide = p_total > n
+    sizes = _global_sizes(eng)
+    eng.slot("Wc", K)
+    eng.slot("P", K)
+    eng.slot("S", max(q, 1))
+    y0 = Y[:, 0:1]
+    fuse = wide and q == 1
+    varxb, m_raw, _ = eng.prepare(standardize, v=y0 if fuse else None, alpha=1.0, g_slot=("S", 0) if fuse else None)
+    varx = varxb.sum()
+    vary = (Y ** 2).sum()
+    F = _psd_factor(Y.T.dot(Y))
+    Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
+    T = [np.empty((n, K)) for _ in range(B)]
+    blk_nrm = np.empty((B, K)); tot_nrm = np.empty(K)
+    evx, evy, evxb, Acorr = [], [], np.empty((B, K)), np.empty((B, K))
+    for k in range(K):
+        if wide:
+            if fuse:
+                M = m_raw.sum(axis=1, keepdims=True)        # X (X^T y) = sum_b X_b g_b
+            else:
+                M = np.empty((n, q))
+                for c in range(q):
+                    tr, _ = eng.sweep(Y[:, c:c + 1], 1.0, None)
+                    M[:, c] = tr.sum(axis=1)
+            ts = _tlsv(M.dot(F))                            # (:489-493)
+            v = Y.T.dot(ts) / ts.T.dot(ts)                  # (:496)
+            u = Y.dot(v); u = u / np.linalg.norm(u)         # (:499-500)
+            t_raw, ssq = eng.sweep(u, 1.0, ("Wc", k))       # w_raw = X^T u (:503), t~_b = X_b w_raw_b
+        else:
+            eng.xt_v(Y, 1.0, "S", 0)
+            C = eng.fetch("S")[:, :q]
+            w = _tlsv(C)                                    # (:396-400): S = C C^T is symmetric
+            eng.put_col("Wc", k, w)
+            tb = eng.x_w_slot("Wc", k, 1, per_block=True)
+            t_raw = np.hstack(tb)
+            ssq = eng.comm.allreduce_host(np.array([float((w[eng.block_offsets[b]:eng.block_offsets[b + 1]] ** 2).sum())
+                                                    for b in range(B)]))
+            ts = t_raw.sum(axis=1, keepdims=True)           # X w (:416)
+            ts = ts / np.linalg.norm(ts)
+            v = Y.T.dot(ts) / ts.T.dot(ts)
+            u = Y.dot(v); u = u / np.linalg.norm(u)
+        tot = ssq.sum()
+        blk_nrm[:, k] = np.sqrt(ssq); tot_nrm[k] = np.sqrt(tot)
+        a = ssq / tot                                       # ||w_b||^2 of the unit-length w (:512)
+        Tm = t_raw / np.sqrt(ssq)                           # t_b = X_b w_b/||w_b||  (:517)
+        tt = ts.T.dot(ts).item()
+        last = (k == K - 1)
+        nxt = fuse and not last
+        ssq_p, m_raw, _ = eng.deflate_sweep(ts, 1.0 / tt, not last, ("P", k), y0 if nxt else None, 1.0,
+                                            ("S", 0) if nxt else None)   # p (:520), X - ts p^T (:535)
+        Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u; V[:, k:k + 1] = v; A[:, k] = a
+        for b in range(B):
+            T[b][:, k] = Tm[:, b]
+        evx.append(tt * ssq_p.sum() / varx)                 # (:521-533)
+        evxb[:, k] = tt * ssq_p / varxb
+        evy.append(tt * v.T.dot(v).item() / vary)           # (:538-540)
+        Acorr[:, k] = _bip_corrected(a, sizes)              # (:542-553)
+    Wc = eng.fetch("Wc")
+    P = eng.fetch("P")
+    Wunit = Wc / tot_nrm if wide else Wc
+    res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, explained_var_x_=evx, explained_var_y_=evy,
+                    explained_var_xblocks_=evxb, A_corrected_=Acorr)
+    res.W_ = [w / blk_nrm[b] for b, w in enumerate(_split(Wc, eng.block_offsets))]
+    _finalise(eng, res, Wunit, P, V)
+    return res
+
+
+# ----------------------------------------------------------------------------------- KERNEL
+def _kernel_extras(eng, res, Y, P, V, Ts, varxb, wslot, wnorm2):
+    """calc_all outputs of the KERNEL method (mbpls.py:653-689, :740-802) without the second,
+    X-deflating sweep: deflation-free block scores T_b = X_b W_b - Ts triu(P_b^T W_b, 1).
+    ``wslot`` holds columns proportional to W_concat_ on the device, ``wnorm2[b, k]`` their squared
+    per-block norms (already summed over shards)."""
+    B = eng.nblocks
+    K = Ts.shape[1]
+    sizes = _global_sizes(eng)
+    offs = eng.block_offsets
+    Wraw = eng.fetch(wslot)[:, :K]
+    W = [w / np.sqrt(wnorm2[b]) for b, w in enumerate(_split(Wraw, offs))]   # (:748 / :607)
+    A = wnorm2 / wnorm2.sum(axis=0)                         # ||W_concat_[J_b, k]||^2 (:750 / :609)
+    XW = eng.x_w_slot(wslot, 0, K, per_block=True)
+    T = []
+    for b in range(B):
+        PtW = eng.comm.allreduce_host(P[offs[b]:offs[b + 1]].T.dot(W[b]))
+        T.append(XW[b] / np.sqrt(wnorm2[b]) - Ts.dot(np.triu(PtW, 1)))
+    varx = varxb.sum()
+    vary = (Y ** 2).sum()
+    tt = (Ts ** 2).sum(axis=0)
+    pp_b = eng.comm.allreduce_host(np.array([(P[offs[b]:offs[b + 1]] ** 2).sum(axis=0) for b in range(B)]))
+    res.update(T_=T, W_=W, A_=A,
+               A_corrected_=np.column_stack([_bip_corrected(A[:, k], sizes) for k in range(K)]),
+               explained_var_x_=list(tt * pp_b.sum(axis=0) / varx),
+               explained_var_xblocks_=tt * pp_b / varxb[:, None],
+               explained_var_y_=list(tt * (V ** 2).sum(axis=0) / vary))
+
+
+def fit_kernel(eng, Y, K, standardize, calc_all=True):
+    """mbpls.py:576-807.  p>n (:694-805): association matrix A = X X^T on the matrix cores, then the
+    component loop runs on n x q thin factors: the reference's D A D (D = I - ts ts^T, :722-725) is
+    applied implicitly, A_k Y_d = D_k..D_1 A_0 (D_1..D_k Y_d), one A_0 @ (n x q) product per component."""
+    n, B = eng.n, eng.nblocks
+    q = Y.shape[1]
+    p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
+    varxb, _, _ = eng.prepare(standardize)
+    res = FitResult()
+    empty_blocks = dict(W_=[np.empty((sz, 0)) for sz in eng.block_sizes], T_=[np.empty((n, 0)) for _ in range(B)],
+                        A_=np.empty((B, 0)), A_corrected_=np.empty((B, 0)), explained_var_x_=[],
+                        explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)))
+    if p_total > n:
+        eng.gram()                                          # AS_X (:704)
+        Yd = Y.copy()
+        Ts = np.empty((n, 0)); U = np.empty((n, 0))
+        for k in range(K):
+            Z = Yd
+            for i in range(k):                              # D_1..D_k Y_d (no-op up to round-off)
+                ti = Ts[:, i:i + 1]
+                Z = Z - ti.dot(ti.T.dot(Z))
+            AZ = eng.gram_apply(Z)
+            for i in range(k):
+                ti = Ts[:, i:i + 1]
+                AZ = AZ - ti.dot(ti.T.dot(AZ))
+            ts = _tlsv(AZ.dot(_psd_factor(Yd.T.dot(Yd))))  # (:712-715): S = A_k Y_d Y_d^T
+            u = Yd.dot(Yd.T.dot(ts)); u = u / np.linalg.norm(u)   # (:718-719)
+            Yd = Yd - ts.dot(ts.T.dot(Yd))                  # AS_Y = D AS_Y D (:724)
+            Ts = np.hstack((Ts, ts)); U = np.hstack((U, u))
+        eng.slot("UT", 2 * K)
+        ssq = eng.xt_v(np.hstack((U, Ts)), 1.0, "UT", 0, want_ssq=True)   # X^T [U Ts] in one call (:731, :734)
+        UT = eng.fetch("UT")
+        wnorm2 = ssq[:, :K]                                 # per-block ||(X^T U)_b||^2, all shards
+        Wc = UT[:, :K] / np.sqrt(wnorm2.sum(axis=0))        # (:733)
+        G = np.linalg.pinv(Ts.T.dot(Ts))
+        P = UT[:, K:].dot(G)                                # (:734)
+        V = Y.T.dot(Ts).dot(G)                              # (:735)
+        res.update(Ts_=Ts, U_=U, V_=V, W_concat_=Wc)
+        res.update(empty_blocks)
+        if calc_all:
+            _kernel_extras(eng, res, Y, P, V, Ts, varxb, "UT", wnorm2)
+        _finalise(eng, res, Wc, P, V)                       # (:737-738)
+        return res
+    # ---- n >= p (:580-692): everything is p x p, p <= n <= a few thousand -> host algebra on X^T X, X^T Y
+    eng.slot("C", q)
+    eng.xt_v(Y, 1.0, "C", 0)
+    COV = eng.fetch("C")                                    # X^T Y (:587)
+    VAR = _xtx(eng)                                         # X^T X (:586)
+    p = eng.p
+    Wc = np.empty((p, 0)); P = np.empty((p, 0)); V = np.empty((q, 0)); U = np.empty((n, 0))
+    for k in range(K):
+        w = _tlsv(COV)                                      # S = COV COV^T stays true under :631,:633
+        den = np.linalg.multi_dot([w.T, VAR, w]).item()     # (:595)
+        v = w.T.dot(COV) / den                              # (:596)
+        pl = w.T.dot(VAR) / den                             # (:599)
+        if calc_all:
+            u = Y.dot(v.T) / v.dot(v.T)                     # (:624-625)
+            U = np.hstack((U, u / np.linalg.norm(u)))
+        D = np.eye(p) - w.dot(pl)                           # (:630)
+        VAR = np.linalg.multi_dot([D.T, VAR, D])            # (:632)
+        COV = D.T.dot(COV)                                  # (:633)
+        V = np.hstack((V, v.T)); P = np.hstack((P, pl.T)); Wc = np.hstack((Wc, w))
+    R = Wc.dot(np.linalg.pinv(P.T.dot(Wc)))                 # (:642)
+    beta = R.dot(V.T)                                       # (:643)
+    Ts = eng.x_w_host(R)                                    # (:644)
+    nrm = np.linalg.norm(Ts, axis=0)
+    V = V * nrm; P = P * nrm; Ts = Ts / nrm                 # (:646-650)
+    res.update(Ts_=Ts, U_=U, V_=V, W_concat_=Wc)
+    res.update(empty_blocks)
+    if calc_all:
+        offs = eng.block_offsets
+        eng.put("Wblk", Wc)
+        wnorm2 = np.array([(Wc[offs[b]:offs[b + 1]] ** 2).sum(axis=0) for b in range(B)])
+        _kernel_extras(eng, res, Y, P, V, Ts, varxb, "Wblk", wnorm2)
+    res.R_ = R
+    res.beta_ = beta
+    res.P_ = _split(P, eng.block_offsets)
+    return res
+
+
+def _xtx(eng):
+    """X^T X for the n >= p branch (p small): p right-hand sides through x_w on the identity would
+    read X p times; instead form it as (X^T)(X) from one download-free product: X^T X = X^T [X e_j]..."""
+    # p <= n here, so X itself is small (<= n^2 doubles): bring X^T X via xt_v with V = X columns
+    Xh = eng.X.download(order="F")                          # n x p (standardised)
+    eng.slot("XtX", eng.p)
+    eng.xt_v(Xh, 1.0, "XtX", 0)
+    return eng.fetch("XtX")
+
+
+# ----------------------------------------------------------------------------------- SIMPLS
+def fit_simpls(eng, Y, K, standardize):
+    """mbpls.py:995-1048 (de Jong 1993).  X is never deflated: S = X^T Y once, then per component
+    t = X r and p = X^T t (two reads of X)."""
+    n = eng.n
+    q = Y.shape[1]
+    eng.prepare(standardize)
+    eng.slot("S", q); eng.slot("r", 1); eng.slot("p", 1)
+    eng.xt_v(Y, 1.0, "S", 0)
+    S = eng.fetch("S")                                      # (:998)
+    cols = {k: [] for k in ("R", "T", "P", "Q", "U", "Vs", "W")}
+    for comp in range(K):
+        StS = eng.comm.allreduce_host(S.T.dot(S))
+        qv = np.array([[1.0]]) if q == 1 else np.linalg.svd(StS, full_matrices=True)[0][:, 0:1]  # (:1001)
+        r = S.dot(qv)                                       # (:1004)
+        w = r.copy()
+        eng.put("r", r)
+        t = eng.x_w_slot("r", 0, 1)                         # (:1006)
+        t = t - np.mean(t)
+        nt = np.sqrt(t.T.dot(t))
+        t = t / nt; r = r / nt                              # (:1008-1010)
+        eng.xt_v(t, 1.0, "p", 0)
+        pl = eng.fetch("p")                                 # (:1011)
+        qk = Y.T.dot(t)                                     # (:1012)
+        u = Y.dot(qk)
+        v = pl
+        if comp > 0:
+            Vs = np.hstack(cols["Vs"]); Tm = np.hstack(cols["T"])
+            v = v - Vs.dot(eng.comm.allreduce_host(Vs.T.dot(pl)))   # (:1016)
+            u = u - Tm.dot(Tm.T.dot(u))                     # (:1017)
+        v = v / np.sqrt(eng.comm.allreduce_host(v.T.dot(v)))        # (:1018)
+        S = S - v.dot(eng.comm.allreduce_host(v.T.dot(S)))          # (:1019)
+        for key, val in zip(("R", "T", "P", "Q", "U", "Vs", "W"), (r, t, pl, qk, u / np.linalg.norm(u), v, w)):
+            cols[key].append(val)
+    P = np.hstack(cols["P"])
+    res = FitResult(P_=_split(P, eng.block_offsets), Ts_=np.hstack(cols["T"]), U_=np.hstack(cols["U"]),
+                    R_=np.hstack(cols["R"]), V_=np.hstack(cols["Q"]), W_=np.hstack(cols["W"]))
+    res.beta_ = res.R_.dot(res.V_.T)                        # (:1044)
+    return res

@@ -1,0 +1,339 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
+fixtures captured from the reference.  Tolerance: north_star's 1e-6 relative (float64,
+sign-aligned); the kernel-level checks use tighter bounds to catch indexing errors early."""
+import numpy as np
+import pytest
+
+from oracle import mbpls_oracle as orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6          # BASELINE.json north_star: 1e-6 relative float64, sign-aligned
+TIGHT = 1e-11       # what we actually expect (summation-order differences only)
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_required):
+    import mbpls_amd
+    return mbpls_amd.get_context()
+
+
+# ------------------------------------------------------------------ kernel level
+@pytest.mark.parametrize("n,p,order", [(40, 70, "C"), (41, 33, "C"), (129, 257, "F"), (512, 300, "C"),
+                                       (1000, 64, "C"), (2048, 96, "F"), (4096, 40, "C"), (8192, 24, "C")])
+def test_upload_download_roundtrip(ctx, n, p, order):
+    from mbpls_amd import DeviceMatrix
+    rng = np.random.RandomState(n + p)
+    X = np.asarray(rng.standard_normal((n, p)), order=order)
+    m = DeviceMatrix(ctx, n, p)
+    m.upload(X)
+    assert np.array_equal(m.download(order="C"), X)
+    assert np.array_equal(m.download(order="F"), X)
+    # column sub-range and a strided view (column slice of a wider C array)
+    wide = rng.standard_normal((n, p + 7))
+    m.upload(wide[:, 3:3 + p])
+    assert np.array_equal(m.download(2, p - 2), wide[:, 5:3 + p])
+    m.close()
+
+
+@pytest.mark.parametrize("n,p,blocks", [(40, 70, [25, 45]), (41, 33, [33]), (300, 500, [100, 150, 250]),
+                                        (1000, 257, [257]), (2048, 400, [130, 270]), (4096, 300, [300]),
+                                        (8192, 100, [40, 60])])
+def test_column_pass_kernels(ctx, n, p, blocks):
+    """standardize_sweep / sweep / deflate_sweep against numpy on the same data."""
+    from mbpls_amd import DeviceMatrix, _capi
+    rng = np.random.RandomState(7 * n + p)
+    X = rng.standard_normal((n, p)) * rng.uniform(0.5, 3.0, p) + rng.uniform(-2, 2, p)
+    X[:, 3] = 1.75                                   # constant column -> scale 1
+    offs = np.concatenate(([0], np.cumsum(blocks)))
+    B = len(blocks)
+    v = rng.standard_normal(n)
+    m = DeviceMatrix(ctx, n, p, offs)
+    m.upload(X)
+    d_mean, d_scale = ctx.empty(p), ctx.empty(p)
+    d_ssqx, d_ssqg, d_ssqp = ctx.empty(B), ctx.empty(B), ctx.empty(B)
+    d_g, d_t, d_p = ctx.empty(p), ctx.empty(n * B), ctx.empty(p)
+    d_v, d_ts = ctx.from_host(v), ctx.empty(n)
+    alpha = 1.0 / v.dot(v)
+    m.standardize_sweep(m, _capi.SCALE_FIT, d_mean, d_scale, d_ssqx, d_v, alpha, d_g, d_t, d_ssqg)
+    sc = orc.ColumnScaler().fit(X)
+    Z = sc.transform(X)
+    assert util.relerr(d_mean.get(), sc.mean_) < 1e-14
+    assert util.relerr(d_scale.get(), sc.scale_) < 1e-14
+    assert d_scale.get()[3] == 1.0
+    Zd = m.download()
+    assert util.relerr(Zd, Z) < 1e-13
+    g = alpha * Z.T.dot(v)
+    rng_b = list(zip(offs[:-1], offs[1:]))
+    assert util.relerr(d_g.get(), g) < TIGHT
+    t_ref = np.concatenate([Z[:, s:e].dot(g[s:e]) for s, e in rng_b])
+    assert util.relerr(d_t.get(), t_ref) < TIGHT
+    assert util.relerr(d_ssqg.get(), [g[s:e].dot(g[s:e]) for s, e in rng_b]) < TIGHT
+    assert util.relerr(d_ssqx.get(), [(Z[:, s:e] ** 2).sum() for s, e in rng_b]) < TIGHT
+    # plain sweep reproduces the fused one bit for bit (same kernel math, same chunking)
+    d_g2, d_t2, d_s2 = ctx.empty(p), ctx.empty(n * B), ctx.empty(B)
+    m.sweep(d_v, alpha, d_g2, d_t2, d_s2)
+    assert util.relerr(d_t2.get(), t_ref) < TIGHT
+    m.sweep(d_v, alpha, d_g, d_t, d_ssqg)            # determinism: two identical launches
+    assert np.array_equal(d_t.get(), d_t2.get()) and np.array_equal(d_g.get(), d_g2.get())
+    # deflate + fused next sweep
+    ts = rng.standard_normal(n)
+    ts /= np.linalg.norm(ts)
+    d_ts.set(ts)
+    m.deflate_sweep(d_ts, 1.0, True, d_p, d_ssqp, d_v, alpha, d_g, d_t, d_ssqg)
+    pl = Z.T.dot(ts)
+    Zn = Z - np.outer(ts, pl)
+    assert util.relerr(d_p.get(), pl) < TIGHT
+    assert util.relerr(m.download(), Zn) < 1e-12
+    g = alpha * Zn.T.dot(v)
+    assert np.max(np.abs(d_g.get() - g)) < 1e-11 * max(1.0, np.max(np.abs(alpha * Z.T.dot(v))))
+    t_ref = np.concatenate([Zn[:, s:e].dot(g[s:e]) for s, e in rng_b])
+    assert np.max(np.abs(d_t.get() - t_ref)) < 1e-10 * np.max(np.abs(t_ref))
+    assert util.relerr(d_ssqp.get(), [pl[s:e].dot(pl[s:e]) for s, e in rng_b]) < TIGHT
+    # loadings only (last component): X untouched
+    m.deflate_sweep(d_ts, 2.0, False, d_p, d_ssqp)
+    assert util.relerr(d_p.get(), 2.0 * Zn.T.dot(ts)) < 1e-9
+    assert util.relerr(m.download(), Zn) < 1e-12
+    # standardise with given statistics (predict/transform path) and the no-scaling mode
+    m2 = DeviceMatrix(ctx, n, p, offs)
+    m2.upload(X)
+    m2.standardize_sweep(m2, _capi.SCALE_APPLY, d_mean, d_scale, d_ssqx)
+    assert util.relerr(m2.download(), Z) < 1e-13
+    m2.upload(X)
+    m2.standardize_sweep(m2, _capi.SCALE_NONE, None, None, d_ssqx)
+    assert np.array_equal(m2.download(), X)
+    assert util.relerr(d_ssqx.get(), [(X[:, s:e] ** 2).sum() for s, e in rng_b]) < TIGHT
+    m.close(); m2.close()
+
+
+@pytest.mark.parametrize("n,p,c,blocks", [(40, 70, 1, [25, 45]), (41, 33, 3, [33]), (300, 500, 5, [100, 400]),
+                                          (1030, 257, 9, [257]), (4096, 300, 2, [100, 200]), (8192, 64, 4, [64])])
+def test_multi_rhs_products(ctx, n, p, c, blocks):
+    from mbpls_amd import DeviceMatrix
+    rng = np.random.RandomState(n + p + c)
+    X = rng.standard_normal((n, p))
+    offs = np.concatenate(([0], np.cumsum(blocks)))
+    B = len(blocks)
+    m = DeviceMatrix(ctx, n, p, offs)
+    m.upload(X)
+    V = rng.standard_normal((n, c))
+    W = rng.standard_normal((p, c))
+    dV, dW = ctx.from_host(V), ctx.from_host(W)
+    dG, dssq = ctx.empty((p, c)), ctx.empty((B, c))
+    m.xt_v(dV, c, 0.5, dG, dssq)
+    G = 0.5 * X.T.dot(V)
+    assert util.relerr(dG.get(), G) < TIGHT
+    assert util.relerr(dssq.get(), [(G[s:e] ** 2).sum(axis=0) for s, e in zip(offs[:-1], offs[1:])]) < TIGHT
+    out = ctx.empty((n, c))
+    m.x_w(dW, c, out)
+    assert util.relerr(out.get(), X.dot(W)) < TIGHT
+    outb = ctx.empty(n * c * B)
+    m.x_w(dW, c, outb, per_block=True)
+    h = outb.get()
+    for b, (s, e) in enumerate(zip(offs[:-1], offs[1:])):
+        assert util.relerr(h[b * n * c:(b + 1) * n * c].reshape(c, n).T, X[:, s:e].dot(W[s:e])) < TIGHT
+    mu, sc = rng.standard_normal(p), rng.uniform(0.5, 2.0, p)
+    m.x_w(dW, c, out, mean=ctx.from_host(mu), scale=ctx.from_host(sc))
+    assert util.relerr(out.get(), ((X - mu) / sc).dot(W)) < TIGHT
+    m.close()
+
+
+@pytest.mark.parametrize("n,p", [(40, 200), (129, 1000), (256, 515), (1000, 3001), (2048, 4100)])
+def test_gram(ctx, n, p):
+    from mbpls_amd import DeviceMatrix
+    rng = np.random.RandomState(n)
+    X = rng.standard_normal((n, p))
+    m = DeviceMatrix(ctx, n, p)
+    m.upload(X)
+    ldg = n + (n & 1)
+    G = ctx.empty((ldg, n), zero=True)
+    m.gram(G, ldg)
+    Gh = G.get()[:n, :n]          # column-major (ldg x n): symmetric, so orientation is moot
+    assert np.array_equal(Gh, Gh.T)
+    assert util.relerr(Gh, X.dot(X.T)) < TIGHT
+    m.close()
+
+
+def test_fill_latent_statistics(ctx):
+    from mbpls_amd import DeviceMatrix
+    n, p, r = 512, 4096, 8
+    rng = np.random.RandomState(0)
+    Ts = rng.standard_normal((n, r)) * 0.85 ** np.arange(r)
+    m = DeviceMatrix(ctx, n, p)
+    m.fill_latent(ctx.from_host(Ts), r, 0.5, 1234, 0)
+    X = m.download()
+    m2 = DeviceMatrix(ctx, n, p // 2)
+    m2.fill_latent(ctx.from_host(Ts), r, 0.5, 1234, p // 2)     # same global columns from another "rank"
+    assert np.array_equal(m2.download(), X[:, p // 2:])
+    # residual after projecting on the planted scores is the N(0, 0.25) noise
+    Q, _ = np.linalg.qr(Ts)
+    R = X - Q.dot(Q.T.dot(X))
+    assert abs(R.var() / 0.25 * n / (n - r) - 1.0) < 0.02
+    assert abs(np.mean(X)) < 0.02
+    m.close(); m2.close()
+
+
+# ------------------------------------------------------------------ estimator level
+def _fit_flat(model, Xn=None, Yn=None, block_scores=True):
+    flat = util.model_to_flat(model)
+    if Xn is not None:
+        flat["predict"] = model.predict(Xn)
+        if model.method != "SIMPLS" and block_scores:
+            Ts, T, U = model.transform(Xn, Yn, return_block_scores=True)
+            for b, blk in enumerate(T):
+                flat[f"T_new/{b}"] = blk
+        else:
+            Ts, U = model.transform(Xn, Yn)
+        flat["Ts_new"], flat["U_new"] = Ts, U
+    return flat
+
+
+@pytest.mark.parametrize("fixture,methods", [("ref_golden_pgtn", ["UNIPALS", "NIPALS", "KERNEL", "SIMPLS"]),
+                                             ("ref_golden_ngtp", ["UNIPALS", "KERNEL"])])
+def test_reference_golden_csvs(gpu_required, fixture, methods):
+    """The reference's own test (mbpls/tests/test_mbpls.py:34-421) on the HIP path."""
+    from mbpls_amd import MBPLS
+    g = util.load(fixture)
+    X, Xt = [g["x1_train"], g["x2_train"]], [g["x1_test"], g["x2_test"]]
+    preds = []
+    for m in methods:
+        mdl = MBPLS(n_components=2, method=m, standardize=True, full_svd=True).fit(X, g["y_train"])
+        csv = util.sub(g, f"csv/{m}")
+        got = {"Ts": mdl.Ts_, "U": mdl.U_, "V": mdl.V_, "beta": mdl.beta_, "P1": mdl.P_[0], "P2": mdl.P_[1],
+               "Y_predict_test": mdl.predict(Xt)}
+        if m != "SIMPLS":
+            Ts_t, T_t, U_t = mdl.transform(Xt, g["y_test"], return_block_scores=True)
+            got.update(T=np.hstack(mdl.T_), A=mdl.A_, T_test=np.hstack(T_t))
+        else:
+            Ts_t, U_t = mdl.transform(Xt, g["y_test"])
+        got.update(Ts_test=Ts_t, U_test=U_t)
+        assert set(got) == set(csv)
+        for k, ref in csv.items():
+            assert np.allclose(np.abs(got[k]), np.abs(ref)), (m, k)      # the reference's own criterion
+            assert util.relerr(np.abs(got[k]), np.abs(ref)) < TOL, (m, k)
+        util.compare(_fit_flat(mdl, Xt, g["y_test"]), util.sub(g, f"ref/{m}/full1"), TOL, what=f"{fixture}/{m}")
+        preds.append(got["Y_predict_test"])
+    for p in preds:
+        assert np.allclose(preds[0], p, atol=1e-3)
+
+
+def test_quickstart_config1(gpu_required):
+    """BASELINE.json configs[0]: README quick-start, n=40 p=200 K=2."""
+    from mbpls_amd import MBPLS
+    g = util.load("quickstart_c1")
+    for m in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+        mdl = MBPLS(n_components=2, method=m).fit(g["x"], g["y"])
+        w = util.compare(_fit_flat(mdl, g["x"], g["y"]), util.sub(g, f"ref/{m}"), TOL, what=m)
+        assert w < 1e-9
+        if m == "NIPALS":
+            assert mdl.nipals_iterations_ == [2, 2]
+
+
+@pytest.mark.parametrize("fixture", ["matrix_pgtn", "matrix_ngtp"])
+def test_matrix(gpu_required, fixture):
+    from mbpls_amd import MBPLS
+    g = util.load(fixture)
+    splits = np.cumsum(g["splits"])[:-1]
+    worst = 0.0
+    for q in (1, 3):
+        X, Y = g[f"in/q{q}/X"], g[f"in/q{q}/Y"]
+        Xn, Yn = g[f"in/q{q}/Xnew"], g[f"in/q{q}/Ynew"]
+        for blocks in ("single", "multi"):
+            sp = (lambda A: A) if blocks == "single" else (lambda A: list(np.split(A, splits, axis=1)))
+            for m in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+                for std in (True, False):
+                    for ca in (True, False):
+                        pre = f"ref/q{q}/{blocks}/{m}/std{int(std)}/ca{int(ca)}"
+                        ref = util.sub(g, pre)
+                        mdl = MBPLS(n_components=3, method=m, standardize=std, calc_all=ca).fit(sp(X), Y)
+                        has_T_new = any(k.startswith("T_new") for k in ref) and (m != "KERNEL" or ca)
+                        got = _fit_flat(mdl, sp(Xn), Yn, block_scores=has_T_new)
+                        skip = () if has_T_new else ("T_new",)
+                        worst = max(worst, util.compare(got, ref, TOL, skip=skip, what=pre))
+    assert worst < 1e-8
+
+
+def test_edges(gpu_required):
+    from mbpls_amd import MBPLS
+    g = util.load("edges")
+    mdl = MBPLS(n_components=3).fit(g["const/X"], g["const/Y"])
+    assert mdl.x_scalers_[0].scale_[5] == 1.0 and mdl.beta_[5, 0] == 0.0
+    util.compare(_fit_flat(mdl, g["const/X"], g["const/Y"]), util.sub(g, "ref/const"), TOL, what="const")
+    X, Y = g["plain/X"], g["plain/Y"]
+    m0 = MBPLS(n_components=3).fit(X, Y)
+    m1 = MBPLS(n_components=3).fit(X, Y.ravel())
+    m2 = MBPLS(n_components=3).fit([X], Y)
+    assert np.array_equal(m0.beta_, m1.beta_) and np.array_equal(m0.beta_, m2.beta_)
+    Xc = X.copy()
+    MBPLS(n_components=2, copy=False).fit(X, Y)
+    assert np.array_equal(X, Xc)                      # caller arrays are never modified
+    for nm, o in (("1", 1), ("inf", np.inf), ("-inf", -np.inf), ("fro", "fro"), ("nuc", "nuc"), ("-1", -1), ("-2", -2)):
+        mm = MBPLS(n_components=3, nipals_convergence_norm=o).fit(X, Y)
+        assert util.relerr(mm.beta_, g[f"ref/norm/{nm}/beta_"]) < TOL
+    for bad in (0, 3):
+        with pytest.raises(ValueError):
+            MBPLS(n_components=2, nipals_convergence_norm=bad).fit(X, Y)
+    with pytest.raises(NameError):
+        MBPLS(method="nope").fit(X, Y)
+    with pytest.raises(ValueError):
+        MBPLS().fit(X, Y[:-1])
+    Xnan = X.copy(); Xnan[0, 0] = np.nan
+    with pytest.raises(ValueError):
+        MBPLS().fit(Xnan, Y)
+    from sklearn.exceptions import NotFittedError
+    with pytest.raises(NotFittedError):
+        MBPLS().predict(X)
+    X3, Y3 = g["q3/X"], g["q3/Y"]
+    for nm, o in (("2", 2), ("1", 1), ("inf", np.inf)):
+        mm = MBPLS(n_components=3, nipals_convergence_norm=o).fit([X3[:, :50], X3[:, 50:]], Y3)
+        util.compare(_fit_flat(mm, [X3[:, :50], X3[:, 50:]], Y3), util.sub(g, f"ref/q3/norm{nm}"), TOL, what=nm)
+
+
+def test_sklearn_plumbing(gpu_required):
+    from sklearn.base import clone
+    from mbpls_amd import MBPLS
+    m = MBPLS(n_components=3, method="UNIPALS", calc_all=False)
+    c = clone(m)
+    assert c.get_params() == m.get_params()
+    X, Y = orc.make_latent(60, 300, 1, r=5, seed=3)
+    yh = c.fit_predict(X, Y)
+    assert yh.shape == (60, 1)
+    assert 0.0 < c.r2_score(X, Y) <= 1.0
+    Ts, U = c.fit_transform(X, Y)
+    assert Ts.shape == (60, 3) and U.shape == (60, 3)
+
+
+# ------------------------------------------------------------------ medium size vs the oracle
+@pytest.mark.parametrize("method,n,p,q,K,blocks", [
+    ("NIPALS", 4096, 20000, 1, 5, [20000]),
+    ("NIPALS", 1024, 30000, 3, 3, [10000, 8000, 12000]),
+    ("UNIPALS", 4096, 18000, 1, 4, [5000, 6000, 7000]),
+    ("UNIPALS", 512, 12000, 4, 3, [12000]),
+    ("KERNEL", 2048, 16000, 1, 5, [6000, 10000]),
+    ("KERNEL", 1000, 9000, 3, 4, [9000]),
+    ("SIMPLS", 2048, 15000, 2, 4, [15000]),
+    ("NIPALS", 8192, 9000, 1, 3, [4000, 5000]),
+])
+def test_medium_vs_oracle(gpu_required, method, n, p, q, K, blocks):
+    from mbpls_amd import MBPLS
+    X, Y = orc.make_latent(n, p, q, seed=n + p)
+    Xn, Yn = orc.make_latent(64, p, q, seed=1)
+    cuts = np.cumsum(blocks)[:-1]
+    sp = (lambda A: A) if len(blocks) == 1 else (lambda A: [np.ascontiguousarray(b) for b in np.split(A, cuts, axis=1)])
+    ref = orc.fit(sp(X), Y, n_components=K, method=method, full_svd=True)
+    mdl = MBPLS(n_components=K, method=method, full_svd=True).fit(sp(X), Y)
+    got = _fit_flat(mdl, sp(Xn), Yn)
+    rflat = util.model_to_flat(ref)
+    rflat["predict"] = orc.predict(ref, sp(Xn))
+    if method != "SIMPLS":
+        rTs, rT, rU = orc.transform(ref, sp(Xn), Yn, return_block_scores=True)
+        for b, blk in enumerate(rT):
+            rflat[f"T_new/{b}"] = blk
+    else:
+        rTs, rU = orc.transform(ref, sp(Xn), Yn)
+    rflat["Ts_new"], rflat["U_new"] = rTs, rU
+    w = util.compare(got, rflat, TOL, what=f"{method} n={n} p={p}")
+    assert w < 1e-8, w
+    if method == "NIPALS" and q == 1:
+        assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K

@@ -1,0 +1,65 @@
+"""Host-side solver logic (mbpls_amd/solvers.py) against the reference fixtures, with the
+test-only numpy engine standing in for the HIP kernels (no GPU here).  The GPU parity tests
+(test_gpu_parity.py) run the same drivers on the real HipEngine."""
+import numpy as np
+import pytest
+
+from mbpls_amd import solvers
+from mbpls_amd.scaler import ColumnScaler
+from tests import util
+from tests.numpy_engine import NumpyEngine
+
+TOL = 1e-9
+
+
+def run_driver(X, Y, method, K, standardize=True, calc_all=True, norm=2, comm=None):
+    blocks = X if isinstance(X, list) else [X]
+    Y = np.asarray(Y, dtype=np.float64)
+    if Y.ndim == 1:
+        Y = Y.reshape(-1, 1)
+    if standardize:
+        Y = ColumnScaler().fit(Y).transform(Y)
+    eng = NumpyEngine(comm).load_host_blocks(blocks)
+    if method == "NIPALS":
+        return solvers.fit_nipals(eng, Y, K, standardize, 1e-14, norm, calc_all)
+    if method == "UNIPALS":
+        return solvers.fit_unipals(eng, Y, K, standardize)
+    if method == "KERNEL":
+        return solvers.fit_kernel(eng, Y, K, standardize, calc_all)
+    return solvers.fit_simpls(eng, Y, K, standardize)
+
+
+FIT_ONLY_SKIP = ("predict", "Ts_new", "T_new", "U_new")
+
+
+@pytest.mark.parametrize("fixture", ["matrix_pgtn", "matrix_ngtp"])
+def test_matrix(fixture):
+    g = util.load(fixture)
+    splits = np.cumsum(g["splits"])[:-1]
+    for q in (1, 3):
+        X, Y = g[f"in/q{q}/X"], g[f"in/q{q}/Y"]
+        for blocks in ("single", "multi"):
+            Xin = X if blocks == "single" else list(np.split(X, splits, axis=1))
+            for m in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+                for std in (True, False):
+                    for ca in (True, False):
+                        pre = f"ref/q{q}/{blocks}/{m}/std{int(std)}/ca{int(ca)}"
+                        res = run_driver(Xin, Y, m, 3, std, ca)
+                        util.compare(util.model_to_flat(res), util.sub(g, pre), TOL, skip=FIT_ONLY_SKIP, what=pre)
+
+
+def test_reference_csv_inputs():
+    for fixture, methods in (("ref_golden_pgtn", ["UNIPALS", "NIPALS", "KERNEL", "SIMPLS"]),
+                             ("ref_golden_ngtp", ["UNIPALS", "KERNEL"])):
+        g = util.load(fixture)
+        X = [g["x1_train"], g["x2_train"]]
+        for m in methods:
+            res = run_driver(X, g["y_train"], m, 2)
+            util.compare(util.model_to_flat(res), util.sub(g, f"ref/{m}/full1"), TOL, skip=FIT_ONLY_SKIP, what=m)
+
+
+def test_nipals_iterations_q1():
+    g = util.load("quickstart_c1")
+    res = run_driver(g["x"], g["y"], "NIPALS", 2)
+    assert res.nipals_iterations_ == [2, 2]
+    util.compare(util.model_to_flat(res), util.sub(g, "ref/NIPALS"), TOL, skip=FIT_ONLY_SKIP)
