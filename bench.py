@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--K", type=int, default=10)
     ap.add_argument("--q", type=int, default=1)
     ap.add_argument("--method", default="NIPALS")
-    ap.add_argument("--cpu-cols", type=int, default=2048, help="columns of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-cols", type=int, default=16384, help="columns of the CPU-baseline sample (0 = skip)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,10 +173,19 @@ def cpu_baseline(ctx, X, Y, n, cols, K, method):
     column sample of the SAME device-generated matrix; also checks the GPU fit of that sample against it."""
     from mbpls_amd import MBPLS
     from oracle import mbpls_oracle as orc
+    from mbpls_amd.runtime import cpu_quota
     Xs = X.download(0, cols)
+    thr = cpu_quota()      # CPUs this container may really use (cgroup quota), not the visible count
+    try:
+        import threadpoolctl
+        limiter = threadpoolctl.threadpool_limits(limits=thr)
+    except Exception:
+        limiter = None
     t0 = time.perf_counter()
     ref = orc.fit(Xs, Y, n_components=K, method=method, standardize=True, calc_all=True, faithful=True)
     t_cpu = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits()
     iters = ref.get("nipals_iterations_", [2] * K)
     units = sum(2 * i + 3 for i in iters) + 1 + 3
     gbps = units * 8.0 * n * cols / t_cpu / 1e9
@@ -185,14 +194,9 @@ def cpu_baseline(ctx, X, Y, n, cols, K, method):
     err = max(np.max(np.abs(mdl.Ts_ * s - ref.Ts_)) / np.max(np.abs(ref.Ts_)),
               np.max(np.abs(mdl.beta_ - ref.beta_)) / np.max(np.abs(ref.beta_)),
               np.max(np.abs(mdl.P_[0] * s - ref.P_[0])) / np.max(np.abs(ref.P_[0])))
-    try:
-        import threadpoolctl
-        thr = max([d.get("num_threads", 1) for d in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        thr = os.cpu_count()
     return {"value": round(gbps, 3), "unit": "GB/s", "cores": thr, "kind": "port",
             "sample": f"oracle faithful mode (reference numpy op sequence), first {cols} columns of the same matrix, "
-                      f"n={n} K={K}, {t_cpu:.1f} s wall; host has {os.cpu_count()} logical CPUs",
+                      f"n={n} K={K}, {t_cpu:.1f} s wall; BLAS threads = CPU quota = {thr} ({os.cpu_count()} logical CPUs visible)",
             "fit_wall_s": round(t_cpu, 3), "gpu_vs_oracle_relerr_on_sample": float(err)}
 
 

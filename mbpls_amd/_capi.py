@@ -116,9 +116,47 @@ class Context:
         check(self.lib.mbpls_hip_create(int(device), stream, C.byref(h)))
         self.handle = h
         self.device = int(device)
+        # size-keyed cache of freed device buffers: repeated fits (bench steps, cross-validation)
+        # reuse the 8np-byte working matrix instead of paying hipMalloc/hipFree of tens of GB
+        self._pool = {}
+        self._pool_bytes = 0
+        self._pool_cap = None
+
+    # ---- pooled raw allocations
+    def _raw_alloc(self, nbytes):
+        nbytes = max(int(nbytes), 8)
+        lst = self._pool.get(nbytes)
+        if lst:
+            self._pool_bytes -= nbytes
+            return lst.pop()
+        h = _vp()
+        rc = self.lib.mbpls_hip_malloc(self.handle, nbytes, C.byref(h))
+        if rc == -3 and self._pool_bytes:      # out of memory: drop the cache and retry once
+            self.trim_pool()
+            rc = self.lib.mbpls_hip_malloc(self.handle, nbytes, C.byref(h))
+        check(rc)
+        return h.value
+
+    def _raw_free(self, ptr, nbytes):
+        nbytes = max(int(nbytes), 8)
+        if self._pool_cap is None:
+            self._pool_cap = int(0.5 * self.info()["total_bytes"])
+        if nbytes >= (1 << 20) and self._pool_bytes + nbytes <= self._pool_cap:
+            self._pool.setdefault(nbytes, []).append(ptr)
+            self._pool_bytes += nbytes
+        else:
+            self.lib.mbpls_hip_free(self.handle, ptr)
+
+    def trim_pool(self):
+        for lst in self._pool.values():
+            for ptr in lst:
+                self.lib.mbpls_hip_free(self.handle, ptr)
+        self._pool = {}
+        self._pool_bytes = 0
 
     def close(self):
         if getattr(self, "handle", None):
+            self.trim_pool()
             self.lib.mbpls_hip_destroy(self.handle)
             self.handle = None
 
@@ -192,9 +230,7 @@ class DeviceArray:
         self.nbytes = 8 * self.size
         self._own = ptr is None
         if ptr is None:
-            h = _vp()
-            check(ctx.lib.mbpls_hip_malloc(ctx.handle, max(self.nbytes, 8), C.byref(h)))
-            self.ptr = h.value
+            self.ptr = ctx._raw_alloc(self.nbytes)
         else:
             self.ptr = int(ptr)
         if zero:
@@ -231,7 +267,7 @@ class DeviceArray:
 
     def free(self):
         if self._own and self.ptr:
-            self.ctx.lib.mbpls_hip_free(self.ctx.handle, self.ptr)
+            self.ctx._raw_free(self.ptr, self.nbytes)
             self.ptr = None
 
     def __del__(self):
@@ -253,6 +289,10 @@ class DeviceMatrix:
         self.nblocks = len(offs) - 1
         arr = (_i64 * len(offs))(*offs)
         h = _vp()
+        self._storage = None
+        if storage is None:
+            # storage comes from the context's pool (ld = n rounded up to even, as the library lays it out)
+            self._storage = storage = DeviceArray(ctx, (((self.n + 1) & ~1) * self.p,))
         check(ctx.lib.mbpls_hip_mat_create(ctx.handle, self.n, self.p, self.nblocks, arr, _ptr(storage), C.byref(h)))
         self.handle = h
         n_, p_, ld_, d_, nb_, nc_ = _i64(), _i64(), _i64(), _vp(), _int(), _int()
@@ -266,6 +306,9 @@ class DeviceMatrix:
     def close(self):
         if getattr(self, "handle", None) and self.ctx.handle:
             self.ctx.lib.mbpls_hip_mat_destroy(self.handle)
+            if self._storage is not None:
+                self._storage.free()
+                self._storage = None
         self.handle = None
 
     def __del__(self):

@@ -279,7 +279,8 @@ struct Cfg {
 
 // Choose rows-per-thread R and the workgroup size T = roundup(ceil(n/R), 64) <= TMAX.
 static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T) {
-  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}};
+  // preference order: smallest register footprint that still covers n with <= TMAX threads
+  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}, {4, 1024}, {16, 1024}};
   auto fits = [&](const Cfg& c, int* t) {
     int64_t need = (n + c.R - 1) / c.R;
     need = (need + 63) / 64 * 64;
@@ -295,7 +296,7 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T) {
       }
   }
   for (const Cfg& c : table)
-    if (fits(c, T)) {
+    if (c.TMAX * c.R <= 8192 && fits(c, T)) {
       *cfg = c;
       return true;
     }
@@ -315,13 +316,26 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
     return MBPLS_ERR_UNSUPPORTED;
   }
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
-#define MB_LAUNCH(R_, TM_)                                                                              \
-  hipLaunchKernelGGL((k_colpass<R_, TM_, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a)
-  if (cfg.R == 2) MB_LAUNCH(2, 256);
-  else if (cfg.R == 4) MB_LAUNCH(4, 512);
-  else if (cfg.R == 8 && cfg.TMAX == 512) MB_LAUNCH(8, 512);
-  else if (cfg.R == 8) MB_LAUNCH(8, 1024);
-  else MB_LAUNCH(16, 512);
+  const int D = ctx->prefetch >= 1 && ctx->prefetch <= 3 ? ctx->prefetch : 2;
+#define MB_LAUNCH(R_, TM_, D_)                                                                          \
+  hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a)
+#define MB_LAUNCH_D(R_, TM_)            \
+  do {                                  \
+    if (D == 1) MB_LAUNCH(R_, TM_, 1);  \
+    else if (D == 3) MB_LAUNCH(R_, TM_, 3); \
+    else MB_LAUNCH(R_, TM_, 2);         \
+  } while (0)
+  if (cfg.R == 2) MB_LAUNCH_D(2, 256);
+  else if (cfg.R == 4 && cfg.TMAX == 512) MB_LAUNCH_D(4, 512);
+  else if (cfg.R == 4) MB_LAUNCH_D(4, 1024);
+  else if (cfg.R == 8 && cfg.TMAX == 512) MB_LAUNCH_D(8, 512);
+  else if (cfg.R == 8) MB_LAUNCH_D(8, 1024);
+  else if (cfg.R == 16 && cfg.TMAX == 512) MB_LAUNCH_D(16, 512);
+  else {
+    set_error("no kernel for R=%d TMAX=%d", cfg.R, cfg.TMAX);
+    return MBPLS_ERR_UNSUPPORTED;
+  }
+#undef MB_LAUNCH_D
 #undef MB_LAUNCH
   MB_HIP(hipGetLastError());
   return MBPLS_OK;

@@ -59,6 +59,7 @@ struct mbpls_ctx {
   // tunables
   int chunks_per_cu = 4;
   int rows_per_thread = 0;   // 0 = auto
+  int prefetch = 2;          // columns in flight per workgroup (register slots)
   int xw_chunks_per_cu = 1;
   // workspace for chunk partials (grown on demand, never shrunk)
   void* ws = nullptr;

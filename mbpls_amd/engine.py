@@ -9,6 +9,9 @@ the reference); p-length results stay in named device *slots* (p x K, column-maj
 """
 from __future__ import annotations
 
+import contextlib
+import time
+
 import numpy as np
 
 from . import _capi
@@ -28,6 +31,14 @@ class HipEngine:
         self.scale = None
         self.G = None
         self.timings = {}
+
+    @contextlib.contextmanager
+    def _timed(self, name):
+        t0 = time.perf_counter()
+        try:
+            yield
+        finally:
+            self.timings[name] = self.timings.get(name, 0.0) + time.perf_counter() - t0
 
     # ------------------------------------------------------------------ data
     def load_host_blocks(self, blocks):
@@ -89,7 +100,8 @@ class HipEngine:
         return s
 
     def fetch(self, name):
-        return self.slots[name].get()
+        with self._timed("d2h_slots"):
+            return self.slots[name].get()
 
     def put(self, name, arr):
         arr = np.asarray(arr, dtype=np.float64)
@@ -113,8 +125,11 @@ class HipEngine:
     def _finish_pass(self, want_t, want_g, want_p, want_x):
         """all-reduce the exchange buffer (if sharded) and split it on the host."""
         n, B = self.n, self.nblocks
-        self.comm.allreduce_device(self._xchg)
-        h = self._xchg.get()
+        if self.comm.is_distributed:
+            with self._timed("allreduce"):
+                self.comm.allreduce_device(self._xchg)
+        with self._timed("wait_kernel+d2h_small"):
+            h = self._xchg.get()
         t = h[: n * B].reshape(B, n).T.copy() if want_t else None   # n x B
         o = n * B
         return (t, h[o:o + B].copy() if want_g else None, h[o + B:o + 2 * B].copy() if want_p else None,

@@ -127,11 +127,16 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         else:
             Ys = Y
         eng = self._engine()
+        import time as _time
+        t_fit0 = _time.perf_counter()
+        threads = runtime.host_threads()
+        threads.__enter__()
         try:
-            if device_input:
-                eng.load_device(X, copy=self.copy)
-            else:
-                eng.load_host_blocks(blocks)
+            with eng._timed("load"):
+                if device_input:
+                    eng.load_device(X, copy=self.copy)
+                else:
+                    eng.load_host_blocks(blocks)
             K = self.n_components
             if self.method == 'NIPALS':
                 res = solvers.fit_nipals(eng, Ys, K, self.standardize, self.max_tol,
@@ -142,9 +147,14 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
                 res = solvers.fit_kernel(eng, Ys, K, self.standardize, self.calc_all)
             else:
                 res = solvers.fit_simpls(eng, Ys, K, self.standardize)
-            self._store(eng, res)
+            with eng._timed("store_attributes"):
+                self._store(eng, res)
         finally:
-            eng.close()
+            threads.__exit__(None, None, None)
+            with eng._timed("release"):
+                eng.close()
+            eng.timings["total"] = _time.perf_counter() - t_fit0
+            self.fit_timings_ = dict(eng.timings)   # seconds per host-side phase (not in the reference)
         return self
 
     def _store(self, eng, res):

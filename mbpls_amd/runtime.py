@@ -42,3 +42,49 @@ def column_sharded(comm):
         yield comm
     finally:
         _state["comm"] = old
+
+
+def cpu_quota():
+    """CPUs this process may actually use: min(affinity, cgroup-v2/v1 CFS quota).  Containers often
+    expose every host CPU while capping CPU time; BLAS pools sized from the visible CPU count then
+    get throttled for whole scheduler periods (observed: 64 OpenBLAS threads on a 16-CPU quota stall
+    the thread that drives the GPU by 40-2000 ms)."""
+    import math
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.floor(int(q) / int(per))))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+@contextlib.contextmanager
+def host_threads():
+    """Limit BLAS/OpenMP pools to the CPU quota for the host-side K x K / p x K algebra."""
+    if "tp" not in _state:
+        try:
+            import threadpoolctl
+            _state["tp"] = threadpoolctl.ThreadpoolController()   # library scan is done once
+            _state["tp_limit"] = max(1, min(cpu_quota() - 1, 32))
+        except Exception:  # pragma: no cover
+            _state["tp"] = None
+    if _state["tp"] is None:
+        yield
+        return
+    with _state["tp"].limit(limits=_state["tp_limit"]):
+        yield

@@ -137,6 +137,8 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
         t_raw, ssq = t_next, ssq_next
     Wn = eng.fetch("Wn")
     P = eng.fetch("P")
+    import time as _time
+    _t0 = _time.perf_counter()
     res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, nipals_iterations_=iters)
     res.W_non_normal_ = _split(Wn, eng.block_offsets)
     res.W_ = [w / nu_all[b] for b, w in enumerate(res.W_non_normal_)]
@@ -147,6 +149,8 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
                    A_corrected_=np.empty((B, 0)))
     cn2 = eng.comm.allreduce_host((Wn ** 2).sum(axis=0))
     _finalise(eng, res, Wn / np.sqrt(cn2), P, V)            # (:986-991)
+    if hasattr(eng, "timings"):
+        eng.timings["host_finalise"] = eng.timings.get("host_finalise", 0.0) + _time.perf_counter() - _t0
     return res
 
 

@@ -1,0 +1,51 @@
+"""Worker of test_gpu_rccl.py: the product's sharded path with the REAL engine and RCCL (backend nccl),
+run under torch.distributed.run.  With one visible GPU world_size is 1: the all-reduce is then a
+self-reduction, but every piece of plumbing (torch-owned exchange buffer filled by the HIP kernels on
+the null stream, RCCL collective on it, device->host) is the one the 8-GPU run uses."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import mbpls_amd  # noqa: E402
+from mbpls_amd import MBPLS  # noqa: E402
+from mbpls_amd.comm import shard_columns  # noqa: E402
+from oracle import mbpls_oracle as orc  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def main():
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mbpls_amd.set_device(local_rank)
+    comm = mbpls_amd.TorchDistComm(device=f"cuda:{local_rank}")
+    X, Y = orc.make_latent(512, 6000, 2, r=8, seed=5)
+    sizes = [1500, 2500, 2000]
+    full = list(np.split(X, np.cumsum(sizes)[:-1], axis=1))
+    ranges = shard_columns(sizes, rank, world)
+    local = [np.ascontiguousarray(b[:, lo:hi]) for b, (lo, hi) in zip(full, ranges)]
+    for method in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+        ref = orc.fit(full, Y, n_components=3, method=method, full_svd=True)
+        with mbpls_amd.column_sharded(comm):
+            mdl = MBPLS(n_components=3, method=method).fit(local, Y)
+            yh = mdl.predict(local)
+        s = np.sign(np.sum(ref.Ts_ * mdl.Ts_, axis=0))
+        assert util.relerr(mdl.Ts_ * s, ref.Ts_) < 1e-8, method
+        for b, (lo, hi) in enumerate(ranges):
+            assert util.relerr(mdl.P_[b] * s, ref.P_[b][lo:hi]) < 1e-8, method
+        assert util.relerr(yh, orc.predict(ref, full)) < 1e-8, method
+    print(f"rank {rank}/{world}: RCCL-sharded fit == oracle", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
