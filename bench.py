@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--K", type=int, default=10)
     ap.add_argument("--q", type=int, default=1)
     ap.add_argument("--method", default="NIPALS")
-    ap.add_argument("--cpu-cols", type=int, default=16384, help="columns of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-cols", type=int, default=65536, help="columns of the CPU-baseline sample (0 = skip)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -169,6 +169,17 @@ int mbpls_hip_x_w(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int
  * f64 MFMA SYRK; both triangles are written (bitwise symmetric, like numpy's syrk dispatch).      */
 int mbpls_hip_gram(const mbpls_mat* m, double* d_G, int64_t ldg);
 
+/* ---- end-of-fit algebra on p x K device arrays (K <= 32), column-major ------------------------
+ * h_out (c1 x c2 row-major, HOST) = A^T B for p x c1 / p x c2 device arrays: P_^T W (mbpls.py:988,
+ * :569, :737).  Deterministic two-stage reduction; synchronous (the result is on the host on return). */
+int mbpls_hip_cross_product(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1,
+                            const double* d_B, int64_t ldb, int c2, double* h_out);
+/* d_C (p x c2, ldc) = d_A (p x c1, lda) @ h_M (c1 x c2 row-major HOST matrix):
+ * R_ = W (P^T W)^+ and beta_ = R_ V^T (mbpls.py:988-989), column scalings W_b = W~_b diag(1/||w~_b||)
+ * (:860) with a diagonal M on the row range of block b. */
+int mbpls_hip_right_multiply(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1,
+                             const double* h_M, int c2, double* d_C, int64_t ldc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,8 @@ SIGNATURES = {
     "mbpls_hip_xt_v": (_int, [_vp, _vp, _i64, _int, _dbl, _vp, _i64, _vp]),
     "mbpls_hip_x_w": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _i64]),
     "mbpls_hip_gram": (_int, [_vp, _vp, _i64]),
+    "mbpls_hip_cross_product": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp]),
+    "mbpls_hip_right_multiply": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _int, _vp, _i64]),
 }
 
 _lib = None

@@ -68,6 +68,9 @@ struct mbpls_ctx {
   void* stage = nullptr;
   size_t stage_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // ring of small K x K matrices for right_multiply
+  void* small_m = nullptr;
+  unsigned small_m_slot = 0;
   // per-kernel profile (HIP events around the main kernel of every hot-path call)
   bool prof = false;
   struct Pending { hipEvent_t a, b; int kind; double bytes; };

@@ -230,6 +230,7 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->stage) (void)hipFree(ctx->stage);
+  if (ctx->small_m) (void)hipFree(ctx->small_m);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (auto& pd : ctx->pending) {

@@ -1,0 +1,120 @@
+// Small dense helpers on p-length device data (p x K slots, K <= 32), so that the end-of-fit
+// algebra  R_ = W (P^T W)^+,  beta_ = R_ V^T,  W_b = W~_b / ||w~_b||  (mbpls.py:986-989, :569-570,
+// :733-738) never moves p x K arrays through the host more than the one fetch of each attribute.
+#include <algorithm>
+
+#include "common.h"
+
+namespace mbpls {
+
+constexpr int CMAX = 32;
+
+// partial[wg][i][j] = sum over this workgroup's rows of A[r,i] * B[r,j]; two A-columns per pass.
+__global__ __launch_bounds__(256) void k_cross_partial(int64_t p, const double* __restrict__ A, int64_t lda, int c1,
+                                                       const double* __restrict__ B, int64_t ldb, int c2,
+                                                       double* __restrict__ partial) {
+  __shared__ double red[2 * 64];
+  int buf = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int i0 = 0; i0 < c1; i0 += 2) {
+    double acc0[CMAX], acc1[CMAX];
+#pragma unroll
+    for (int j = 0; j < CMAX; ++j) acc0[j] = acc1[j] = 0.0;
+    const bool two = i0 + 1 < c1;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < p; r += stride) {
+      const double a0 = A[(int64_t)i0 * lda + r];
+      const double a1 = two ? A[(int64_t)(i0 + 1) * lda + r] : 0.0;
+#pragma unroll
+      for (int j = 0; j < CMAX; ++j)
+        if (j < c2) {
+          const double b = B[(int64_t)j * ldb + r];
+          acc0[j] = fma(a0, b, acc0[j]);
+          acc1[j] = fma(a1, b, acc1[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CMAX; ++j)
+      if (j < c2) {
+        double v[2] = {acc0[j], acc1[j]};
+        block_sum<2>(v, red, buf);
+        if (threadIdx.x == 0) {
+          double* out = partial + (int64_t)blockIdx.x * c1 * c2;
+          out[i0 * c2 + j] = v[0];
+          if (two) out[(i0 + 1) * c2 + j] = v[1];
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_cross_final(const double* __restrict__ partial, int nwg, int cc,
+                                                    double* __restrict__ out) {
+  const int e = blockIdx.x;  // one wave per output element
+  double s = 0.0;
+  for (int w = threadIdx.x; w < nwg; w += 64) s += partial[(int64_t)w * cc + e];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[e] = s;
+}
+
+// C[r, j] = sum_i A[r, i] * M[i, j]   (M: c1 x c2 row-major in device memory)
+__global__ __launch_bounds__(256) void k_right_multiply(int64_t p, const double* __restrict__ A, int64_t lda, int c1,
+                                                        const double* __restrict__ M, int c2,
+                                                        double* __restrict__ Cm, int64_t ldc) {
+  __shared__ double sM[CMAX * CMAX];
+  for (int e = threadIdx.x; e < c1 * c2; e += blockDim.x) sM[e] = M[e];
+  __syncthreads();
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < p; r += (int64_t)gridDim.x * blockDim.x) {
+    double a[CMAX];
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) a[i] = (i < c1) ? A[(int64_t)i * lda + r] : 0.0;
+    for (int j = 0; j < c2; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < CMAX; ++i)
+        if (i < c1) s = fma(a[i], sM[i * c2 + j], s);
+      Cm[(int64_t)j * ldc + r] = s;
+    }
+  }
+}
+
+}  // namespace mbpls
+
+using namespace mbpls;
+
+extern "C" {
+
+int mbpls_hip_cross_product(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1, const double* d_B,
+                            int64_t ldb, int c2, double* h_out) {
+  MB_ARG(ctx && d_A && d_B && h_out, "NULL argument");
+  MB_ARG(p >= 1 && c1 >= 1 && c2 >= 1 && c1 <= CMAX && c2 <= CMAX, "need 1 <= c1, c2 <= %d", CMAX);
+  MB_ARG(lda >= p && ldb >= p, "leading dimension < p");
+  const int nwg = (int)std::min<int64_t>((p + 255) / 256, (int64_t)ctx->cus * 4);
+  const int cc = c1 * c2;
+  MB_TRY(ensure_ws(ctx, sizeof(double) * ((size_t)nwg * cc + cc)));
+  double* partial = (double*)ctx->ws;
+  double* d_out = partial + (size_t)nwg * cc;
+  hipLaunchKernelGGL(k_cross_partial, dim3(nwg), dim3(256), 0, ctx->stream, p, d_A, lda, c1, d_B, ldb, c2, partial);
+  MB_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_cross_final, dim3(cc), dim3(64), 0, ctx->stream, (const double*)partial, nwg, cc, d_out);
+  MB_HIP(hipGetLastError());
+  MB_HIP(hipMemcpyAsync(h_out, d_out, sizeof(double) * cc, hipMemcpyDeviceToHost, ctx->stream));
+  MB_HIP(hipStreamSynchronize(ctx->stream));
+  return MBPLS_OK;
+}
+
+int mbpls_hip_right_multiply(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1, const double* h_M,
+                             int c2, double* d_C, int64_t ldc) {
+  MB_ARG(ctx && d_A && h_M && d_C, "NULL argument");
+  MB_ARG(p >= 1 && c1 >= 1 && c2 >= 1 && c1 <= CMAX && c2 <= CMAX, "need 1 <= c1, c2 <= %d", CMAX);
+  MB_ARG(lda >= p && ldc >= p, "leading dimension < p");
+  // M travels through a small dedicated device buffer (not the workspace: calls may be queued back to back)
+  if (!ctx->small_m) MB_HIP(hipMalloc(&ctx->small_m, sizeof(double) * CMAX * CMAX * 16));
+  double* dM = (double*)ctx->small_m + (size_t)(ctx->small_m_slot++ % 16) * CMAX * CMAX;
+  MB_HIP(hipMemcpyAsync(dM, h_M, sizeof(double) * c1 * c2, hipMemcpyHostToDevice, ctx->stream));
+  const int nwg = (int)std::min<int64_t>((p + 255) / 256, (int64_t)ctx->cus * 8);
+  hipLaunchKernelGGL(k_right_multiply, dim3(nwg), dim3(256), 0, ctx->stream, p, d_A, lda, c1, (const double*)dM, c2,
+                     d_C, ldc);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+}  // extern "C"

@@ -109,6 +109,30 @@ class HipEngine:
             arr = arr.reshape(-1, 1)
         return self.slot(name, arr.shape[1]).set(arr)
 
+    def cross(self, a, b):
+        """(slot a[:, ka:ka+ca])^T (slot b[:, kb:kb+cb]) -> host ca x cb, summed over shards.
+        a, b are (name, k0, ncols) triples."""
+        (na, ka, ca), (nb, kb, cb) = a, b
+        A, Bm = self.slots[na], self.slots[nb]
+        out = np.empty((ca, cb), dtype=np.float64)
+        _capi.check(self.ctx.lib.mbpls_hip_cross_product(self.ctx.handle, self.p, A.ptr + 8 * self.p * ka, self.p, ca,
+                                                         Bm.ptr + 8 * self.p * kb, self.p, cb, out.ctypes.data))
+        return self.comm.allreduce_host(out)
+
+    def right_mul(self, a, M, c, rows=None):
+        """slot c[rows, kc:kc+c2] = slot a[rows, ka:ka+c1] @ M  (M: c1 x c2 host).  rows = (r0, r1) or all."""
+        (na, ka, c1), (nc, kc) = a, c
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        assert M.shape[0] == c1
+        r0, r1 = rows if rows is not None else (0, self.p)
+        if r1 <= r0:
+            return
+        A, Cm = self.slots[na], self.slots[nc]
+        _capi.check(self.ctx.lib.mbpls_hip_right_multiply(self.ctx.handle, r1 - r0, A.ptr + 8 * (self.p * ka + r0),
+                                                          self.p, c1, M.ctypes.data, M.shape[1],
+                                                          Cm.ptr + 8 * (self.p * kc + r0), self.p))
+        self._keep_m = getattr(self, "_keep_m", [])[-32:] + [M]
+
     def put_col(self, name, k, vec):
         self.slots[name].col(k).set(np.ascontiguousarray(vec, dtype=np.float64).ravel())
 

@@ -74,6 +74,32 @@ def _finalise(eng, res, Wcols, P, V):
     res.P_ = _split(P, eng.block_offsets)
 
 
+def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P"):
+    """End-of-fit algebra on the device (mbpls.py:986-991, :569-572, :733-738).
+
+    wslot holds raw weight columns; the unit-length weights are W = wslot diag(1/col_norm) and the
+    block weights W_b = wslot_b diag(1/blk_norm[b]).  With C = P^T wslot (K x K, device reduction,
+    all-reduced over shards) and D = diag(1/col_norm):
+        R_ = W (P^T W)^+ = wslot [D (C D)^+],   beta_ = R_ V^T = wslot [D (C D)^+ V^T]
+    so only K x K matrices touch the host; p x K arrays are fetched once each, as attributes."""
+    D = 1.0 / np.asarray(col_norm, dtype=np.float64)
+    C = eng.cross((pslot, 0, K), (wslot, 0, K))
+    M = D[:, None] * np.linalg.pinv(C * D[None, :])
+    q = V.shape[0]
+    eng.slot("R", K)
+    eng.right_mul((wslot, 0, K), M, ("R", 0))
+    eng.slot("beta", q)
+    eng.right_mul((wslot, 0, K), M.dot(V.T), ("beta", 0))
+    eng.slot("Wblk", K)
+    offs = eng.block_offsets
+    for b in range(eng.nblocks):
+        eng.right_mul((wslot, 0, K), np.diag(1.0 / blk_norm[b]), ("Wblk", 0), rows=(offs[b], offs[b + 1]))
+    res.R_ = eng.fetch("R")
+    res.beta_ = eng.fetch("beta")
+    res.W_ = _split(eng.fetch("Wblk"), offs)
+    res.P_ = _split(eng.fetch(pslot), offs)
+
+
 # ----------------------------------------------------------------------------------- NIPALS
 def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max_iter=None):
     """mbpls.py:809-993.  Per component: iterate {sweep(u) -> T -> sw, ts -> v -> u} until
@@ -135,22 +161,15 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
             evxb[:, k] = tt * ssq_p / varxb
             Acorr[:, k] = _bip_corrected(sw ** 2, sizes)
         t_raw, ssq = t_next, ssq_next
-    Wn = eng.fetch("Wn")
-    P = eng.fetch("P")
-    import time as _time
-    _t0 = _time.perf_counter()
     res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, nipals_iterations_=iters)
-    res.W_non_normal_ = _split(Wn, eng.block_offsets)
-    res.W_ = [w / nu_all[b] for b, w in enumerate(res.W_non_normal_)]
     if calc_all:
         res.update(explained_var_x_=evx, explained_var_y_=evy, explained_var_xblocks_=evxb, A_corrected_=Acorr)
     else:
         res.update(explained_var_x_=[], explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)),
                    A_corrected_=np.empty((B, 0)))
-    cn2 = eng.comm.allreduce_host((Wn ** 2).sum(axis=0))
-    _finalise(eng, res, Wn / np.sqrt(cn2), P, V)            # (:986-991)
-    if hasattr(eng, "timings"):
-        eng.timings["host_finalise"] = eng.timings.get("host_finalise", 0.0) + _time.perf_counter() - _t0
+    # ||W~[:, k]||^2 = sum_b ||w~_b||^2 of the last iteration (already summed over shards)  (:986-987)
+    _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V)
+    res.W_non_normal_ = _split(eng.fetch("Wn"), eng.block_offsets)
     return res
 
 
@@ -218,13 +237,9 @@ def fit_unipals(eng, Y, K, standardize):
         evxb[:, k] = tt * ssq_p / varxb
         evy.append(tt * v.T.dot(v).item() / vary)           # (:538-540)
         Acorr[:, k] = _bip_corrected(a, sizes)              # (:542-553)
-    Wc = eng.fetch("Wc")
-    P = eng.fetch("P")
-    Wunit = Wc / tot_nrm if wide else Wc
     res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, explained_var_x_=evx, explained_var_y_=evy,
                     explained_var_xblocks_=evxb, A_corrected_=Acorr)
-    res.W_ = [w / blk_nrm[b] for b, w in enumerate(_split(Wc, eng.block_offsets))]
-    _finalise(eng, res, Wunit, P, V)
+    _finalise_device(eng, res, "Wc", K, tot_nrm if wide else np.ones(K), blk_nrm, V)   # (:569-572 / :476-479)
     return res
 
 

@@ -45,6 +45,16 @@ class NumpyEngine:
             arr = arr.reshape(-1, 1)
         self.slots[name] = arr.copy()
 
+    def cross(self, a, b):
+        (na, ka, ca), (nb, kb, cb) = a, b
+        return self.comm.allreduce_host(self.slots[na][:, ka:ka + ca].T.dot(self.slots[nb][:, kb:kb + cb]))
+
+    def right_mul(self, a, M, c, rows=None):
+        (na, ka, c1), (nc, kc) = a, c
+        M = np.asarray(M, dtype=np.float64)
+        r0, r1 = rows if rows is not None else (0, self.p)
+        self.slots[nc][r0:r1, kc:kc + M.shape[1]] = self.slots[na][r0:r1, ka:ka + c1].dot(M)
+
     def put_col(self, name, k, vec):
         self.slots[name][:, k] = np.asarray(vec).ravel()
 

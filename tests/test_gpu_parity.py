@@ -339,3 +339,29 @@ def test_medium_vs_oracle(gpu_required, method, n, p, q, K, blocks):
     assert w < 1e-8, w
     if method == "NIPALS" and q == 1:
         assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K
+
+
+@pytest.mark.parametrize("p,c1,c2", [(70, 2, 2), (1001, 3, 1), (50000, 10, 10), (300001, 20, 7), (4097, 32, 32)])
+def test_small_dense_helpers(ctx, p, c1, c2):
+    """cross_product / right_multiply through the engine's slot interface."""
+    from mbpls_amd.engine import HipEngine
+    from mbpls_amd import DeviceMatrix
+    rng = np.random.RandomState(p)
+    eng = HipEngine(ctx)
+    eng.load_device(DeviceMatrix(ctx, 8, p), copy=False)
+    A, Bm = rng.standard_normal((p, c1)), rng.standard_normal((p, c2))
+    eng.put("A", A); eng.put("B", Bm)
+    assert util.relerr(eng.cross(("A", 0, c1), ("B", 0, c2)), A.T.dot(Bm)) < TIGHT
+    if c1 > 1:
+        assert util.relerr(eng.cross(("A", 1, c1 - 1), ("B", 0, 1)), A[:, 1:].T.dot(Bm[:, :1])) < TIGHT
+    M = rng.standard_normal((c1, c2))
+    eng.slot("C", c2)
+    eng.right_mul(("A", 0, c1), M, ("C", 0))
+    assert util.relerr(eng.fetch("C"), A.dot(M)) < TIGHT
+    r0, r1 = p // 3, p // 3 + max(1, p // 2)
+    eng.slot("D", c1)
+    eng.right_mul(("A", 0, c1), np.diag(np.arange(1, c1 + 1.0)), ("D", 0), rows=(r0, r1))
+    Dh = eng.fetch("D")
+    assert util.relerr(Dh[r0:r1], A[r0:r1] * np.arange(1, c1 + 1.0)) < TIGHT
+    assert not Dh[:r0].any() and not Dh[r1:].any()
+    eng.close()
