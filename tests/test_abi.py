@@ -1,0 +1,46 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol that
+include/mbpls_hip.h declares; the ctypes binding covers all of them.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mbpls_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mbpls_hip_\w+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from mbpls_amd import _capi
+    names = declared_symbols()
+    assert len(names) >= 30
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for nm in names:
+        assert hasattr(lib, nm), f"{nm} declared in the header but not exported by the library"
+    assert sorted(_capi.SIGNATURES) == names, set(names) ^ set(_capi.SIGNATURES)
+    assert _capi.load().mbpls_hip_abi_version() == _capi.ABI_VERSION
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a device the product must raise, never fall back to a CPU path."""
+    from mbpls_amd import _capi
+    if _capi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    import numpy as np
+    from mbpls_amd import MBPLS
+    with pytest.raises(_capi.HipError):
+        MBPLS().fit(np.random.rand(10, 20), np.random.rand(10))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "mbpls_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", ""), f
