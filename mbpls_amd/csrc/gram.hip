@@ -54,34 +54,78 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
 
   const int64_t jbeg = (int64_t)slice * a.slice_len;
   const int64_t jend = std::min<int64_t>(a.p, jbeg + a.slice_len);
-  // per-lane row offsets (clamped; out-of-range samples are masked to zero)
-  int64_t ra[4], rb[4];
-  bool va[4], vb[4];
+  // per-lane BYTE offsets inside a group of 4 features: (lane>>4) selects the feature, (lane&15) the
+  // sample; out-of-range samples are clamped (their rows/columns are never stored).  32-bit offsets +
+  // a wave-uniform group base -> global_load with an SGPR base, no 64-bit address VALU work.
+  unsigned oa[4], ob[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    ra[t] = a0 + t * 16 + li;
-    rb[t] = b0 + t * 16 + li;
-    va[t] = ra[t] < a.n;
-    vb[t] = rb[t] < a.n;
-    if (!va[t]) ra[t] = 0;
-    if (!vb[t]) rb[t] = 0;
+    int64_t ra = a0 + t * 16 + li, rb = b0 + t * 16 + li;
+    if (ra >= a.n) ra = 0;
+    if (rb >= a.n) rb = 0;
+    oa[t] = (unsigned)((lk * a.ld + ra) * 8);
+    ob[t] = (unsigned)((lk * a.ld + rb) * 8);
   }
-  for (int64_t j = jbeg; j < jend; j += 4) {
-    const int64_t jf = j + lk;
-    const bool vj = jf < jend;
-    const double* row = a.X + (vj ? jf : j) * a.ld;
-    double av[4], bv[4];
+  // Software pipeline over k-steps (4 features each): a ring of PD register slots; at step s the group
+  // PD-1 steps ahead is loaded into the slot consumed one step earlier, then the 16 MFMAs of the current
+  // group issue.  A load therefore has (PD-1) x 16 MFMAs (~3000 cycles) to land: HBM/L2 latency is
+  // covered without relying on the second wave of the SIMD.  No select and no branch sits between a load
+  // and its MFMA (prefetch index clamped, not guarded), sched_barrier pins the staggered order.
+  constexpr int PD = 4;
+  const int64_t nsteps = (jend - jbeg) / 4;           // complete groups of 4 features
+  const int64_t nmain = (nsteps / PD) * PD;
+  const char* xb = (const char*)(a.X + jbeg * a.ld);
+  const int64_t gstride = 4 * a.ld * 8;               // bytes between consecutive groups
+  double av[PD][4], bv[PD][4];
+  if (nmain > 0) {
+#pragma unroll
+    for (int s = 0; s < PD - 1; ++s) {
+      const char* g = xb + s * gstride;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        av[s][t] = *(const double*)(g + oa[t]);
+        bv[s][t] = *(const double*)(g + ob[t]);
+      }
+    }
+    static_assert(PD == 4, "the step macro below is written for a ring of 4 slots");
+#define MB_GRAM_STEP(S, SL)                                                                                 \
+  {                                                                                                         \
+    int64_t nx = it + (S) + PD - 1;               /* group to prefetch */                                   \
+    nx = nx < nmain ? nx : nmain - 1;             /* clamp: a valid group that is never consumed */         \
+    const char* g = xb + nx * gstride;                                                                      \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                         \
+      av[SL][t] = *(const double*)(g + oa[t]);                                                              \
+      bv[SL][t] = *(const double*)(g + ob[t]);                                                              \
+    }                                                                                                       \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)       \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[S][mi], bv[S][ni], acc[mi][ni], 0, 0, 0);     \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+  }
+    for (int64_t it = 0; it < nmain; it += PD) {
+      MB_GRAM_STEP(0, 3)
+      MB_GRAM_STEP(1, 0)
+      MB_GRAM_STEP(2, 1)
+      MB_GRAM_STEP(3, 2)
+    }
+#undef MB_GRAM_STEP
+  }
+  // remaining complete groups (< PD of them) and the ragged feature tail (p % 4), unpipelined
+  for (int64_t st = nmain; st * 4 < jend - jbeg; ++st) {
+    const int64_t j = jbeg + 4 * st;
+    const bool vj = j + lk < jend;
+    const char* g = (const char*)(a.X + (vj ? j : jbeg) * a.ld);
+    double ta[4], tb[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const double xa = row[ra[t]], xb = row[rb[t]];
-      av[t] = (vj && va[t]) ? xa : 0.0;
-      bv[t] = (vj && vb[t]) ? xb : 0.0;
+      const double xa = vj ? *(const double*)(g + oa[t]) : 0.0, xq = vj ? *(const double*)(g + ob[t]) : 0.0;
+      ta[t] = xa;
+      tb[t] = xq;
     }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[mi], tb[ni], acc[mi][ni], 0, 0, 0);
   }
   // D layout (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
   double* out = a.out + (int64_t)slice * a.n * a.ldg;
