@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--K", type=int, default=10)
     ap.add_argument("--q", type=int, default=1)
     ap.add_argument("--method", default="NIPALS")
+    ap.add_argument("--dist", action="store_true",
+                    help="use the torch.distributed/RCCL exchange path and the N>1 block layout even at world size 1")
     ap.add_argument("--cpu-cols", type=int, default=65536, help="columns of the CPU-baseline sample (0 = skip)")
     a = ap.parse_args()
 
@@ -66,7 +68,11 @@ def main():
     from mbpls_amd import MBPLS, DeviceMatrix
 
     dist = None
-    if world > 1:
+    if world > 1 or a.dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -88,12 +94,12 @@ def main():
     r = 32
     Ts, Y = planted(n, q, r, seed=0)
     # global matrix: world*p columns; N>1 = 4 equal blocks, every block split evenly over ranks
-    B = 1 if world == 1 else 4
+    B = 1 if dist is None else 4
     pb = p // B
     offs = [b * pb for b in range(B)] + [p]
     X = DeviceMatrix(ctx, n, p, offs)
     dT = ctx.from_host(Ts)
-    if world == 1:
+    if dist is None:
         X.fill_latent(dT, r, 0.5, 1234, 0)
     else:
         # rank r owns columns [r*pb_loc, (r+1)*pb_loc) of each global block (global block size world*pb)
@@ -136,8 +142,9 @@ def main():
         roof = None
         if dom[0]:
             k = dom[1]
+            traffic = pmc_traffic(dom[0], n, p)
             roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(k["GBps"], 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(k["GBps"] / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(k["GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "bytes_per_launch": k["bytes_per_launch"], "avg_ms": round(k["avg_ms"], 4),
                     "launches": k["launches"]}
         out = {
@@ -146,7 +153,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (planted latent structure, generated on device)",
             "config": {"workload": (f"single-block PLS NIPALS n={n} p={p} K={K} q={q} f64 (BASELINE config[1])"
-                                    if world == 1 else
+                                    if dist is None else
                                     f"multiblock NIPALS n={n} total p={p * world} ({B} blocks) K={K} q={q} f64, "
                                     f"feature columns sharded over {world} GPUs (BASELINE config[4])"),
                        "method": a.method, "standardize": True, "calc_all": True, "nipals_iterations": iters},
@@ -157,7 +164,7 @@ def main():
             "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4), "GBps": round(v["GBps"], 1)}
                         for k, v in prof.items()},
         }
-        if world == 1 and a.cpu_cols > 0:
+        if dist is None and a.cpu_cols > 0:
             out["cpu_baseline"] = cpu_baseline(ctx, X, Y, n, min(a.cpu_cols, p), K, a.method)
         else:
             out["cpu_baseline"] = None
@@ -166,6 +173,19 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, n, p):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
+    separate runs, gfx950 x2 read correction) -- only when they were taken on this exact shape, else None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_c2.json")) as f:
+            d = json.load(f)
+        if d["config"]["n"] == n and d["config"]["p"] == p:
+            return d["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(ctx, X, Y, n, cols, K, method):
