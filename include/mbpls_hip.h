@@ -75,6 +75,10 @@ int mbpls_hip_malloc(mbpls_ctx* ctx, size_t bytes, void** d_ptr);
 int mbpls_hip_free(mbpls_ctx* ctx, void* d_ptr);
 int mbpls_hip_memcpy_h2d(mbpls_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int mbpls_hip_memcpy_d2h(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);  /* synchronous */
+/* D2H on a separate non-blocking stream: does NOT wait for kernels queued on the context's stream, so
+ * results that are already final (e.g. loadings column k-1) reach the host while the next pass runs.
+ * The caller guarantees that d_src is complete; synchronous w.r.t. the host on return. */
+int mbpls_hip_memcpy_d2h_overlap(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int mbpls_hip_memcpy_d2d(mbpls_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 int mbpls_hip_memset(mbpls_ctx* ctx, void* d_ptr, int value, size_t bytes);
 

@@ -35,6 +35,7 @@ SIGNATURES = {
     "mbpls_hip_free": (_int, [_vp, _vp]),
     "mbpls_hip_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
     "mbpls_hip_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz]),
+    "mbpls_hip_memcpy_d2h_overlap": (_int, [_vp, _vp, _vp, _sz]),
     "mbpls_hip_memcpy_d2d": (_int, [_vp, _vp, _vp, _sz]),
     "mbpls_hip_memset": (_int, [_vp, _vp, _int, _sz]),
     "mbpls_hip_timer_start": (_int, [_vp]),

@@ -42,16 +42,25 @@ struct PassArgs {
   // partial outputs
   double* part_t;  // [nchunks][n]
   double* part_s;  // [nchunks][4]: ssq_g, ssq_p, ssq_x, -
+  int nt;          // bit 0: non-temporal loads of X, bit 1: non-temporal stores of X
 };
 
 template <int R>
 __device__ __forceinline__ void load_col(double (&x)[R], const double* __restrict__ col, int64_t n, int64_t ld,
-                                         int tid, int T) {
+                                         int tid, int T, bool nt = false) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int k = 0; k < R / 2; ++k) {
     const int64_t r0 = 2 * ((int64_t)k * T + tid);
     double2 t = make_double2(0.0, 0.0);
-    if (r0 < ld) t = *reinterpret_cast<const double2*>(col + r0);
+    if (r0 < ld) {
+      if (nt) {   // workgroup-uniform: streamed once, do not keep in L2/MALL
+        const v2d q = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(col + r0));
+        t = make_double2(q.x, q.y);
+      } else {
+        t = *reinterpret_cast<const double2*>(col + r0);
+      }
+    }
     x[2 * k] = (r0 < n) ? t.x : 0.0;
     x[2 * k + 1] = (r0 + 1 < n) ? t.y : 0.0;
   }
@@ -70,11 +79,21 @@ __device__ __forceinline__ void load_vec(double (&x)[R], const double* __restric
 
 template <int R>
 __device__ __forceinline__ void store_col(const double (&x)[R], double* __restrict__ col, int64_t ld, int tid,
-                                          int T) {
+                                          int T, bool nt = false) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int k = 0; k < R / 2; ++k) {
     const int64_t r0 = 2 * ((int64_t)k * T + tid);
-    if (r0 < ld) *reinterpret_cast<double2*>(col + r0) = make_double2(x[2 * k], x[2 * k + 1]);
+    if (r0 < ld) {
+      if (nt) {
+        v2d q;
+        q.x = x[2 * k];
+        q.y = x[2 * k + 1];
+        __builtin_nontemporal_store(q, reinterpret_cast<v2d*>(col + r0));
+      } else {
+        *reinterpret_cast<double2*>(col + r0) = make_double2(x[2 * k], x[2 * k + 1]);
+      }
+    }
   }
 }
 
@@ -86,6 +105,7 @@ __global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
   const int64_t n = a.n, ld = a.ld;
   const int chunk = blockIdx.x;
   const int64_t j0 = a.c0[chunk], j1 = a.c1[chunk];
+  const bool ntl = (a.nt & 1) != 0, nts = (a.nt & 2) != 0;
 
   double v[SWEEP ? R : 1], ts[DEFL ? R : 1], acc[SWEEP ? R : 1];
   double tsv = 0.0;
@@ -108,7 +128,7 @@ __global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
   double x[D][R];
 #pragma unroll
   for (int d = 0; d < D; ++d)
-    if (j0 + d < j1) load_col<R>(x[d], a.src + (j0 + d) * ld, n, ld, tid, T);
+    if (j0 + d < j1) load_col<R>(x[d], a.src + (j0 + d) * ld, n, ld, tid, T, ntl);
 
   for (int64_t j = j0; j < j1; j += D) {
 #pragma unroll
@@ -160,7 +180,7 @@ __global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) ssq_x = fma(xc[k], xc[k], ssq_x);
-        store_col<R>(xc, a.dst + jj * ld, ld, tid, T);
+        store_col<R>(xc, a.dst + jj * ld, ld, tid, T, nts);
       }
 
       double gj = 0.0;
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
         if (a.deflate) {
 #pragma unroll
           for (int k = 0; k < R; ++k) xc[k] = fma(-pj, ts[k], xc[k]);
-          store_col<R>(xc, a.dst + jj * ld, ld, tid, T);
+          store_col<R>(xc, a.dst + jj * ld, ld, tid, T, nts);
           if constexpr (SWEEP) gj = a.alpha * fma(-pj, tsv, ab[1]);  // <x - p ts, v> = <x,v> - p <ts,v>
         } else {
           if constexpr (SWEEP) gj = a.alpha * ab[1];
@@ -202,7 +222,7 @@ __global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
         for (int k = 0; k < R; ++k) acc[k] = fma(gj, xc[k], acc[k]);
       }
       // refill this register slot with the column D ahead (in flight while the next ones are processed)
-      if (jj + D < j1) load_col<R>(xc, a.src + (jj + D) * ld, n, ld, tid, T);
+      if (jj + D < j1) load_col<R>(xc, a.src + (jj + D) * ld, n, ld, tid, T, ntl);
     }
   }
 
@@ -278,7 +298,7 @@ struct Cfg {
 };
 
 // Choose rows-per-thread R and the workgroup size T = roundup(ceil(n/R), 64) <= TMAX.
-static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T) {
+static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std_pass = false) {
   // preference order: smallest register footprint that still covers n with <= TMAX threads
   static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}, {4, 1024}, {16, 1024}};
   auto fits = [&](const Cfg& c, int* t) {
@@ -288,6 +308,15 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T) {
     *t = (int)need;
     return true;
   };
+  // the standardise pass has three reductions + divisions per column: fewer, fatter threads win
+  // (measured at n=4096: R=16/T=256 5.46 TB/s vs R=8/T=512 4.77 TB/s)
+  if (std_pass && ctx->rows_per_thread <= 0 && n > 2048) {
+    const Cfg c16 = {16, 512};
+    if (fits(c16, T)) {
+      *cfg = c16;
+      return true;
+    }
+  }
   if (ctx->rows_per_thread > 0) {
     for (const Cfg& c : table)
       if (c.R == ctx->rows_per_thread && fits(c, T)) {
@@ -311,14 +340,16 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   ProfScope prof(ctx, kind, 8.0 * (double)a.n * (double)p * (writes ? 2.0 : 1.0));
   Cfg cfg;
   int T = 0;
-  if (!pick_cfg(ctx, a.n, &cfg, &T)) {
+  if (!pick_cfg(ctx, a.n, &cfg, &T, STD)) {
     set_error("fused column pass supports n <= 8192 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;
   }
+  PassArgs an = a;
+  an.nt = ctx->nontemporal;
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
   const int D = ctx->prefetch >= 1 && ctx->prefetch <= 3 ? ctx->prefetch : 2;
 #define MB_LAUNCH(R_, TM_, D_)                                                                          \
-  hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a)
+  hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, an)
 #define MB_LAUNCH_D(R_, TM_)            \
   do {                                  \
     if (D == 1) MB_LAUNCH(R_, TM_, 1);  \

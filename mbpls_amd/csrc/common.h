@@ -61,6 +61,7 @@ struct mbpls_ctx {
   int rows_per_thread = 0;   // 0 = auto
   int prefetch = 2;          // columns in flight per workgroup (register slots)
   int xw_chunks_per_cu = 1;
+  int nontemporal = 3;       // bit 0: nt loads, bit 1: nt stores in the column passes (X is streamed once per pass)
   // workspace for chunk partials (grown on demand, never shrunk)
   void* ws = nullptr;
   size_t ws_bytes = 0;
@@ -68,6 +69,7 @@ struct mbpls_ctx {
   void* stage = nullptr;
   size_t stage_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t copy_stream = nullptr;   // non-blocking: D2H of finished results while kernels run
   // ring of small K x K matrices for right_multiply
   void* small_m = nullptr;
   unsigned small_m_slot = 0;
@@ -97,6 +99,9 @@ int ensure_ws(mbpls_ctx* ctx, size_t bytes);
 int ensure_stage(mbpls_ctx* ctx, size_t bytes);
 int build_chunks(mbpls_ctx* ctx, const std::vector<int64_t>& offs, int target, ChunkTable* t);
 void free_chunks(ChunkTable* t);
+// xtv_mfma.hip: G = alpha X^T V on the f64 matrix cores (any n, any c)
+int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv, int c, double alpha, double* d_G,
+             int64_t ldg, double* d_ssq);
 
 // RAII bracket: records an event pair around a kernel launch when profiling is on.
 struct ProfScope {

@@ -213,6 +213,7 @@ int mbpls_hip_create(int device, void* stream, mbpls_ctx** out) {
   if (const char* e = getenv("MBPLS_HIP_CHUNKS_PER_CU")) ctx->chunks_per_cu = std::max(1, atoi(e));
   if (const char* e = getenv("MBPLS_HIP_ROWS_PER_THREAD")) ctx->rows_per_thread = atoi(e);
   if (const char* e = getenv("MBPLS_HIP_PREFETCH")) ctx->prefetch = atoi(e);
+  if (const char* e = getenv("MBPLS_HIP_NONTEMPORAL")) ctx->nontemporal = atoi(e);
   if (const char* e = getenv("MBPLS_HIP_XW_CHUNKS_PER_CU")) ctx->xw_chunks_per_cu = std::max(1, atoi(e));
   hipError_t e0 = hipEventCreate(&ctx->ev0), e1 = hipEventCreate(&ctx->ev1);
   if (e0 != hipSuccess || e1 != hipSuccess) {
@@ -231,6 +232,7 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->small_m) (void)hipFree(ctx->small_m);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (auto& pd : ctx->pending) {
@@ -273,6 +275,7 @@ int mbpls_hip_set_tunable(mbpls_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "rows_per_thread")) ctx->rows_per_thread = value;
   else if (!strcmp(key, "xw_chunks_per_cu")) ctx->xw_chunks_per_cu = std::max(1, value);
   else if (!strcmp(key, "prefetch")) ctx->prefetch = value;
+  else if (!strcmp(key, "nontemporal")) ctx->nontemporal = value;
   else MB_ARG(false, "unknown tunable '%s'", key);
   return MBPLS_OK;
 }
@@ -334,6 +337,15 @@ int mbpls_hip_memcpy_d2h(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t 
   if (bytes == 0) return MBPLS_OK;
   MB_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   MB_HIP(hipStreamSynchronize(ctx->stream));
+  return MBPLS_OK;
+}
+
+int mbpls_hip_memcpy_d2h_overlap(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  MB_ARG(ctx && (bytes == 0 || (h_dst && d_src)), "NULL argument");
+  if (bytes == 0) return MBPLS_OK;
+  if (!ctx->copy_stream) MB_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  MB_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+  MB_HIP(hipStreamSynchronize(ctx->copy_stream));
   return MBPLS_OK;
 }
 

@@ -182,10 +182,8 @@ int mbpls_hip_xt_v(const mbpls_mat* m, const double* d_V, int64_t ldv, int c, do
   mbpls_ctx* ctx = m->ctx;
   Cfg cfg;
   int T = 0;
-  if (!pick_cfg(ctx, m->n, &cfg, &T)) {
-    set_error("xt_v supports n <= 8192 (got n=%lld)", (long long)m->n);
-    return MBPLS_ERR_UNSUPPORTED;
-  }
+  // many right-hand sides (or columns too long for the register-resident kernel): matrix-core path, X read once
+  if (c >= 3 || !pick_cfg(ctx, m->n, &cfg, &T)) return xtv_mfma(ctx, m, d_V, ldv, c, alpha, d_G, ldg, d_ssq);
   const ChunkTable& ct = m->fine;
   MB_TRY(ensure_ws(ctx, sizeof(double) * (size_t)ct.nchunks * 4));
   double* part_s = (double*)ctx->ws;

@@ -1,0 +1,168 @@
+// G = alpha * X^T V for MANY right-hand sides (c >= 3: KERNEL post-pass X^T [U Ts] with c = 2K,
+// SIMPLS/UNIPALS with several responses, n >= p branches) on the f64 matrix cores, X read ONCE.
+//
+// Tall-skinny GEMM  G (p x c) = Xfm (p x n) . V (n x c)  with M = features, N = right-hand sides,
+// K = samples.  v_mfma_f64_16x16x4_f64 wants A[i][k] with the 16 lanes of a group spread over 16
+// FEATURES (rows 8n bytes apart) -- un-coalesced if each lane fetched one sample.  Instead every lane
+// loads FOUR consecutive samples of its feature (two 16-byte loads): the wave then touches 16 features
+// x 128 contiguous bytes = whole cache lines, and the four samples feed four successive MFMAs.  The
+// k-index of MFMA #m is therefore the sample set {i0 + 4g + m : g = 0..3}; V is pre-packed once into
+// exactly that fragment order (k_pack_v), so a B fragment is one contiguous 512-byte wave load from L2.
+// Each wave owns FT = 2 feature tiles (32 features) so a V fragment is reused twice.  No LDS, no
+// atomics; accumulators live in 16*NT VGPRs, so occupancy hides the HBM latency.
+#include <algorithm>
+
+#include "common.h"
+
+namespace mbpls {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// Vp[((ks*4 + m)*NT + nt)*64 + lane] = V[(16 nt + (lane&15)) * ldv + 16 ks + 4 (lane>>4) + m]  (0 outside)
+__global__ __launch_bounds__(256) void k_pack_v(const double* __restrict__ V, int64_t ldv, int64_t n, int c, int NT,
+                                                int64_t total, double* __restrict__ Vp) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int lane = (int)(e & 63);
+  int64_t r = e >> 6;
+  const int nt = (int)(r % NT);
+  r /= NT;
+  const int m = (int)(r & 3);
+  const int64_t ks = r >> 2;
+  const int64_t i = 16 * ks + 4 * (lane >> 4) + m;
+  const int k = 16 * nt + (lane & 15);
+  Vp[e] = (i < n && k < c) ? V[(int64_t)k * ldv + i] : 0.0;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_xtv_mfma(const double* __restrict__ X, int64_t ld, int64_t n, int64_t p,
+                                                  const double* __restrict__ Vp, int c, double alpha,
+                                                  double* __restrict__ G, int64_t ldg) {
+  constexpr int FT = 2;
+  const int lane = threadIdx.x & 63;
+  const int f = lane & 15, g = lane >> 4;
+  const int64_t ntiles = (p + 16 * FT - 1) / (16 * FT);
+  const int64_t nk = (n + 15) / 16;
+  const int64_t nk_full = ld / 16;   // k-steps whose 16 samples lie inside the row allocation for every lane
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const double* xrow[FT];
+#pragma unroll
+    for (int t = 0; t < FT; ++t) {
+      int64_t j = tile * 16 * FT + t * 16 + f;
+      if (j >= p) j = p - 1;   // clamped rows are computed but never stored
+      xrow[t] = X + j * ld + 4 * g;
+    }
+    double4_t acc[FT][NT];
+#pragma unroll
+    for (int t = 0; t < FT; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const double* vp = Vp + lane;
+
+    for (int64_t ks = 0; ks < nk_full; ++ks) {
+      double x[FT][4];
+#pragma unroll
+      for (int t = 0; t < FT; ++t) {
+        const double2 lo = *reinterpret_cast<const double2*>(xrow[t] + 16 * ks);
+        const double2 hi = *reinterpret_cast<const double2*>(xrow[t] + 16 * ks + 2);
+        x[t][0] = lo.x; x[t][1] = lo.y; x[t][2] = hi.x; x[t][3] = hi.y;
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const double b = vp[((ks * 4 + m) * NT + nt) * 64];
+#pragma unroll
+          for (int t = 0; t < FT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[t][m], b, acc[t][nt], 0, 0, 0);
+        }
+    }
+    for (int64_t ks = nk_full; ks < nk; ++ks) {   // ragged end of the rows: guarded scalar loads
+      double x[FT][4];
+#pragma unroll
+      for (int t = 0; t < FT; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int64_t i = 16 * ks + 4 * g + m;
+          x[t][m] = (i < n) ? xrow[t][16 * ks + m] : 0.0;
+        }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const double b = vp[((ks * 4 + m) * NT + nt) * 64];
+#pragma unroll
+          for (int t = 0; t < FT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[t][m], b, acc[t][nt], 0, 0, 0);
+        }
+    }
+    // D layout (f64 16x16x4): column (rhs) = lane & 15, row (feature) = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int t = 0; t < FT; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int64_t j = tile * 16 * FT + t * 16 + g + 4 * rg;
+          const int k = 16 * nt + f;
+          if (j < p && k < c) G[(int64_t)k * ldg + j] = alpha * acc[t][nt][rg];
+        }
+  }
+}
+
+// ssq[k * nblocks + b] = sum_{j in block b} G[j, k]^2, fixed-order (one workgroup per (b, k))
+__global__ __launch_bounds__(256) void k_block_colssq(const double* __restrict__ G, int64_t ldg,
+                                                      const int64_t* __restrict__ blk_off, int nblocks,
+                                                      double* __restrict__ ssq) {
+  __shared__ double red[2 * 64];
+  int buf = 0;
+  const int b = blockIdx.x, k = blockIdx.y;
+  const double* col = G + (int64_t)k * ldg;
+  double s[1] = {0.0};
+  for (int64_t j = blk_off[b] + threadIdx.x; j < blk_off[b + 1]; j += 256) s[0] = fma(col[j], col[j], s[0]);
+  block_sum<1>(s, red, buf);
+  if (threadIdx.x == 0) ssq[(int64_t)k * nblocks + b] = s[0];
+}
+
+int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv, int c, double alpha, double* d_G,
+             int64_t ldg, double* d_ssq) {
+  const int NT = (c + 15) / 16;
+  if (NT > 4) {   // more than 64 right-hand sides: process in groups of 64
+    for (int k0 = 0; k0 < c; k0 += 64) {
+      const int cb = std::min(64, c - k0);
+      MB_TRY(xtv_mfma(ctx, m, d_V + (int64_t)k0 * ldv, ldv, cb, alpha, d_G + (int64_t)k0 * ldg, ldg,
+                      d_ssq ? d_ssq + (int64_t)k0 * m->nblocks : nullptr));
+    }
+    return MBPLS_OK;
+  }
+  const int64_t nk = (m->n + 15) / 16;
+  const int64_t total = nk * 4 * NT * 64;
+  const size_t off_bytes = sizeof(int64_t) * (size_t)(m->nblocks + 1);
+  MB_TRY(ensure_ws(ctx, sizeof(double) * (size_t)total + off_bytes + 256));
+  double* Vp = (double*)ctx->ws;
+  hipLaunchKernelGGL(k_pack_v, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_V, ldv, m->n, c, NT,
+                     total, Vp);
+  MB_HIP(hipGetLastError());
+  const int64_t ntiles = (m->p + 31) / 32;
+  const unsigned grid = (unsigned)std::min<int64_t>((ntiles + 3) / 4, (int64_t)ctx->cus * 8);
+  {
+    ProfScope prof(ctx, MBPLS_K_XT_V, 8.0 * (double)m->n * (double)m->p);
+#define MB_XTV(NT_)                                                                                               \
+  hipLaunchKernelGGL((k_xtv_mfma<NT_>), dim3(grid), dim3(256), 0, ctx->stream, (const double*)m->data, m->ld, m->n, \
+                     m->p, (const double*)Vp, c, alpha, d_G, ldg)
+    if (NT == 1) MB_XTV(1);
+    else if (NT == 2) MB_XTV(2);
+    else if (NT == 3) MB_XTV(3);
+    else MB_XTV(4);
+#undef MB_XTV
+  }
+  MB_HIP(hipGetLastError());
+  if (d_ssq) {
+    int64_t* d_off = (int64_t*)((char*)ctx->ws + ((sizeof(double) * (size_t)total + 255) / 256) * 256);
+    MB_HIP(hipMemcpyAsync(d_off, m->block_offsets.data(), off_bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_block_colssq, dim3((unsigned)m->nblocks, (unsigned)c), dim3(256), 0, ctx->stream,
+                       (const double*)d_G, ldg, (const int64_t*)d_off, m->nblocks, d_ssq);
+    MB_HIP(hipGetLastError());
+  }
+  return MBPLS_OK;
+}
+
+}  // namespace mbpls

@@ -99,6 +99,16 @@ class HipEngine:
             self.slots[name] = s
         return s
 
+    def fetch_col(self, name, k, out):
+        """D2H of column k of a slot into column k of the F-ordered host array ``out`` on the copy stream:
+        it does not wait for the kernel currently running on the compute stream (the column must be final)."""
+        S = self.slots[name]
+        col = out[:, k]
+        assert col.flags.c_contiguous and col.size == self.p
+        with self._timed("d2h_overlapped"):
+            _capi.check(self.ctx.lib.mbpls_hip_memcpy_d2h_overlap(self.ctx.handle, col.ctypes.data,
+                                                                  S.ptr + 8 * self.p * k, 8 * self.p))
+
     def fetch(self, name):
         with self._timed("d2h_slots"):
             return self.slots[name].get()
@@ -188,15 +198,18 @@ class HipEngine:
         t, g, _, x = self._finish_pass(v is not None, v is not None, False, True)
         return x, t, g
 
-    def sweep(self, v, alpha, g_slot):
-        """a2+a3: g = alpha X^T v (into the slot column), t~_b = X_b g_b, ||g_b||^2.  One read of X."""
+    def sweep(self, v, alpha, g_slot, overlap=None):
+        """a2+a3: g = alpha X^T v (into the slot column), t~_b = X_b g_b, ||g_b||^2.  One read of X.
+        ``overlap``: host work to do while the kernel runs (e.g. fetching finished columns)."""
         n, B = self.n, self.nblocks
         dv = self._put_vec(0, v)
         self.X.sweep(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B))
+        if overlap is not None:
+            overlap()
         t, g, _, _ = self._finish_pass(True, True, False, False)
         return t, g
 
-    def deflate_sweep(self, ts, inv_tt, deflate, p_slot, v=None, alpha=1.0, g_slot=None):
+    def deflate_sweep(self, ts, inv_tt, deflate, p_slot, v=None, alpha=1.0, g_slot=None, overlap=None):
         """a5+a7 (+ next component's first sweep): p = inv_tt X^T ts, X -= ts p^T.  One read + one write."""
         n, B = self.n, self.nblocks
         dts = self._put_vec(1, ts)
@@ -204,6 +217,8 @@ class HipEngine:
         self.X.deflate_sweep(dts, inv_tt, deflate, self._slot_col(p_slot), self._xptr(n * B + B), dv, alpha,
                              self._slot_col(g_slot), self._xptr(0) if v is not None else None,
                              self._xptr(n * B) if v is not None else None)
+        if overlap is not None:
+            overlap()
         t, g, p, _ = self._finish_pass(v is not None, v is not None, True, False)
         return p, t, g
 

@@ -80,7 +80,10 @@ def host_threads():
         try:
             import threadpoolctl
             _state["tp"] = threadpoolctl.ThreadpoolController()   # library scan is done once
-            _state["tp_limit"] = max(1, min(cpu_quota() - 1, 32))
+            # one process per GPU shares the node's quota with its siblings (torchrun exports LOCAL_WORLD_SIZE)
+            import os
+            siblings = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+            _state["tp_limit"] = max(1, min((cpu_quota() - 1) // siblings, 32))
         except Exception:  # pragma: no cover
             _state["tp"] = None
     if _state["tp"] is None:

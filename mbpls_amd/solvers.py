@@ -74,7 +74,7 @@ def _finalise(eng, res, Wcols, P, V):
     res.P_ = _split(P, eng.block_offsets)
 
 
-def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P"):
+def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_host=None, P_host=None):
     """End-of-fit algebra on the device (mbpls.py:986-991, :569-572, :733-738).
 
     wslot holds raw weight columns; the unit-length weights are W = wslot diag(1/col_norm) and the
@@ -90,14 +90,15 @@ def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P"):
     eng.right_mul((wslot, 0, K), M, ("R", 0))
     eng.slot("beta", q)
     eng.right_mul((wslot, 0, K), M.dot(V.T), ("beta", 0))
-    eng.slot("Wblk", K)
     offs = eng.block_offsets
-    for b in range(eng.nblocks):
-        eng.right_mul((wslot, 0, K), np.diag(1.0 / blk_norm[b]), ("Wblk", 0), rows=(offs[b], offs[b + 1]))
+    if W_host is None:      # block weights not streamed out during the fit: scale on the device
+        eng.slot("Wblk", K)
+        for b in range(eng.nblocks):
+            eng.right_mul((wslot, 0, K), np.diag(1.0 / blk_norm[b]), ("Wblk", 0), rows=(offs[b], offs[b + 1]))
     res.R_ = eng.fetch("R")
     res.beta_ = eng.fetch("beta")
-    res.W_ = _split(eng.fetch("Wblk"), offs)
-    res.P_ = _split(eng.fetch(pslot), offs)
+    res.W_ = _split(W_host if W_host is not None else eng.fetch("Wblk"), offs)
+    res.P_ = _split(P_host if P_host is not None else eng.fetch(pslot), offs)
 
 
 # ----------------------------------------------------------------------------------- NIPALS
@@ -120,6 +121,8 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     T = [np.empty((n, K)) for _ in range(B)]
     nu_all = np.empty((B, K))
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
+    # host copies of the p x K attributes, filled column by column while later passes run on the GPU
+    Wn_h = np.empty((eng.p, K), order="F"); W_h = np.empty((eng.p, K), order="F"); P_h = np.empty((eng.p, K), order="F")
     for k in range(K):
         u = u0
         diff, run, ts_old = 1.0, 1, None
@@ -146,10 +149,21 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
                 break
         iters.append(run - 1)
         last = (k == K - 1)
+
+        def stream_out(k=k, nu=nu):
+            # runs on the host WHILE the deflation pass of component k executes: W~[:, k] is final (its last
+            # sweep has completed) and so is P[:, k-1]; W_b[:, k] = w~_b / ||w~_b|| (:860) is formed here too
+            eng.fetch_col("Wn", k, Wn_h)
+            for b in range(B):
+                r0, r1 = eng.block_offsets[b], eng.block_offsets[b + 1]
+                np.divide(Wn_h[r0:r1, k], nu[b], out=W_h[r0:r1, k])
+            if k > 0:
+                eng.fetch_col("P", k - 1, P_h)
+
         # loadings (:928, no division: ts is unit length) + deflation (:969) + next first sweep
         ssq_p, t_next, ssq_next = eng.deflate_sweep(ts, 1.0, not last, ("P", k),
                                                     None if last else u0, alpha0,
-                                                    None if last else ("Wn", k + 1))
+                                                    None if last else ("Wn", k + 1), overlap=stream_out)
         Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u; V[:, k:k + 1] = v; A[:, k:k + 1] = sw ** 2
         nu_all[:, k] = nu
         for b in range(B):
@@ -168,8 +182,9 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
         res.update(explained_var_x_=[], explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)),
                    A_corrected_=np.empty((B, 0)))
     # ||W~[:, k]||^2 = sum_b ||w~_b||^2 of the last iteration (already summed over shards)  (:986-987)
-    _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V)
-    res.W_non_normal_ = _split(eng.fetch("Wn"), eng.block_offsets)
+    eng.fetch_col("P", K - 1, P_h)
+    _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V, W_host=W_h, P_host=P_h)
+    res.W_non_normal_ = _split(Wn_h, eng.block_offsets)
     return res
 
 

@@ -36,6 +36,9 @@ class NumpyEngine:
             self.slots[name] = np.zeros((self.p, K))
         return self.slots[name]
 
+    def fetch_col(self, name, k, out):
+        out[:, k] = self.slots[name][:, k]
+
     def fetch(self, name):
         return self.slots[name].copy()
 
@@ -90,10 +93,15 @@ class NumpyEngine:
         t, g = self._sweep_core(v, alpha, g_slot)
         return ssq_x, t, g
 
-    def sweep(self, v, alpha, g_slot):
-        return self._sweep_core(v, alpha, g_slot)
+    def sweep(self, v, alpha, g_slot, overlap=None):
+        r = self._sweep_core(v, alpha, g_slot)
+        if overlap is not None:
+            overlap()
+        return r
 
-    def deflate_sweep(self, ts, inv_tt, deflate, p_slot, v=None, alpha=1.0, g_slot=None):
+    def deflate_sweep(self, ts, inv_tt, deflate, p_slot, v=None, alpha=1.0, g_slot=None, overlap=None):
+        if overlap is not None:
+            overlap()
         p = inv_tt * self.Xm.T.dot(ts).ravel()
         if p_slot is not None:
             self.slots[p_slot[0]][:, p_slot[1]] = p
