@@ -131,7 +131,9 @@ def main():
 
     iters = getattr(mdl, "nipals_iterations_", [2] * K)
     ref_units = sum(2 * i + 3 for i in iters) + 1 + 3
-    fused_units = 2 + sum((i - 1) for i in iters) + 2 * (K - 1) + 1
+    # X traffic the HIP path really generates per fit = sum of the kernels' algorithmic bytes (HIP-event
+    # profile of the timed region); with lazy deflation every pass after the standardisation is read-only
+    fused_units = round(sum(v["bytes_per_launch"] * v["launches"] for v in prof.values()) / a.steps / (8.0 * n * p), 2)
     unit_bytes = 8.0 * n * p * world
     per_step = dt / a.steps
     value = ref_units * unit_bytes / per_step / 1e9

@@ -155,6 +155,23 @@ int mbpls_hip_deflate_sweep(mbpls_mat* m, const double* d_ts, double inv_tt, int
                             const double* d_v, double alpha,
                             double* d_g, double* d_t, double* d_ssq_g);
 
+/* LAZY (implicit) deflation: X in HBM stays the standardised X_0; the deflated matrix
+ *   X_k = X_0 - sum_{i<kprev} ts_i P[:,i]^T           (mbpls.py:969 applied algebraically)
+ * is never written.  With d_cu[i] = <ts_i, v>, d_ce[i] = <ts_i, ts> (host-computed, kprev doubles):
+ *   g_j  = alpha (<x_j, v> - sum_i P[j,i] cu_i),   p_j = inv_tt (<x_j, ts> - sum_i P[j,i] ce_i)
+ *   t_b  = sum_{j in b} g_j x_j   (RAW accumulation; the caller subtracts  Ts d_b,  d_b[i] = sum_j g_j P[j,i])
+ * so loadings + deflation + next sweep is ONE READ of X (8np bytes) instead of read + write.
+ * d_P: the p x K loadings array (column-major, ldp), columns [0, kprev) final.  d_d: nblocks x kprev
+ * (sweep) or nblocks x (kprev+1) (loadings_sweep: entry kprev belongs to the component being extracted,
+ * whose deflation the fused sweep already sees).  d_v == NULL in loadings_sweep: loadings only. */
+int mbpls_hip_sweep_lazy(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t,
+                         double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
+                         double* d_d);
+int mbpls_hip_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double inv_tt, double* d_p,
+                                  double* d_ssq_p, const double* d_v, double alpha, double* d_g, double* d_t,
+                                  double* d_ssq_g, const double* d_P, int64_t ldp, int kprev,
+                                  const double* d_cu, const double* d_ce, double* d_d);
+
 /* G = alpha * X^T V for c right-hand sides (mbpls.py:503,:731,:734,:998,:1011).
  *   d_V: n x c column-major (leading dim ldv), d_G: p x c column-major (leading dim ldg).
  *   d_ssq (optional): nblocks x c, d_ssq[k*nblocks + b] = ||G[block b, k]||^2.                     */

@@ -54,6 +54,9 @@ SIGNATURES = {
     "mbpls_hip_standardize_sweep": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
     "mbpls_hip_sweep": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp]),
     "mbpls_hip_deflate_sweep": (_int, [_vp, _vp, _dbl, _int, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
+    "mbpls_hip_sweep_lazy": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp]),
+    "mbpls_hip_loadings_sweep_lazy": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int,
+                                             _vp, _vp, _vp]),
     "mbpls_hip_xt_v": (_int, [_vp, _vp, _i64, _int, _dbl, _vp, _i64, _vp]),
     "mbpls_hip_x_w": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _i64]),
     "mbpls_hip_gram": (_int, [_vp, _vp, _i64]),
@@ -364,6 +367,15 @@ class DeviceMatrix:
     def deflate_sweep(self, ts, inv_tt, deflate, p, ssq_p, v=None, alpha=1.0, g=None, t=None, ssq_g=None):
         check(self.ctx.lib.mbpls_hip_deflate_sweep(self.handle, _ptr(ts), float(inv_tt), int(bool(deflate)), _ptr(p),
                                                    _ptr(ssq_p), _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g)))
+
+    def sweep_lazy(self, v, alpha, g, t, ssq_g, P, ldp, kprev, cu, d):
+        check(self.ctx.lib.mbpls_hip_sweep_lazy(self.handle, _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g),
+                                                _ptr(P), int(ldp), int(kprev), _ptr(cu), _ptr(d)))
+
+    def loadings_sweep_lazy(self, ts, inv_tt, p, ssq_p, v, alpha, g, t, ssq_g, P, ldp, kprev, cu, ce, d):
+        check(self.ctx.lib.mbpls_hip_loadings_sweep_lazy(self.handle, _ptr(ts), float(inv_tt), _ptr(p), _ptr(ssq_p),
+                                                         _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g),
+                                                         _ptr(P), int(ldp), int(kprev), _ptr(cu), _ptr(ce), _ptr(d)))
 
     def xt_v(self, V, c, alpha, G, ssq=None, ldv=None, ldg=None):
         check(self.ctx.lib.mbpls_hip_xt_v(self.handle, _ptr(V), int(ldv or self.n), int(c), float(alpha), _ptr(G),

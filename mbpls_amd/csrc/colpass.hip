@@ -42,27 +42,68 @@ struct PassArgs {
   // partial outputs
   double* part_t;  // [nchunks][n]
   double* part_s;  // [nchunks][4]: ssq_g, ssq_p, ssq_x, -
-  int nt;          // bit 0: non-temporal loads of X, bit 1: non-temporal stores of X
+  // lazy (implicit) deflation: X in HBM stays X_0; X_k = X_0 - sum_{i<kprev} ts_i P[:,i]^T is applied algebraically
+  int lazy;            // 0: explicit in-place deflation, 1: implicit
+  int kprev;           // components already deflated (<= KD-1)
+  const double* Pm;    // p x K loadings of the previous components (column-major, leading dim ldp)
+  int64_t ldp;
+  const double* cu;    // [kprev]  <ts_i, v>   corrections of the sweep dot
+  const double* ce;    // [kprev]  <ts_i, ts>  corrections of the loadings dot
+  double* part_d;      // [nchunks][KD]  sum_j g_j P[j,i] (i < kprev) and sum_j g_j p_j (i = kprev)
+};
+constexpr int KD = 40;
+
+// Row ownership of one thread: pair k covers rows 2(kT + tid), 2(kT + tid) + 1.  Byte offsets are 32-bit
+// and identical for every column, so a column load is  global_load_dwordx4 v, v_off, s[col_base]  (SGPR base
+// + VGPR offset): no 64-bit address arithmetic and no address registers per load in flight.
+template <int R>
+struct RowMap {
+  unsigned off[R / 2];   // byte offset of the pair inside a column
+  unsigned in_ld;        // bit k: pair k lies inside the column allocation (r0 < ld)
+  unsigned in_n0, in_n1; // bit k: row r0 / r0+1 is a real sample (< n)
+  __device__ __forceinline__ void init(int64_t n, int64_t ld, int tid, int T) {
+    in_ld = in_n0 = in_n1 = 0u;
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) {
+      // 32-bit arithmetic on purpose: the offset must reach the load as zext(i32) for the SGPR-base form
+      const unsigned r0 = 2u * ((unsigned)k * (unsigned)T + (unsigned)tid);
+      const bool inside = (int64_t)r0 < ld;
+      off[k] = inside ? r0 * 8u : 0u;   // out-of-allocation pairs re-read pair 0 (masked below)
+      in_ld |= (inside ? 1u : 0u) << k;
+      in_n0 |= ((int64_t)r0 < n ? 1u : 0u) << k;
+      in_n1 |= ((int64_t)r0 + 1 < n ? 1u : 0u) << k;
+    }
+  }
 };
 
-template <int R>
-__device__ __forceinline__ void load_col(double (&x)[R], const double* __restrict__ col, int64_t n, int64_t ld,
-                                         int tid, int T, bool nt = false) {
-  typedef double v2d __attribute__((ext_vector_type(2)));
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+// force a wave-uniform 64-bit value into SGPRs (values fetched through possibly-aliased pointers land in
+// VGPRs, which would turn every column base address into per-lane 64-bit address arithmetic)
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffll));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// X is streamed exactly once per pass: non-temporal loads/stores keep it out of L2/MALL
+// (measured on MI355X: read-only sweep 6.2 -> 6.8 TB/s, read+write pass 5.5 -> 5.7 TB/s).
+// FULL: n == T*R == ld, every pair of every thread is a real sample -> no masks, and (more important) no
+// select right behind the load that would force an s_waitcnt before the prefetched column is needed.
+template <int R, bool FULL>
+__device__ __forceinline__ void load_col(double (&x)[R], const double* __restrict__ col, const RowMap<R>& m) {
+  const char* base = reinterpret_cast<const char*>(col);   // workgroup-uniform
 #pragma unroll
   for (int k = 0; k < R / 2; ++k) {
-    const int64_t r0 = 2 * ((int64_t)k * T + tid);
-    double2 t = make_double2(0.0, 0.0);
-    if (r0 < ld) {
-      if (nt) {   // workgroup-uniform: streamed once, do not keep in L2/MALL
-        const v2d q = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(col + r0));
-        t = make_double2(q.x, q.y);
-      } else {
-        t = *reinterpret_cast<const double2*>(col + r0);
-      }
+    // unconditional (clamped offset): no exec-mask branch per load, masking happens on the value
+    const v2d_t q = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(base + m.off[k]));
+    if constexpr (FULL) {
+      x[2 * k] = q.x;
+      x[2 * k + 1] = q.y;
+    } else {
+      x[2 * k] = ((m.in_n0 >> k) & 1u) ? q.x : 0.0;
+      x[2 * k + 1] = ((m.in_n1 >> k) & 1u) ? q.y : 0.0;
     }
-    x[2 * k] = (r0 < n) ? t.x : 0.0;
-    x[2 * k + 1] = (r0 + 1 < n) ? t.y : 0.0;
   }
 }
 
@@ -77,58 +118,102 @@ __device__ __forceinline__ void load_vec(double (&x)[R], const double* __restric
   }
 }
 
-template <int R>
-__device__ __forceinline__ void store_col(const double (&x)[R], double* __restrict__ col, int64_t ld, int tid,
-                                          int T, bool nt = false) {
-  typedef double v2d __attribute__((ext_vector_type(2)));
+template <int R, bool FULL>
+__device__ __forceinline__ void store_col(const double (&x)[R], double* __restrict__ col, const RowMap<R>& m) {
+  char* base = reinterpret_cast<char*>(col);
 #pragma unroll
   for (int k = 0; k < R / 2; ++k) {
-    const int64_t r0 = 2 * ((int64_t)k * T + tid);
-    if (r0 < ld) {
-      if (nt) {
-        v2d q;
-        q.x = x[2 * k];
-        q.y = x[2 * k + 1];
-        __builtin_nontemporal_store(q, reinterpret_cast<v2d*>(col + r0));
-      } else {
-        *reinterpret_cast<double2*>(col + r0) = make_double2(x[2 * k], x[2 * k + 1]);
-      }
+    if (FULL || ((m.in_ld >> k) & 1u)) {
+      v2d_t q;
+      q.x = x[2 * k];
+      q.y = x[2 * k + 1];
+      __builtin_nontemporal_store(q, reinterpret_cast<v2d_t*>(base + m.off[k]));
     }
   }
 }
 
-template <int R, int TMAX, int D, bool STD, bool DEFL, bool SWEEP>
-__global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
+// The n=4096 workhorse (R=8, 512 threads = 8 waves) must stay at <= 128 VGPRs: 4 waves/SIMD = two
+// workgroups per CU.  At 129+ VGPRs only ONE 8-wave workgroup fits a CU and the pass runs ~2x slower
+// (measured: the lazy loadings+sweep variant at 157 VGPRs took 9.3 ms instead of 4.8 ms).
+template <int R, int TMAX, int D, bool STD, bool DEFL, bool SWEEP, bool FULL>
+__global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpass(PassArgs a) {
   __shared__ double red[2 * 64];
   int buf = 0;
   const int tid = threadIdx.x, T = blockDim.x;
   const int64_t n = a.n, ld = a.ld;
   const int chunk = blockIdx.x;
-  const int64_t j0 = a.c0[chunk], j1 = a.c1[chunk];
-  const bool ntl = (a.nt & 1) != 0, nts = (a.nt & 2) != 0;
+  const int64_t j0 = uniform64(a.c0[chunk]), j1 = uniform64(a.c1[chunk]);
+  RowMap<R> rm;
+  rm.init(n, ld, tid, T);
 
-  double v[SWEEP ? R : 1], ts[DEFL ? R : 1], acc[SWEEP ? R : 1];
+  // The fused loadings+sweep variant of the n=4096 configuration needs x[2], ts, v, acc = 80 VGPRs of
+  // column data; with the lazy-deflation state that no longer fits 128.  Its score vector ts therefore
+  // lives in LDS (32 KB, each thread re-reads only its own row pairs: conflict-free ds_read_b128).
+  constexpr bool TS_LDS = DEFL && SWEEP && R == 8 && TMAX == 512;
+  __shared__ double2 s_ts[TS_LDS ? (TMAX * R / 2) : 1];
+  __shared__ double2 s_v[TS_LDS ? (TMAX * R / 2) : 1];   // same treatment for the sweep vector there
+  double v[(SWEEP && !TS_LDS) ? R : 1], ts[(DEFL && !TS_LDS) ? R : 1], acc[SWEEP ? R : 1];
   double tsv = 0.0;
   if constexpr (SWEEP) {
-    load_vec<R>(v, a.v, n, tid, T);
+    if constexpr (TS_LDS) {
+      double tmp[R];
+      load_vec<R>(tmp, a.v, n, tid, T);
+#pragma unroll
+      for (int k = 0; k < R / 2; ++k) s_v[k * T + tid] = make_double2(tmp[2 * k], tmp[2 * k + 1]);
+    } else {
+      load_vec<R>(v, a.v, n, tid, T);
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) acc[k] = 0.0;
   }
-  if constexpr (DEFL) load_vec<R>(ts, a.ts, n, tid, T);
+  auto v_pair = [&](int k) -> double2 {
+    if constexpr (TS_LDS) return s_v[k * T + tid];
+    else return make_double2(v[2 * k], v[2 * k + 1]);
+  };
+  if constexpr (DEFL && !TS_LDS) load_vec<R>(ts, a.ts, n, tid, T);
+  if constexpr (TS_LDS) {
+    double tmp[R];
+    load_vec<R>(tmp, a.ts, n, tid, T);
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) s_ts[k * T + tid] = make_double2(tmp[2 * k], tmp[2 * k + 1]);
+  }
+  // row pair k of the score vector, from registers or LDS (a thread only ever reads what it wrote)
+  auto ts_pair = [&](int k) -> double2 {
+    if constexpr (TS_LDS) return s_ts[k * T + tid];
+    else return make_double2(ts[2 * k], ts[2 * k + 1]);
+  };
   if constexpr (DEFL && SWEEP) {
     double s[1] = {0.0};
 #pragma unroll
-    for (int k = 0; k < R; ++k) s[0] = fma(ts[k], v[k], s[0]);
+    for (int k = 0; k < R / 2; ++k) {
+      const double2 t2 = ts_pair(k);
+      const double2 v2 = v_pair(k);
+      s[0] = fma(t2.x, v2.x, s[0]);
+      s[0] = fma(t2.y, v2.y, s[0]);
+    }
     block_sum<1>(s, red, buf);
     tsv = s[0];
   }
   double ssq_g = 0.0, ssq_p = 0.0, ssq_x = 0.0;
   const double dn = (double)n;
+  // lazy deflation: thread i < kprev carries the correction of previous component i
+  const bool lazy = !STD && a.lazy != 0;
+  const bool mine = lazy && tid < a.kprev;
+  const double cu_i = (mine && a.cu) ? a.cu[tid] : 0.0;
+  const double ce_i = (mine && a.ce) ? a.ce[tid] : 0.0;
+  const double* prow = mine ? a.Pm + (int64_t)tid * a.ldp : nullptr;
+  double dacc = 0.0, dk = 0.0;
 
   double x[D][R];
+  double pp[D];   // P[column, tid] of the column held in slot d (0 for threads >= kprev)
 #pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (j0 + d < j1) load_col<R>(x[d], a.src + (j0 + d) * ld, n, ld, tid, T, ntl);
+  for (int d = 0; d < D; ++d) {
+    pp[d] = 0.0;
+    if (j0 + d < j1) {
+      load_col<R, FULL>(x[d], a.src + (j0 + d) * ld, rm);
+      if (mine) pp[d] = prow[j0 + d];
+    }
+  }
 
   for (int64_t j = j0; j < j1; j += D) {
 #pragma unroll
@@ -150,8 +235,8 @@ __global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
             double cq[2] = {0.0, 0.0};
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-              const int64_t r = 2 * ((int64_t)(k >> 1) * T + tid) + (k & 1);
-              const double dlt = (r < n) ? xc[k] - mean : 0.0;
+              const bool real = FULL || ((((k & 1) ? rm.in_n1 : rm.in_n0) >> (k >> 1)) & 1u);
+              const double dlt = real ? xc[k] - mean : 0.0;
               xc[k] = dlt;
               cq[0] += dlt;
               cq[1] = fma(dlt, dlt, cq[1]);
@@ -171,8 +256,8 @@ __global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
             scale = a.scale[jj];
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-              const int64_t r = 2 * ((int64_t)(k >> 1) * T + tid) + (k & 1);
-              xc[k] = (r < n) ? xc[k] - mean : 0.0;
+              const bool real = FULL || ((((k & 1) ? rm.in_n1 : rm.in_n0) >> (k >> 1)) & 1u);
+              xc[k] = real ? xc[k] - mean : 0.0;
             }
           }
 #pragma unroll
@@ -180,16 +265,23 @@ __global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) ssq_x = fma(xc[k], xc[k], ssq_x);
-        store_col<R>(xc, a.dst + jj * ld, ld, tid, T, nts);
+        store_col<R, FULL>(xc, a.dst + jj * ld, rm);
       }
 
       double gj = 0.0;
       if constexpr (DEFL) {
-        double ab[2] = {0.0, 0.0};
+        // lazy: <x_k, ts> = <x_0, ts> - sum_i P[j,i] <ts_i, ts>, folded into the same reduction
+        double ab[2] = {-pp[d] * ce_i, -pp[d] * cu_i};
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-          ab[0] = fma(xc[k], ts[k], ab[0]);
-          if constexpr (SWEEP) ab[1] = fma(xc[k], v[k], ab[1]);
+        for (int k = 0; k < R / 2; ++k) {
+          const double2 t2 = ts_pair(k);
+          ab[0] = fma(xc[2 * k], t2.x, ab[0]);
+          ab[0] = fma(xc[2 * k + 1], t2.y, ab[0]);
+          if constexpr (SWEEP) {
+            const double2 v2 = v_pair(k);
+            ab[1] = fma(xc[2 * k], v2.x, ab[1]);
+            ab[1] = fma(xc[2 * k + 1], v2.y, ab[1]);
+          }
         }
         if constexpr (SWEEP) block_sum<2>(ab, red, buf);
         else {
@@ -201,15 +293,22 @@ __global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
         ssq_p = fma(pj, pj, ssq_p);
         if (tid == 0 && a.pvec) a.pvec[jj] = pj;
         if (a.deflate) {
+          if (!lazy) {
 #pragma unroll
-          for (int k = 0; k < R; ++k) xc[k] = fma(-pj, ts[k], xc[k]);
-          store_col<R>(xc, a.dst + jj * ld, ld, tid, T, nts);
+            for (int k = 0; k < R / 2; ++k) {
+              const double2 t2 = ts_pair(k);
+              xc[2 * k] = fma(-pj, t2.x, xc[2 * k]);
+              xc[2 * k + 1] = fma(-pj, t2.y, xc[2 * k + 1]);
+            }
+            store_col<R, FULL>(xc, a.dst + jj * ld, rm);
+          }
           if constexpr (SWEEP) gj = a.alpha * fma(-pj, tsv, ab[1]);  // <x - p ts, v> = <x,v> - p <ts,v>
+          if constexpr (SWEEP) dk = fma(gj, pj, dk);
         } else {
           if constexpr (SWEEP) gj = a.alpha * ab[1];
         }
       } else if constexpr (SWEEP) {
-        double b[1] = {0.0};
+        double b[1] = {-pp[d] * cu_i};
 #pragma unroll
         for (int k = 0; k < R; ++k) b[0] = fma(xc[k], v[k], b[0]);
         block_sum<1>(b, red, buf);
@@ -220,9 +319,13 @@ __global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
         if (tid == 0 && a.g) a.g[jj] = gj;
 #pragma unroll
         for (int k = 0; k < R; ++k) acc[k] = fma(gj, xc[k], acc[k]);
+        dacc = fma(gj, pp[d], dacc);
       }
       // refill this register slot with the column D ahead (in flight while the next ones are processed)
-      if (jj + D < j1) load_col<R>(xc, a.src + (jj + D) * ld, n, ld, tid, T, ntl);
+      if (jj + D < j1) {
+        load_col<R, FULL>(xc, a.src + (jj + D) * ld, rm);
+        if (mine) pp[d] = prow[jj + D];
+      }
     }
   }
 
@@ -231,7 +334,7 @@ __global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
 #pragma unroll
     for (int k = 0; k < R / 2; ++k) {
       const int64_t r0 = 2 * ((int64_t)k * T + tid);
-      if (r0 + 1 < n) *reinterpret_cast<double2*>(out + r0) = make_double2(acc[2 * k], acc[2 * k + 1]);
+      if (FULL || r0 + 1 < n) *reinterpret_cast<double2*>(out + r0) = make_double2(acc[2 * k], acc[2 * k + 1]);
       else if (r0 < n) out[r0] = acc[2 * k];
     }
   }
@@ -247,6 +350,11 @@ __global__ __launch_bounds__(TMAX) void k_colpass(PassArgs a) {
     ps[2] = ssq_x;
     ps[3] = 0.0;
   }
+  if (lazy && a.part_d) {
+    double* pd = a.part_d + (int64_t)chunk * KD;
+    if (mine) pd[tid] = dacc;
+    if (tid == 0) pd[a.kprev] = dk;
+  }
 }
 
 // Second stage: fixed-order sum of the chunk partials of each block.
@@ -256,7 +364,9 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const double* __restrict_
                                                        const double* __restrict__ part_s,
                                                        const int* __restrict__ blk_start, int64_t n,
                                                        double* __restrict__ out_t, double* __restrict__ out_ssq_g,
-                                                       double* __restrict__ out_ssq_p, double* __restrict__ out_ssq_x) {
+                                                       double* __restrict__ out_ssq_p, double* __restrict__ out_ssq_x,
+                                                       const double* __restrict__ part_d, int nd,
+                                                       double* __restrict__ out_d /* [nblocks][nd] */) {
   __shared__ double comb[4][64];
   const int b = blockIdx.y;
   const int cs = blk_start[b], ce = blk_start[b + 1];
@@ -288,6 +398,14 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const double* __restrict_
       for (int c = cs + lane; c < ce; c += 64) s += part_s[(int64_t)c * 4 + w];
       s = wave_sum(s);
       if (lane == 0) o[b] = s;
+    }
+  }
+  if (blockIdx.x == 0 && w == 3 && out_d) {
+    for (int i = 0; i < nd; ++i) {
+      double s = 0.0;
+      for (int c = cs + lane; c < ce; c += 64) s += part_d[(int64_t)c * KD + i];
+      s = wave_sum(s);
+      if (lane == 0) out_d[(int64_t)b * nd + i] = s;
     }
   }
 }
@@ -335,7 +453,7 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
 template <bool STD, bool DEFL, bool SWEEP>
 static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, int64_t p) {
   // algorithmic bytes: read 8np, plus 8np write when the pass stores X
-  const bool writes = STD || (DEFL && a.deflate);
+  const bool writes = STD || (DEFL && a.deflate && !a.lazy);
   const int kind = STD ? MBPLS_K_STANDARDIZE : (DEFL ? (SWEEP ? MBPLS_K_DEFLATE_SWEEP : MBPLS_K_DEFLATE) : MBPLS_K_SWEEP);
   ProfScope prof(ctx, kind, 8.0 * (double)a.n * (double)p * (writes ? 2.0 : 1.0));
   Cfg cfg;
@@ -344,12 +462,18 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
     set_error("fused column pass supports n <= 8192 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;
   }
-  PassArgs an = a;
-  an.nt = ctx->nontemporal;
+  const PassArgs& an = a;
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
   const int D = ctx->prefetch >= 1 && ctx->prefetch <= 3 ? ctx->prefetch : 2;
+  // FULL: every thread's every row pair is a real sample and columns are unpadded (n=4096, 8192, ...)
+  const bool full = (a.n == (int64_t)T * cfg.R) && (a.ld == a.n) && cfg.R >= 8;
 #define MB_LAUNCH(R_, TM_, D_)                                                                          \
-  hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, an)
+  do {                                                                                                  \
+    if (full && (R_) >= 8)                                                                              \
+      hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, ((R_) >= 8)>), grid, block, 0, ctx->stream, an); \
+    else                                                                                                \
+      hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, false>), grid, block, 0, ctx->stream, an);       \
+  } while (0)
 #define MB_LAUNCH_D(R_, TM_)            \
   do {                                  \
     if (D == 1) MB_LAUNCH(R_, TM_, 1);  \
@@ -373,19 +497,23 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
 }
 
 static int reduce_chunks(mbpls_ctx* ctx, const mbpls_mat* m, const double* part_t, const double* part_s,
-                         double* d_t, double* d_ssq_g, double* d_ssq_p, double* d_ssq_x) {
+                         double* d_t, double* d_ssq_g, double* d_ssq_p, double* d_ssq_x,
+                         const double* part_d = nullptr, int nd = 0, double* d_d = nullptr) {
   dim3 grid(d_t ? (unsigned)((m->n + 63) / 64) : 1u, (unsigned)m->nblocks);
   hipLaunchKernelGGL(k_reduce_chunks, grid, dim3(256), 0, ctx->stream, part_t, part_s,
-                     (const int*)m->fine.d_blk_start, m->n, d_t, d_ssq_g, d_ssq_p, d_ssq_x);
+                     (const int*)m->fine.d_blk_start, m->n, d_t, d_ssq_g, d_ssq_p, d_ssq_x, part_d, nd, d_d);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }
 
-static int partial_buffers(mbpls_ctx* ctx, const mbpls_mat* m, double** part_t, double** part_s) {
+static int partial_buffers(mbpls_ctx* ctx, const mbpls_mat* m, double** part_t, double** part_s,
+                           double** part_d = nullptr) {
   const size_t nt = (size_t)m->fine.nchunks * (size_t)m->n, ns = (size_t)m->fine.nchunks * 4;
-  MB_TRY(ensure_ws(ctx, sizeof(double) * (nt + ns)));
+  const size_t nd = (size_t)m->fine.nchunks * KD;
+  MB_TRY(ensure_ws(ctx, sizeof(double) * (nt + ns + nd)));
   *part_t = (double*)ctx->ws;
   *part_s = *part_t + nt;
+  if (part_d) *part_d = *part_s + ns;
   return MBPLS_OK;
 }
 
@@ -422,6 +550,46 @@ int mbpls_hip_deflate_sweep(mbpls_mat* m, const double* d_ts, double inv_tt, int
   if (d_v) {
     MB_TRY((launch_pass<false, true, true>(ctx, m->fine, a, m->p)));
     return reduce_chunks(ctx, m, a.part_t, a.part_s, d_t, d_ssq_g, d_ssq_p, nullptr);
+  }
+  MB_TRY((launch_pass<false, true, false>(ctx, m->fine, a, m->p)));
+  if (d_ssq_p) return reduce_chunks(ctx, m, a.part_t, a.part_s, nullptr, nullptr, d_ssq_p, nullptr);
+  return MBPLS_OK;
+}
+
+int mbpls_hip_sweep_lazy(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t,
+                         double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
+                         double* d_d) {
+  MB_ARG(m && d_v, "NULL argument");
+  MB_ARG(kprev >= 0 && kprev < KD && (kprev == 0 || (d_P && d_cu && d_d)), "bad lazy-deflation arguments (kprev=%d)", kprev);
+  mbpls_ctx* ctx = m->ctx;
+  PassArgs a{};
+  MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s, &a.part_d));
+  a.src = m->data; a.dst = nullptr; a.ld = m->ld; a.n = m->n;
+  a.c0 = m->fine.d_c0; a.c1 = m->fine.d_c1;
+  a.v = d_v; a.alpha = alpha; a.g = d_g;
+  a.lazy = 1; a.kprev = kprev; a.Pm = d_P; a.ldp = ldp; a.cu = d_cu; a.ce = nullptr;
+  MB_TRY((launch_pass<false, false, true>(ctx, m->fine, a, m->p)));
+  return reduce_chunks(ctx, m, a.part_t, a.part_s, d_t, d_ssq_g, nullptr, nullptr, a.part_d, kprev, kprev ? d_d : nullptr);
+}
+
+int mbpls_hip_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double inv_tt, double* d_p,
+                                  double* d_ssq_p, const double* d_v, double alpha, double* d_g, double* d_t,
+                                  double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
+                                  const double* d_ce, double* d_d) {
+  MB_ARG(m && d_ts, "NULL argument");
+  MB_ARG(kprev >= 0 && kprev < KD - 1 && (kprev == 0 || (d_P && d_ce)), "bad lazy-deflation arguments (kprev=%d)", kprev);
+  MB_ARG(!d_v || (d_d && (kprev == 0 || d_cu)), "sweep part needs d_cu / d_d");
+  mbpls_ctx* ctx = m->ctx;
+  PassArgs a{};
+  MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s, &a.part_d));
+  a.src = m->data; a.dst = m->data; a.ld = m->ld; a.n = m->n;
+  a.c0 = m->fine.d_c0; a.c1 = m->fine.d_c1;
+  a.ts = d_ts; a.inv_tt = inv_tt; a.deflate = d_v ? 1 : 0; a.pvec = d_p;   // deflate=1: the fused sweep sees X_{k+1}
+  a.v = d_v; a.alpha = alpha; a.g = d_g;
+  a.lazy = 1; a.kprev = kprev; a.Pm = d_P; a.ldp = ldp; a.cu = d_cu; a.ce = d_ce;
+  if (d_v) {
+    MB_TRY((launch_pass<false, true, true>(ctx, m->fine, a, m->p)));
+    return reduce_chunks(ctx, m, a.part_t, a.part_s, d_t, d_ssq_g, d_ssq_p, nullptr, a.part_d, kprev + 1, d_d);
   }
   MB_TRY((launch_pass<false, true, false>(ctx, m->fine, a, m->p)));
   if (d_ssq_p) return reduce_chunks(ctx, m, a.part_t, a.part_s, nullptr, nullptr, d_ssq_p, nullptr);

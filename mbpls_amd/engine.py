@@ -19,6 +19,12 @@ from .comm import LocalComm
 
 
 class HipEngine:
+    KD = 40                     # == KD of csrc/colpass.hip (max lazily deflated components + 1)
+    # Deflation strategy of the NIPALS / UNIPALS(p>n) drivers.  "lazy": X in HBM is never rewritten, the
+    # rank-1 updates X <- X - ts p^T (mbpls.py:969) are applied algebraically inside the next passes
+    # (one READ of X per loadings+deflation+sweep instead of read+write).  "explicit": in-place update.
+    deflation = "lazy"
+
     def __init__(self, ctx=None, comm=None, device=0):
         self.ctx = ctx if ctx is not None else _capi.Context(device)
         self.comm = comm if comm is not None else LocalComm()
@@ -72,8 +78,11 @@ class HipEngine:
         self.block_offsets = list(X.block_offsets)
         self.block_sizes = [self.block_offsets[b + 1] - self.block_offsets[b] for b in range(self.nblocks)]
         B, n = self.nblocks, self.n
-        self._xchg = self.comm.exchange_buffer(self.ctx, n * B + 3 * B)
+        self._xchg = self.comm.exchange_buffer(self.ctx, n * B + 3 * B + B * self.KD)
         self._vec_n = [self.ctx.empty(n), self.ctx.empty(n)]
+        self._coef = [self.ctx.empty(self.KD), self.ctx.empty(self.KD)]   # <ts_i, v>, <ts_i, ts>
+        self._lazy_ts = []          # score vectors of the components deflated so far (lazy mode)
+        self._lazy_pslot = None
         if not hasattr(self, "_src"):
             self._src = None
 
@@ -156,9 +165,36 @@ class HipEngine:
     def _xptr(self, off):
         return self._xchg.ptr + 8 * off
 
-    def _finish_pass(self, want_t, want_g, want_p, want_x):
+    def use_lazy_deflation(self, K, pslot):
+        """Called by a solver whose passes all go through sweep/deflate_sweep: enable lazy deflation
+        when the component count fits the kernel's correction registers."""
+        import os
+        mode = os.environ.get("MBPLS_DEFLATION", self.deflation)
+        self._lazy_pslot = pslot if (mode == "lazy" and K < self.KD - 1) else None
+        self._lazy_ts = []
+        return self._lazy_pslot is not None
+
+    def _lazy_coef(self, idx, vec):
+        """upload <ts_i, vec> for the deflated components; returns the device array (or None)"""
+        if not self._lazy_ts:
+            return None
+        c = np.array([float(t.ravel().dot(vec.ravel())) for t in self._lazy_ts])
+        buf = np.zeros(self.KD)
+        buf[:c.size] = c
+        return self._coef[idx].set(buf)
+
+    def _lazy_fix(self, t, d, extra_ts=None):
+        """t~_b = A_b - Ts d_b  (A_b: raw accumulation over the undeflated columns)"""
+        cols = list(self._lazy_ts) + ([extra_ts] if extra_ts is not None else [])
+        if not cols or t is None:
+            return t
+        Tm = np.column_stack([c.ravel() for c in cols])            # n x k
+        return t - Tm.dot(d[:, :Tm.shape[1]].T)                     # d: B x k
+
+    def _finish_pass(self, want_t, want_g, want_p, want_x, nd=0):
         """all-reduce the exchange buffer (if sharded) and split it on the host."""
         n, B = self.n, self.nblocks
+        self._last_d = None
         if self.comm.is_distributed:
             with self._timed("allreduce"):
                 self.comm.allreduce_device(self._xchg)
@@ -166,6 +202,8 @@ class HipEngine:
             h = self._xchg.get()
         t = h[: n * B].reshape(B, n).T.copy() if want_t else None   # n x B
         o = n * B
+        if nd:
+            self._last_d = h[o + 3 * B:o + 3 * B + B * nd].reshape(B, nd).copy()
         return (t, h[o:o + B].copy() if want_g else None, h[o + B:o + 2 * B].copy() if want_p else None,
                 h[o + 2 * B:o + 3 * B].copy() if want_x else None)
 
@@ -203,10 +241,18 @@ class HipEngine:
         ``overlap``: host work to do while the kernel runs (e.g. fetching finished columns)."""
         n, B = self.n, self.nblocks
         dv = self._put_vec(0, v)
-        self.X.sweep(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B))
+        k = len(self._lazy_ts) if self._lazy_pslot else 0
+        if k:
+            P = self.slots[self._lazy_pslot]
+            self.X.sweep_lazy(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B), P, self.p, k,
+                              self._lazy_coef(0, v), self._xptr(n * B + 3 * B))
+        else:
+            self.X.sweep(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B))
         if overlap is not None:
             overlap()
-        t, g, _, _ = self._finish_pass(True, True, False, False)
+        t, g, _, _ = self._finish_pass(True, True, False, False, nd=k)
+        if k:
+            t = self._lazy_fix(t, self._last_d)
         return t, g
 
     def deflate_sweep(self, ts, inv_tt, deflate, p_slot, v=None, alpha=1.0, g_slot=None, overlap=None):
@@ -214,6 +260,23 @@ class HipEngine:
         n, B = self.n, self.nblocks
         dts = self._put_vec(1, ts)
         dv = self._put_vec(0, v) if v is not None else None
+        if self._lazy_pslot:
+            assert p_slot is not None and p_slot[0] == self._lazy_pslot and p_slot[1] == len(self._lazy_ts)
+            k = len(self._lazy_ts)
+            P = self.slots[self._lazy_pslot]
+            self.X.loadings_sweep_lazy(dts, inv_tt, self._slot_col(p_slot), self._xptr(n * B + B), dv, alpha,
+                                       self._slot_col(g_slot), self._xptr(0) if v is not None else None,
+                                       self._xptr(n * B) if v is not None else None, P, self.p, k,
+                                       self._lazy_coef(0, v) if v is not None else None, self._lazy_coef(1, ts),
+                                       self._xptr(n * B + 3 * B) if v is not None else None)
+            if overlap is not None:
+                overlap()
+            t, g, p, _ = self._finish_pass(v is not None, v is not None, True, False, nd=(k + 1) if v is not None else 0)
+            if v is not None:
+                t = self._lazy_fix(t, self._last_d, extra_ts=np.asarray(ts))
+            if deflate:
+                self._lazy_ts.append(np.array(ts, dtype=np.float64).ravel())
+            return p, t, g
         self.X.deflate_sweep(dts, inv_tt, deflate, self._slot_col(p_slot), self._xptr(n * B + B), dv, alpha,
                              self._slot_col(g_slot), self._xptr(0) if v is not None else None,
                              self._xptr(n * B) if v is not None else None)

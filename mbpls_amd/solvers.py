@@ -114,6 +114,8 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     alpha0 = 1.0 / u0.T.dot(u0).item()
     eng.slot("Wn", K)
     eng.slot("P", K)
+    if hasattr(eng, "use_lazy_deflation"):
+        eng.use_lazy_deflation(K, "P")
     varxb, t_raw, ssq = eng.prepare(standardize, v=u0, alpha=alpha0, g_slot=("Wn", 0))
     varx = varxb.sum()
     vary = (Y ** 2).sum()
@@ -201,6 +203,8 @@ def fit_unipals(eng, Y, K, standardize):
     eng.slot("P", K)
     eng.slot("S", max(q, 1))
     y0 = Y[:, 0:1]
+    if wide and hasattr(eng, "use_lazy_deflation"):
+        eng.use_lazy_deflation(K, "P")      # the n >= p branch mixes in xt_v / x_w on the deflated X: explicit
     fuse = wide and q == 1
     varxb, m_raw, _ = eng.prepare(standardize, v=y0 if fuse else None, alpha=1.0, g_slot=("S", 0) if fuse else None)
     varx = varxb.sum()
