@@ -418,7 +418,9 @@ struct Cfg {
 // Choose rows-per-thread R and the workgroup size T = roundup(ceil(n/R), 64) <= TMAX.
 static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std_pass = false) {
   // preference order: smallest register footprint that still covers n with <= TMAX threads
-  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}, {4, 1024}, {16, 1024}};
+  // the last two are correctness fallbacks for very long columns (8192 < n <= 65536): the column no longer
+  // fits the register budget of 1024 threads, the compiler spills to scratch -> slow but exact
+  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}, {4, 1024}, {32, 1024}, {64, 1024}};
   auto fits = [&](const Cfg& c, int* t) {
     int64_t need = (n + c.R - 1) / c.R;
     need = (need + 63) / 64 * 64;
@@ -443,7 +445,7 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
       }
   }
   for (const Cfg& c : table)
-    if (c.TMAX * c.R <= 8192 && fits(c, T)) {
+    if (fits(c, T)) {
       *cfg = c;
       return true;
     }
@@ -459,7 +461,7 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   Cfg cfg;
   int T = 0;
   if (!pick_cfg(ctx, a.n, &cfg, &T, STD)) {
-    set_error("fused column pass supports n <= 8192 (got n=%lld)", (long long)a.n);
+    set_error("column passes support n <= 65536 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;
   }
   const PassArgs& an = a;
@@ -486,6 +488,8 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   else if (cfg.R == 8 && cfg.TMAX == 512) MB_LAUNCH_D(8, 512);
   else if (cfg.R == 8) MB_LAUNCH_D(8, 1024);
   else if (cfg.R == 16 && cfg.TMAX == 512) MB_LAUNCH_D(16, 512);
+  else if (cfg.R == 32) hipLaunchKernelGGL((k_colpass<32, 1024, 1, STD, DEFL, SWEEP, false>), grid, block, 0, ctx->stream, an);
+  else if (cfg.R == 64) hipLaunchKernelGGL((k_colpass<64, 1024, 1, STD, DEFL, SWEEP, false>), grid, block, 0, ctx->stream, an);
   else {
     set_error("no kernel for R=%d TMAX=%d", cfg.R, cfg.TMAX);
     return MBPLS_ERR_UNSUPPORTED;

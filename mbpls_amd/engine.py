@@ -234,6 +234,9 @@ class HipEngine:
                               self._xptr(n * B) if v is not None else None)
         self._src = None
         t, g, _, x = self._finish_pass(v is not None, v is not None, False, True)
+        if not np.all(np.isfinite(x)):
+            # any NaN / inf in a column poisons its sum of squares (and its mean / scale)
+            raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
         return x, t, g
 
     def sweep(self, v, alpha, g_slot, overlap=None):

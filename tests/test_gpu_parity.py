@@ -39,7 +39,7 @@ def test_upload_download_roundtrip(ctx, n, p, order):
 
 @pytest.mark.parametrize("n,p,blocks", [(40, 70, [25, 45]), (41, 33, [33]), (300, 500, [100, 150, 250]),
                                         (1000, 257, [257]), (2048, 400, [130, 270]), (4096, 300, [300]),
-                                        (8192, 100, [40, 60])])
+                                        (8192, 100, [40, 60]), (9001, 48, [20, 28]), (33000, 24, [24])])
 def test_column_pass_kernels(ctx, n, p, blocks):
     """standardize_sweep / sweep / deflate_sweep against numpy on the same data."""
     from mbpls_amd import DeviceMatrix, _capi
@@ -283,6 +283,13 @@ def test_edges(gpu_required):
     Xnan = X.copy(); Xnan[0, 0] = np.nan
     with pytest.raises(ValueError):
         MBPLS().fit(Xnan, Y)
+    with pytest.raises(ValueError):
+        MBPLS(standardize=False).fit(Xnan, Y)
+    Xinf = X.copy(); Xinf[3, 7] = np.inf
+    with pytest.raises(ValueError):
+        MBPLS(method="KERNEL").fit(Xinf, Y)
+    with pytest.raises(ValueError):
+        m0.predict(Xnan)
     from sklearn.exceptions import NotFittedError
     with pytest.raises(NotFittedError):
         MBPLS().predict(X)
@@ -316,6 +323,8 @@ def test_sklearn_plumbing(gpu_required):
     ("KERNEL", 1000, 9000, 3, 4, [9000]),
     ("SIMPLS", 2048, 15000, 2, 4, [15000]),
     ("NIPALS", 8192, 9000, 1, 3, [4000, 5000]),
+    ("NIPALS", 10000, 3000, 1, 2, [3000]),          # n > 8192: long-column fallback kernels
+    ("UNIPALS", 4096, 12000, 2, 12, [12000]),       # K = 12 lazily deflated components, q = 2
 ])
 def test_medium_vs_oracle(gpu_required, method, n, p, q, K, blocks):
     from mbpls_amd import MBPLS
