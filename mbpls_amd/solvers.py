@@ -125,6 +125,9 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
     # host copies of the p x K attributes, filled column by column while later passes run on the GPU
     Wn_h = np.empty((eng.p, K), order="F"); W_h = np.empty((eng.p, K), order="F"); P_h = np.empty((eng.p, K), order="F")
+    import os
+    q1_fixed_point = (q == 1 and os.environ.get("MBPLS_NIPALS_Q1_FIXED_POINT", "0") == "1"
+                      and hasattr(eng, "right_mul"))
     for k in range(K):
         u = u0
         diff, run, ts_old = 1.0, 1, None
@@ -145,6 +148,17 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
             u = Y.dot(v) / v.T.dot(v)                       # (:911)
             u = u / np.linalg.norm(u)
             run += 1
+            if q1_fixed_point and run == 2:
+                # OPT-IN (off by default).  One response: u after the first pass is sign(v) Y/||Y|| whatever ts
+                # was (v is 1 x 1, and v = Y^T ts > 0 because Y^T ts is a sum of squares), so the second pass
+                # would compute w~_2 = ||Y|| w~_1 and reproduce ts exactly: the iteration is at its fixed point
+                # and the reference's second sweep (:841, run 2) only re-derives it.  Skip it, rescale w~.
+                ynorm = float(np.linalg.norm(u0))
+                eng.right_mul(("Wn", k, 1), np.array([[ynorm]]), ("Wn", k))
+                if hasattr(eng, "ctx"):
+                    eng.ctx.sync()      # the column is streamed to the host on another stream right after
+                nu = nu * ynorm
+                diff = 0.0
             if run - 1 >= max_iter and diff > max_tol:
                 warnings.warn(f"NIPALS component {k}: no convergence to max_tol={max_tol} after {max_iter} "
                               f"iterations (last diff {diff:.3e}); the reference would loop forever here.")

@@ -374,3 +374,16 @@ def test_small_dense_helpers(ctx, p, c1, c2):
     assert util.relerr(Dh[r0:r1], A[r0:r1] * np.arange(1, c1 + 1.0)) < TIGHT
     assert not Dh[:r0].any() and not Dh[r1:].any()
     eng.close()
+
+
+def test_q1_fixed_point_option(gpu_required, monkeypatch):
+    """Opt-in shortcut (MBPLS_NIPALS_Q1_FIXED_POINT=1): same attributes, one pass per component less."""
+    from mbpls_amd import MBPLS
+    X, Y = orc.make_latent(4096, 12000, 1, seed=21)
+    blocks = [np.ascontiguousarray(X[:, :5000]), np.ascontiguousarray(X[:, 5000:])]
+    ref = orc.fit(blocks, Y, n_components=4, method="NIPALS")
+    monkeypatch.setenv("MBPLS_NIPALS_Q1_FIXED_POINT", "1")
+    mdl = MBPLS(n_components=4).fit(blocks, Y)
+    assert mdl.nipals_iterations_ == [1, 1, 1, 1]
+    w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="q1 fixed point")
+    assert w < 1e-9

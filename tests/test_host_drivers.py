@@ -63,3 +63,17 @@ def test_nipals_iterations_q1():
     res = run_driver(g["x"], g["y"], "NIPALS", 2)
     assert res.nipals_iterations_ == [2, 2]
     util.compare(util.model_to_flat(res), util.sub(g, "ref/NIPALS"), TOL, skip=FIT_ONLY_SKIP)
+
+
+def test_q1_fixed_point_option(monkeypatch):
+    """Opt-in: for one response the second NIPALS pass is skipped; every attribute must be unchanged."""
+    g = util.load("quickstart_c1")
+    monkeypatch.setenv("MBPLS_NIPALS_Q1_FIXED_POINT", "1")
+    res = run_driver(g["x"], g["y"], "NIPALS", 2)
+    assert res.nipals_iterations_ == [1, 1]
+    util.compare(util.model_to_flat(res), util.sub(g, "ref/NIPALS"), TOL, skip=FIT_ONLY_SKIP)
+    g = util.load("matrix_pgtn")
+    splits = np.cumsum(g["splits"])[:-1]
+    X, Y = g["in/q1/X"], g["in/q1/Y"]
+    res = run_driver(list(np.split(X, splits, axis=1)), Y, "NIPALS", 3)
+    util.compare(util.model_to_flat(res), util.sub(g, "ref/q1/multi/NIPALS/std1/ca1"), TOL, skip=FIT_ONLY_SKIP)
