@@ -137,6 +137,16 @@ int mbpls_hip_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode,
                                 const double* d_v, double alpha,
                                 double* d_g, double* d_t, double* d_ssq_g);
 
+/* Same, for a fit on a ROW SUBSET of a resident matrix (cross-validation folds, mbpls users call
+ * cross_val_predict(MBPLS(k), X, y, cv=n)): d_rowmask has n doubles, 0 = sample excluded.  Excluded rows
+ * are written as 0 into dst -- every later pass then ignores them for free -- and mean / variance are
+ * taken over the n_eff included samples.  d_rowmask == NULL is the plain call. */
+int mbpls_hip_standardize_sweep_masked(const mbpls_mat* src, mbpls_mat* dst, int mode,
+                                       const double* d_rowmask, double n_eff,
+                                       double* d_mean, double* d_scale, double* d_ssq_x,
+                                       const double* d_v, double alpha,
+                                       double* d_g, double* d_t, double* d_ssq_g);
+
 /* One NIPALS inner iteration over X in ONE read (mbpls.py:856 + :875, a2+a3 of SURVEY 8a):
  *   g = alpha * X^T v                (w~_b = X_b^T u / (u^T u), all blocks at once)
  *   t_b = X_b g_b                    (UN-normalised block scores; caller divides by ||g_b||)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mbpls_hip_mat_copy": (_int, [_vp, _vp]),
     "mbpls_hip_mat_fill_latent": (_int, [_vp, _vp, _int, _dbl, C.c_uint64, _i64]),
     "mbpls_hip_standardize_sweep": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
+    "mbpls_hip_standardize_sweep_masked": (_int, [_vp, _vp, _int, _vp, _dbl, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
     "mbpls_hip_sweep": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp]),
     "mbpls_hip_deflate_sweep": (_int, [_vp, _vp, _dbl, _int, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
     "mbpls_hip_sweep_lazy": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp]),
@@ -357,9 +358,11 @@ class DeviceMatrix:
         check(self.ctx.lib.mbpls_hip_mat_fill_latent(self.handle, Ts_dev.ptr, int(r), float(noise), int(seed), int(col_base)))
 
     # ---- hot path
-    def standardize_sweep(self, dst, mode, mean, scale, ssq_x, v=None, alpha=1.0, g=None, t=None, ssq_g=None):
-        check(self.ctx.lib.mbpls_hip_standardize_sweep(self.handle, dst.handle, int(mode), _ptr(mean), _ptr(scale),
-                                                       _ptr(ssq_x), _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g)))
+    def standardize_sweep(self, dst, mode, mean, scale, ssq_x, v=None, alpha=1.0, g=None, t=None, ssq_g=None,
+                          rowmask=None, n_eff=0.0):
+        check(self.ctx.lib.mbpls_hip_standardize_sweep_masked(
+            self.handle, dst.handle, int(mode), _ptr(rowmask), float(n_eff), _ptr(mean), _ptr(scale), _ptr(ssq_x),
+            _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g)))
 
     def sweep(self, v, alpha, g, t, ssq_g):
         check(self.ctx.lib.mbpls_hip_sweep(self.handle, _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g)))

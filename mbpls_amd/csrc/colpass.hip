@@ -42,6 +42,8 @@ struct PassArgs {
   // partial outputs
   double* part_t;  // [nchunks][n]
   double* part_s;  // [nchunks][4]: ssq_g, ssq_p, ssq_x, -
+  const double* rowmask;   // standardise pass only: samples excluded from the fit (cross-validation folds)
+  double n_eff;            // number of included samples (used instead of n for mean / variance)
   // lazy (implicit) deflation: X in HBM stays X_0; X_k = X_0 - sum_{i<kprev} ts_i P[:,i]^T is applied algebraically
   int lazy;            // 0: explicit in-place deflation, 1: implicit
   int kprev;           // components already deflated (<= KD-1)
@@ -61,7 +63,10 @@ struct RowMap {
   unsigned off[R / 2];   // byte offset of the pair inside a column
   unsigned in_ld;        // bit k: pair k lies inside the column allocation (r0 < ld)
   unsigned in_n0, in_n1; // bit k: row r0 / r0+1 is a real sample (< n)
-  __device__ __forceinline__ void init(int64_t n, int64_t ld, int tid, int T) {
+  // rowmask (optional, n doubles, 0 = sample excluded): excluded rows are treated exactly like rows
+  // beyond n -- they load as 0 -- which is all a fit on a ROW SUBSET needs (cross-validation folds on a
+  // matrix that stays resident in HBM).
+  __device__ __forceinline__ void init(int64_t n, int64_t ld, int tid, int T, const double* rowmask = nullptr) {
     in_ld = in_n0 = in_n1 = 0u;
 #pragma unroll
     for (int k = 0; k < R / 2; ++k) {
@@ -70,8 +75,13 @@ struct RowMap {
       const bool inside = (int64_t)r0 < ld;
       off[k] = inside ? r0 * 8u : 0u;   // out-of-allocation pairs re-read pair 0 (masked below)
       in_ld |= (inside ? 1u : 0u) << k;
-      in_n0 |= ((int64_t)r0 < n ? 1u : 0u) << k;
-      in_n1 |= ((int64_t)r0 + 1 < n ? 1u : 0u) << k;
+      bool k0 = (int64_t)r0 < n, k1 = (int64_t)r0 + 1 < n;
+      if (rowmask) {
+        if (k0) k0 = rowmask[r0] != 0.0;
+        if (k1) k1 = rowmask[r0 + 1] != 0.0;
+      }
+      in_n0 |= (k0 ? 1u : 0u) << k;
+      in_n1 |= (k1 ? 1u : 0u) << k;
     }
   }
 };
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   const int chunk = blockIdx.x;
   const int64_t j0 = uniform64(a.c0[chunk]), j1 = uniform64(a.c1[chunk]);
   RowMap<R> rm;
-  rm.init(n, ld, tid, T);
+  rm.init(n, ld, tid, T, STD ? a.rowmask : nullptr);
 
   // The fused loadings+sweep variant of the n=4096 configuration needs x[2], ts, v, acc = 80 VGPRs of
   // column data; with the lazy-deflation state that no longer fits 128.  Its score vector ts therefore
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
     tsv = s[0];
   }
   double ssq_g = 0.0, ssq_p = 0.0, ssq_x = 0.0;
-  const double dn = (double)n;
+  const double dn = (STD && a.rowmask) ? a.n_eff : (double)n;   // samples that take part in the statistics
   // lazy deflation: thread i < kprev carries the correction of previous component i
   const bool lazy = !STD && a.lazy != 0;
   const bool mine = lazy && tid < a.kprev;
@@ -468,7 +478,7 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
   const int D = ctx->prefetch >= 1 && ctx->prefetch <= 3 ? ctx->prefetch : 2;
   // FULL: every thread's every row pair is a real sample and columns are unpadded (n=4096, 8192, ...)
-  const bool full = (a.n == (int64_t)T * cfg.R) && (a.ld == a.n) && cfg.R >= 8;
+  const bool full = (a.n == (int64_t)T * cfg.R) && (a.ld == a.n) && cfg.R >= 8 && !(STD && a.rowmask);
 #define MB_LAUNCH(R_, TM_, D_)                                                                          \
   do {                                                                                                  \
     if (full && (R_) >= 8)                                                                              \
@@ -603,7 +613,15 @@ int mbpls_hip_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double
 int mbpls_hip_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode, double* d_mean, double* d_scale,
                                 double* d_ssq_x, const double* d_v, double alpha, double* d_g, double* d_t,
                                 double* d_ssq_g) {
+  return mbpls_hip_standardize_sweep_masked(src, dst, mode, nullptr, 0.0, d_mean, d_scale, d_ssq_x, d_v, alpha, d_g,
+                                            d_t, d_ssq_g);
+}
+
+int mbpls_hip_standardize_sweep_masked(const mbpls_mat* src, mbpls_mat* dst, int mode, const double* d_rowmask,
+                                       double n_eff, double* d_mean, double* d_scale, double* d_ssq_x,
+                                       const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g) {
   MB_ARG(src && dst, "NULL argument");
+  MB_ARG(!d_rowmask || n_eff >= 1.0, "n_eff must be the number of included samples");
   MB_ARG(src->n == dst->n && src->p == dst->p && src->ld == dst->ld, "src/dst shape mismatch");
   MB_ARG(mode == MBPLS_SCALE_FIT || mode == MBPLS_SCALE_APPLY || mode == MBPLS_SCALE_NONE, "bad mode %d", mode);
   MB_ARG(mode == MBPLS_SCALE_NONE || (d_mean && d_scale), "mean/scale buffers required");
@@ -613,6 +631,7 @@ int mbpls_hip_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode, 
   a.src = src->data; a.dst = dst->data; a.ld = dst->ld; a.n = dst->n;
   a.c0 = dst->fine.d_c0; a.c1 = dst->fine.d_c1;
   a.mode = mode; a.mean = d_mean; a.scale = d_scale;
+  a.rowmask = d_rowmask; a.n_eff = n_eff;
   a.v = d_v; a.alpha = alpha; a.g = d_g;
   if (d_v) {
     MB_TRY((launch_pass<true, false, true>(ctx, dst->fine, a, dst->p)));

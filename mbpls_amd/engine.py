@@ -229,9 +229,16 @@ class HipEngine:
             mode = _capi.SCALE_NONE
         src = self._src if self._src is not None else self.X
         dv = self._put_vec(0, v) if v is not None else None
+        # row subset (cross-validation fold): excluded samples become zero rows of the working copy and the
+        # column statistics are taken over the included ones only
+        dm, n_eff = None, 0.0
+        if getattr(self, "rowmask", None) is not None:
+            m = np.ascontiguousarray(self.rowmask, dtype=np.float64).ravel()
+            assert m.size == n
+            dm, n_eff = self.ctx.from_host(m), float(np.count_nonzero(m))
         src.standardize_sweep(self.X, mode, self.mean, self.scale, self._xptr(n * B + 2 * B), dv, alpha,
                               self._slot_col(g_slot), self._xptr(0) if v is not None else None,
-                              self._xptr(n * B) if v is not None else None)
+                              self._xptr(n * B) if v is not None else None, rowmask=dm, n_eff=n_eff)
         self._src = None
         t, g, _, x = self._finish_pass(v is not None, v is not None, False, True)
         if not np.all(np.isfinite(x)):

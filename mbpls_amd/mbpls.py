@@ -121,6 +121,12 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
 
         X : 2-D array, list of 2-D arrays (blocks), or a ``DeviceMatrix`` resident in HBM
         Y : 1-D or 2-D array"""
+        return self._fit(X, Y, None)
+
+    def _fit(self, X, Y, row_mask):
+        """fit() on the samples where ``row_mask`` is True (None = all): the engine zeroes the excluded rows
+        of its working copy, so the matrix never has to be re-uploaded or sliced for cross-validation folds
+        (``mbpls_amd.model_selection``).  n-row attributes are returned for the included samples only."""
         if self.sparse_data is True:
             raise NotImplementedError(
                 "sparse_data=True (NaN-aware NIPALS, reference mbpls.py:846-909) is outside the HIP hot path")
@@ -138,12 +144,21 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             raise NameError('Method you called is unknown')                         # :1050
         if self.method == 'SIMPLS':
             warnings.warn("Method 'SIMPLS' does not calculate A_ and T_!")          # :996
+        if row_mask is not None:
+            row_mask = np.asarray(row_mask, dtype=bool).ravel()
+            if row_mask.size != Y.shape[0] or not row_mask.any():
+                raise ValueError("row_mask must select at least one of the n samples")
+            if not device_input or not self.copy:
+                raise ValueError("row-subset fits need a DeviceMatrix and copy=True (the resident matrix is kept)")
         if self.standardize:
-            self.y_scaler_ = ColumnScaler().fit(Y)                                  # :325-326
+            self.y_scaler_ = ColumnScaler().fit(Y if row_mask is None else Y[row_mask])   # :325-326
             Ys = self.y_scaler_.transform(Y)
         else:
             Ys = Y
+        if row_mask is not None:
+            Ys = np.where(row_mask[:, None], Ys, 0.0)      # excluded samples take no part in any sum
         eng = self._engine()
+        eng.rowmask = None if row_mask is None else row_mask.astype(np.float64)
         import time as _time
         t_fit0 = _time.perf_counter()
         threads = runtime.host_threads()
@@ -164,6 +179,12 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
                 res = solvers.fit_kernel(eng, Ys, K, self.standardize, self.calc_all)
             else:
                 res = solvers.fit_simpls(eng, Ys, K, self.standardize)
+            if row_mask is not None:                        # n-row outputs: included samples only
+                for key in ("Ts_", "U_"):
+                    if key in res:
+                        res[key] = res[key][row_mask]
+                if isinstance(res.get("T_"), list):
+                    res["T_"] = [t[row_mask] for t in res["T_"]]
             with eng._timed("store_attributes"):
                 self._store(eng, res)
         finally:

@@ -1,0 +1,62 @@
+"""Cross-validation on a matrix that stays resident in HBM.
+
+The reference's users call ``sklearn.model_selection.cross_val_predict(MBPLS(k), X, y, cv=len(X))``
+(examples/real_world_applications/*.ipynb): leave-one-out = n complete refits, each on a fresh row
+slice of X.  Here X is uploaded once; a fold is a *row mask* handed to the standardise pass, which
+writes zero rows for the held-out samples into the working copy (every later pass then ignores them
+for free) and takes the column statistics over the training samples only.  Predictions for the held-out
+rows come from one ``x_w`` pass over the same resident matrix.  No re-upload, no host slicing.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _capi, runtime
+from .mbpls import MBPLS, _is_block_list
+
+
+def _resident(X):
+    """Upload host blocks once (feature-major, side by side); pass a DeviceMatrix through."""
+    if isinstance(X, _capi.DeviceMatrix):
+        return X, False
+    blocks = X if _is_block_list(X) else [X]
+    blocks = [np.asarray(b, dtype=np.float64) for b in blocks]
+    n = blocks[0].shape[0]
+    offs = np.concatenate(([0], np.cumsum([b.shape[1] for b in blocks]))).astype(np.int64)
+    ctx = runtime.get_context()
+    dm = _capi.DeviceMatrix(ctx, n, int(offs[-1]), offs)
+    for b, o in zip(blocks, offs[:-1]):
+        dm.upload(b, int(o))
+    return dm, True
+
+
+def cross_val_predict(estimator, X, y, cv=5, groups=None):
+    """Out-of-fold predictions of ``estimator`` (an ``MBPLS``), like sklearn's ``cross_val_predict``.
+
+    cv: int (KFold without shuffling, as sklearn does for regressors), a CV splitter, or an iterable of
+    (train, test) index pairs.  Returns an (n, q) array (``predict``'s shape)."""
+    if not isinstance(estimator, MBPLS):
+        raise TypeError("cross_val_predict of mbpls_amd works on mbpls_amd.MBPLS estimators")
+    y = np.asarray(y, dtype=np.float64)
+    y2 = y.reshape(-1, 1) if y.ndim == 1 else y
+    n = y2.shape[0]
+    if hasattr(cv, "split") or isinstance(cv, (int, np.integer)) or cv is None:
+        from sklearn.model_selection import check_cv
+        splits = list(check_cv(cv, y2, classifier=False).split(np.zeros((n, 1)), y2, groups))
+    else:
+        splits = [(np.asarray(tr), np.asarray(te)) for tr, te in cv]
+    Xdev, owned = _resident(X)
+    try:
+        if Xdev.n != n:
+            raise ValueError(f"Found input variables with inconsistent numbers of samples: [{Xdev.n}, {n}]")
+        out = np.full((n, y2.shape[1]), np.nan)
+        for train, test in splits:
+            est = MBPLS(**{**estimator.get_params(), "copy": True})
+            mask = np.zeros(n, dtype=bool)
+            mask[train] = True
+            est._fit(Xdev, y2, mask)
+            out[test] = est.predict(Xdev)[test]
+        return out
+    finally:
+        if owned:
+            Xdev.close()

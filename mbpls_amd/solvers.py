@@ -413,7 +413,12 @@ def fit_simpls(eng, Y, K, standardize):
         w = r.copy()
         eng.put("r", r)
         t = eng.x_w_slot("r", 0, 1)                         # (:1006)
-        t = t - np.mean(t)
+        rm = getattr(eng, "rowmask", None)
+        if rm is None:
+            t = t - np.mean(t)
+        else:                                               # row-subset fit: centre over the included samples
+            inc = np.asarray(rm).ravel() != 0
+            t = np.where(inc[:, None], t - t[inc].mean(), 0.0)
         nt = np.sqrt(t.T.dot(t))
         t = t / nt; r = r / nt                              # (:1008-1010)
         eng.xt_v(t, 1.0, "p", 0)

@@ -74,10 +74,15 @@ class NumpyEngine:
 
     def prepare(self, standardize, v=None, alpha=1.0, g_slot=None, mean=None, scale=None):
         X = self.Xm
+        rm = getattr(self, "rowmask", None)
+        inc = None if rm is None else (np.asarray(rm).ravel() != 0)
+        if inc is not None:
+            X = np.where(inc[:, None], X, 0.0)
+            self.Xm = X
         if standardize:
-            n = X.shape[0]
+            n = X.shape[0] if inc is None else int(inc.sum())
             mu = X.sum(axis=0) / n
-            d = X - mu
+            d = X - mu if inc is None else np.where(inc[:, None], X - mu, 0.0)
             var = ((d ** 2).sum(axis=0) - d.sum(axis=0) ** 2 / n) / n
             sc = np.sqrt(var)
             sc[var <= n * _EPS * var + (n * mu * _EPS) ** 2] = 1.0

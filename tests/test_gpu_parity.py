@@ -387,3 +387,42 @@ def test_q1_fixed_point_option(gpu_required, monkeypatch):
     assert mdl.nipals_iterations_ == [1, 1, 1, 1]
     w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="q1 fixed point")
     assert w < 1e-9
+
+
+def test_row_subset_fit_and_cross_val_predict(gpu_required):
+    """Fits on a ROW SUBSET of a resident matrix == the oracle on the sliced arrays; cross_val_predict on the
+    device == a loop of oracle fits (what sklearn's cross_val_predict does with the reference)."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix
+    from mbpls_amd.model_selection import cross_val_predict
+    n, p = 120, 900
+    X, Y = orc.make_latent(n, p, 2, r=6, seed=4)
+    blocks = [np.ascontiguousarray(X[:, :400]), np.ascontiguousarray(X[:, 400:])]
+    ctx = mbpls_amd.get_context()
+    Xd = DeviceMatrix(ctx, n, p, [0, 400, p])
+    Xd.upload(X)
+    rng = np.random.RandomState(0)
+    mask = rng.rand(n) > 0.25
+    for method in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+        for std in (True, False):
+            ref = orc.fit([b[mask] for b in blocks], Y[mask], n_components=3, method=method, standardize=std,
+                          full_svd=True)
+            mdl = MBPLS(n_components=3, method=method, standardize=std)._fit(Xd, Y, mask)
+            w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"subset/{method}/{std}")
+            assert w < 1e-9, (method, std, w)
+            assert util.relerr(mdl.predict(Xd)[~mask], orc.predict(ref, [b[~mask] for b in blocks])) < 1e-9
+    assert np.array_equal(Xd.download(), X)          # the resident matrix is untouched by all those fits
+    # k-fold and leave-one-out style CV (5 folds + an explicit split list)
+    for cv in (5, [(np.arange(n)[np.arange(n) % 3 != f], np.arange(n)[np.arange(n) % 3 == f]) for f in range(3)]):
+        got = cross_val_predict(MBPLS(n_components=2), Xd, Y, cv=cv)
+        from sklearn.model_selection import check_cv
+        splits = list(check_cv(cv, Y, classifier=False).split(np.zeros((n, 1)), Y)) if isinstance(cv, int) else cv
+        want = np.empty_like(Y)
+        for tr, te in splits:
+            r = orc.fit([b[tr] for b in blocks], Y[tr], n_components=2)
+            want[te] = orc.predict(r, [b[te] for b in blocks])
+        assert util.relerr(got, want) < 1e-9
+    # host input is uploaded once
+    got2 = cross_val_predict(MBPLS(n_components=2), blocks, Y, cv=5)
+    assert util.relerr(got2, cross_val_predict(MBPLS(n_components=2), Xd, Y, cv=5)) < 1e-12
+    Xd.close()
