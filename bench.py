@@ -73,8 +73,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # N processes share one node's CPU quota: keep torch's host pools from oversubscribing it
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
         import torch
         import torch.distributed as dist
+        torch.set_num_threads(1)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         mbpls_amd.set_device(local_rank)
