@@ -240,6 +240,10 @@ class HipEngine:
                               self._slot_col(g_slot), self._xptr(0) if v is not None else None,
                               self._xptr(n * B) if v is not None else None, rowmask=dm, n_eff=n_eff)
         self._src = None
+        cb = getattr(self, "on_first_pass", None)
+        if cb is not None:          # host work hidden behind the longest pass of the fit
+            self.on_first_pass = None
+            cb()
         t, g, _, x = self._finish_pass(v is not None, v is not None, False, True)
         if not np.all(np.isfinite(x)):
             # any NaN / inf in a column poisons its sum of squares (and its mean / scale)

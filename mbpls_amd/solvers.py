@@ -398,7 +398,57 @@ def _xtx(eng):
 # ----------------------------------------------------------------------------------- SIMPLS
 def fit_simpls(eng, Y, K, standardize):
     """mbpls.py:995-1048 (de Jong 1993).  X is never deflated: S = X^T Y once, then per component
-    t = X r and p = X^T t (two reads of X)."""
+    t = X r and p = X^T t (two reads of X).  All p-length algebra (r = S q, the Gram-Schmidt step on v,
+    S <- S - v v^T S) runs on the device in one p x (K+1+q) slot  Z = [V_s | p | S]; only q x q and
+    k x 1 matrices visit the host."""
+    n = eng.n
+    q = Y.shape[1]
+    if K + 1 + q > 32 or not hasattr(eng, "right_mul"):
+        return _fit_simpls_hostvec(eng, Y, K, standardize)
+    eng.prepare(standardize)
+    nz = K + 1 + q
+    cS = K + 1                                              # first S column inside Z
+    eng.slot("Z", nz); eng.slot("R", K); eng.slot("W", K); eng.slot("P", K)
+    eng.xt_v(Y, 1.0, "Z", cS)                               # S = X^T Y (:998)
+    rm = getattr(eng, "rowmask", None)
+    inc = None if rm is None else (np.asarray(rm).ravel() != 0)
+    Ts = np.empty((n, K)); U = np.empty((n, K)); Q = np.empty((q, K))
+    for comp in range(K):
+        StS = eng.cross(("Z", cS, q), ("Z", cS, q))
+        qv = np.array([[1.0]]) if q == 1 else np.linalg.svd(StS, full_matrices=True)[0][:, 0:1]  # (:1001)
+        eng.right_mul(("Z", cS, q), qv, ("W", comp))        # w = r = S q (:1004-1005)
+        t = eng.x_w_slot("W", comp, 1)                      # (:1006)
+        t = t - np.mean(t) if inc is None else np.where(inc[:, None], t - t[inc].mean(), 0.0)   # (:1007)
+        nt = np.sqrt(t.T.dot(t)).item()
+        t = t / nt                                          # (:1008-1009)
+        eng.right_mul(("W", comp, 1), np.array([[1.0 / nt]]), ("R", comp))   # r / ||t|| (:1010)
+        eng.xt_v(t, 1.0, "Z", K)                            # p = X^T t (:1011) into the scratch column
+        eng.right_mul(("Z", K, 1), np.array([[1.0]]), ("P", comp))
+        qk = Y.T.dot(t)                                     # (:1012)
+        u = Y.dot(qk)                                       # (:1013)
+        coef = np.zeros((nz, 1))
+        coef[K, 0] = 1.0
+        if comp > 0:
+            coef[:comp] = -eng.cross(("Z", 0, comp), ("Z", K, 1))     # v = p - V_s (V_s^T p) (:1016)
+            u = u - Ts[:, :comp].dot(Ts[:, :comp].T.dot(u))            # (:1017)
+        eng.right_mul(("Z", 0, nz), coef, ("Z", comp))
+        vv = eng.cross(("Z", comp, 1), ("Z", comp, 1)).item()
+        eng.right_mul(("Z", comp, 1), np.array([[1.0 / np.sqrt(vv)]]), ("Z", comp))     # (:1018)
+        vS = eng.cross(("Z", comp, 1), ("Z", cS, q))        # v^T S (1 x q)
+        M = np.zeros((nz, q))
+        M[cS:, :] = np.eye(q)
+        M[comp, :] = -vS
+        eng.right_mul(("Z", 0, nz), M, ("Z", cS))           # S <- S - v (v^T S) (:1019), in place
+        Ts[:, comp:comp + 1] = t; U[:, comp:comp + 1] = u / np.linalg.norm(u); Q[:, comp:comp + 1] = qk
+    P = eng.fetch("P")
+    res = FitResult(P_=_split(P, eng.block_offsets), Ts_=Ts, U_=U, R_=eng.fetch("R"), V_=Q, W_=eng.fetch("W"))
+    res.beta_ = res.R_.dot(res.V_.T)                        # (:1044)
+    return res
+
+
+def _fit_simpls_hostvec(eng, Y, K, standardize):
+    """SIMPLS with the p-length vectors on the host (used when K + 1 + q exceeds the 32-column limit of the
+    device helpers)."""
     n = eng.n
     q = Y.shape[1]
     eng.prepare(standardize)
