@@ -61,7 +61,6 @@ struct mbpls_ctx {
   int rows_per_thread = 0;   // 0 = auto
   int prefetch = 2;          // columns in flight per workgroup (register slots)
   int xw_chunks_per_cu = 1;
-  int nontemporal = 3;       // bit 0: nt loads, bit 1: nt stores in the column passes (X is streamed once per pass)
   // workspace for chunk partials (grown on demand, never shrunk)
   void* ws = nullptr;
   size_t ws_bytes = 0;

@@ -213,7 +213,6 @@ int mbpls_hip_create(int device, void* stream, mbpls_ctx** out) {
   if (const char* e = getenv("MBPLS_HIP_CHUNKS_PER_CU")) ctx->chunks_per_cu = std::max(1, atoi(e));
   if (const char* e = getenv("MBPLS_HIP_ROWS_PER_THREAD")) ctx->rows_per_thread = atoi(e);
   if (const char* e = getenv("MBPLS_HIP_PREFETCH")) ctx->prefetch = atoi(e);
-  if (const char* e = getenv("MBPLS_HIP_NONTEMPORAL")) ctx->nontemporal = atoi(e);
   if (const char* e = getenv("MBPLS_HIP_XW_CHUNKS_PER_CU")) ctx->xw_chunks_per_cu = std::max(1, atoi(e));
   hipError_t e0 = hipEventCreate(&ctx->ev0), e1 = hipEventCreate(&ctx->ev1);
   if (e0 != hipSuccess || e1 != hipSuccess) {
@@ -275,7 +274,6 @@ int mbpls_hip_set_tunable(mbpls_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "rows_per_thread")) ctx->rows_per_thread = value;
   else if (!strcmp(key, "xw_chunks_per_cu")) ctx->xw_chunks_per_cu = std::max(1, value);
   else if (!strcmp(key, "prefetch")) ctx->prefetch = value;
-  else if (!strcmp(key, "nontemporal")) ctx->nontemporal = value;
   else MB_ARG(false, "unknown tunable '%s'", key);
   return MBPLS_OK;
 }

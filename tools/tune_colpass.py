@@ -25,7 +25,6 @@ results = []
 Rs = [int(x) for x in os.environ.get("TUNE_R", "4,8,16").split(",")]
 Ds = [int(x) for x in os.environ.get("TUNE_D", "1,2,3").split(",")]
 Cs = [int(x) for x in os.environ.get("TUNE_C", "2,4,8").split(",")]
-NTs = [int(x) for x in os.environ.get("TUNE_NT", "0").split(",")]
 for cpc in Cs:
     ctx.set_tunable("chunks_per_cu", cpc)
     X = DeviceMatrix(ctx, n, p)
@@ -35,10 +34,9 @@ for cpc in Cs:
     d_mean, d_scale = ctx.empty(p), ctx.empty(p)
     d_s = [ctx.empty(B) for _ in range(3)]
     d_g, d_t, d_p = ctx.empty(p), ctx.empty(n * B), ctx.empty(p)
-    for R, D, NT in itertools.product(Rs, Ds, NTs):
+    for R, D in itertools.product(Rs, Ds):
         ctx.set_tunable("rows_per_thread", R)
         ctx.set_tunable("prefetch", D)
-        ctx.set_tunable("nontemporal", NT)
         try:
             X.standardize_sweep(W, _capi.SCALE_FIT, d_mean, d_scale, d_s[0], dv, 1.0, d_g, d_t, d_s[1])
             ctx.sync()
@@ -52,10 +50,10 @@ for cpc in Cs:
             W.deflate_sweep(dts, 1.0, True, d_p, d_s[2], dv, 1.0, d_g, d_t, d_s[1])
             W.deflate_sweep(dts, 1.0, False, d_p, d_s[2])
         pr = ctx.profile_get(); ctx.profile(False)
-        row = (cpc, R, D * 10 + NT, pr["standardize_sweep"]["GBps"], pr["sweep"]["GBps"], pr["deflate_sweep"]["GBps"],
+        row = (cpc, R, D, pr["standardize_sweep"]["GBps"], pr["sweep"]["GBps"], pr["deflate_sweep"]["GBps"],
                pr["deflate"]["GBps"])
         results.append(row)
-        print("chunks/CU %d  R %2d  D*10+NT %2d | standardize %6.0f  sweep %6.0f  deflate_sweep %6.0f  loadings %6.0f GB/s"
+        print("chunks/CU %d  R %2d  D %d | standardize %6.0f  sweep %6.0f  deflate_sweep %6.0f  loadings %6.0f GB/s"
               % row, flush=True)
     X.close(); W.close()
 best = max(results, key=lambda r: r[5])
