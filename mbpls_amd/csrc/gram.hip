@@ -77,14 +77,23 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   const char* xb = (const char*)(a.X + jbeg * a.ld);
   const int64_t gstride = 4 * a.ld * 8;               // bytes between consecutive groups
   double av[PD][4], bv[PD][4];
+  // The ring's loads are inline asm on purpose: hipcc's own waitcnt insertion loses the exact queue depth
+  // across the loop back-edge and emits vmcnt(8) -- i.e. it waits for the groups issued one and two steps
+  // ago as well, which leaves ONE step of latency cover and 35 % of the requests miss L2 here.  With the
+  // loads invisible to that pass the wait is counted by hand: after issuing group g+3 there are 4 groups
+  // (32 loads) in flight and vmcnt(24) retires exactly the oldest one, the group about to be consumed.
+  // Rules kept (cdna_hip_programming.md 5.7): no asm output is read before its wait; sched_barrier pins
+  // the order; vmcnt(0) right behind the loop so no late load lands in a re-used register.
+#define MB_GLD(dst, off, base) \
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory")
   if (nmain > 0) {
 #pragma unroll
     for (int s = 0; s < PD - 1; ++s) {
       const char* g = xb + s * gstride;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        av[s][t] = *(const double*)(g + oa[t]);
-        bv[s][t] = *(const double*)(g + ob[t]);
+        MB_GLD(av[s][t], oa[t], g);
+        MB_GLD(bv[s][t], ob[t], g);
       }
     }
     static_assert(PD == 4, "the step macro below is written for a ring of 4 slots");
@@ -94,9 +103,11 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
     nx = nx < nmain ? nx : nmain - 1;             /* clamp: a valid group that is never consumed */         \
     const char* g = xb + nx * gstride;                                                                      \
     _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                         \
-      av[SL][t] = *(const double*)(g + oa[t]);                                                              \
-      bv[SL][t] = *(const double*)(g + ob[t]);                                                              \
+      MB_GLD(av[SL][t], oa[t], g);                                                                          \
+      MB_GLD(bv[SL][t], ob[t], g);                                                                          \
     }                                                                                                       \
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)       \
         acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[S][mi], bv[S][ni], acc[mi][ni], 0, 0, 0);     \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -108,7 +119,10 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
       MB_GRAM_STEP(3, 2)
     }
 #undef MB_GRAM_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   }
+#undef MB_GLD
   // remaining complete groups (< PD of them) and the ragged feature tail (p % 4), unpipelined
   for (int64_t st = nmain; st * 4 < jend - jbeg; ++st) {
     const int64_t j = jbeg + 4 * st;
