@@ -128,14 +128,17 @@ class HipEngine:
             arr = arr.reshape(-1, 1)
         return self.slot(name, arr.shape[1]).set(arr)
 
-    def cross(self, a, b):
-        """(slot a[:, ka:ka+ca])^T (slot b[:, kb:kb+cb]) -> host ca x cb, summed over shards.
-        a, b are (name, k0, ncols) triples."""
+    def cross(self, a, b, rows=None):
+        """(slot a[rows, ka:ka+ca])^T (slot b[rows, kb:kb+cb]) -> host ca x cb, summed over shards.
+        a, b are (name, k0, ncols) triples; rows = (r0, r1) restricts the sum to a block of features."""
         (na, ka, ca), (nb, kb, cb) = a, b
         A, Bm = self.slots[na], self.slots[nb]
-        out = np.empty((ca, cb), dtype=np.float64)
-        _capi.check(self.ctx.lib.mbpls_hip_cross_product(self.ctx.handle, self.p, A.ptr + 8 * self.p * ka, self.p, ca,
-                                                         Bm.ptr + 8 * self.p * kb, self.p, cb, out.ctypes.data))
+        r0, r1 = rows if rows is not None else (0, self.p)
+        out = np.zeros((ca, cb), dtype=np.float64)
+        if r1 > r0:
+            _capi.check(self.ctx.lib.mbpls_hip_cross_product(self.ctx.handle, r1 - r0, A.ptr + 8 * (self.p * ka + r0),
+                                                             self.p, ca, Bm.ptr + 8 * (self.p * kb + r0), self.p, cb,
+                                                             out.ctypes.data))
         return self.comm.allreduce_host(out)
 
     def right_mul(self, a, M, c, rows=None):

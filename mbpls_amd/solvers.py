@@ -305,6 +305,31 @@ def _kernel_extras(eng, res, Y, P, V, Ts, varxb, wslot, wnorm2):
                explained_var_y_=list(tt * (V ** 2).sum(axis=0) / vary))
 
 
+def _kernel_extras_device(eng, res, Y, V, Ts, varxb, wslot, wnorm2):
+    """_kernel_extras with the p x K operands left on the device: slot "P" holds the loadings, slot "Wblk"
+    the per-block normalised weights (both produced by _finalise_device); K x K cross products per block."""
+    B = eng.nblocks
+    K = Ts.shape[1]
+    sizes = _global_sizes(eng)
+    offs = eng.block_offsets
+    A = wnorm2 / wnorm2.sum(axis=0)                         # ||W_concat_[J_b, k]||^2 (:750)
+    XW = eng.x_w_slot(wslot, 0, K, per_block=True)
+    T, pp_b = [], np.empty((B, K))
+    for b in range(B):
+        rows = (offs[b], offs[b + 1])
+        PtW = eng.cross(("P", 0, K), ("Wblk", 0, K), rows=rows)
+        T.append(XW[b] / np.sqrt(wnorm2[b]) - Ts.dot(np.triu(PtW, 1)))
+        pp_b[b] = np.diag(eng.cross(("P", 0, K), ("P", 0, K), rows=rows))
+    varx = varxb.sum()
+    vary = (Y ** 2).sum()
+    tt = (Ts ** 2).sum(axis=0)
+    res.update(T_=T, A_=A,
+               A_corrected_=np.column_stack([_bip_corrected(A[:, k], sizes) for k in range(K)]),
+               explained_var_x_=list(tt * pp_b.sum(axis=0) / varx),
+               explained_var_xblocks_=tt * pp_b / varxb[:, None],
+               explained_var_y_=list(tt * (V ** 2).sum(axis=0) / vary))
+
+
 def fit_kernel(eng, Y, K, standardize, calc_all=True):
     """mbpls.py:576-807.  p>n (:694-805): association matrix A = X X^T on the matrix cores, then the
     component loop runs on n x q thin factors: the reference's D A D (D = I - ts ts^T, :722-725) is
@@ -336,6 +361,25 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
             Ts = np.hstack((Ts, ts)); U = np.hstack((U, u))
         eng.slot("UT", 2 * K)
         ssq = eng.xt_v(np.hstack((U, Ts)), 1.0, "UT", 0, want_ssq=True)   # X^T [U Ts] in one call (:731, :734)
+        if K <= 32 and hasattr(eng, "right_mul"):
+            # post-processing on the device: only K x K matrices visit the host, every p x K attribute is
+            # fetched once
+            wnorm2 = ssq[:, :K]                             # per-block ||(X^T U)_b||^2, all shards
+            cn = np.sqrt(wnorm2.sum(axis=0))
+            G = np.linalg.pinv(Ts.T.dot(Ts))
+            V = Y.T.dot(Ts).dot(G)                          # (:735)
+            eng.slot("P", K)
+            eng.right_mul(("UT", K, K), G, ("P", 0))        # P = X^T Ts (Ts^T Ts)^+ (:734)
+            eng.slot("Wc", K)
+            eng.right_mul(("UT", 0, K), np.diag(1.0 / cn), ("Wc", 0))     # column-normalised weights (:733)
+            res.update(Ts_=Ts, U_=U, V_=V)
+            _finalise_device(eng, res, "UT", K, cn, np.sqrt(wnorm2), V)   # R_, beta_ (:737-738), W_b, P_
+            res.W_concat_ = eng.fetch("Wc")
+            if calc_all:
+                _kernel_extras_device(eng, res, Y, V, Ts, varxb, "UT", wnorm2)
+            else:
+                res.update(empty_blocks)
+            return res
         UT = eng.fetch("UT")
         wnorm2 = ssq[:, :K]                                 # per-block ||(X^T U)_b||^2, all shards
         Wc = UT[:, :K] / np.sqrt(wnorm2.sum(axis=0))        # (:733)

@@ -48,9 +48,10 @@ class NumpyEngine:
             arr = arr.reshape(-1, 1)
         self.slots[name] = arr.copy()
 
-    def cross(self, a, b):
+    def cross(self, a, b, rows=None):
         (na, ka, ca), (nb, kb, cb) = a, b
-        return self.comm.allreduce_host(self.slots[na][:, ka:ka + ca].T.dot(self.slots[nb][:, kb:kb + cb]))
+        r0, r1 = rows if rows is not None else (0, self.p)
+        return self.comm.allreduce_host(self.slots[na][r0:r1, ka:ka + ca].T.dot(self.slots[nb][r0:r1, kb:kb + cb]))
 
     def right_mul(self, a, M, c, rows=None):
         (na, ka, c1), (nc, kc) = a, c
