@@ -129,3 +129,27 @@ def test_scaler_matches_fixture():
     pre = "ref/q1/single/NIPALS/std1/ca1"
     assert np.array_equal(s.mean_, g[pre + "/x_mean/0"])
     assert util.relerr(s.scale_, g[pre + "/x_scale/0"]) < 1e-15
+
+
+def test_sparse_oracle_vs_reference_fixture():
+    """sparse_data=True: the NaN-aware oracle against attributes captured from the imported reference."""
+    from oracle import mbpls_oracle_sparse as ors
+    g = util.load("sparse")
+    n_cases = 0
+    for q in (1, 2):
+        X, Y = g[f"in/q{q}/X"], g[f"in/q{q}/Y"]
+        Xn, Yn = g[f"in/q{q}/Xnew"], g[f"in/q{q}/Ynew"]
+        for blocks in ("single", "multi"):
+            sp = (lambda A: A) if blocks == "single" else (lambda A: [A[:, :40], A[:, 40:]])
+            for std in (True, False):
+                ref = util.sub(g, f"ref/q{q}/{blocks}/std{int(std)}")
+                mdl = ors.fit(sp(X), Y, n_components=3, standardize=std)
+                flat = util.model_to_flat(mdl)
+                flat["predict"] = ors.predict(mdl, sp(Xn))
+                Ts, T, U = ors.transform(mdl, sp(Xn), Yn, return_block_scores=True)
+                flat["Ts_new"], flat["U_new"] = Ts, U
+                for b, blk in enumerate(T):
+                    flat[f"T_new/{b}"] = blk
+                util.compare(flat, ref, 1e-8, what=f"sparse q{q} {blocks} std{std}")
+                n_cases += 1
+    assert n_cases == 8

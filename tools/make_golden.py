@@ -16,6 +16,7 @@ Fixture sets follow SURVEY.md 8(c'):
   G3 matrix_pgtn       method x blocks x q x standardize x calc_all, p>n
   G4 matrix_ngtp       n>=p branches
   G5 edges             constant column, 1-D Y, list-of-one, norm variants
+  G6 sparse            sparse_data=True (NaN-aware NIPALS), dense Y
 """
 import os
 import sys
@@ -202,6 +203,35 @@ def golden_edges():
     np.savez_compressed(os.path.join(OUT, "edges.npz"), **store)
 
 
+def golden_sparse():
+    """sparse_data=True (NaN-aware NIPALS): no case in the reference's own tests -> pinned from the import."""
+    store = {}
+    for q in (1, 2):
+        X, Y = orc.make_latent(40, 90, q, r=5, seed=3)
+        Xn2, Yn = orc.make_latent(12, 90, q, r=5, seed=4)
+        rng = np.random.RandomState(1)
+        X = X.copy(); X[rng.rand(*X.shape) < 0.05] = np.nan
+        Xn2 = Xn2.copy(); Xn2[rng.rand(*Xn2.shape) < 0.05] = np.nan
+        store[f"in/q{q}/X"] = X; store[f"in/q{q}/Y"] = Y; store[f"in/q{q}/Xnew"] = Xn2; store[f"in/q{q}/Ynew"] = Yn
+        for blocks in ("single", "multi"):
+            sp = (lambda A: A.copy()) if blocks == "single" else (lambda A: [A[:, :40].copy(), A[:, 40:].copy()])
+            for std in (True, False):
+                mdl = MBPLS(n_components=3, sparse_data=True, standardize=std)
+                mdl.fit(sp(X), Y.copy())
+                pre = f"ref/q{q}/{blocks}/std{int(std)}"
+                capture(mdl, store, pre)
+                store[f"{pre}/predict"] = mdl.predict(sp(Xn2))
+                try:
+                    Ts, T, U = mdl.transform(sp(Xn2), Yn.copy(), return_block_scores=True)
+                except UnboundLocalError:   # same reference bug as in capture(): std=False with 2-D Y
+                    Ts, U = mdl.transform(sp(Xn2), Yn.copy())
+                    Ts, T = mdl.transform(sp(Xn2), return_block_scores=True)
+                store[f"{pre}/Ts_new"] = Ts; store[f"{pre}/U_new"] = U
+                for b, blk in enumerate(T):
+                    store[f"{pre}/T_new/{b}"] = blk
+    np.savez_compressed(os.path.join(OUT, "sparse.npz"), **store)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rep = golden_ref_tests()
@@ -213,6 +243,7 @@ def main():
     golden_matrix("matrix_pgtn", 48, 180, [54, 54, 72], 12, (7, 8), ["NIPALS", "UNIPALS", "KERNEL", "SIMPLS"])
     golden_matrix("matrix_ngtp", 96, 60, [18, 18, 24], 12, (9, 10), ["NIPALS", "UNIPALS", "KERNEL", "SIMPLS"])
     golden_edges()
+    golden_sparse()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
