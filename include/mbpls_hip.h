@@ -196,6 +196,35 @@ int mbpls_hip_xt_v(const mbpls_mat* m, const double* d_V, int64_t ldv, int c, do
 int mbpls_hip_x_w(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block,
                   const double* d_mean, const double* d_scale, double* d_out, int64_t ldo);
 
+/* ---- missing values: sparse_data=True, NaN-aware NIPALS (mbpls.py:255-271, :846-854, :865-873, :919-926) -----
+ * A NaN in X marks a missing entry.  It stays NaN in HBM through standardisation and deflation (as in the
+ * reference) and every sum skips it:
+ *   g_j = sum_{i present} x_ij v_i / sum_{i present} v_i^2            un-normalised block weights (:848-852)
+ *   t_i = sum_{j present} x_ij g_j ,  d_i = sum_{j present} g_j^2     per block; the block score over the
+ *         normalised weights w = g/||g|| is  t_i ||g|| / d_i  for a row with missing entries (:869-872) and
+ *         t_i / ||g|| without (where d_i = ||g||^2) -- the caller forms it
+ *   p_j = sum_{i present} x_ij ts_i / sum_{i present} ts_i^2          loadings (:921-925)
+ * Buffers as in the dense passes: d_g / d_p p-vectors, d_t / d_d n x nblocks column-major, d_ssq_* nblocks.
+ *
+ * Standardise with the statistics of the present entries of every column (sklearn StandardScaler on NaN data;
+ * d_count, optional: present samples per column), d_ssq_x = nansum(X_b^2) (:826,:943); fused first sweep when
+ * d_v is given.                                                                                           */
+int mbpls_hip_nan_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode, double* d_mean,
+                                    double* d_scale, double* d_count, double* d_ssq_x, const double* d_v,
+                                    double* d_g, double* d_t, double* d_d, double* d_ssq_g);
+/* One NIPALS sweep over data with missing values (one read of X).                                          */
+int mbpls_hip_nan_sweep(const mbpls_mat* m, const double* d_v, double* d_g, double* d_t, double* d_d,
+                        double* d_ssq_g);
+/* Loadings, X <- X - ts p^T on the present entries (:969; deflate = 0: loadings only) and, when d_v is
+ * given, the first sweep of the next component on the deflated columns.  One read + one write of X.       */
+int mbpls_hip_nan_deflate_sweep(mbpls_mat* m, const double* d_ts, int deflate, double* d_p, double* d_ssq_p,
+                                const double* d_v, double* d_g, double* d_t, double* d_d, double* d_ssq_g);
+/* mbpls_hip_x_w on data with missing values (predict :1376-1384, transform :1106-1115, :1133-1153).
+ * indicator = 0: missing entries contribute nothing to X W.  indicator = 1: OUT[i,c] = sum over the PRESENT
+ * columns j of row i of W[j,c] (the masked sums the sequential-deflation block scores of new data need).   */
+int mbpls_hip_x_w_nan(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block,
+                      const double* d_mean, const double* d_scale, int indicator, double* d_out, int64_t ldo);
+
 /* Association matrix of the KERNEL method: d_G (n x n, leading dim ldg) = X X^T (mbpls.py:704),
  * f64 MFMA SYRK; both triangles are written (bitwise symmetric, like numpy's syrk dispatch).      */
 int mbpls_hip_gram(const mbpls_mat* m, double* d_G, int64_t ldg);

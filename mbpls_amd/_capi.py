@@ -60,6 +60,10 @@ SIGNATURES = {
                                              _vp, _vp, _vp]),
     "mbpls_hip_xt_v": (_int, [_vp, _vp, _i64, _int, _dbl, _vp, _i64, _vp]),
     "mbpls_hip_x_w": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _i64]),
+    "mbpls_hip_nan_standardize_sweep": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbpls_hip_nan_sweep": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbpls_hip_nan_deflate_sweep": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbpls_hip_x_w_nan": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _int, _vp, _i64]),
     "mbpls_hip_gram": (_int, [_vp, _vp, _i64]),
     "mbpls_hip_cross_product": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp]),
     "mbpls_hip_right_multiply": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _int, _vp, _i64]),
@@ -387,6 +391,24 @@ class DeviceMatrix:
     def x_w(self, W, c, out, per_block=False, mean=None, scale=None, ldw=None, ldo=None):
         check(self.ctx.lib.mbpls_hip_x_w(self.handle, _ptr(W), int(ldw or self.p), int(c), int(bool(per_block)),
                                          _ptr(mean), _ptr(scale), _ptr(out), int(ldo or self.n)))
+
+    # ---- missing values (sparse_data=True)
+    def nan_standardize_sweep(self, dst, mode, mean, scale, count, ssq_x, v=None, g=None, t=None, d=None, ssq_g=None):
+        check(self.ctx.lib.mbpls_hip_nan_standardize_sweep(
+            self.handle, dst.handle, int(mode), _ptr(mean), _ptr(scale), _ptr(count), _ptr(ssq_x), _ptr(v), _ptr(g),
+            _ptr(t), _ptr(d), _ptr(ssq_g)))
+
+    def nan_sweep(self, v, g, t, d, ssq_g):
+        check(self.ctx.lib.mbpls_hip_nan_sweep(self.handle, _ptr(v), _ptr(g), _ptr(t), _ptr(d), _ptr(ssq_g)))
+
+    def nan_deflate_sweep(self, ts, deflate, p, ssq_p, v=None, g=None, t=None, d=None, ssq_g=None):
+        check(self.ctx.lib.mbpls_hip_nan_deflate_sweep(self.handle, _ptr(ts), int(bool(deflate)), _ptr(p), _ptr(ssq_p),
+                                                       _ptr(v), _ptr(g), _ptr(t), _ptr(d), _ptr(ssq_g)))
+
+    def x_w_nan(self, W, c, out, per_block=False, mean=None, scale=None, indicator=False, ldw=None, ldo=None):
+        check(self.ctx.lib.mbpls_hip_x_w_nan(self.handle, _ptr(W), int(ldw or self.p), int(c), int(bool(per_block)),
+                                             _ptr(mean), _ptr(scale), int(bool(indicator)), _ptr(out),
+                                             int(ldo or self.n)))
 
     def gram(self, G, ldg=None):
         check(self.ctx.lib.mbpls_hip_gram(self.handle, _ptr(G), int(ldg or self.n)))

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmbpls_hip.so")
-SOURCES = ["ctx.hip", "colpass.hip", "gemv.hip", "gram.hip", "gen.hip", "small.hip", "xtv_mfma.hip"]
+SOURCES = ["ctx.hip", "colpass.hip", "colpass_nan.hip", "gemv.hip", "gram.hip", "gen.hip", "small.hip", "xtv_mfma.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
@@ -36,7 +36,7 @@ def build(force=False, save_temps=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "mbpls_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "colpass_util.h"), os.path.join(HERE, "..", "include", "mbpls_hip.h")]
     hipcc = _hipcc()
     jobs = []
     for s in SOURCES:

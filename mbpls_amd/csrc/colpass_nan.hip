@@ -1,0 +1,350 @@
+// Column passes for data with missing values (sparse_data=True, NaN-aware NIPALS of Martens & Martens;
+// reference mbpls/mbpls.py:846-854 weights, :865-873 block scores, :919-926 loadings, :969 deflation).
+//
+// Same ownership as colpass.hip: one workgroup per chunk of contiguous feature columns, a column lives in
+// the registers of the whole workgroup.  A NaN marks a missing entry; it stays NaN in HBM through
+// standardisation and deflation (as in the reference, where NaN - x = NaN), and every sum simply skips it:
+//   weights   g_j = sum_{i present} x_ij u_i / sum_{i present} u_i^2                 (:848-852)
+//   scores    A_i = sum_{j present} x_ij g_j,   D_i = sum_{j present} g_j^2           (:866-872, the host forms
+//             t_i = nu A_i / D_i with nu = ||g_b||: the score over the present columns of the NORMALISED weights)
+//   loadings  p_j = sum_{i present} x_ij ts_i / sum_{i present} ts_i^2              (:921-925)
+// For a column (row) without missing entries the masked denominator equals the full one, so the reference's
+// separate dense branch (u^T u, ||w|| = 1) is the same number up to the rounding of one summation.
+// Lazy deflation does not apply (the correction terms would depend on every row's own mask): X is rewritten.
+//
+// Bytes per column: SWEEP 8n read; STD / DEFL (+SWEEP) 8n read + 8n write.
+#include <algorithm>
+
+#include "colpass_util.h"
+
+namespace mbpls {
+
+struct NanArgs {
+  const double* src;
+  double* dst;
+  int64_t ld, n;
+  const int64_t* c0;
+  const int64_t* c1;
+  const double* v;    // sweep vector (u)
+  double* g;          // [p] un-normalised weights
+  const double* ts;   // superscore
+  int deflate;
+  double* pvec;       // [p] loadings
+  int mode;
+  double* mean;
+  double* scale;
+  double* count;      // [p] present samples per column (standardise pass, optional)
+  double* part_t;     // [nchunks][n]  A
+  double* part_d;     // [nchunks][n]  D
+  double* part_s;     // [nchunks][4]  ssq_g, ssq_p, ssq_x, -
+};
+
+// Workgroup sum of NV <= 8 values (LDS scratch double[2][16][8]; one barrier per call).
+template <int NV>
+__device__ __forceinline__ void block_sum8(double (&v)[NV], double* red, int& buf) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+  const int nw = blockDim.x >> 6;
+  if (nw == 1) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double* r = red + buf * 128;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) r[w * 8 + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double s = r[k];
+    for (int i = 1; i < nw; ++i) s += r[i * 8 + k];
+    v[k] = s;
+  }
+  buf ^= 1;
+}
+
+template <int R, int TMAX, bool STD, bool DEFL, bool SWEEP>
+__global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512 && !STD && !DEFL) ? 4 : 1) void k_colpass_nan(NanArgs a) {
+  constexpr int D = 2;   // columns in flight
+  __shared__ double red[2 * 128];
+  int buf = 0;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int64_t n = a.n, ld = a.ld;
+  const int chunk = blockIdx.x;
+  const int64_t j0 = uniform64(a.c0[chunk]), j1 = uniform64(a.c1[chunk]);
+  RowMap<R> rm;
+  rm.init(n, ld, tid, T);
+  auto real = [&](int k) -> bool { return (((k & 1) ? rm.in_n1 : rm.in_n0) >> (k >> 1)) & 1u; };
+
+  double v[SWEEP ? R : 1], ts[DEFL ? R : 1], acc[SWEEP ? R : 1], dac[SWEEP ? R : 1];
+  if constexpr (SWEEP) {
+    load_vec<R>(v, a.v, n, tid, T);
+#pragma unroll
+    for (int k = 0; k < R; ++k) acc[k] = dac[k] = 0.0;
+  }
+  if constexpr (DEFL) load_vec<R>(ts, a.ts, n, tid, T);
+  double ssq_g = 0.0, ssq_p = 0.0, ssq_x = 0.0;
+
+  double x[D][R];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (j0 + d < j1) load_col<R, false>(x[d], a.src + (j0 + d) * ld, rm);
+
+  for (int64_t j = j0; j < j1; j += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int64_t jj = j + d;
+      if (jj >= j1) break;
+      double(&xc)[R] = x[d];
+      // rows beyond n were loaded as 0: present, and without weight in any sum
+      unsigned pm = 0u;
+#pragma unroll
+      for (int k = 0; k < R; ++k) pm |= ((xc[k] == xc[k]) ? 1u : 0u) << k;
+      auto present = [&](int k) -> bool { return (pm >> k) & 1u; };
+
+      if constexpr (STD) {
+        if (a.mode != MBPLS_SCALE_NONE) {
+          double mean, scale;
+          if (a.mode == MBPLS_SCALE_FIT) {
+            // sklearn StandardScaler on data with NaN (_incremental_mean_and_var with per-column counts)
+            double sc[2] = {0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+              const bool use = present(k) && real(k);
+              sc[0] += use ? xc[k] : 0.0;
+              sc[1] += use ? 1.0 : 0.0;
+            }
+            block_sum8<2>(sc, red, buf);
+            const double cnt = sc[1];
+            mean = sc[0] / cnt;
+            double cq[2] = {0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+              const bool use = present(k) && real(k);
+              const double dlt = use ? xc[k] - mean : 0.0;
+              if (real(k)) xc[k] = xc[k] - mean;    // NaN stays NaN
+              cq[0] += dlt;
+              cq[1] = fma(dlt, dlt, cq[1]);
+            }
+            block_sum8<2>(cq, red, buf);
+            const double var = (cq[1] - cq[0] * cq[0] / cnt) / cnt;
+            const double eps = 2.220446049250313e-16;
+            const double nme = cnt * mean * eps;
+            const double bound = cnt * eps * var + nme * nme;
+            scale = (var <= bound) ? 1.0 : sqrt(var);
+            if (tid == 0) {
+              a.mean[jj] = mean;
+              a.scale[jj] = scale;
+              if (a.count) a.count[jj] = cnt;
+            }
+          } else {
+            mean = a.mean[jj];
+            scale = a.scale[jj];
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+              if (real(k)) xc[k] = xc[k] - mean;
+          }
+#pragma unroll
+          for (int k = 0; k < R; ++k) xc[k] = xc[k] / scale;
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const double z = present(k) ? xc[k] : 0.0;
+          ssq_x = fma(z, z, ssq_x);                     // nansum(X^2), mbpls.py:826
+        }
+        store_col<R, false>(xc, a.dst + jj * ld, rm);
+      }
+
+      double gj = 0.0;
+      if constexpr (DEFL) {
+        // one reduction: <x,ts>_present, <ts,ts>_present and, for the fused sweep, <x,u>, <u,u>, <ts,u>
+        double r5[SWEEP ? 5 : 2];
+#pragma unroll
+        for (int q = 0; q < (SWEEP ? 5 : 2); ++q) r5[q] = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const bool pr = present(k);
+          const double xz = pr ? xc[k] : 0.0;
+          const double tz = pr ? ts[k] : 0.0;
+          r5[0] = fma(xz, ts[k], r5[0]);
+          r5[1] = fma(tz, ts[k], r5[1]);
+          if constexpr (SWEEP) {
+            const double vz = pr ? v[k] : 0.0;
+            r5[2] = fma(xz, v[k], r5[2]);
+            r5[3] = fma(vz, v[k], r5[3]);
+            r5[4] = fma(tz, v[k], r5[4]);
+          }
+        }
+        block_sum8<(SWEEP ? 5 : 2)>(r5, red, buf);
+        const double pj = (r5[1] != 0.0) ? r5[0] / r5[1] : 0.0;
+        ssq_p = fma(pj, pj, ssq_p);
+        if (tid == 0 && a.pvec) a.pvec[jj] = pj;
+        if (a.deflate) {
+#pragma unroll
+          for (int k = 0; k < R; ++k) xc[k] = fma(-pj, ts[k], xc[k]);    // NaN stays NaN (:969)
+          store_col<R, false>(xc, a.dst + jj * ld, rm);
+          if constexpr (SWEEP) gj = (r5[3] != 0.0) ? fma(-pj, r5[4], r5[2]) / r5[3] : 0.0;
+        } else {
+          if constexpr (SWEEP) gj = (r5[3] != 0.0) ? r5[2] / r5[3] : 0.0;
+        }
+      } else if constexpr (SWEEP) {
+        double r2[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const bool pr = present(k);
+          r2[0] = fma(pr ? xc[k] : 0.0, v[k], r2[0]);
+          r2[1] = fma(pr ? v[k] : 0.0, v[k], r2[1]);
+        }
+        block_sum8<2>(r2, red, buf);
+        gj = (r2[1] != 0.0) ? r2[0] / r2[1] : 0.0;
+      }
+      if constexpr (SWEEP) {
+        ssq_g = fma(gj, gj, ssq_g);
+        if (tid == 0 && a.g) a.g[jj] = gj;
+        const double g2 = gj * gj;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const bool pr = present(k);
+          acc[k] = fma(gj, pr ? xc[k] : 0.0, acc[k]);
+          dac[k] += pr ? g2 : 0.0;
+        }
+      }
+      if (jj + D < j1) load_col<R, false>(xc, a.src + (jj + D) * ld, rm);
+    }
+  }
+
+  if constexpr (SWEEP) {
+    double* out = a.part_t + (int64_t)chunk * n;
+    double* outd = a.part_d + (int64_t)chunk * n;
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) {
+      const int64_t r0 = 2 * ((int64_t)k * T + tid);
+      if (r0 < n) {
+        out[r0] = acc[2 * k];
+        outd[r0] = dac[2 * k];
+      }
+      if (r0 + 1 < n) {
+        out[r0 + 1] = acc[2 * k + 1];
+        outd[r0 + 1] = dac[2 * k + 1];
+      }
+    }
+  }
+  if constexpr (STD) {
+    double s[1] = {ssq_x};
+    block_sum8<1>(s, red, buf);
+    ssq_x = s[0];
+  }
+  if (tid == 0) {
+    double* ps = a.part_s + (int64_t)chunk * 4;
+    ps[0] = ssq_g;
+    ps[1] = ssq_p;
+    ps[2] = ssq_x;
+    ps[3] = 0.0;
+  }
+}
+
+template <bool STD, bool DEFL, bool SWEEP>
+static int launch_nan(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, int64_t p) {
+  const bool writes = STD || (DEFL && a.deflate);
+  const int kind = STD ? MBPLS_K_STANDARDIZE : (DEFL ? (SWEEP ? MBPLS_K_DEFLATE_SWEEP : MBPLS_K_DEFLATE) : MBPLS_K_SWEEP);
+  ProfScope prof(ctx, kind, 8.0 * (double)a.n * (double)p * (writes ? 2.0 : 1.0));
+  Cfg cfg;
+  int T = 0;
+  if (!pick_cfg(ctx, a.n, &cfg, &T, false)) {
+    set_error("column passes support n <= 65536 (got n=%lld)", (long long)a.n);
+    return MBPLS_ERR_UNSUPPORTED;
+  }
+  dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
+#define MB_LAUNCH(R_, TM_) hipLaunchKernelGGL((k_colpass_nan<R_, TM_, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a)
+  if (cfg.R == 2) MB_LAUNCH(2, 256);
+  else if (cfg.R == 4 && cfg.TMAX == 512) MB_LAUNCH(4, 512);
+  else if (cfg.R == 4) MB_LAUNCH(4, 1024);
+  else if (cfg.R == 8 && cfg.TMAX == 512) MB_LAUNCH(8, 512);
+  else if (cfg.R == 8) MB_LAUNCH(8, 1024);
+  else if (cfg.R == 16) MB_LAUNCH(16, 512);
+  else if (cfg.R == 32) MB_LAUNCH(32, 1024);
+  else if (cfg.R == 64) MB_LAUNCH(64, 1024);
+  else {
+    set_error("no kernel for R=%d TMAX=%d", cfg.R, cfg.TMAX);
+    return MBPLS_ERR_UNSUPPORTED;
+  }
+#undef MB_LAUNCH
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+static int nan_buffers(mbpls_ctx* ctx, const mbpls_mat* m, NanArgs* a) {
+  const size_t nt = (size_t)m->fine.nchunks * (size_t)m->n, ns = (size_t)m->fine.nchunks * 4;
+  MB_TRY(ensure_ws(ctx, sizeof(double) * (2 * nt + ns)));
+  a->part_t = (double*)ctx->ws;
+  a->part_d = a->part_t + nt;
+  a->part_s = a->part_d + nt;
+  return MBPLS_OK;
+}
+
+// A and the scalars first, then D through the same fixed-order reduction
+static int nan_reduce(mbpls_ctx* ctx, const mbpls_mat* m, const NanArgs& a, bool sweep, double* d_t, double* d_d,
+                      double* d_ssq_g, double* d_ssq_p, double* d_ssq_x) {
+  if (!sweep) {
+    if (d_ssq_p || d_ssq_x) return reduce_chunks(ctx, m, a.part_t, a.part_s, nullptr, nullptr, d_ssq_p, d_ssq_x);
+    return MBPLS_OK;
+  }
+  MB_TRY(reduce_chunks(ctx, m, a.part_t, a.part_s, d_t, d_ssq_g, d_ssq_p, d_ssq_x));
+  return reduce_chunks(ctx, m, a.part_d, a.part_s, d_d, nullptr, nullptr, nullptr);
+}
+
+}  // namespace mbpls
+
+using namespace mbpls;
+
+extern "C" {
+
+int mbpls_hip_nan_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode, double* d_mean, double* d_scale,
+                                    double* d_count, double* d_ssq_x, const double* d_v, double* d_g, double* d_t,
+                                    double* d_d, double* d_ssq_g) {
+  MB_ARG(src && dst, "NULL argument");
+  MB_ARG(src->n == dst->n && src->p == dst->p && src->ld == dst->ld, "src/dst shape mismatch");
+  MB_ARG(mode == MBPLS_SCALE_FIT || mode == MBPLS_SCALE_APPLY || mode == MBPLS_SCALE_NONE, "bad mode %d", mode);
+  MB_ARG(mode == MBPLS_SCALE_NONE || (d_mean && d_scale), "mean/scale buffers required");
+  MB_ARG(!d_v || (d_t && d_d), "the fused sweep needs d_t and d_d");
+  mbpls_ctx* ctx = dst->ctx;
+  NanArgs a{};
+  MB_TRY(nan_buffers(ctx, dst, &a));
+  a.src = src->data; a.dst = dst->data; a.ld = dst->ld; a.n = dst->n;
+  a.c0 = dst->fine.d_c0; a.c1 = dst->fine.d_c1;
+  a.mode = mode; a.mean = d_mean; a.scale = d_scale; a.count = d_count;
+  a.v = d_v; a.g = d_g;
+  if (d_v) MB_TRY((launch_nan<true, false, true>(ctx, dst->fine, a, dst->p)));
+  else MB_TRY((launch_nan<true, false, false>(ctx, dst->fine, a, dst->p)));
+  return nan_reduce(ctx, dst, a, d_v != nullptr, d_t, d_d, d_ssq_g, nullptr, d_ssq_x);
+}
+
+int mbpls_hip_nan_sweep(const mbpls_mat* m, const double* d_v, double* d_g, double* d_t, double* d_d,
+                        double* d_ssq_g) {
+  MB_ARG(m && d_v && d_t && d_d, "NULL argument");
+  mbpls_ctx* ctx = m->ctx;
+  NanArgs a{};
+  MB_TRY(nan_buffers(ctx, m, &a));
+  a.src = m->data; a.dst = nullptr; a.ld = m->ld; a.n = m->n;
+  a.c0 = m->fine.d_c0; a.c1 = m->fine.d_c1;
+  a.v = d_v; a.g = d_g;
+  MB_TRY((launch_nan<false, false, true>(ctx, m->fine, a, m->p)));
+  return nan_reduce(ctx, m, a, true, d_t, d_d, d_ssq_g, nullptr, nullptr);
+}
+
+int mbpls_hip_nan_deflate_sweep(mbpls_mat* m, const double* d_ts, int deflate, double* d_p, double* d_ssq_p,
+                                const double* d_v, double* d_g, double* d_t, double* d_d, double* d_ssq_g) {
+  MB_ARG(m && d_ts, "NULL argument");
+  MB_ARG(!d_v || (d_t && d_d), "the fused sweep needs d_t and d_d");
+  mbpls_ctx* ctx = m->ctx;
+  NanArgs a{};
+  MB_TRY(nan_buffers(ctx, m, &a));
+  a.src = m->data; a.dst = m->data; a.ld = m->ld; a.n = m->n;
+  a.c0 = m->fine.d_c0; a.c1 = m->fine.d_c1;
+  a.ts = d_ts; a.deflate = deflate ? 1 : 0; a.pvec = d_p;
+  a.v = d_v; a.g = d_g;
+  if (d_v) MB_TRY((launch_nan<false, true, true>(ctx, m->fine, a, m->p)));
+  else MB_TRY((launch_nan<false, true, false>(ctx, m->fine, a, m->p)));
+  return nan_reduce(ctx, m, a, d_v != nullptr, d_t, d_d, d_ssq_g, d_ssq_p, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+// Column-pass building blocks shared by colpass.hip (dense) and colpass_nan.hip (missing values):
+// row ownership of a thread, register-resident column loads / stores, launch-shape selection.
+#pragma once
+#include "common.h"
+
+namespace mbpls {
+
+// Row ownership of one thread: pair k covers rows 2(kT + tid), 2(kT + tid) + 1.  Byte offsets are 32-bit
+// and identical for every column, so a column load is  global_load_dwordx4 v, v_off, s[col_base]  (SGPR base
+// + VGPR offset): no 64-bit address arithmetic and no address registers per load in flight.
+template <int R>
+struct RowMap {
+  unsigned off[R / 2];   // byte offset of the pair inside a column
+  unsigned in_ld;        // bit k: pair k lies inside the column allocation (r0 < ld)
+  unsigned in_n0, in_n1; // bit k: row r0 / r0+1 is a real sample (< n)
+  // rowmask (optional, n doubles, 0 = sample excluded): excluded rows are treated exactly like rows
+  // beyond n -- they load as 0 -- which is all a fit on a ROW SUBSET needs (cross-validation folds on a
+  // matrix that stays resident in HBM).
+  __device__ __forceinline__ void init(int64_t n, int64_t ld, int tid, int T, const double* rowmask = nullptr) {
+    in_ld = in_n0 = in_n1 = 0u;
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) {
+      // 32-bit arithmetic on purpose: the offset must reach the load as zext(i32) for the SGPR-base form
+      const unsigned r0 = 2u * ((unsigned)k * (unsigned)T + (unsigned)tid);
+      const bool inside = (int64_t)r0 < ld;
+      off[k] = inside ? r0 * 8u : 0u;   // out-of-allocation pairs re-read pair 0 (masked below)
+      in_ld |= (inside ? 1u : 0u) << k;
+      bool k0 = (int64_t)r0 < n, k1 = (int64_t)r0 + 1 < n;
+      if (rowmask) {
+        if (k0) k0 = rowmask[r0] != 0.0;
+        if (k1) k1 = rowmask[r0 + 1] != 0.0;
+      }
+      in_n0 |= (k0 ? 1u : 0u) << k;
+      in_n1 |= (k1 ? 1u : 0u) << k;
+    }
+  }
+};
+
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+// force a wave-uniform 64-bit value into SGPRs (values fetched through possibly-aliased pointers land in
+// VGPRs, which would turn every column base address into per-lane 64-bit address arithmetic)
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffll));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// X is streamed exactly once per pass: non-temporal loads/stores keep it out of L2/MALL
+// (measured on MI355X: read-only sweep 6.2 -> 6.8 TB/s, read+write pass 5.5 -> 5.7 TB/s).
+// FULL: n == T*R == ld, every pair of every thread is a real sample -> no masks, and (more important) no
+// select right behind the load that would force an s_waitcnt before the prefetched column is needed.
+template <int R, bool FULL>
+__device__ __forceinline__ void load_col(double (&x)[R], const double* __restrict__ col, const RowMap<R>& m) {
+  const char* base = reinterpret_cast<const char*>(col);   // workgroup-uniform
+#pragma unroll
+  for (int k = 0; k < R / 2; ++k) {
+    // unconditional (clamped offset): no exec-mask branch per load, masking happens on the value
+    const v2d_t q = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(base + m.off[k]));
+    if constexpr (FULL) {
+      x[2 * k] = q.x;
+      x[2 * k + 1] = q.y;
+    } else {
+      x[2 * k] = ((m.in_n0 >> k) & 1u) ? q.x : 0.0;
+      x[2 * k + 1] = ((m.in_n1 >> k) & 1u) ? q.y : 0.0;
+    }
+  }
+}
+
+// plain n-vector (u, ts): may be unpadded / only 8-byte aligned -> scalar loads, done once per workgroup
+template <int R>
+__device__ __forceinline__ void load_vec(double (&x)[R], const double* __restrict__ vec, int64_t n, int tid, int T) {
+#pragma unroll
+  for (int k = 0; k < R / 2; ++k) {
+    const int64_t r0 = 2 * ((int64_t)k * T + tid);
+    x[2 * k] = (r0 < n) ? vec[r0] : 0.0;
+    x[2 * k + 1] = (r0 + 1 < n) ? vec[r0 + 1] : 0.0;
+  }
+}
+
+template <int R, bool FULL>
+__device__ __forceinline__ void store_col(const double (&x)[R], double* __restrict__ col, const RowMap<R>& m) {
+  char* base = reinterpret_cast<char*>(col);
+#pragma unroll
+  for (int k = 0; k < R / 2; ++k) {
+    if (FULL || ((m.in_ld >> k) & 1u)) {
+      v2d_t q;
+      q.x = x[2 * k];
+      q.y = x[2 * k + 1];
+      __builtin_nontemporal_store(q, reinterpret_cast<v2d_t*>(base + m.off[k]));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- launch shape
+struct Cfg {
+  int R, TMAX;
+};
+
+// Choose rows-per-thread R and the workgroup size T = roundup(ceil(n/R), 64) <= TMAX.
+static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std_pass = false) {
+  // preference order: smallest register footprint that still covers n with <= TMAX threads
+  // the last two are correctness fallbacks for very long columns (8192 < n <= 65536): the column no longer
+  // fits the register budget of 1024 threads, the compiler spills to scratch -> slow but exact
+  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}, {4, 1024}, {32, 1024}, {64, 1024}};
+  auto fits = [&](const Cfg& c, int* t) {
+    int64_t need = (n + c.R - 1) / c.R;
+    need = (need + 63) / 64 * 64;
+    if (need > c.TMAX) return false;
+    *t = (int)need;
+    return true;
+  };
+  // the standardise pass has three reductions + divisions per column: fewer, fatter threads win
+  // (measured at n=4096: R=16/T=256 5.46 TB/s vs R=8/T=512 4.77 TB/s)
+  if (std_pass && ctx->rows_per_thread <= 0 && n > 2048) {
+    const Cfg c16 = {16, 512};
+    if (fits(c16, T)) {
+      *cfg = c16;
+      return true;
+    }
+  }
+  if (ctx->rows_per_thread > 0) {
+    for (const Cfg& c : table)
+      if (c.R == ctx->rows_per_thread && fits(c, T)) {
+        *cfg = c;
+        return true;
+      }
+  }
+  for (const Cfg& c : table)
+    if (fits(c, T)) {
+      *cfg = c;
+      return true;
+    }
+  return false;
+}
+
+// colpass.hip: second stage, fixed-order sum of the chunk partials of each block (n-vectors into d_t,
+// the per-chunk scalars [ssq_g, ssq_p, ssq_x, -] into the d_ssq_* outputs, lazy-deflation sums into d_d)
+int reduce_chunks(mbpls_ctx* ctx, const mbpls_mat* m, const double* part_t, const double* part_s,
+                  double* d_t, double* d_ssq_g, double* d_ssq_p, double* d_ssq_x,
+                  const double* part_d = nullptr, int nd = 0, double* d_d = nullptr);
+
+}  // namespace mbpls

@@ -92,7 +92,9 @@ __global__ __launch_bounds__(64) void k_reduce_ssq(const double* __restrict__ pa
 
 // ------------------------------------------------------------------------------------ x_w
 // grid (nchunks, nslabs); a workgroup owns rows [slab*512, slab*512+512) of the columns of its chunk.
-template <int CB, bool SCALE>
+// NANM: 0 plain; 1 missing entries (NaN) contribute nothing (mbpls.py:1379-1383, :1108-1113);
+//       2 the PRESENCE indicator takes the place of x (sums of W over the present columns of every row)
+template <int CB, bool SCALE, int NANM = 0>
 __global__ __launch_bounds__(256) void k_xw(const double* __restrict__ X, int64_t ld, int64_t n,
                                             const int64_t* __restrict__ c0, const int64_t* __restrict__ c1,
                                             const double* __restrict__ W, int64_t ldw, int cb,
@@ -115,6 +117,13 @@ __global__ __launch_bounds__(256) void k_xw(const double* __restrict__ X, int64_
       const double mu = mean[j], sc = scale[j];
       x0 = in0 ? (x0 - mu) / sc : 0.0;
       x1 = in1 ? (x1 - mu) / sc : 0.0;
+    }
+    if constexpr (NANM == 1) {
+      x0 = (x0 == x0) ? x0 : 0.0;
+      x1 = (x1 == x1) ? x1 : 0.0;
+    } else if constexpr (NANM == 2) {
+      x0 = (in0 && x0 == x0) ? 1.0 : 0.0;
+      x1 = (in1 && x1 == x1) ? 1.0 : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < CB; ++q) {
@@ -215,8 +224,10 @@ int mbpls_hip_xt_v(const mbpls_mat* m, const double* d_V, int64_t ldv, int c, do
   return MBPLS_OK;
 }
 
-int mbpls_hip_x_w(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block, const double* d_mean,
-                  const double* d_scale, double* d_out, int64_t ldo) {
+}  // extern "C"
+
+static int x_w_impl(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block, const double* d_mean,
+                    const double* d_scale, int nanm, double* d_out, int64_t ldo) {
   MB_ARG(m && d_W && d_out, "NULL argument");
   MB_ARG(c >= 1 && ldw >= m->p && ldo >= m->n, "bad shape (c=%d ldw=%lld ldo=%lld)", c, (long long)ldw,
          (long long)ldo);
@@ -233,12 +244,15 @@ int mbpls_hip_x_w(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int
     dim3 grid((unsigned)ct.nchunks, slabs);
     {
     ProfScope prof(ctx, MBPLS_K_X_W, 8.0 * (double)m->n * (double)m->p);
-    if (d_mean)
-      hipLaunchKernelGGL((k_xw<CB, true>), grid, dim3(256), 0, ctx->stream, (const double*)m->data, m->ld, m->n,
-                         (const int64_t*)ct.d_c0, (const int64_t*)ct.d_c1, W, ldw, cb, d_mean, d_scale, part);
-    else
-      hipLaunchKernelGGL((k_xw<CB, false>), grid, dim3(256), 0, ctx->stream, (const double*)m->data, m->ld, m->n,
-                         (const int64_t*)ct.d_c0, (const int64_t*)ct.d_c1, W, ldw, cb, d_mean, d_scale, part);
+#define MB_XW(SC_, NM_)                                                                                            \
+  hipLaunchKernelGGL((k_xw<CB, SC_, NM_>), grid, dim3(256), 0, ctx->stream, (const double*)m->data, m->ld, m->n,   \
+                     (const int64_t*)ct.d_c0, (const int64_t*)ct.d_c1, W, ldw, cb, d_mean, d_scale, part)
+    if (nanm == 2) MB_XW(false, 2);                       // the indicator needs no scaling
+    else if (nanm == 1 && d_mean) MB_XW(true, 1);
+    else if (nanm == 1) MB_XW(false, 1);
+    else if (d_mean) MB_XW(true, 0);
+    else MB_XW(false, 0);
+#undef MB_XW
     }
     MB_HIP(hipGetLastError());
     dim3 rgrid((unsigned)((m->n + 255) / 256), (unsigned)cb, per_block ? (unsigned)m->nblocks : 1u);
@@ -247,6 +261,18 @@ int mbpls_hip_x_w(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int
     MB_HIP(hipGetLastError());
   }
   return MBPLS_OK;
+}
+
+extern "C" {
+
+int mbpls_hip_x_w(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block, const double* d_mean,
+                  const double* d_scale, double* d_out, int64_t ldo) {
+  return x_w_impl(m, d_W, ldw, c, per_block, d_mean, d_scale, 0, d_out, ldo);
+}
+
+int mbpls_hip_x_w_nan(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block, const double* d_mean,
+                      const double* d_scale, int indicator, double* d_out, int64_t ldo) {
+  return x_w_impl(m, d_W, ldw, c, per_block, d_mean, d_scale, indicator ? 2 : 1, d_out, ldo);
 }
 
 }  // extern "C"

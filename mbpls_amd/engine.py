@@ -37,6 +37,8 @@ class HipEngine:
         self.scale = None
         self.G = None
         self.timings = {}
+        # missing values (sparse_data=True): NaN-aware column passes (csrc/colpass_nan.hip); set before load_*
+        self.sparse = False
 
     @contextlib.contextmanager
     def _timed(self, name):
@@ -78,7 +80,9 @@ class HipEngine:
         self.block_offsets = list(X.block_offsets)
         self.block_sizes = [self.block_offsets[b + 1] - self.block_offsets[b] for b in range(self.nblocks)]
         B, n = self.nblocks, self.n
-        self._xchg = self.comm.exchange_buffer(self.ctx, n * B + 3 * B + B * self.KD)
+        # exchange buffer: [t: n*B][ssq_g, ssq_p, ssq_x: 3*B][lazy-deflation sums: B*KD][sparse only, d: n*B]
+        self._d_off = n * B + 3 * B + B * self.KD
+        self._xchg = self.comm.exchange_buffer(self.ctx, self._d_off + (n * B if self.sparse else 0))
         self._vec_n = [self.ctx.empty(n), self.ctx.empty(n)]
         self._coef = [self.ctx.empty(self.KD), self.ctx.empty(self.KD)]   # <ts_i, v>, <ts_i, ts>
         self._lazy_ts = []          # score vectors of the components deflated so far (lazy mode)
@@ -173,6 +177,8 @@ class HipEngine:
         when the component count fits the kernel's correction registers."""
         import os
         mode = os.environ.get("MBPLS_DEFLATION", self.deflation)
+        if self.sparse:
+            mode = "explicit"      # the implicit correction would need every row's own missing-value mask
         self._lazy_pslot = pslot if (mode == "lazy" and K < self.KD - 1) else None
         self._lazy_ts = []
         return self._lazy_pslot is not None
@@ -205,6 +211,13 @@ class HipEngine:
             h = self._xchg.get()
         t = h[: n * B].reshape(B, n).T.copy() if want_t else None   # n x B
         o = n * B
+        if self.sparse and want_t:
+            # t_i = nu A_i / D_i over the present columns (mbpls.py:869-872); handed back as nu^2 A_i / D_i so
+            # that the caller's t / nu is the block score.  Rows without missing entries have D_i = nu^2.
+            d = h[self._d_off:self._d_off + n * B].reshape(B, n).T
+            ssq = h[o:o + B]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = np.where(d > 0.0, t * (ssq[None, :] / d), 0.0)
         if nd:
             self._last_d = h[o + 3 * B:o + 3 * B + B * nd].reshape(B, nd).copy()
         return (t, h[o:o + B].copy() if want_g else None, h[o + B:o + 2 * B].copy() if want_p else None,
@@ -235,13 +248,22 @@ class HipEngine:
         # row subset (cross-validation fold): excluded samples become zero rows of the working copy and the
         # column statistics are taken over the included ones only
         dm, n_eff = None, 0.0
-        if getattr(self, "rowmask", None) is not None:
+        if self.sparse:
+            if getattr(self, "rowmask", None) is not None:
+                raise NotImplementedError("row-subset fits are not available with sparse_data=True")
+            self.count = self.ctx.empty(self.p) if standardize else None
+            src.nan_standardize_sweep(self.X, mode, self.mean, self.scale, self.count, self._xptr(n * B + 2 * B), dv,
+                                      self._slot_col(g_slot), self._xptr(0) if v is not None else None,
+                                      self._xptr(self._d_off) if v is not None else None,
+                                      self._xptr(n * B) if v is not None else None)
+        elif getattr(self, "rowmask", None) is not None:
             m = np.ascontiguousarray(self.rowmask, dtype=np.float64).ravel()
             assert m.size == n
             dm, n_eff = self.ctx.from_host(m), float(np.count_nonzero(m))
-        src.standardize_sweep(self.X, mode, self.mean, self.scale, self._xptr(n * B + 2 * B), dv, alpha,
-                              self._slot_col(g_slot), self._xptr(0) if v is not None else None,
-                              self._xptr(n * B) if v is not None else None, rowmask=dm, n_eff=n_eff)
+        if not self.sparse:
+            src.standardize_sweep(self.X, mode, self.mean, self.scale, self._xptr(n * B + 2 * B), dv, alpha,
+                                  self._slot_col(g_slot), self._xptr(0) if v is not None else None,
+                                  self._xptr(n * B) if v is not None else None, rowmask=dm, n_eff=n_eff)
         self._src = None
         cb = getattr(self, "on_first_pass", None)
         if cb is not None:          # host work hidden behind the longest pass of the fit
@@ -259,7 +281,9 @@ class HipEngine:
         n, B = self.n, self.nblocks
         dv = self._put_vec(0, v)
         k = len(self._lazy_ts) if self._lazy_pslot else 0
-        if k:
+        if self.sparse:      # alpha is implied: every column divides by its own masked <u, u>
+            self.X.nan_sweep(dv, self._slot_col(g_slot), self._xptr(0), self._xptr(self._d_off), self._xptr(n * B))
+        elif k:
             P = self.slots[self._lazy_pslot]
             self.X.sweep_lazy(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B), P, self.p, k,
                               self._lazy_coef(0, v), self._xptr(n * B + 3 * B))
@@ -277,6 +301,15 @@ class HipEngine:
         n, B = self.n, self.nblocks
         dts = self._put_vec(1, ts)
         dv = self._put_vec(0, v) if v is not None else None
+        if self.sparse:      # inv_tt is implied: every column divides by its own masked <ts, ts>
+            self.X.nan_deflate_sweep(dts, deflate, self._slot_col(p_slot), self._xptr(n * B + B), dv,
+                                     self._slot_col(g_slot), self._xptr(0) if v is not None else None,
+                                     self._xptr(self._d_off) if v is not None else None,
+                                     self._xptr(n * B) if v is not None else None)
+            if overlap is not None:
+                overlap()
+            t, g, p, _ = self._finish_pass(v is not None, v is not None, True, False)
+            return p, t, g
         if self._lazy_pslot:
             assert p_slot is not None and p_slot[0] == self._lazy_pslot and p_slot[1] == len(self._lazy_ts)
             k = len(self._lazy_ts)
@@ -319,12 +352,18 @@ class HipEngine:
         dV.free()
         return out
 
-    def _xw(self, Wdev, c, per_block, mean=None, scale=None, mat=None):
+    def _xw(self, Wdev, c, per_block, mean=None, scale=None, mat=None, nan=None):
+        """nan: None dense; "skip" missing entries contribute nothing; "indicator" sums of W over the present
+        columns of every row (csrc/gemv.hip k_xw NANM)."""
         mat = mat if mat is not None else self.X
         n = mat.n
         nb = mat.nblocks if per_block else 1
         buf = self.comm.exchange_buffer(self.ctx, n * c * nb)
-        mat.x_w(Wdev, c, buf, per_block=per_block, mean=mean, scale=scale, ldw=mat.p, ldo=n)
+        if nan is None:
+            mat.x_w(Wdev, c, buf, per_block=per_block, mean=mean, scale=scale, ldw=mat.p, ldo=n)
+        else:
+            mat.x_w_nan(Wdev, c, buf, per_block=per_block, mean=mean, scale=scale, indicator=(nan == "indicator"),
+                        ldw=mat.p, ldo=n)
         self.comm.allreduce_device(buf)
         h = buf.get()
         if hasattr(buf, "free"):

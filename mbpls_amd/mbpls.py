@@ -6,8 +6,9 @@ attribute names, types and shapes, same errors.  There is no CPU 
 the HIP library or a GPU every method raises.
 
 Deliberate deviations from the reference (documented in DESIGN.md):
-* ``sparse_data=True`` (NaN-aware NIPALS, per-row/column Python loops, mbpls.py:846-909) is out of
-  scope of the accelerated path -> ``NotImplementedError``.
+* ``sparse_data=True`` (NaN-aware NIPALS, per-row/column Python loops in the reference, mbpls.py:846-926)
+  runs on masked column passes (csrc/colpass_nan.hip) for missing values in X; missing values in Y are not
+  supported (``NotImplementedError``) and the ``sparse_X_info_`` index lists are not produced.
 * NIPALS has an iteration cap (``solvers.NIPALS_MAX_ITER``) with a warning; the reference loops
   forever on data without latent structure (mbpls.py:841).
 * SIMPLS with one response and ``full_svd=False`` works (the reference raises inside scipy ``svds``).
@@ -127,10 +128,21 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         """fit() on the samples where ``row_mask`` is True (None = all): the engine zeroes the excluded rows
         of its working copy, so the matrix never has to be re-uploaded or sliced for cross-validation folds
         (``mbpls_amd.model_selection``).  n-row attributes are returned for the included samples only."""
-        if self.sparse_data is True:
-            raise NotImplementedError(
-                "sparse_data=True (NaN-aware NIPALS, reference mbpls.py:846-909) is outside the HIP hot path")
-        Y = check_array(Y, dtype=np.float64, ensure_2d=False, copy=self.copy)      # :293
+        sparse = self.sparse_data is True
+        if sparse and self.method != 'NIPALS':                                      # :285-289
+            warnings.warn("The parameter sparse data was set to 'True', but the chosen method is not 'NIPALS'."
+                          "The method will be set to 'NIPALS'")
+            self.method = 'NIPALS'
+        if sparse:
+            Y = _check_array_no_scan(np.asarray(Y, dtype=np.float64).reshape(len(Y), -1))
+            if np.isnan(Y).any():
+                raise NotImplementedError("sparse_data=True is accelerated for missing values in X only; "
+                                          "Y must be complete")
+            if row_mask is not None:
+                raise NotImplementedError("row-subset fits are not available with sparse_data=True")
+            Y = np.array(Y, copy=True) if self.copy else Y
+        else:
+            Y = check_array(Y, dtype=np.float64, ensure_2d=False, copy=self.copy)  # :293
         if Y.ndim == 1:
             Y = Y.reshape(-1, 1)                                                    # :297-298
         device_input = isinstance(X, _capi.DeviceMatrix)
@@ -158,6 +170,7 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         if row_mask is not None:
             Ys = np.where(row_mask[:, None], Ys, 0.0)      # excluded samples take no part in any sum
         eng = self._engine()
+        eng.sparse = sparse
         eng.rowmask = None if row_mask is None else row_mask.astype(np.float64)
         # A refit replaces the previous p x K attributes; releasing ~0.4 GB of numpy memory (page-table
         # teardown) costs ~15 ms of host time at p = 1e6 -- do it while the standardise pass runs on the GPU.
@@ -207,7 +220,8 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         self._block_offsets = list(eng.block_offsets)
         if self.standardize:
             mean, scale = eng.mean.get(), eng.scale.get()
-            self.x_scalers_ = [ColumnScaler(mean[s:e], scale[s:e], eng.n)
+            seen = eng.count.get().astype(np.int64) if eng.sparse else None    # per-column present samples
+            self.x_scalers_ = [ColumnScaler(mean[s:e], scale[s:e], eng.n if seen is None else seen[s:e])
                                for s, e in zip(eng.block_offsets[:-1], eng.block_offsets[1:])]
         # containers exactly as the reference leaves them (mbpls.py:359-382)
         self.W_non_normal_ = [np.empty((sz, 0)) for sz in sizes]
@@ -250,7 +264,8 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         try:
             mat, mean, scale = self._device_new(eng, X)
             dB = eng.ctx.from_host(self.beta_)
-            y = eng._xw(dB, self.beta_.shape[1], False, mean, scale, mat=mat)      # :1386 / :1408
+            y = eng._xw(dB, self.beta_.shape[1], False, mean, scale, mat=mat,      # :1386 / :1408
+                        nan="skip" if self.sparse_data is True else None)           # :1376-1384
             _require_finite(y)
         finally:
             eng.close()
@@ -268,17 +283,35 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             mat, mean, scale = self._device_new(eng, X)
             K = self.R_.shape[1]
             dR = eng.ctx.from_host(self.R_)
-            Ts = eng._xw(dR, K, False, mean, scale, mat=mat)                        # :1117 / :1250
+            nan = "skip" if self.sparse_data is True else None
+            Ts = eng._xw(dR, K, False, mean, scale, mat=mat, nan=nan)               # :1117 / :1250, :1106-1115
             _require_finite(Ts)
             T = None
             if self.method != 'SIMPLS' and (return_block_scores):
                 W = np.vstack(self.W_)
                 dW = eng.ctx.from_host(W)
-                XW = eng._xw(dW, K, True, mean, scale, mat=mat)
+                XW = eng._xw(dW, K, True, mean, scale, mat=mat, nan=nan)
                 T = []
-                for b in range(self.num_blocks_):
-                    PtW = eng.comm.allreduce_host(self.P_[b].T.dot(self.W_[b]))
-                    T.append(XW[b] - Ts.dot(np.triu(PtW, 1)))
+                if nan is None:
+                    for b in range(self.num_blocks_):
+                        PtW = eng.comm.allreduce_host(self.P_[b].T.dot(self.W_[b]))
+                        T.append(XW[b] - Ts.dot(np.triu(PtW, 1)))
+                else:
+                    # missing values: the deflated row i is x_i - sum_l Ts[i,l] P[:,l] on its PRESENT columns only
+                    # (:1133-1153), so P_b[:,l]^T W_b[:,k] becomes a per-row sum over the present columns:
+                    # one indicator product with the columns P[:,l] * W[:,k], l < k
+                    pairs = [(l, k) for k in range(K) for l in range(k)]
+                    T = [xw.copy() for xw in XW]
+                    if pairs:
+                        P = np.vstack(self.P_)
+                        C = np.empty((W.shape[0], len(pairs)), order="F")
+                        for i, (l, k) in enumerate(pairs):
+                            np.multiply(P[:, l], W[:, k], out=C[:, i])
+                        dC = eng.ctx.from_host(C)
+                        M = eng._xw(dC, len(pairs), True, None, None, mat=mat, nan="indicator")
+                        for b in range(self.num_blocks_):
+                            for i, (l, k) in enumerate(pairs):
+                                T[b][:, k] -= Ts[:, l] * M[b][:, i]
         finally:
             eng.close()
         out = [Ts]

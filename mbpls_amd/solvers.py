@@ -126,7 +126,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     # host copies of the p x K attributes, filled column by column while later passes run on the GPU
     Wn_h = np.empty((eng.p, K), order="F"); W_h = np.empty((eng.p, K), order="F"); P_h = np.empty((eng.p, K), order="F")
     import os
-    q1_fixed_point = (q == 1 and os.environ.get("MBPLS_NIPALS_Q1_FIXED_POINT", "0") == "1"
+    q1_fixed_point = (q == 1 and os.environ.get("MBPLS_NIPALS_Q1_FIXED_POINT", "0") == "1" and not getattr(eng, "sparse", False)
                       and hasattr(eng, "right_mul"))
     for k in range(K):
         u = u0

@@ -1,0 +1,111 @@
+"""GPU parity for sparse_data=True (missing values in X, NaN-aware NIPALS).
+
+Reference behaviour: mbpls/mbpls.py:846-854 (weights), :865-873 (block scores), :919-926 (loadings),
+:1376-1384 (predict), :1106-1153 (transform).  Checked against fixtures captured from the imported
+reference (tests/golden/sparse.npz) and against the NaN-aware oracle on larger seeded problems.
+Tolerance: 1e-6 relative, sign-aligned (north_star)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import mbpls_oracle as orc
+from oracle import mbpls_oracle_sparse as ors
+from tests import util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _flat(model, Xn, Yn):
+    flat = util.model_to_flat(model)
+    flat["predict"] = model.predict(Xn)
+    Ts, T, U = model.transform(Xn, Yn, return_block_scores=True)
+    flat["Ts_new"], flat["U_new"] = Ts, U
+    for b, blk in enumerate(T):
+        flat[f"T_new/{b}"] = blk
+    return flat
+
+
+def _oracle_flat(ref, Xn, Yn):
+    flat = util.model_to_flat(ref)
+    flat["predict"] = ors.predict(ref, Xn)
+    Ts, T, U = ors.transform(ref, Xn, Yn, return_block_scores=True)
+    flat["Ts_new"], flat["U_new"] = Ts, U
+    for b, blk in enumerate(T):
+        flat[f"T_new/{b}"] = blk
+    return flat
+
+
+def test_reference_fixture(gpu_required):
+    from mbpls_amd import MBPLS
+    g = util.load("sparse")
+    worst = 0.0
+    for q in (1, 2):
+        X, Y = g[f"in/q{q}/X"], g[f"in/q{q}/Y"]
+        Xn, Yn = g[f"in/q{q}/Xnew"], g[f"in/q{q}/Ynew"]
+        for blocks in ("single", "multi"):
+            sp = (lambda A: A) if blocks == "single" else (lambda A: [np.ascontiguousarray(A[:, :40]),
+                                                                       np.ascontiguousarray(A[:, 40:])])
+            for std in (True, False):
+                ref = util.sub(g, f"ref/q{q}/{blocks}/std{int(std)}")
+                mdl = MBPLS(n_components=3, sparse_data=True, standardize=std).fit(sp(X), Y)
+                worst = max(worst, util.compare(_flat(mdl, sp(Xn), Yn), ref, TOL, what=f"q{q} {blocks} std{std}"))
+                if std:
+                    ok = ~np.isnan(X)
+                    seen = np.concatenate([s.n_samples_seen_ for s in mdl.x_scalers_])
+                    assert np.array_equal(seen, ok.sum(axis=0))
+    assert worst < 1e-8, worst
+
+
+@pytest.mark.parametrize("n,p,q,K,blocks,frac", [
+    (501, 3000, 2, 3, [1000, 800, 1200], 0.03),     # odd n: padded columns, several blocks
+    (4096, 6000, 1, 3, [6000], 0.01),               # the n = 4096 configuration of the dense hot path
+    (1200, 2500, 3, 4, [2500], 0.10),
+    (9000, 700, 1, 2, [300, 400], 0.02),            # n > 8192: long-column kernels
+])
+def test_medium_vs_oracle(gpu_required, n, p, q, K, blocks, frac):
+    from mbpls_amd import MBPLS
+    X, Y = orc.make_latent(n, p, q, seed=n + p)
+    Xn, Yn = orc.make_latent(65, p, q, seed=2)
+    rng = np.random.RandomState(n)
+    X = X.copy(); X[rng.rand(n, p) < frac] = np.nan
+    Xn = Xn.copy(); Xn[rng.rand(65, p) < frac] = np.nan
+    Xn[3] = orc.make_latent(65, p, q, seed=2)[0][3]      # a complete row among the sparse ones
+    cuts = np.cumsum(blocks)[:-1]
+    sp = (lambda A: A) if len(blocks) == 1 else (lambda A: [np.ascontiguousarray(b) for b in np.split(A, cuts, axis=1)])
+    ref = ors.fit(sp(X), Y, n_components=K)
+    mdl = MBPLS(n_components=K, sparse_data=True).fit(sp(X), Y)
+    w = util.compare(_flat(mdl, sp(Xn), Yn), _oracle_flat(ref, sp(Xn), Yn), TOL, what=f"sparse n={n} p={p}")
+    assert w < 1e-8, w
+    assert mdl.nipals_iterations_ == ref.nipals_iterations_
+
+
+def test_complete_data_equals_dense_fit(gpu_required):
+    """Without a single NaN the masked passes must give the dense model."""
+    from mbpls_amd import MBPLS
+    X, Y = orc.make_latent(300, 2000, 2, seed=5)
+    Xs = [np.ascontiguousarray(X[:, :900]), np.ascontiguousarray(X[:, 900:])]
+    a = MBPLS(n_components=3).fit(Xs, Y)
+    b = MBPLS(n_components=3, sparse_data=True).fit(Xs, Y)
+    w = util.compare(util.model_to_flat(b), util.model_to_flat(a), 1e-10, what="complete")
+    assert w < 1e-11, w
+    assert np.allclose(a.predict(Xs), b.predict(Xs), rtol=0, atol=1e-11)
+
+
+def test_method_is_switched_to_nipals_and_y_must_be_complete(gpu_required):
+    from mbpls_amd import MBPLS
+    X, Y = orc.make_latent(60, 120, 1, seed=9)
+    X = X.copy(); X[4, 7] = np.nan
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        mdl = MBPLS(n_components=2, method="KERNEL", sparse_data=True).fit(X, Y)      # mbpls.py:285-289
+    assert mdl.method == "NIPALS" and any("NIPALS" in str(r.message) for r in rec)
+    ref = ors.fit(X, Y, n_components=2)
+    assert util.relerr(mdl.beta_, ref.beta_) < 1e-9
+    Yb = Y.copy(); Yb[0, 0] = np.nan
+    with pytest.raises(NotImplementedError):
+        MBPLS(n_components=2, sparse_data=True).fit(X, Yb)
+    # and without sparse_data a NaN is still an input error
+    with pytest.raises(ValueError):
+        MBPLS(n_components=2).fit(X, Y)
