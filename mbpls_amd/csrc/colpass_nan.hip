@@ -102,6 +102,13 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512 && !STD && !DEFL) ? 4 
       auto present = [&](int k) -> bool { return (pm >> k) & 1u; };
 
       if constexpr (STD) {
+        if (a.mode != MBPLS_SCALE_FIT && a.count) {      // present samples per column (FIT counts them anyway)
+          double c1[1] = {0.0};
+#pragma unroll
+          for (int k = 0; k < R; ++k) c1[0] += (present(k) && real(k)) ? 1.0 : 0.0;
+          block_sum8<1>(c1, red, buf);
+          if (tid == 0) a.count[jj] = c1[0];
+        }
         if (a.mode != MBPLS_SCALE_NONE) {
           double mean, scale;
           if (a.mode == MBPLS_SCALE_FIT) {

@@ -251,7 +251,7 @@ class HipEngine:
         if self.sparse:
             if getattr(self, "rowmask", None) is not None:
                 raise NotImplementedError("row-subset fits are not available with sparse_data=True")
-            self.count = self.ctx.empty(self.p) if standardize else None
+            self.count = self.ctx.empty(self.p)          # present samples per column
             src.nan_standardize_sweep(self.X, mode, self.mean, self.scale, self.count, self._xptr(n * B + 2 * B), dv,
                                       self._slot_col(g_slot), self._xptr(0) if v is not None else None,
                                       self._xptr(self._d_off) if v is not None else None,
@@ -371,6 +371,13 @@ class HipEngine:
         if per_block:
             return [h[b * n * c:(b + 1) * n * c].reshape(c, n).T.copy() for b in range(nb)]
         return h.reshape(c, n).T.copy()
+
+    def present_per_row(self):
+        """number of present (non-NaN) entries of every sample in every block, n x B (one indicator pass)"""
+        ones = self.ctx.from_host(np.ones((self.p, 1)))
+        cnt = self._xw(ones, 1, True, nan="indicator")
+        ones.free()
+        return np.column_stack([c[:, 0] for c in cnt])
 
     def x_w_slot(self, slot, k0, c, per_block=False):
         """X @ slot[:, k0:k0+c]  -> n x c (or one n x c per block)."""

@@ -8,7 +8,7 @@ the HIP library or a GPU every method raises.
 Deliberate deviations from the reference (documented in DESIGN.md):
 * ``sparse_data=True`` (NaN-aware NIPALS, per-row/column Python loops in the reference, mbpls.py:846-926)
   runs on masked column passes (csrc/colpass_nan.hip) for missing values in X; missing values in Y are not
-  supported (``NotImplementedError``) and the ``sparse_X_info_`` index lists are not produced.
+  supported (``NotImplementedError``).
 * NIPALS has an iteration cap (``solvers.NIPALS_MAX_ITER``) with a warning; the reference loops
   forever on data without latent structure (mbpls.py:841).
 * SIMPLS with one response and ``full_svd=False`` works (the reference raises inside scipy ``svds``).
@@ -77,6 +77,11 @@ def _require_finite(out):
     """NaN/inf in new data shows up in every product with it (same error type as sklearn's check_array)."""
     if not np.all(np.isfinite(out)):
         raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
+
+
+def _global_block_sizes(eng):
+    """block widths of the whole problem (summed over column shards)"""
+    return eng.comm.allreduce_host(np.asarray(eng.block_sizes, dtype=np.float64))
 
 
 def _is_block_list(X):
@@ -203,6 +208,8 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
                         res[key] = res[key][row_mask]
                 if isinstance(res.get("T_"), list):
                     res["T_"] = [t[row_mask] for t in res["T_"]]
+            if sparse:
+                self._sparsity_info(eng, Y)
             with eng._timed("store_attributes"):
                 self._store(eng, res)
         finally:
@@ -212,6 +219,25 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             eng.timings["total"] = _time.perf_counter() - t_fit0
             self.fit_timings_ = dict(eng.timings)   # seconds per host-side phase (not in the reference)
         return self
+
+    def _sparsity_info(self, eng, Y):
+        """``sparse_X_info_[b]`` / ``sparse_Y_info_['Y']`` = (sparse_rows, sparse_columns, dense_rows,
+        dense_columns) index arrays and the high-sparsity warnings of check_sparsity_level (mbpls.py:255-271,
+        :295-296, :313, :321), from the per-column counts of the standardise pass and one indicator pass."""
+        def info(sparse_rows, sparse_cols):
+            for flags in (sparse_cols, sparse_rows):                                  # :265-270
+                if flags.size and flags.sum() / flags.size > 0.5:
+                    warnings.warn("The sparsity of your data is likely to high for this algorithm. This can cause "
+                                  "either convergenceproblems or crash the algorithm.")
+            return (np.where(sparse_rows)[0], np.where(sparse_cols)[0],
+                    np.where(~sparse_rows)[0], np.where(~sparse_cols)[0])
+        col_present = eng.count.get()
+        row_present = eng.present_per_row()
+        sizes = _global_block_sizes(eng)
+        self.sparse_X_info_ = {}
+        for b, (s, e) in enumerate(zip(eng.block_offsets[:-1], eng.block_offsets[1:])):
+            self.sparse_X_info_[b] = info(row_present[:, b] < sizes[b], col_present[s:e] < eng.n)
+        self.sparse_Y_info_ = {'Y': info(np.isnan(Y).any(axis=1), np.isnan(Y).any(axis=0))}
 
     def _store(self, eng, res):
         B = eng.nblocks

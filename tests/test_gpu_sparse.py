@@ -51,10 +51,18 @@ def test_reference_fixture(gpu_required):
                 ref = util.sub(g, f"ref/q{q}/{blocks}/std{int(std)}")
                 mdl = MBPLS(n_components=3, sparse_data=True, standardize=std).fit(sp(X), Y)
                 worst = max(worst, util.compare(_flat(mdl, sp(Xn), Yn), ref, TOL, what=f"q{q} {blocks} std{std}"))
+                ok = ~np.isnan(X)
                 if std:
-                    ok = ~np.isnan(X)
                     seen = np.concatenate([s.n_samples_seen_ for s in mdl.x_scalers_])
                     assert np.array_equal(seen, ok.sum(axis=0))
+                # check_sparsity_level bookkeeping (mbpls.py:255-271)
+                for b, blk in enumerate(sp(ok) if blocks == "multi" else [ok]):
+                    sr, sc, dr, dc = mdl.sparse_X_info_[b]
+                    assert np.array_equal(sr, np.where(~blk.all(axis=1))[0])
+                    assert np.array_equal(sc, np.where(~blk.all(axis=0))[0])
+                    assert np.array_equal(dr, np.where(blk.all(axis=1))[0])
+                    assert np.array_equal(dc, np.where(blk.all(axis=0))[0])
+                assert all(len(v) == 0 for v in mdl.sparse_Y_info_['Y'][:2])
     assert worst < 1e-8, worst
 
 
@@ -109,3 +117,15 @@ def test_method_is_switched_to_nipals_and_y_must_be_complete(gpu_required):
     # and without sparse_data a NaN is still an input error
     with pytest.raises(ValueError):
         MBPLS(n_components=2).fit(X, Y)
+
+
+def test_high_sparsity_warning(gpu_required):
+    """mbpls.py:265-270: more than half of the rows (or columns) with missing entries -> UserWarning."""
+    from mbpls_amd import MBPLS
+    X, Y = orc.make_latent(50, 80, 1, seed=3)
+    X = X.copy()
+    X[:30, 0] = np.nan
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        MBPLS(n_components=2, sparse_data=True, standardize=False).fit(X, Y)
+    assert any("sparsity" in str(r.message) for r in rec)

@@ -1,5 +1,5 @@
 """Timing of the sparse_data=True path (missing values): per-kernel GB/s from the HIP-event profile.
-    python tools/time_sparse.py [p] [frac_missing]"""
+    python tools/time_sparse.py [p] [frac_missing] [rows_per_thread]"""
 import os
 import sys
 import time
@@ -20,6 +20,8 @@ blk = ts.dot(rng.randn(4, pb)) + 0.5 * rng.randn(n, pb)
 Y = ts[:, :1] + 0.1 * rng.randn(n, 1)
 blk[rng.rand(n, pb) < frac] = np.nan
 ctx = mbpls_amd.get_context()
+if len(sys.argv) > 3:
+    ctx.set_tunable("rows_per_thread", int(sys.argv[3]))
 X = DeviceMatrix(ctx, n, p)
 for o in range(0, p, pb):
     X.upload(blk[:, :min(pb, p - o)], o)
