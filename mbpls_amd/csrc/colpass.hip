@@ -416,6 +416,7 @@ int mbpls_hip_sweep(const mbpls_mat* m, const double* d_v, double alpha, double*
                     double* d_ssq_g) {
   MB_ARG(m && d_v, "NULL argument");
   mbpls_ctx* ctx = m->ctx;
+  if (long_columns(ctx, m->n)) return long_sweep(m, d_v, alpha, d_g, d_t, d_ssq_g);
   PassArgs a{};
   MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s));
   a.src = m->data; a.dst = nullptr; a.ld = m->ld; a.n = m->n;
@@ -430,6 +431,8 @@ int mbpls_hip_deflate_sweep(mbpls_mat* m, const double* d_ts, double inv_tt, int
                             double* d_ssq_g) {
   MB_ARG(m && d_ts, "NULL argument");
   mbpls_ctx* ctx = m->ctx;
+  if (long_columns(ctx, m->n))
+    return long_deflate_sweep(m, d_ts, inv_tt, deflate, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g);
   PassArgs a{};
   MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s));
   a.src = m->data; a.dst = m->data; a.ld = m->ld; a.n = m->n;
@@ -451,6 +454,10 @@ int mbpls_hip_sweep_lazy(const mbpls_mat* m, const double* d_v, double alpha, do
   MB_ARG(m && d_v, "NULL argument");
   MB_ARG(kprev >= 0 && kprev < KD && (kprev == 0 || (d_P && d_cu && d_d)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   mbpls_ctx* ctx = m->ctx;
+  if (long_columns(ctx, m->n)) {
+    set_error("lazy deflation needs register-resident columns (n=%lld): use the explicit passes", (long long)m->n);
+    return MBPLS_ERR_UNSUPPORTED;
+  }
   PassArgs a{};
   MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s, &a.part_d));
   a.src = m->data; a.dst = nullptr; a.ld = m->ld; a.n = m->n;
@@ -469,6 +476,10 @@ int mbpls_hip_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double
   MB_ARG(kprev >= 0 && kprev < KD - 1 && (kprev == 0 || (d_P && d_ce)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   MB_ARG(!d_v || (d_d && (kprev == 0 || d_cu)), "sweep part needs d_cu / d_d");
   mbpls_ctx* ctx = m->ctx;
+  if (long_columns(ctx, m->n)) {
+    set_error("lazy deflation needs register-resident columns (n=%lld): use the explicit passes", (long long)m->n);
+    return MBPLS_ERR_UNSUPPORTED;
+  }
   PassArgs a{};
   MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s, &a.part_d));
   a.src = m->data; a.dst = m->data; a.ld = m->ld; a.n = m->n;
@@ -501,6 +512,9 @@ int mbpls_hip_standardize_sweep_masked(const mbpls_mat* src, mbpls_mat* dst, int
   MB_ARG(mode == MBPLS_SCALE_FIT || mode == MBPLS_SCALE_APPLY || mode == MBPLS_SCALE_NONE, "bad mode %d", mode);
   MB_ARG(mode == MBPLS_SCALE_NONE || (d_mean && d_scale), "mean/scale buffers required");
   mbpls_ctx* ctx = dst->ctx;
+  if (long_columns(ctx, dst->n))
+    return long_standardize_sweep(src, dst, mode, d_rowmask, n_eff, d_mean, d_scale, d_ssq_x, d_v, alpha, d_g, d_t,
+                                  d_ssq_g);
   PassArgs a{};
   MB_TRY(partial_buffers(ctx, dst, &a.part_t, &a.part_s));
   a.src = src->data; a.dst = dst->data; a.ld = dst->ld; a.n = dst->n;

@@ -257,7 +257,7 @@ static int launch_nan(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, in
   Cfg cfg;
   int T = 0;
   if (!pick_cfg(ctx, a.n, &cfg, &T, false)) {
-    set_error("column passes support n <= 65536 (got n=%lld)", (long long)a.n);
+    set_error("the missing-value column passes support n <= 65536 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;
   }
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);

@@ -140,4 +140,14 @@ int reduce_chunks(mbpls_ctx* ctx, const mbpls_mat* m, const double* part_t, cons
                   double* d_t, double* d_ssq_g, double* d_ssq_p, double* d_ssq_x,
                   const double* part_d = nullptr, int nd = 0, double* d_d = nullptr);
 
+
+// colpass_long.hip: the same passes for columns too long to hold in registers (n > ctx->long_columns_from)
+bool long_columns(const mbpls_ctx* ctx, int64_t n);
+int long_sweep(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g);
+int long_deflate_sweep(mbpls_mat* m, const double* d_ts, double inv_tt, int deflate, double* d_p, double* d_ssq_p,
+                       const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g);
+int long_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode, const double* d_rowmask, double n_eff,
+                           double* d_mean, double* d_scale, double* d_ssq_x, const double* d_v, double alpha,
+                           double* d_g, double* d_t, double* d_ssq_g);
+
 }  // namespace mbpls

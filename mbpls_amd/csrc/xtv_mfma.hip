@@ -10,6 +10,8 @@
 // exactly that fragment order (k_pack_v), so a B fragment is one contiguous 512-byte wave load from L2.
 // Each wave owns FT = 2 feature tiles (32 features) so a V fragment is reused twice.  No LDS, no
 // atomics; accumulators live in 16*NT VGPRs, so occupancy hides the HBM latency.
+// Tall data (few features, many samples) has too few feature tiles to fill the chip: the sample range is
+// then cut into slices (grid.y), each slice writes its partial G and k_sum_slices adds them in fixed order.
 #include <algorithm>
 
 #include "common.h"
@@ -37,13 +39,16 @@ __global__ __launch_bounds__(256) void k_pack_v(const double* __restrict__ V, in
 template <int NT>
 __global__ __launch_bounds__(256) void k_xtv_mfma(const double* __restrict__ X, int64_t ld, int64_t n, int64_t p,
                                                   const double* __restrict__ Vp, int c, double alpha,
-                                                  double* __restrict__ G, int64_t ldg) {
+                                                  double* __restrict__ G, int64_t ldg, int64_t ks_per_slice,
+                                                  int64_t slice_stride) {
   constexpr int FT = 2;
+  G += (int64_t)blockIdx.y * slice_stride;
+  const int64_t ks_begin = (int64_t)blockIdx.y * ks_per_slice;
   const int lane = threadIdx.x & 63;
   const int f = lane & 15, g = lane >> 4;
   const int64_t ntiles = (p + 16 * FT - 1) / (16 * FT);
-  const int64_t nk = (n + 15) / 16;
-  const int64_t nk_full = ld / 16;   // k-steps whose 16 samples lie inside the row allocation for every lane
+  const int64_t nk = std::min((n + 15) / 16, ks_begin + ks_per_slice);
+  const int64_t nk_full = std::min(ld / 16, nk);   // k-steps whose 16 samples lie inside the row allocation
   for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += (int64_t)gridDim.x * 4) {
     const double* xrow[FT];
 #pragma unroll
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(256) void k_xtv_mfma(const double* __restrict__ X, 
       for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (double4_t){0.0, 0.0, 0.0, 0.0};
     const double* vp = Vp + lane;
 
-    for (int64_t ks = 0; ks < nk_full; ++ks) {
+    for (int64_t ks = ks_begin; ks < nk_full; ++ks) {
       double x[FT][4];
 #pragma unroll
       for (int t = 0; t < FT; ++t) {
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256) void k_xtv_mfma(const double* __restrict__ X, 
           for (int t = 0; t < FT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[t][m], b, acc[t][nt], 0, 0, 0);
         }
     }
-    for (int64_t ks = nk_full; ks < nk; ++ks) {   // ragged end of the rows: guarded scalar loads
+    for (int64_t ks = std::max(nk_full, ks_begin); ks < nk; ++ks) {   // ragged end of the rows: guarded scalar loads
       double x[FT][4];
 #pragma unroll
       for (int t = 0; t < FT; ++t)
@@ -108,6 +113,17 @@ __global__ __launch_bounds__(256) void k_xtv_mfma(const double* __restrict__ X, 
   }
 }
 
+// G[k, j] = sum over slices (fixed order) of part[s][k][j]
+__global__ __launch_bounds__(256) void k_sum_slices(const double* __restrict__ part, int S, int64_t slice_stride,
+                                                    int64_t p, double* __restrict__ G, int64_t ldg) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (j >= p) return;
+  double s = 0.0;
+  for (int i = 0; i < S; ++i) s += part[(int64_t)i * slice_stride + (int64_t)k * p + j];
+  G[(int64_t)k * ldg + j] = s;
+}
+
 // ssq[k * nblocks + b] = sum_{j in block b} G[j, k]^2, fixed-order (one workgroup per (b, k))
 __global__ __launch_bounds__(256) void k_block_colssq(const double* __restrict__ G, int64_t ldg,
                                                       const int64_t* __restrict__ blk_off, int nblocks,
@@ -136,18 +152,28 @@ int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv,
   const int64_t nk = (m->n + 15) / 16;
   const int64_t total = nk * 4 * NT * 64;
   const size_t off_bytes = sizeof(int64_t) * (size_t)(m->nblocks + 1);
-  MB_TRY(ensure_ws(ctx, sizeof(double) * (size_t)total + off_bytes + 256));
+  const int64_t ntiles = (m->p + 31) / 32;
+  const int64_t wgs = (ntiles + 3) / 4;
+  // sample slices: only when the feature tiles alone leave most of the chip idle; >= 1024 samples per slice
+  int S = 1;
+  if (wgs < 2 * (int64_t)ctx->cus)
+    S = (int)std::max<int64_t>(1, std::min<int64_t>({(2 * (int64_t)ctx->cus + wgs - 1) / wgs, nk / 64, 256}));
+  const int64_t ks_per_slice = (nk + S - 1) / S;
+  const int64_t slice_stride = (int64_t)c * m->p;
+  const size_t part_off = ((sizeof(double) * (size_t)total + off_bytes + 511) / 256) * 256;
+  MB_TRY(ensure_ws(ctx, part_off + (S > 1 ? sizeof(double) * (size_t)S * (size_t)slice_stride : 0)));
   double* Vp = (double*)ctx->ws;
+  double* part = (double*)((char*)ctx->ws + part_off);
   hipLaunchKernelGGL(k_pack_v, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_V, ldv, m->n, c, NT,
                      total, Vp);
   MB_HIP(hipGetLastError());
-  const int64_t ntiles = (m->p + 31) / 32;
-  const unsigned grid = (unsigned)std::min<int64_t>((ntiles + 3) / 4, (int64_t)ctx->cus * 8);
+  const unsigned grid = (unsigned)std::min<int64_t>(wgs, (int64_t)ctx->cus * 8);
   {
     ProfScope prof(ctx, MBPLS_K_XT_V, 8.0 * (double)m->n * (double)m->p);
 #define MB_XTV(NT_)                                                                                               \
-  hipLaunchKernelGGL((k_xtv_mfma<NT_>), dim3(grid), dim3(256), 0, ctx->stream, (const double*)m->data, m->ld, m->n, \
-                     m->p, (const double*)Vp, c, alpha, d_G, ldg)
+  hipLaunchKernelGGL((k_xtv_mfma<NT_>), dim3(grid, (unsigned)S), dim3(256), 0, ctx->stream, (const double*)m->data, \
+                     m->ld, m->n, m->p, (const double*)Vp, c, alpha, S > 1 ? part : d_G, S > 1 ? m->p : ldg,      \
+                     ks_per_slice, S > 1 ? slice_stride : (int64_t)0)
     if (NT == 1) MB_XTV(1);
     else if (NT == 2) MB_XTV(2);
     else if (NT == 3) MB_XTV(3);
@@ -155,6 +181,11 @@ int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv,
 #undef MB_XTV
   }
   MB_HIP(hipGetLastError());
+  if (S > 1) {
+    hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((m->p + 255) / 256), (unsigned)c), dim3(256), 0, ctx->stream,
+                       (const double*)part, S, slice_stride, m->p, d_G, ldg);
+    MB_HIP(hipGetLastError());
+  }
   if (d_ssq) {
     int64_t* d_off = (int64_t*)((char*)ctx->ws + ((sizeof(double) * (size_t)total + 255) / 256) * 256);
     MB_HIP(hipMemcpyAsync(d_off, m->block_offsets.data(), off_bytes, hipMemcpyHostToDevice, ctx->stream));

@@ -179,6 +179,8 @@ class HipEngine:
         mode = os.environ.get("MBPLS_DEFLATION", self.deflation)
         if self.sparse:
             mode = "explicit"      # the implicit correction would need every row's own missing-value mask
+        if self.n > getattr(self.ctx, "long_columns_from", 8192):
+            mode = "explicit"      # streamed-column passes (csrc/colpass_long.hip) rewrite X
         self._lazy_pslot = pslot if (mode == "lazy" and K < self.KD - 1) else None
         self._lazy_ts = []
         return self._lazy_pslot is not None

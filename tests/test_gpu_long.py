@@ -1,0 +1,123 @@
+"""GPU parity for LONG columns (n beyond the register-resident column passes): csrc/colpass_long.hip.
+
+Tall data -- many samples, few features -- is what the reference's n >= p branches exist for
+(mbpls.py:388-479 UNIPALS, :580-692 KERNEL); NIPALS / SIMPLS take the same passes.  Checked (a) with the
+streamed-column kernels forced on small problems (every fixture case of the n >= p and p > n matrices,
+row-subset fits) and (b) at n = 100 000 against the oracle.  Tolerance 1e-6 relative, sign-aligned."""
+import numpy as np
+import pytest
+
+from oracle import mbpls_oracle as orc
+from tests import util
+from tests.test_gpu_parity import _fit_flat
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+@pytest.fixture()
+def forced_long(gpu_required):
+    import mbpls_amd
+    ctx = mbpls_amd.get_context()
+    ctx.set_tunable("long_columns_from", 0)
+    yield ctx
+    ctx.set_tunable("long_columns_from", 8192)
+
+
+def _oracle_flat(ref, Xn, Yn, method):
+    flat = util.model_to_flat(ref)
+    flat["predict"] = orc.predict(ref, Xn)
+    if method != "SIMPLS":
+        Ts, T, U = orc.transform(ref, Xn, Yn, return_block_scores=True)
+        for b, blk in enumerate(T):
+            flat[f"T_new/{b}"] = blk
+    else:
+        Ts, U = orc.transform(ref, Xn, Yn)
+    flat["Ts_new"], flat["U_new"] = Ts, U
+    return flat
+
+
+@pytest.mark.parametrize("fixture", ["matrix_pgtn", "matrix_ngtp"])
+def test_fixture_matrix_with_streamed_columns(forced_long, fixture):
+    from mbpls_amd import MBPLS
+    g = util.load(fixture)
+    splits = np.cumsum(g["splits"])[:-1]
+    worst = 0.0
+    for q in (1, 3):
+        X, Y = g[f"in/q{q}/X"], g[f"in/q{q}/Y"]
+        Xn, Yn = g[f"in/q{q}/Xnew"], g[f"in/q{q}/Ynew"]
+        for blocks in ("single", "multi"):
+            sp = (lambda A: A) if blocks == "single" else (
+                lambda A: [np.ascontiguousarray(b) for b in np.split(A, splits, axis=1)])
+            for m in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+                for std in (True, False):
+                    pre = f"ref/q{q}/{blocks}/{m}/std{int(std)}/ca1"
+                    ref = util.sub(g, pre)
+                    mdl = MBPLS(n_components=3, method=m, standardize=std, full_svd=(m == "SIMPLS")).fit(sp(X), Y)
+                    has_T_new = any(k.startswith("T_new") for k in ref)
+                    worst = max(worst, util.compare(_fit_flat(mdl, sp(Xn), Yn, block_scores=has_T_new), ref, TOL,
+                                                    what=pre))
+    assert worst < 1e-8, worst
+
+
+@pytest.mark.parametrize("method,n,p,q,K,blocks", [
+    ("NIPALS", 1001, 3000, 2, 3, [1000, 2000]),
+    ("UNIPALS", 777, 2500, 1, 3, [2500]),
+    ("NIPALS", 100_000, 300, 1, 3, [100, 200]),       # genuinely long columns (n > 65536), n >= p
+    ("UNIPALS", 100_000, 240, 2, 3, [240]),
+    ("KERNEL", 70_001, 200, 1, 3, [80, 120]),
+    ("SIMPLS", 90_000, 150, 2, 3, [150]),
+])
+def test_vs_oracle(gpu_required, method, n, p, q, K, blocks):
+    import mbpls_amd
+    from mbpls_amd import MBPLS
+    ctx = mbpls_amd.get_context()
+    ctx.set_tunable("long_columns_from", 0 if n <= 8192 else 8192)
+    try:
+        X, Y = orc.make_latent(n, p, q, seed=n + p)
+        Xn, Yn = orc.make_latent(64, p, q, seed=1)
+        cuts = np.cumsum(blocks)[:-1]
+        sp = (lambda A: A) if len(blocks) == 1 else (
+            lambda A: [np.ascontiguousarray(b) for b in np.split(A, cuts, axis=1)])
+        ref = orc.fit(sp(X), Y, n_components=K, method=method, full_svd=True)
+        mdl = MBPLS(n_components=K, method=method, full_svd=True).fit(sp(X), Y)
+        w = util.compare(_fit_flat(mdl, sp(Xn), Yn), _oracle_flat(ref, sp(Xn), Yn, method), TOL,
+                         what=f"{method} n={n} p={p}")
+        assert w < 1e-8, w
+    finally:
+        ctx.set_tunable("long_columns_from", 8192)
+
+
+def test_row_subset_fit_with_streamed_columns(forced_long):
+    """cross-validation folds (row mask in the standardise pass) through the streamed-column kernels"""
+    from mbpls_amd import MBPLS, DeviceMatrix
+    X, Y = orc.make_latent(301, 900, 1, seed=11)
+    mask = np.ones(301, dtype=bool)
+    mask[::7] = False
+    dX = DeviceMatrix(forced_long, 301, 900, [0, 400, 900])
+    dX.upload(X, 0)
+    for method in ("NIPALS", "UNIPALS"):
+        mdl = MBPLS(n_components=3, method=method)._fit(dX, Y, mask)
+        ref = orc.fit([X[mask][:, :400], X[mask][:, 400:]], Y[mask], n_components=3, method=method)
+        w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=method)
+        assert w < 1e-9, w
+    dX.close()
+
+
+def test_register_resident_configs_above_8192(gpu_required):
+    """long_columns_from = 65536 keeps the register-resident passes (R = 32 / 64 rows per thread, spilling;
+    also what lazy deflation needs) for 8192 < n <= 65536 -- slower than the streamed passes, same numbers."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS
+    ctx = mbpls_amd.get_context()
+    X, Y = orc.make_latent(10_000, 2000, 1, seed=12)
+    a = MBPLS(n_components=3).fit(X, Y)                      # streamed columns, explicit deflation
+    ctx.set_tunable("long_columns_from", 65536)
+    try:
+        b = MBPLS(n_components=3).fit(X, Y)                  # register-resident, lazy deflation
+    finally:
+        ctx.set_tunable("long_columns_from", 8192)
+    ref = orc.fit(X, Y, n_components=3)
+    for mdl in (a, b):
+        w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="n=10000")
+        assert w < 1e-8, w
