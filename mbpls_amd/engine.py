@@ -168,6 +168,14 @@ class HipEngine:
         name, k = spec
         return self.slots[name].col(k)
 
+    def run_deferred(self, count=1, all_of_it=False):
+        """Host chores queued by the estimator (releasing the attributes a refit replaces): a few per column
+        pass, called right after a launch so they run while the GPU works."""
+        work = getattr(self, "deferred_host_work", None)
+        while work and (all_of_it or count > 0):
+            work.pop()()
+            count -= 1
+
     # ------------------------------------------------------------------ exchange helpers
     def _xptr(self, off):
         return self._xchg.ptr + 8 * off
@@ -267,10 +275,7 @@ class HipEngine:
                                   self._slot_col(g_slot), self._xptr(0) if v is not None else None,
                                   self._xptr(n * B) if v is not None else None, rowmask=dm, n_eff=n_eff)
         self._src = None
-        cb = getattr(self, "on_first_pass", None)
-        if cb is not None:          # host work hidden behind the longest pass of the fit
-            self.on_first_pass = None
-            cb()
+        self.run_deferred(2)        # the standardise pass is the longest of the fit
         t, g, _, x = self._finish_pass(v is not None, v is not None, False, True)
         if not np.all(np.isfinite(x)):
             # any NaN / inf in a column poisons its sum of squares (and its mean / scale)
@@ -293,6 +298,8 @@ class HipEngine:
             self.X.sweep(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B))
         if overlap is not None:
             overlap()
+        else:
+            self.run_deferred()
         t, g, _, _ = self._finish_pass(True, True, False, False, nd=k)
         if k:
             t = self._lazy_fix(t, self._last_d)
@@ -310,6 +317,8 @@ class HipEngine:
                                      self._xptr(n * B) if v is not None else None)
             if overlap is not None:
                 overlap()
+            else:
+                self.run_deferred()
             t, g, p, _ = self._finish_pass(v is not None, v is not None, True, False)
             return p, t, g
         if self._lazy_pslot:
@@ -323,6 +332,8 @@ class HipEngine:
                                        self._xptr(n * B + 3 * B) if v is not None else None)
             if overlap is not None:
                 overlap()
+            else:
+                self.run_deferred()
             t, g, p, _ = self._finish_pass(v is not None, v is not None, True, False, nd=(k + 1) if v is not None else 0)
             if v is not None:
                 t = self._lazy_fix(t, self._last_d, extra_ts=np.asarray(ts))
@@ -334,6 +345,8 @@ class HipEngine:
                              self._xptr(n * B) if v is not None else None)
         if overlap is not None:
             overlap()
+        else:
+            self.run_deferred()
         t, g, p, _ = self._finish_pass(v is not None, v is not None, True, False)
         return p, t, g
 

@@ -178,10 +178,11 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         eng.sparse = sparse
         eng.rowmask = None if row_mask is None else row_mask.astype(np.float64)
         # A refit replaces the previous p x K attributes; releasing ~0.4 GB of numpy memory (page-table
-        # teardown) costs ~15 ms of host time at p = 1e6 -- do it while the standardise pass runs on the GPU.
+        # teardown) costs ~15 ms of host time at p = 1e6 -- more than any single pass hides.  The engine drops
+        # one stale object per column pass, right after the launch, while the host would only wait anyway.
         stale = [self.__dict__.pop(k) for k in ("P_", "W_", "W_non_normal_", "R_", "beta_", "W_concat_", "T_")
                  if k in self.__dict__]
-        eng.on_first_pass = stale.clear
+        eng.deferred_host_work = [stale.pop for _ in stale]
         import time as _time
         t_fit0 = _time.perf_counter()
         threads = runtime.host_threads()
@@ -213,6 +214,7 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             with eng._timed("store_attributes"):
                 self._store(eng, res)
         finally:
+            eng.run_deferred(all_of_it=True)
             threads.__exit__(None, None, None)
             with eng._timed("release"):
                 eng.close()
