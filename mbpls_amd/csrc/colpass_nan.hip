@@ -62,8 +62,10 @@ __device__ __forceinline__ void block_sum8(double (&v)[NV], double* red, int& bu
   buf ^= 1;
 }
 
-template <int R, int TMAX, bool STD, bool DEFL, bool SWEEP>
-__global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512 && !STD && !DEFL) ? 4 : 1) void k_colpass_nan(NanArgs a) {
+// FULL: n == T*R == ld -- no row masks and, more important, no select right behind the column load that would
+// force an s_waitcnt before the prefetched column is needed (see colpass.hip).
+template <int R, int TMAX, bool STD, bool DEFL, bool SWEEP, bool FULL>
+__global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpass_nan(NanArgs a) {
   constexpr int D = 2;   // columns in flight
   __shared__ double red[2 * 128];
   int buf = 0;
@@ -73,21 +75,50 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512 && !STD && !DEFL) ? 4 
   const int64_t j0 = uniform64(a.c0[chunk]), j1 = uniform64(a.c1[chunk]);
   RowMap<R> rm;
   rm.init(n, ld, tid, T);
-  auto real = [&](int k) -> bool { return (((k & 1) ? rm.in_n1 : rm.in_n0) >> (k >> 1)) & 1u; };
+  auto real = [&](int k) -> bool { return FULL || ((((k & 1) ? rm.in_n1 : rm.in_n0) >> (k >> 1)) & 1u); };
 
-  double v[SWEEP ? R : 1], ts[DEFL ? R : 1], acc[SWEEP ? R : 1], dac[SWEEP ? R : 1];
+  // The n = 4096 configuration (R = 8, 512 threads) must stay at <= 128 VGPRs for two workgroups per CU (see
+  // colpass.hip); its fused variants keep the n-vectors u / ts in LDS (each thread re-reads its own row pairs).
+  constexpr bool VEC_LDS = (R == 8 && TMAX == 512) && (STD || DEFL);
+  __shared__ double2 s_v[(VEC_LDS && SWEEP) ? (TMAX * R / 2) : 1];
+  __shared__ double2 s_ts[(VEC_LDS && DEFL) ? (TMAX * R / 2) : 1];
+  double v_reg[(SWEEP && !VEC_LDS) ? R : 1], ts_reg[(DEFL && !VEC_LDS) ? R : 1], acc[SWEEP ? R : 1], dac[SWEEP ? R : 1];
   if constexpr (SWEEP) {
-    load_vec<R>(v, a.v, n, tid, T);
+    if constexpr (VEC_LDS) {
+      double tmp[R];
+      load_vec<R>(tmp, a.v, n, tid, T);
+#pragma unroll
+      for (int k = 0; k < R / 2; ++k) s_v[k * T + tid] = make_double2(tmp[2 * k], tmp[2 * k + 1]);
+    } else {
+      load_vec<R>(v_reg, a.v, n, tid, T);
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) acc[k] = dac[k] = 0.0;
   }
-  if constexpr (DEFL) load_vec<R>(ts, a.ts, n, tid, T);
+  if constexpr (DEFL) {
+    if constexpr (VEC_LDS) {
+      double tmp[R];
+      load_vec<R>(tmp, a.ts, n, tid, T);
+#pragma unroll
+      for (int k = 0; k < R / 2; ++k) s_ts[k * T + tid] = make_double2(tmp[2 * k], tmp[2 * k + 1]);
+    } else {
+      load_vec<R>(ts_reg, a.ts, n, tid, T);
+    }
+  }
+  auto v_pair = [&](int k) -> double2 {
+    if constexpr (VEC_LDS) return s_v[k * T + tid];
+    else return make_double2(v_reg[2 * k], v_reg[2 * k + 1]);
+  };
+  auto ts_pair = [&](int k) -> double2 {
+    if constexpr (VEC_LDS) return s_ts[k * T + tid];
+    else return make_double2(ts_reg[2 * k], ts_reg[2 * k + 1]);
+  };
   double ssq_g = 0.0, ssq_p = 0.0, ssq_x = 0.0;
 
   double x[D][R];
 #pragma unroll
   for (int d = 0; d < D; ++d)
-    if (j0 + d < j1) load_col<R, false>(x[d], a.src + (j0 + d) * ld, rm);
+    if (j0 + d < j1) load_col<R, FULL>(x[d], a.src + (j0 + d) * ld, rm);
 
   for (int64_t j = j0; j < j1; j += D) {
 #pragma unroll
@@ -158,7 +189,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512 && !STD && !DEFL) ? 4 
           const double z = present(k) ? xc[k] : 0.0;
           ssq_x = fma(z, z, ssq_x);                     // nansum(X^2), mbpls.py:826
         }
-        store_col<R, false>(xc, a.dst + jj * ld, rm);
+        store_col<R, FULL>(xc, a.dst + jj * ld, rm);
       }
 
       double gj = 0.0;
@@ -168,17 +199,25 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512 && !STD && !DEFL) ? 4 
 #pragma unroll
         for (int q = 0; q < (SWEEP ? 5 : 2); ++q) r5[q] = 0.0;
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-          const bool pr = present(k);
-          const double xz = pr ? xc[k] : 0.0;
-          const double tz = pr ? ts[k] : 0.0;
-          r5[0] = fma(xz, ts[k], r5[0]);
-          r5[1] = fma(tz, ts[k], r5[1]);
-          if constexpr (SWEEP) {
-            const double vz = pr ? v[k] : 0.0;
-            r5[2] = fma(xz, v[k], r5[2]);
-            r5[3] = fma(vz, v[k], r5[3]);
-            r5[4] = fma(tz, v[k], r5[4]);
+        for (int kp = 0; kp < R / 2; ++kp) {
+          const double2 t2 = ts_pair(kp);
+          double2 v2 = make_double2(0.0, 0.0);
+          if constexpr (SWEEP) v2 = v_pair(kp);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int k = 2 * kp + h;
+            const double tk = h ? t2.y : t2.x, vk = h ? v2.y : v2.x;
+            const bool pr = present(k);
+            const double xz = pr ? xc[k] : 0.0;
+            const double tz = pr ? tk : 0.0;
+            r5[0] = fma(xz, tk, r5[0]);
+            r5[1] = fma(tz, tk, r5[1]);
+            if constexpr (SWEEP) {
+              const double vz = pr ? vk : 0.0;
+              r5[2] = fma(xz, vk, r5[2]);
+              r5[3] = fma(vz, vk, r5[3]);
+              r5[4] = fma(tz, vk, r5[4]);
+            }
           }
         }
         block_sum8<(SWEEP ? 5 : 2)>(r5, red, buf);
@@ -187,8 +226,12 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512 && !STD && !DEFL) ? 4 
         if (tid == 0 && a.pvec) a.pvec[jj] = pj;
         if (a.deflate) {
 #pragma unroll
-          for (int k = 0; k < R; ++k) xc[k] = fma(-pj, ts[k], xc[k]);    // NaN stays NaN (:969)
-          store_col<R, false>(xc, a.dst + jj * ld, rm);
+          for (int kp = 0; kp < R / 2; ++kp) {                            // NaN stays NaN (:969)
+            const double2 t2 = ts_pair(kp);
+            xc[2 * kp] = fma(-pj, t2.x, xc[2 * kp]);
+            xc[2 * kp + 1] = fma(-pj, t2.y, xc[2 * kp + 1]);
+          }
+          store_col<R, FULL>(xc, a.dst + jj * ld, rm);
           if constexpr (SWEEP) gj = (r5[3] != 0.0) ? fma(-pj, r5[4], r5[2]) / r5[3] : 0.0;
         } else {
           if constexpr (SWEEP) gj = (r5[3] != 0.0) ? r5[2] / r5[3] : 0.0;
@@ -196,10 +239,16 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512 && !STD && !DEFL) ? 4 
       } else if constexpr (SWEEP) {
         double r2[2] = {0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-          const bool pr = present(k);
-          r2[0] = fma(pr ? xc[k] : 0.0, v[k], r2[0]);
-          r2[1] = fma(pr ? v[k] : 0.0, v[k], r2[1]);
+        for (int kp = 0; kp < R / 2; ++kp) {
+          const double2 v2 = v_pair(kp);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int k = 2 * kp + h;
+            const double vk = h ? v2.y : v2.x;
+            const bool pr = present(k);
+            r2[0] = fma(pr ? xc[k] : 0.0, vk, r2[0]);
+            r2[1] = fma(pr ? vk : 0.0, vk, r2[1]);
+          }
         }
         block_sum8<2>(r2, red, buf);
         gj = (r2[1] != 0.0) ? r2[0] / r2[1] : 0.0;
@@ -215,7 +264,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512 && !STD && !DEFL) ? 4 
           dac[k] += pr ? g2 : 0.0;
         }
       }
-      if (jj + D < j1) load_col<R, false>(xc, a.src + (jj + D) * ld, rm);
+      if (jj + D < j1) load_col<R, FULL>(xc, a.src + (jj + D) * ld, rm);
     }
   }
 
@@ -225,11 +274,11 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512 && !STD && !DEFL) ? 4 
 #pragma unroll
     for (int k = 0; k < R / 2; ++k) {
       const int64_t r0 = 2 * ((int64_t)k * T + tid);
-      if (r0 < n) {
+      if (FULL || r0 < n) {
         out[r0] = acc[2 * k];
         outd[r0] = dac[2 * k];
       }
-      if (r0 + 1 < n) {
+      if (FULL || r0 + 1 < n) {
         out[r0 + 1] = acc[2 * k + 1];
         outd[r0 + 1] = dac[2 * k + 1];
       }
@@ -261,7 +310,15 @@ static int launch_nan(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, in
     return MBPLS_ERR_UNSUPPORTED;
   }
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
-#define MB_LAUNCH(R_, TM_) hipLaunchKernelGGL((k_colpass_nan<R_, TM_, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a)
+  const bool full = (a.n == (int64_t)T * cfg.R) && (a.ld == a.n) && cfg.R >= 8;
+#define MB_LAUNCH(R_, TM_)                                                                                       \
+  do {                                                                                                           \
+    if (full && (R_) >= 8 && (R_) <= 16)                                                                         \
+      hipLaunchKernelGGL((k_colpass_nan<R_, TM_, STD, DEFL, SWEEP, ((R_) >= 8 && (R_) <= 16)>), grid, block, 0,  \
+                         ctx->stream, a);                                                                        \
+    else                                                                                                         \
+      hipLaunchKernelGGL((k_colpass_nan<R_, TM_, STD, DEFL, SWEEP, false>), grid, block, 0, ctx->stream, a);     \
+  } while (0)
   if (cfg.R == 2) MB_LAUNCH(2, 256);
   else if (cfg.R == 4 && cfg.TMAX == 512) MB_LAUNCH(4, 512);
   else if (cfg.R == 4) MB_LAUNCH(4, 1024);

@@ -33,6 +33,7 @@ for sparse in (True, False) if frac == 0.0 else (True,):
         ctx.profile_reset()
         t0 = time.perf_counter(); m.fit(X, Y); ctx.sync(); t1 = time.perf_counter()
         print(f"sparse={sparse} fit {rep}: {1e3 * (t1 - t0):.1f} ms  iterations {m.nipals_iterations_}", flush=True)
+    print({k: round(1e3 * v, 1) for k, v in m.fit_timings_.items()})
     prof = ctx.profile_get()
     ctx.profile(False)
     print(prof)
