@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
 fixtures captured from the reference.  Tolerance: north_star's 1e-6 relative (float64,
 sign-aligned); the kernel-level checks use tighter bounds to catch indexing errors early."""
+import warnings
+
 import numpy as np
 import pytest
 
@@ -426,3 +428,20 @@ def test_row_subset_fit_and_cross_val_predict(gpu_required):
     got2 = cross_val_predict(MBPLS(n_components=2), blocks, Y, cv=5)
     assert util.relerr(got2, cross_val_predict(MBPLS(n_components=2), Xd, Y, cv=5)) < 1e-12
     Xd.close()
+
+
+@pytest.mark.parametrize("n,p,q,K", [(5, 1, 1, 1), (3, 2, 1, 1), (7, 3, 2, 2), (64, 1, 1, 1), (2, 5, 1, 1), (6, 4, 1, 3),
+                                     (9, 300, 3, 3), (513, 2, 1, 2)])
+def test_tiny_and_ragged_shapes(gpu_required, n, p, q, K):
+    """Smallest inputs the reference accepts: one feature, two samples, fewer columns than compute units,
+    odd sample counts (padded columns) -- every method against the oracle."""
+    from mbpls_amd import MBPLS
+    X, Y = orc.make_latent(n, p, q, r=min(3, p), seed=n + p)
+    for method in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = orc.fit(X, Y, n_components=K, method=method, full_svd=True)
+            mdl = MBPLS(n_components=K, method=method, full_svd=True).fit(X, Y)
+        w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} {n}x{p}")
+        assert w < 1e-9, (method, w)
+        assert util.relerr(mdl.predict(X), orc.predict(ref, X)) < 1e-9
