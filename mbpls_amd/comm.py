@@ -51,7 +51,10 @@ class TorchDistComm:
     """All-reduce over a torch.distributed process group.
 
     device: torch.device of this rank's GPU ("cuda:<local_rank>") for the nccl/RCCL backend,
-    or None/"cpu" for gloo (host tensors; used by the world_size-2 CPU tests)."""
+    or None/"cpu" for gloo (host tensors; used by the world_size-2 CPU tests).  A GPU device together with
+    the gloo backend stages the exchange through the host: that is how several ranks can share ONE GPU
+    (RCCL refuses duplicate devices), used to exercise the real engine's sharded path with world_size 2 on
+    a single-GPU box."""
     is_distributed = True
 
     def __init__(self, group=None, device=None):
@@ -64,6 +67,7 @@ class TorchDistComm:
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
         self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self._host_staged = self.device.type != "cpu" and str(dist.get_backend(group)) == "gloo"
 
     def exchange_buffer(self, ctx, count):
         t = self._torch.zeros(int(count), dtype=self._torch.float64, device=self.device)
@@ -71,13 +75,18 @@ class TorchDistComm:
 
     def allreduce_device(self, buf):
         # kernels ran on the null stream == torch's default stream, so ordering is implicit
-        self._dist.all_reduce(buf.tensor, op=self._dist.ReduceOp.SUM, group=self.group)
+        if self._host_staged:
+            h = buf.tensor.cpu()
+            self._dist.all_reduce(h, op=self._dist.ReduceOp.SUM, group=self.group)
+            buf.tensor.copy_(h)
+        else:
+            self._dist.all_reduce(buf.tensor, op=self._dist.ReduceOp.SUM, group=self.group)
         return buf
 
     def allreduce_host(self, arr):
         a = np.ascontiguousarray(arr, dtype=np.float64)
         t = self._torch.from_numpy(a.reshape(-1).copy())
-        if self.device.type != "cpu":
+        if self.device.type != "cpu" and not self._host_staged:
             t = t.to(self.device)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy().reshape(a.shape)

@@ -22,3 +22,16 @@ def test_rccl_sharded_fit(gpu_required):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("RCCL-sharded fit == oracle") == n, r.stdout
+
+
+def test_two_ranks_share_one_gpu(gpu_required):
+    """world_size 2 with the real engine on ONE GPU (gloo, host-staged exchange): see _shared_gpu_worker.py."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_shared_gpu_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("sharded fit on a shared GPU == oracle") == 2, r.stdout
