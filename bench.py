@@ -78,8 +78,15 @@ def main():
         import torch
         import torch.distributed as dist
         torch.set_num_threads(1)
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if os.environ.get("MBPLS_BENCH_SHARED_GPU") == "1":
+            # dry run of the N>1 code path on a single-GPU box: all ranks drive cuda:0, exchange host-staged
+            # over gloo (RCCL refuses duplicate devices).  Not a measurement configuration.
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         mbpls_amd.set_device(local_rank)
         mbpls_amd.set_comm(mbpls_amd.TorchDistComm(device=f"cuda:{local_rank}"))
     ctx = mbpls_amd.get_context()
