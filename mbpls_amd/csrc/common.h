@@ -61,6 +61,7 @@ struct mbpls_ctx {
   int rows_per_thread = 0;   // 0 = auto
   int prefetch = 2;          // columns in flight per workgroup (register slots)
   int xw_chunks_per_cu = 1;
+  int64_t gram_slice_features = 131072;   // Gram: features per split-K slice for long feature ranges (0 = off)
   int64_t long_columns_from = 8192;    // n above this: streamed-column kernels (colpass_long.hip)
   // workspace for chunk partials (grown on demand, never shrunk)
   void* ws = nullptr;
