@@ -343,6 +343,7 @@ int mbpls_hip_memcpy_d2h(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t 
 int mbpls_hip_memcpy_d2h_overlap(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   MB_ARG(ctx && (bytes == 0 || (h_dst && d_src)), "NULL argument");
   if (bytes == 0) return MBPLS_OK;
+  MB_HIP(hipSetDevice(ctx->device));   // may be called from a helper thread (the current device is per thread)
   if (!ctx->copy_stream) MB_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   MB_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
   MB_HIP(hipStreamSynchronize(ctx->copy_stream));

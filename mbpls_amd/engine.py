@@ -122,9 +122,16 @@ class HipEngine:
             _capi.check(self.ctx.lib.mbpls_hip_memcpy_d2h_overlap(self.ctx.handle, col.ctypes.data,
                                                                   S.ptr + 8 * self.p * k, 8 * self.p))
 
-    def fetch(self, name):
-        with self._timed("d2h_slots"):
-            return self.slots[name].get()
+    def fetch(self, name, overlapped=False):
+        """D2H of a whole slot.  overlapped=True: on the copy stream, not ordered behind the kernels queued on
+        the compute stream (the slot must be final); safe to call from a helper thread."""
+        if not overlapped:
+            with self._timed("d2h_slots"):
+                return self.slots[name].get()
+        S = self.slots[name]
+        out = np.empty(S.shape, order="F")
+        _capi.check(self.ctx.lib.mbpls_hip_memcpy_d2h_overlap(self.ctx.handle, out.ctypes.data, S.ptr, out.nbytes))
+        return out
 
     def put(self, name, arr):
         arr = np.asarray(arr, dtype=np.float64)

@@ -74,7 +74,7 @@ def _finalise(eng, res, Wcols, P, V):
     res.P_ = _split(P, eng.block_offsets)
 
 
-def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_host=None, P_host=None):
+def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_host=None, P_host=None, fetch=True):
     """End-of-fit algebra on the device (mbpls.py:986-991, :569-572, :733-738).
 
     wslot holds raw weight columns; the unit-length weights are W = wslot diag(1/col_norm) and the
@@ -95,10 +95,17 @@ def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_hos
         eng.slot("Wblk", K)
         for b in range(eng.nblocks):
             eng.right_mul((wslot, 0, K), np.diag(1.0 / blk_norm[b]), ("Wblk", 0), rows=(offs[b], offs[b + 1]))
-    res.R_ = eng.fetch("R")
-    res.beta_ = eng.fetch("beta")
-    res.W_ = _split(W_host if W_host is not None else eng.fetch("Wblk"), offs)
-    res.P_ = _split(P_host if P_host is not None else eng.fetch(pslot), offs)
+    def fetch_all(**kw):
+        """D2H of the p x K attributes; kw = dict(overlapped=True) copies on the copy stream (the slots are
+        final) so it can run beside further passes over X."""
+        res.R_ = eng.fetch("R", **kw)
+        res.beta_ = eng.fetch("beta", **kw)
+        res.W_ = _split(W_host if W_host is not None else eng.fetch("Wblk", **kw), offs)
+        res.P_ = _split(P_host if P_host is not None else eng.fetch(pslot, **kw), offs)
+
+    if not fetch:
+        return fetch_all
+    fetch_all()
 
 
 # ----------------------------------------------------------------------------------- NIPALS
@@ -373,7 +380,31 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
             eng.slot("Wc", K)
             eng.right_mul(("UT", 0, K), np.diag(1.0 / cn), ("Wc", 0))     # column-normalised weights (:733)
             res.update(Ts_=Ts, U_=U, V_=V)
-            _finalise_device(eng, res, "UT", K, cn, np.sqrt(wnorm2), V)   # R_, beta_ (:737-738), W_b, P_
+            # R_, beta_ (:737-738), W_b, P_ on the device; their D2H (five p x K arrays) runs on the copy stream
+            # in a helper thread while the block-score passes of calc_all stream X on the compute stream
+            fetch_all = _finalise_device(eng, res, "UT", K, cn, np.sqrt(wnorm2), V, fetch=False)
+            if calc_all and hasattr(eng, "ctx"):
+                import threading
+                eng.ctx.sync()                              # every slot the helper reads is final
+                err = []
+
+                def helper():
+                    try:
+                        fetch_all(overlapped=True)
+                        res.W_concat_ = eng.fetch("Wc", overlapped=True)
+                    except BaseException as e:              # re-raised on the calling thread
+                        err.append(e)
+
+                th = threading.Thread(target=helper)
+                th.start()
+                try:
+                    _kernel_extras_device(eng, res, Y, V, Ts, varxb, "UT", wnorm2)
+                finally:
+                    th.join()
+                if err:
+                    raise err[0]
+                return res
+            fetch_all()
             res.W_concat_ = eng.fetch("Wc")
             if calc_all:
                 _kernel_extras_device(eng, res, Y, V, Ts, varxb, "UT", wnorm2)
