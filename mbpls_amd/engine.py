@@ -187,11 +187,12 @@ class HipEngine:
     def _xptr(self, off):
         return self._xchg.ptr + 8 * off
 
-    def use_lazy_deflation(self, K, pslot):
+    def use_lazy_deflation(self, K, pslot, prefer=None):
         """Called by a solver whose passes all go through sweep/deflate_sweep: enable lazy deflation
-        when the component count fits the kernel's correction registers."""
+        when the component count fits the kernel's correction registers.  ``prefer`` is the solver's own
+        choice ("lazy"/"explicit"); the MBPLS_DEFLATION environment variable overrides both."""
         import os
-        mode = os.environ.get("MBPLS_DEFLATION", self.deflation)
+        mode = os.environ.get("MBPLS_DEFLATION", prefer or self.deflation)
         if self.sparse:
             mode = "explicit"      # the implicit correction would need every row's own missing-value mask
         if self.n > getattr(self.ctx, "long_columns_from", 8192):

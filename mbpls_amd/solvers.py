@@ -122,7 +122,10 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     eng.slot("Wn", K)
     eng.slot("P", K)
     if hasattr(eng, "use_lazy_deflation"):
-        eng.use_lazy_deflation(K, "P")
+        # One response converges in two passes per component: lazy deflation (no rewrite of X) wins.  Several
+        # responses iterate 50-500 times per component (paper protocol, q = 10): every sweep then pays the lazy
+        # correction (~6 %), far more than one rewrite of X per component (measured 7.05 s -> 6.72 s).
+        eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
     varxb, t_raw, ssq = eng.prepare(standardize, v=u0, alpha=alpha0, g_slot=("Wn", 0))
     varx = varxb.sum()
     vary = (Y ** 2).sum()

@@ -445,3 +445,18 @@ def test_tiny_and_ragged_shapes(gpu_required, n, p, q, K):
         w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} {n}x{p}")
         assert w < 1e-9, (method, w)
         assert util.relerr(mdl.predict(X), orc.predict(ref, X)) < 1e-9
+
+
+@pytest.mark.parametrize("mode", ["lazy", "explicit"])
+@pytest.mark.parametrize("method,q", [("NIPALS", 1), ("NIPALS", 3), ("UNIPALS", 2)])
+def test_both_deflation_modes(gpu_required, monkeypatch, mode, method, q):
+    """Implicit (X never rewritten) and explicit (in-place) deflation give the reference's numbers; the default
+    picks lazy for one response and explicit for several (many NIPALS iterations per component)."""
+    from mbpls_amd import MBPLS
+    monkeypatch.setenv("MBPLS_DEFLATION", mode)
+    X, Y = orc.make_latent(700, 5000, q, seed=21 + q)
+    Xs = [np.ascontiguousarray(X[:, :2000]), np.ascontiguousarray(X[:, 2000:])]
+    ref = orc.fit(Xs, Y, n_components=5, method=method)
+    mdl = MBPLS(n_components=5, method=method).fit(Xs, Y)
+    w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} q={q} {mode}")
+    assert w < 1e-8, w
