@@ -238,6 +238,9 @@ def fit_unipals(eng, Y, K, standardize):
     T = [np.empty((n, K)) for _ in range(B)]
     blk_nrm = np.empty((B, K)); tot_nrm = np.empty(K)
     evx, evy, evxb, Acorr = [], [], np.empty((B, K)), np.empty((B, K))
+    # p > n: W_ and P_ are streamed to the host column by column while the deflation passes run (as in NIPALS)
+    W_h = np.empty((eng.p, K), order="F") if wide else None
+    P_h = np.empty((eng.p, K), order="F") if wide else None
     for k in range(K):
         if wide:
             if fuse:
@@ -271,8 +274,19 @@ def fit_unipals(eng, Y, K, standardize):
         tt = ts.T.dot(ts).item()
         last = (k == K - 1)
         nxt = fuse and not last
+
+        def stream_out(k=k, nrm=np.sqrt(ssq)):
+            # host work WHILE the deflation pass runs: the weight column k is final, so is P[:, k-1]
+            eng.fetch_col("Wc", k, W_h)
+            for b in range(B):
+                r0, r1 = eng.block_offsets[b], eng.block_offsets[b + 1]
+                W_h[r0:r1, k] /= nrm[b]                     # w_b / ||w_b|| (:510-512)
+            if k > 0:
+                eng.fetch_col("P", k - 1, P_h)
+
         ssq_p, m_raw, _ = eng.deflate_sweep(ts, 1.0 / tt, not last, ("P", k), y0 if nxt else None, 1.0,
-                                            ("S", 0) if nxt else None)   # p (:520), X - ts p^T (:535)
+                                            ("S", 0) if nxt else None,   # p (:520), X - ts p^T (:535)
+                                            overlap=stream_out if wide else None)
         Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u; V[:, k:k + 1] = v; A[:, k] = a
         for b in range(B):
             T[b][:, k] = Tm[:, b]
@@ -282,7 +296,10 @@ def fit_unipals(eng, Y, K, standardize):
         Acorr[:, k] = _bip_corrected(a, sizes)              # (:542-553)
     res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, explained_var_x_=evx, explained_var_y_=evy,
                     explained_var_xblocks_=evxb, A_corrected_=Acorr)
-    _finalise_device(eng, res, "Wc", K, tot_nrm if wide else np.ones(K), blk_nrm, V)   # (:569-572 / :476-479)
+    if wide:
+        eng.fetch_col("P", K - 1, P_h)
+    _finalise_device(eng, res, "Wc", K, tot_nrm if wide else np.ones(K), blk_nrm, V,   # (:569-572 / :476-479)
+                     W_host=W_h, P_host=P_h)
     return res
 
 
