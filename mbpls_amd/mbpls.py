@@ -222,6 +222,24 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             self.fit_timings_ = dict(eng.timings)   # seconds per host-side phase (not in the reference)
         return self
 
+    def check_sparsity_level(self, data):
+        """(sparse_rows, sparse_columns, dense_rows, dense_columns) index arrays of a HOST array, with the
+        reference's warning when more than half of the rows or columns have missing entries (mbpls.py:255-271).
+        ``fit`` derives the same lists for the device-resident blocks from kernel outputs instead."""
+        miss = np.isnan(np.asarray(data, dtype=np.float64))
+        rows, cols = miss.any(axis=1), miss.any(axis=0)
+        for flags in (cols, rows):
+            if flags.size and flags.sum() / flags.size > 0.5:
+                warnings.warn("The sparsity of your data is likely to high for this algorithm. This can cause "
+                              "either convergenceproblems or crash the algorithm.")
+        return np.where(rows)[0], np.where(cols)[0], np.where(~rows)[0], np.where(~cols)[0]
+
+    def plot(self, num_components=2):
+        """The reference's matplotlib overview figure (mbpls.py:1439) is presentation, not part of the accelerated
+        path: every quantity it draws is a fitted attribute of this estimator (``A_``, ``P_``, ``Ts_``,
+        ``explained_var_xblocks_`` ...)."""
+        raise NotImplementedError("MBPLS.plot is not provided by mbpls_amd; plot the fitted attributes directly")
+
     def _sparsity_info(self, eng, Y):
         """``sparse_X_info_[b]`` / ``sparse_Y_info_['Y']`` = (sparse_rows, sparse_columns, dense_rows,
         dense_columns) index arrays and the high-sparsity warnings of check_sparsity_level (mbpls.py:255-271,
