@@ -68,6 +68,7 @@ int mbpls_hip_sync(mbpls_ctx* ctx);
 int mbpls_hip_device_info(mbpls_ctx* ctx, char* name, size_t name_len, int* compute_units,
                           size_t* total_bytes, size_t* free_bytes);
 /* Tunables (all optional): "chunks_per_cu", "rows_per_thread", "prefetch", "xw_chunks_per_cu",
+ * "xw_mfma_from" (x_w with more right-hand sides than this uses the matrix-core kernel, default 8),
  * "gram_slice_features" (features per split-K slice of the Gram kernel for long feature ranges, 0 = off),
  * "long_columns_from" (0..65536, default 8192: matrices with more samples than this use the streamed-column
  * passes instead of the register-resident ones, which spill above 8192; lazy deflation is not available there).

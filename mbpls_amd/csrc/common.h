@@ -61,6 +61,7 @@ struct mbpls_ctx {
   int rows_per_thread = 0;   // 0 = auto
   int prefetch = 2;          // columns in flight per workgroup (register slots)
   int xw_chunks_per_cu = 1;
+  int xw_mfma_from = 8;      // x_w with more right-hand sides than this runs on the matrix cores
   int64_t gram_slice_features = 131072;   // Gram: features per split-K slice for long feature ranges (0 = off)
   int64_t long_columns_from = 8192;    // n above this: streamed-column kernels (colpass_long.hip)
   // workspace for chunk partials (grown on demand, never shrunk)
@@ -103,6 +104,10 @@ void free_chunks(ChunkTable* t);
 // xtv_mfma.hip: G = alpha X^T V on the f64 matrix cores (any n, any c)
 int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv, int c, double alpha, double* d_G,
              int64_t ldg, double* d_ssq);
+
+// xw_mfma.hip: OUT = X W on the f64 matrix cores, X read once per 64 right-hand sides
+int xw_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block,
+            const double* d_mean, const double* d_scale, int nanm, double* d_out, int64_t ldo);
 
 // RAII bracket: records an event pair around a kernel launch when profiling is on.
 struct ProfScope {

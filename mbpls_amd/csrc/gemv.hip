@@ -226,6 +226,15 @@ int mbpls_hip_xt_v(const mbpls_mat* m, const double* d_V, int64_t ldv, int c, do
 
 }  // extern "C"
 
+namespace mbpls {
+void launch_reduce_xw(mbpls_ctx* ctx, const mbpls_mat* m, const double* part, int CB, int cb, int per_block,
+                      double* d_out, int64_t ldo, int c_total, int k0) {
+  dim3 rgrid((unsigned)((m->n + 255) / 256), (unsigned)cb, per_block ? (unsigned)m->nblocks : 1u);
+  hipLaunchKernelGGL(k_reduce_xw, rgrid, dim3(256), 0, ctx->stream, part, CB, cb, m->n,
+                     (const int*)m->coarse.d_blk_start, m->nblocks, per_block ? 1 : 0, d_out, ldo, c_total, k0);
+}
+}  // namespace mbpls
+
 static int x_w_impl(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block, const double* d_mean,
                     const double* d_scale, int nanm, double* d_out, int64_t ldo) {
   MB_ARG(m && d_W && d_out, "NULL argument");
@@ -233,6 +242,8 @@ static int x_w_impl(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, i
          (long long)ldo);
   MB_ARG((d_mean == nullptr) == (d_scale == nullptr), "mean and scale must be given together");
   mbpls_ctx* ctx = m->ctx;
+  // many right-hand sides: matrix-core path, X read once per 64 of them (this kernel: once per 8)
+  if (c > ctx->xw_mfma_from) return xw_mfma(ctx, m, d_W, ldw, c, per_block, d_mean, d_scale, nanm, d_out, ldo);
   const ChunkTable& ct = m->coarse;
   constexpr int CB = 8;
   MB_TRY(ensure_ws(ctx, sizeof(double) * (size_t)ct.nchunks * CB * (size_t)m->n));

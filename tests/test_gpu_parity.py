@@ -112,7 +112,10 @@ def test_column_pass_kernels(ctx, n, p, blocks):
 
 
 @pytest.mark.parametrize("n,p,c,blocks", [(40, 70, 1, [25, 45]), (41, 33, 3, [33]), (300, 500, 5, [100, 400]),
-                                          (1030, 257, 9, [257]), (4096, 300, 2, [100, 200]), (8192, 64, 4, [64])])
+                                          (1030, 257, 9, [257]), (4096, 300, 2, [100, 200]), (8192, 64, 4, [64]),
+                                          # c > 8: x_w on the matrix cores (odd n, ragged blocks, > 64 rhs)
+                                          (41, 33, 12, [33]), (517, 1001, 20, [3, 498, 500]), (4096, 700, 45, [700]),
+                                          (300, 90, 70, [40, 50])])
 def test_multi_rhs_products(ctx, n, p, c, blocks):
     from mbpls_amd import DeviceMatrix
     rng = np.random.RandomState(n + p + c)
@@ -141,6 +144,19 @@ def test_multi_rhs_products(ctx, n, p, c, blocks):
     m.x_w(dW, c, out, mean=ctx.from_host(mu), scale=ctx.from_host(sc))
     assert util.relerr(out.get(), ((X - mu) / sc).dot(W)) < TIGHT
     m.close()
+    # missing values: NaN contributes nothing / presence-indicator sums (mbpls_hip_x_w_nan), per block
+    Xn = X.copy()
+    Xn[rng.rand(n, p) < 0.1] = np.nan
+    mn = DeviceMatrix(ctx, n, p, offs)
+    mn.upload(Xn)
+    ok = ~np.isnan(Xn)
+    mn.x_w_nan(dW, c, out, mean=ctx.from_host(mu), scale=ctx.from_host(sc))
+    assert util.relerr(out.get(), np.where(ok, (Xn - mu) / sc, 0.0).dot(W)) < TIGHT
+    mn.x_w_nan(dW, c, outb, per_block=True, indicator=True)
+    h = outb.get()
+    for b, (s, e) in enumerate(zip(offs[:-1], offs[1:])):
+        assert util.relerr(h[b * n * c:(b + 1) * n * c].reshape(c, n).T, ok[:, s:e].astype(float).dot(W[s:e])) < TIGHT
+    mn.close()
 
 
 @pytest.mark.parametrize("n,p", [(40, 200), (129, 1000), (256, 515), (1000, 3001), (2048, 4100)])
