@@ -187,6 +187,47 @@ int mbpls_hip_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double
                                   double* d_ssq_g, const double* d_P, int64_t ldp, int kprev,
                                   const double* d_cu, const double* d_ce, double* d_d);
 
+/* ---- implicit standardisation: the fit never writes X -------------------------------------------------------
+ * With lazy deflation no pass after the first needs the standardised matrix in HBM either: Z = (X - mean)/scale is
+ * applied algebraically to the RAW columns.  Every vector of a fit on standardised data (u, ts, the columns of the
+ * centred Y) sums to zero, so the column means drop out of the dot products, <x_j - mean_j 1, v> = <x_j, v>.
+ * Everything is computed in raw-column space, with raw-space weights g~_j = scale_j g_j and loadings
+ * p~_j = scale_j p_j:
+ *   scale_j z_j^(k) = x_j - mean_j 1 - sum_i ts_i P~[j,i],
+ *   g~_j = alpha (<x_j, v> - sum_i P~[j,i] <ts_i, v>),      p~_j = inv_tt (<x_j, ts> - sum_i P~[j,i] <ts_i, ts>),
+ *   sum_j g_j z_j = sum_j c_j x_j - const 1 - sum_i ts_i (sum_j c_j P~[j,i]),      c_j = g~_j / scale_j^2,
+ * i.e. the plain lazy pass plus one per-column scalar 1/scale_j^2 in the accumulations.  The constant is the mean
+ * of the accumulated vector (block scores of centred columns are centred): the caller subtracts it, and rescales
+ * finished g~ / p~ columns by 1/scale (mbpls_hip_scale_rows).  The first pass only takes the statistics (no store:
+ * 8np instead of 16np bytes) and X stays the caller's matrix (copy=True costs no second 8np-byte buffer).
+ * Rounding of the raw dot products is amplified by |mean_j|/scale_j; the statistics pass reports its maximum per
+ * block so the caller can fall back to the storing pass for badly offset data.  The caller must pass zero-sum
+ * vectors (re-centre to rounding).
+ *
+ * StandardScaler statistics (MBPLS_SCALE_FIT; MBPLS_SCALE_NONE: sums of squares only) + the first sweep on the
+ * raw columns held in registers; nothing is written to X.  d_rscale / d_r2 (required with MBPLS_SCALE_FIT):
+ * 1/scale_j and 1/scale_j^2 (0 for a constant column); d_amp[nblocks] (optional) = the SQUARE of
+ * max_j max(|mean_j|/scale_j, ((x_0j - mean_j)/scale_j)^2), the rounding amplification of the raw-space sums.    */
+int mbpls_hip_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_mean, double* d_scale,
+                                      double* d_rscale, double* d_r2, double* d_ssq_x, double* d_amp,
+                                      const double* d_v, double alpha, double* d_g, double* d_t,
+                                      double* d_ssq_g);
+/* mbpls_hip_sweep_lazy / mbpls_hip_loadings_sweep_lazy on a RAW matrix with implicit standardisation (d_r2: p
+ * values 1/scale_j^2; NULL = the plain lazy passes).  d_g / d_p receive and d_P holds the RAW-SPACE columns g~,
+ * p~; d_ssq_g / d_ssq_p are the squared norms of the TRUE g_b, p_b; d_d as in the plain variants with c_j in
+ * place of g_j.                                                                                                */
+int mbpls_hip_sweep_lazy_scaled(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t,
+                                double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
+                                double* d_d, const double* d_r2);
+int mbpls_hip_loadings_sweep_lazy_scaled(const mbpls_mat* m, const double* d_ts, double inv_tt, double* d_p,
+                                         double* d_ssq_p, const double* d_v, double alpha, double* d_g,
+                                         double* d_t, double* d_ssq_g, const double* d_P, int64_t ldp, int kprev,
+                                         const double* d_cu, const double* d_ce, double* d_d,
+                                         const double* d_r2);
+/* d_C[j, k] = d_A[j, k] * d_r[j] for a p x c column-major array (row scaling; raw-space -> true loadings).      */
+int mbpls_hip_scale_rows(mbpls_ctx* ctx, int64_t p, int c, const double* d_A, int64_t lda, const double* d_r,
+                         double* d_C, int64_t ldc);
+
 /* G = alpha * X^T V for c right-hand sides (mbpls.py:503,:731,:734,:998,:1011).
  *   d_V: n x c column-major (leading dim ldv), d_G: p x c column-major (leading dim ldg).
  *   d_ssq (optional): nblocks x c, d_ssq[k*nblocks + b] = ||G[block b, k]||^2.                     */

@@ -56,6 +56,11 @@ SIGNATURES = {
     "mbpls_hip_sweep": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp]),
     "mbpls_hip_deflate_sweep": (_int, [_vp, _vp, _dbl, _int, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
     "mbpls_hip_sweep_lazy": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp]),
+    "mbpls_hip_standardize_stats_sweep": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
+    "mbpls_hip_scale_rows": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _vp, _i64]),
+    "mbpls_hip_sweep_lazy_scaled": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp]),
+    "mbpls_hip_loadings_sweep_lazy_scaled": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int,
+                                                    _vp, _vp, _vp, _vp]),
     "mbpls_hip_loadings_sweep_lazy": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int,
                                              _vp, _vp, _vp]),
     "mbpls_hip_xt_v": (_int, [_vp, _vp, _i64, _int, _dbl, _vp, _i64, _vp]),
@@ -379,11 +384,27 @@ class DeviceMatrix:
         check(self.ctx.lib.mbpls_hip_deflate_sweep(self.handle, _ptr(ts), float(inv_tt), int(bool(deflate)), _ptr(p),
                                                    _ptr(ssq_p), _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g)))
 
-    def sweep_lazy(self, v, alpha, g, t, ssq_g, P, ldp, kprev, cu, d):
+    def standardize_stats_sweep(self, mode, mean, scale, rscale, r2, ssq_x, amp, v, alpha, g, t, ssq_g):
+        check(self.ctx.lib.mbpls_hip_standardize_stats_sweep(self.handle, int(mode), _ptr(mean), _ptr(scale),
+                                                             _ptr(rscale), _ptr(r2), _ptr(ssq_x), _ptr(amp), _ptr(v),
+                                                             float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g)))
+
+    def sweep_lazy(self, v, alpha, g, t, ssq_g, P, ldp, kprev, cu, d, r2=None):
+        if r2 is not None:
+            check(self.ctx.lib.mbpls_hip_sweep_lazy_scaled(self.handle, _ptr(v), float(alpha), _ptr(g), _ptr(t),
+                                                           _ptr(ssq_g), _ptr(P), int(ldp), int(kprev), _ptr(cu),
+                                                           _ptr(d), _ptr(r2)))
+            return
         check(self.ctx.lib.mbpls_hip_sweep_lazy(self.handle, _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g),
                                                 _ptr(P), int(ldp), int(kprev), _ptr(cu), _ptr(d)))
 
-    def loadings_sweep_lazy(self, ts, inv_tt, p, ssq_p, v, alpha, g, t, ssq_g, P, ldp, kprev, cu, ce, d):
+    def loadings_sweep_lazy(self, ts, inv_tt, p, ssq_p, v, alpha, g, t, ssq_g, P, ldp, kprev, cu, ce, d,
+                            r2=None):
+        if r2 is not None:
+            check(self.ctx.lib.mbpls_hip_loadings_sweep_lazy_scaled(
+                self.handle, _ptr(ts), float(inv_tt), _ptr(p), _ptr(ssq_p), _ptr(v), float(alpha), _ptr(g), _ptr(t),
+                _ptr(ssq_g), _ptr(P), int(ldp), int(kprev), _ptr(cu), _ptr(ce), _ptr(d), _ptr(r2)))
+            return
         check(self.ctx.lib.mbpls_hip_loadings_sweep_lazy(self.handle, _ptr(ts), float(inv_tt), _ptr(p), _ptr(ssq_p),
                                                          _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g),
                                                          _ptr(P), int(ldp), int(kprev), _ptr(cu), _ptr(ce), _ptr(d)))

@@ -52,7 +52,21 @@ struct PassArgs {
   int64_t ldp;
   const double* cu;    // [kprev]  <ts_i, v>   corrections of the sweep dot
   const double* ce;    // [kprev]  <ts_i, ts>  corrections of the loadings dot
-  double* part_d;      // [nchunks][KD]  sum_j g_j P[j,i] (i < kprev) and sum_j g_j p_j (i = kprev)
+  double* part_d;      // [nchunks][KD]  sum_j c_j P[j,i] (i < kprev) and sum_j c_j p_j (i = kprev)
+  // implicit standardisation (lazy passes only, template flag ISTD): X in HBM is the RAW matrix and
+  // Z = (X - mean)/scale is applied algebraically, everything computed in RAW-column space.  Every vector v / ts
+  // of a fit on standardised data sums to zero (Y is centred, scores of centred columns are centred; the caller
+  // re-centres to rounding), so the column means drop out of the dot products, <x_j - mean_j 1, v> = <x_j, v>.
+  // With raw-space weights g~_j = scale_j g_j and loadings p~_j = scale_j p_j (what the slots then hold):
+  //   scale_j z_j^(k) = x_j - mean_j 1 - sum_i ts_i P~[j,i],   g~_j = alpha (<x_j, v> - sum_i P~[j,i] cu_i),
+  //   p~_j = inv_tt (<x_j, ts> - sum_i P~[j,i] ce_i),
+  //   sum_j g_j z_j = sum_j c_j x_j - const 1 - sum_i ts_i (sum_j c_j P~[j,i]),   c_j = g~_j / scale_j^2
+  // so the kernel is the plain lazy pass plus ONE per-column scalar ir2_j = 1/scale_j^2 in the accumulations
+  // (||g_b||^2 = sum g~_j c_j, ||p_b||^2 = sum p~_j^2 ir2_j); the constant is the mean of the accumulated vector
+  // (scores are centred), removed by the caller, who also rescales finished g~ / p~ columns by 1/scale.
+  const double* ir2;
+  double* rs_out;      // standardise pass: 1 / scale_j   (optional)
+  double* r2_out;      // standardise pass: 1 / scale_j^2 (optional)
 };
 constexpr int KD = 40;
 
@@ -60,7 +74,7 @@ constexpr int KD = 40;
 // The n=4096 workhorse (R=8, 512 threads = 8 waves) must stay at <= 128 VGPRs: 4 waves/SIMD = two
 // workgroups per CU.  At 129+ VGPRs only ONE 8-wave workgroup fits a CU and the pass runs ~2x slower
 // (measured: the lazy loadings+sweep variant at 157 VGPRs took 9.3 ms instead of 4.8 ms).
-template <int R, int TMAX, int D, bool STD, bool DEFL, bool SWEEP, bool FULL>
+template <int R, int TMAX, int D, bool STD, bool DEFL, bool SWEEP, bool FULL, bool ISTD = false>
 __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpass(PassArgs a) {
   __shared__ double red[2 * 64];
   int buf = 0;
@@ -120,6 +134,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
     tsv = s[0];
   }
   double ssq_g = 0.0, ssq_p = 0.0, ssq_x = 0.0;
+  double amp = 0.0;   // max_j |mean_j| / scale_j of this chunk: rounding amplification of implicit standardisation
   const double dn = (STD && a.rowmask) ? a.n_eff : (double)n;   // samples that take part in the statistics
   // lazy deflation: thread i < kprev carries the correction of previous component i
   const bool lazy = !STD && a.lazy != 0;
@@ -130,13 +145,16 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   double dacc = 0.0, dk = 0.0;
 
   double x[D][R];
+  __shared__ double s_out[(STD && ISTD) ? 4 : 1][64];   // statistics-only pass: per-column outputs of 64 columns
   double pp[D];   // P[column, tid] of the column held in slot d (0 for threads >= kprev)
+  double k0v[(STD && ISTD) ? D : 1];   // statistics-only pass: first sample of the column in slot d (the shift)
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     pp[d] = 0.0;
     if (j0 + d < j1) {
       load_col<R, FULL>(x[d], a.src + (j0 + d) * ld, rm);
       if (mine) pp[d] = prow[j0 + d];
+      if constexpr (STD && ISTD) k0v[d] = a.src[(j0 + d) * ld];
     }
   }
 
@@ -146,9 +164,73 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
       const int64_t jj = j + d;
       if (jj >= j1) break;
       double(&xc)[R] = x[d];
+      // STD + ISTD = statistics-only flavour of the standardise pass: nothing is stored, the column stays RAW in
+      // registers and the first sweep runs in raw-column space exactly like the implicit-standardisation passes that
+      // follow (same arithmetic on the same inputs: the second NIPALS pass reproduces ts to a few ulp).  ONE
+      // workgroup reduction per column: shifted sums (shift = the column's first sample) give mean and variance,
+      //   mean = K + S1/n,  var = (S2 - S1^2/n)/n,  S1 = sum (x - K), S2 = sum (x - K)^2,
+      // accurate while |K - mean| is a modest multiple of scale (reported through `amp` otherwise).
+      constexpr bool NOSTORE = STD && ISTD && SWEEP;
+      bool handled = false;
+      if constexpr (NOSTORE) {
+        if (a.mode == MBPLS_SCALE_FIT) {
+          const double K0 = k0v[d];       // prefetched with the column
+          double s3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            const bool real = FULL || ((((k & 1) ? rm.in_n1 : rm.in_n0) >> (k >> 1)) & 1u);
+            const double e = real ? xc[k] - K0 : 0.0;
+            s3[0] += e;
+            s3[1] = fma(e, e, s3[1]);
+            s3[2] = fma(xc[k], v[k], s3[2]);
+          }
+          block_sum<3>(s3, red, buf);
+          // every thread needs only c_j = g~_j / var (one division); sqrt and the outputs are thread 0's business --
+          // per-column scalar math is redundant in all 512 lanes and would otherwise cost more than the column itself
+          const double inv_n = 1.0 / dn;                     // loop-invariant
+          const double m1 = s3[0] * inv_n;
+          const double mean = K0 + m1;
+          const double var = fmax((s3[1] - s3[0] * m1) * inv_n, 0.0);
+          const double eps = 2.220446049250313e-16;
+          const double nme = dn * mean * eps;
+          const bool constant = var <= dn * eps * var + nme * nme;
+          const double r2 = constant ? 0.0 : 1.0 / var;      // a constant column: no weight, no loading
+          const double gt = a.alpha * s3[2];                 // raw-space weight g~_j
+          const double cj = gt * r2;
+          ssq_g = fma(gt, cj, ssq_g);
+          if (tid < 64) {
+            // Per-column outputs: lane 0 parks them in LDS, wave 0 writes 64 columns at a time as four coalesced
+            // 512-byte rows (four scattered 8-byte stores per column were partial-line writes on the critical path).
+            // No sqrt / division here either: var goes to scale[], g~ to g[]; k_finish_stats turns them into scale,
+            // 1/scale and g afterwards.  Only wave 0 touches s_out, in program order: no barrier needed.
+            const int slot = (int)((jj - j0) & 63);
+            if (tid == 0) {
+              const double m2 = m1 * m1 * r2;
+              amp = fmax(amp, fmax(mean * mean * r2, m2 * m2));   // SQUARED offsets |mean|/scale, ((K-mean)/scale)^2
+              ssq_x = fma(dn * var, r2, ssq_x);                   // sum z^2 of the column
+              s_out[0][slot] = mean;
+              s_out[1][slot] = var;
+              s_out[2][slot] = r2;
+              s_out[3][slot] = gt;
+            }
+            if (slot == 63 || jj == j1 - 1) {
+              const int64_t jb = jj - slot;
+              if (tid <= slot) {
+                a.mean[jb + tid] = s_out[0][tid];
+                a.scale[jb + tid] = s_out[1][tid];
+                if (a.r2_out) a.r2_out[jb + tid] = s_out[2][tid];
+                if (a.g) a.g[jb + tid] = s_out[3][tid];
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < R; ++k) acc[k] = fma(cj, xc[k], acc[k]);
+          handled = true;
+        }
+      }
 
       if constexpr (STD) {
-        if (a.mode != MBPLS_SCALE_NONE) {
+        if (!handled && a.mode != MBPLS_SCALE_NONE) {
           double mean, scale;
           if (a.mode == MBPLS_SCALE_FIT) {
             // sklearn _incremental_mean_and_var: mean, then corrected two-pass variance
@@ -172,6 +254,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
             const double nme = dn * mean * eps;
             const double bound = dn * eps * var + nme * nme;
             scale = (var <= bound) ? 1.0 : sqrt(var);
+            amp = fmax(amp, fabs(mean) / scale);
             if (tid == 0) {
               a.mean[jj] = mean;
               a.scale[jj] = scale;
@@ -188,12 +271,14 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
 #pragma unroll
           for (int k = 0; k < R; ++k) xc[k] = xc[k] / scale;
         }
+        if (!handled) {
 #pragma unroll
-        for (int k = 0; k < R; ++k) ssq_x = fma(xc[k], xc[k], ssq_x);
-        store_col<R, FULL>(xc, a.dst + jj * ld, rm);
+          for (int k = 0; k < R; ++k) ssq_x = fma(xc[k], xc[k], ssq_x);
+        }
+        if constexpr (!NOSTORE) store_col<R, FULL>(xc, a.dst + jj * ld, rm);
       }
 
-      double gj = 0.0;
+      double gj = 0.0, pjk = 0.0;
       if constexpr (DEFL) {
         // lazy: <x_k, ts> = <x_0, ts> - sum_i P[j,i] <ts_i, ts>, folded into the same reduction
         double ab[2] = {-pp[d] * ce_i, -pp[d] * cu_i};
@@ -214,8 +299,9 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
           block_sum<1>(a1, red, buf);
           ab[0] = a1[0];
         }
-        const double pj = ab[0] * a.inv_tt;
-        ssq_p = fma(pj, pj, ssq_p);
+        const double pj = ab[0] * a.inv_tt;        // ISTD: the raw-space loading p~_j
+        if constexpr (ISTD) ssq_p = fma(pj * pj, a.ir2[jj], ssq_p);
+        else ssq_p = fma(pj, pj, ssq_p);
         if (tid == 0 && a.pvec) a.pvec[jj] = pj;
         if (a.deflate) {
           if (!lazy) {
@@ -228,28 +314,36 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
             store_col<R, FULL>(xc, a.dst + jj * ld, rm);
           }
           if constexpr (SWEEP) gj = a.alpha * fma(-pj, tsv, ab[1]);  // <x - p ts, v> = <x,v> - p <ts,v>
-          if constexpr (SWEEP) dk = fma(gj, pj, dk);
+          pjk = pj;
         } else {
           if constexpr (SWEEP) gj = a.alpha * ab[1];
         }
       } else if constexpr (SWEEP) {
-        double b[1] = {-pp[d] * cu_i};
+        if (!handled) {                      // workgroup-uniform
+          double b[1] = {-pp[d] * cu_i};
 #pragma unroll
-        for (int k = 0; k < R; ++k) b[0] = fma(xc[k], v[k], b[0]);
-        block_sum<1>(b, red, buf);
-        gj = a.alpha * b[0];
+          for (int k = 0; k < R; ++k) b[0] = fma(xc[k], v[k], b[0]);
+          block_sum<1>(b, red, buf);
+          gj = a.alpha * b[0];
+        }
       }
       if constexpr (SWEEP) {
-        ssq_g = fma(gj, gj, ssq_g);
-        if (tid == 0 && a.g) a.g[jj] = gj;
+        if (!handled) {
+          double cj = gj;                    // ISTD: gj is g~_j, cj the weight of the RAW column in the scores
+          if constexpr (ISTD && !STD) cj = gj * a.ir2[jj];
+          ssq_g = fma(gj, cj, ssq_g);
+          if (tid == 0 && a.g) a.g[jj] = gj;
 #pragma unroll
-        for (int k = 0; k < R; ++k) acc[k] = fma(gj, xc[k], acc[k]);
-        dacc = fma(gj, pp[d], dacc);
+          for (int k = 0; k < R; ++k) acc[k] = fma(cj, xc[k], acc[k]);
+          dacc = fma(cj, pp[d], dacc);
+          if constexpr (DEFL) dk = fma(cj, pjk, dk);
+        }
       }
       // refill this register slot with the column D ahead (in flight while the next ones are processed)
       if (jj + D < j1) {
         load_col<R, FULL>(xc, a.src + (jj + D) * ld, rm);
         if (mine) pp[d] = prow[jj + D];
+        if constexpr (STD && ISTD) k0v[d] = a.src[(jj + D) * ld];
       }
     }
   }
@@ -273,13 +367,27 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
     ps[0] = ssq_g;
     ps[1] = ssq_p;
     ps[2] = ssq_x;
-    ps[3] = 0.0;
+    ps[3] = amp;
   }
   if (lazy && a.part_d) {
     double* pd = a.part_d + (int64_t)chunk * KD;
     if (mine) pd[tid] = dacc;
     if (tid == 0) pd[a.kprev] = dk;
   }
+}
+
+// After the statistics-only pass: scale[] holds var -> scale, rs = 1/scale (0 for a constant column, flagged by
+// r2 == 0), g~ -> g = g~ rs.
+__global__ __launch_bounds__(256) void k_finish_stats(int64_t p, double* __restrict__ scale, const double* __restrict__ r2,
+                                                      double* __restrict__ rs, double* __restrict__ g) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  const bool constant = r2[j] == 0.0;
+  const double sc = constant ? 1.0 : sqrt(scale[j]);
+  const double r = constant ? 0.0 : 1.0 / sc;
+  scale[j] = sc;
+  if (rs) rs[j] = r;
+  if (g) g[j] *= r;
 }
 
 // Second stage: fixed-order sum of the chunk partials of each block.
@@ -291,7 +399,8 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const double* __restrict_
                                                        double* __restrict__ out_t, double* __restrict__ out_ssq_g,
                                                        double* __restrict__ out_ssq_p, double* __restrict__ out_ssq_x,
                                                        const double* __restrict__ part_d, int nd,
-                                                       double* __restrict__ out_d /* [nblocks][nd] */) {
+                                                       double* __restrict__ out_d /* [nblocks][nd] */,
+                                                       double* __restrict__ out_amp /* [nblocks] max of slot 3 */) {
   __shared__ double comb[4][64];
   const int b = blockIdx.y;
   const int cs = blk_start[b], ce = blk_start[b + 1];
@@ -325,6 +434,13 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const double* __restrict_
       if (lane == 0) o[b] = s;
     }
   }
+  if (blockIdx.x == 0 && w == 3 && out_amp) {
+    double s = 0.0;
+    for (int c = cs + lane; c < ce; c += 64) s = fmax(s, part_s[(int64_t)c * 4 + 3]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s = fmax(s, __shfl_xor(s, off, 64));
+    if (lane == 0) out_amp[b] = s;
+  }
   if (blockIdx.x == 0 && w == 3 && out_d) {
     for (int i = 0; i < nd; ++i) {
       double s = 0.0;
@@ -340,12 +456,12 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const double* __restrict_
 template <bool STD, bool DEFL, bool SWEEP>
 static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, int64_t p) {
   // algorithmic bytes: read 8np, plus 8np write when the pass stores X
-  const bool writes = STD || (DEFL && a.deflate && !a.lazy);
+  const bool writes = (STD && a.dst) || (DEFL && a.deflate && !a.lazy);
   const int kind = STD ? MBPLS_K_STANDARDIZE : (DEFL ? (SWEEP ? MBPLS_K_DEFLATE_SWEEP : MBPLS_K_DEFLATE) : MBPLS_K_SWEEP);
   ProfScope prof(ctx, kind, 8.0 * (double)a.n * (double)p * (writes ? 2.0 : 1.0));
   Cfg cfg;
   int T = 0;
-  if (!pick_cfg(ctx, a.n, &cfg, &T, STD)) {
+  if (!pick_cfg(ctx, a.n, &cfg, &T, STD && a.dst != nullptr)) {
     set_error("column passes support n <= 65536 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;
   }
@@ -354,12 +470,21 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   const int D = ctx->prefetch >= 1 && ctx->prefetch <= 3 ? ctx->prefetch : 2;
   // FULL: every thread's every row pair is a real sample and columns are unpadded (n=4096, 8192, ...)
   const bool full = (a.n == (int64_t)T * cfg.R) && (a.ld == a.n) && cfg.R >= 8 && !(STD && a.rowmask);
+  // the ISTD instantiations: implicit standardisation for the lazy passes, statistics-only for the standardise pass
+  const bool istd = STD ? (SWEEP && a.dst == nullptr) : (a.lazy && a.ir2 != nullptr);
 #define MB_LAUNCH(R_, TM_, D_)                                                                          \
   do {                                                                                                  \
-    if (full && (R_) >= 8)                                                                              \
-      hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, ((R_) >= 8)>), grid, block, 0, ctx->stream, an); \
+    constexpr bool F_ = ((R_) >= 8);                                                                    \
+    constexpr bool IS_ = !STD || SWEEP;   /* no statistics-only flavour without the fused sweep */      \
+    if (istd) {                                                                                         \
+      if (full && F_)                                                                                   \
+        hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, F_, IS_>), grid, block, 0, ctx->stream, an);     \
+      else                                                                                              \
+        hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, false, IS_>), grid, block, 0, ctx->stream, an);  \
+    } else if (full && F_)                                                                              \
+      hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, F_>), grid, block, 0, ctx->stream, an);           \
     else                                                                                                \
-      hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, false>), grid, block, 0, ctx->stream, an);       \
+      hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, false>), grid, block, 0, ctx->stream, an);        \
   } while (0)
 #define MB_LAUNCH_D(R_, TM_)            \
   do {                                  \
@@ -373,6 +498,10 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   else if (cfg.R == 8 && cfg.TMAX == 512) MB_LAUNCH_D(8, 512);
   else if (cfg.R == 8) MB_LAUNCH_D(8, 1024);
   else if (cfg.R == 16 && cfg.TMAX == 512) MB_LAUNCH_D(16, 512);
+  else if (istd) {
+    set_error("implicit standardisation / statistics-only passes need n <= 8192 (got n=%lld)", (long long)a.n);
+    return MBPLS_ERR_UNSUPPORTED;
+  }
   else if (cfg.R == 32) hipLaunchKernelGGL((k_colpass<32, 1024, 1, STD, DEFL, SWEEP, false>), grid, block, 0, ctx->stream, an);
   else if (cfg.R == 64) hipLaunchKernelGGL((k_colpass<64, 1024, 1, STD, DEFL, SWEEP, false>), grid, block, 0, ctx->stream, an);
   else {
@@ -387,10 +516,10 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
 
 int reduce_chunks(mbpls_ctx* ctx, const mbpls_mat* m, const double* part_t, const double* part_s,
                   double* d_t, double* d_ssq_g, double* d_ssq_p, double* d_ssq_x,
-                  const double* part_d, int nd, double* d_d) {
+                  const double* part_d, int nd, double* d_d, double* d_amp) {
   dim3 grid(d_t ? (unsigned)((m->n + 63) / 64) : 1u, (unsigned)m->nblocks);
   hipLaunchKernelGGL(k_reduce_chunks, grid, dim3(256), 0, ctx->stream, part_t, part_s,
-                     (const int*)m->fine.d_blk_start, m->n, d_t, d_ssq_g, d_ssq_p, d_ssq_x, part_d, nd, d_d);
+                     (const int*)m->fine.d_blk_start, m->n, d_t, d_ssq_g, d_ssq_p, d_ssq_x, part_d, nd, d_d, d_amp);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }
@@ -451,6 +580,12 @@ int mbpls_hip_deflate_sweep(mbpls_mat* m, const double* d_ts, double inv_tt, int
 int mbpls_hip_sweep_lazy(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t,
                          double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
                          double* d_d) {
+  return mbpls_hip_sweep_lazy_scaled(m, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu, d_d, nullptr);
+}
+
+int mbpls_hip_sweep_lazy_scaled(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t,
+                                double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
+                                double* d_d, const double* d_r2) {
   MB_ARG(m && d_v, "NULL argument");
   MB_ARG(kprev >= 0 && kprev < KD && (kprev == 0 || (d_P && d_cu && d_d)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   mbpls_ctx* ctx = m->ctx;
@@ -464,6 +599,7 @@ int mbpls_hip_sweep_lazy(const mbpls_mat* m, const double* d_v, double alpha, do
   a.c0 = m->fine.d_c0; a.c1 = m->fine.d_c1;
   a.v = d_v; a.alpha = alpha; a.g = d_g;
   a.lazy = 1; a.kprev = kprev; a.Pm = d_P; a.ldp = ldp; a.cu = d_cu; a.ce = nullptr;
+  a.ir2 = d_r2;
   MB_TRY((launch_pass<false, false, true>(ctx, m->fine, a, m->p)));
   return reduce_chunks(ctx, m, a.part_t, a.part_s, d_t, d_ssq_g, nullptr, nullptr, a.part_d, kprev, kprev ? d_d : nullptr);
 }
@@ -472,6 +608,15 @@ int mbpls_hip_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double
                                   double* d_ssq_p, const double* d_v, double alpha, double* d_g, double* d_t,
                                   double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
                                   const double* d_ce, double* d_d) {
+  return mbpls_hip_loadings_sweep_lazy_scaled(m, d_ts, inv_tt, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp,
+                                              kprev, d_cu, d_ce, d_d, nullptr);
+}
+
+int mbpls_hip_loadings_sweep_lazy_scaled(const mbpls_mat* m, const double* d_ts, double inv_tt, double* d_p,
+                                         double* d_ssq_p, const double* d_v, double alpha, double* d_g, double* d_t,
+                                         double* d_ssq_g, const double* d_P, int64_t ldp, int kprev,
+                                         const double* d_cu, const double* d_ce, double* d_d,
+                                         const double* d_r2) {
   MB_ARG(m && d_ts, "NULL argument");
   MB_ARG(kprev >= 0 && kprev < KD - 1 && (kprev == 0 || (d_P && d_ce)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   MB_ARG(!d_v || (d_d && (kprev == 0 || d_cu)), "sweep part needs d_cu / d_d");
@@ -487,6 +632,7 @@ int mbpls_hip_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double
   a.ts = d_ts; a.inv_tt = inv_tt; a.deflate = d_v ? 1 : 0; a.pvec = d_p;   // deflate=1: the fused sweep sees X_{k+1}
   a.v = d_v; a.alpha = alpha; a.g = d_g;
   a.lazy = 1; a.kprev = kprev; a.Pm = d_P; a.ldp = ldp; a.cu = d_cu; a.ce = d_ce;
+  a.ir2 = d_r2;
   if (d_v) {
     MB_TRY((launch_pass<false, true, true>(ctx, m->fine, a, m->p)));
     return reduce_chunks(ctx, m, a.part_t, a.part_s, d_t, d_ssq_g, d_ssq_p, nullptr, a.part_d, kprev + 1, d_d);
@@ -529,6 +675,34 @@ int mbpls_hip_standardize_sweep_masked(const mbpls_mat* src, mbpls_mat* dst, int
   MB_TRY((launch_pass<true, false, false>(ctx, dst->fine, a, dst->p)));
   if (d_ssq_x) return reduce_chunks(ctx, dst, a.part_t, a.part_s, nullptr, nullptr, nullptr, d_ssq_x);
   return MBPLS_OK;
+}
+
+int mbpls_hip_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_mean, double* d_scale,
+                                      double* d_rscale, double* d_r2, double* d_ssq_x, double* d_amp,
+                                      const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g) {
+  MB_ARG((d_rscale == nullptr) == (d_r2 == nullptr), "d_rscale and d_r2 must be given together");
+  MB_ARG(mode != MBPLS_SCALE_FIT || d_r2, "MBPLS_SCALE_FIT needs d_rscale / d_r2");
+  MB_ARG(src && d_v && d_t, "NULL argument");
+  MB_ARG(mode == MBPLS_SCALE_FIT || mode == MBPLS_SCALE_NONE, "bad mode %d", mode);
+  MB_ARG(mode == MBPLS_SCALE_NONE || (d_mean && d_scale), "mean/scale buffers required");
+  mbpls_ctx* ctx = src->ctx;
+  if (long_columns(ctx, src->n)) {
+    set_error("the statistics-only pass needs register-resident columns (n=%lld)", (long long)src->n);
+    return MBPLS_ERR_UNSUPPORTED;
+  }
+  PassArgs a{};
+  MB_TRY(partial_buffers(ctx, src, &a.part_t, &a.part_s));
+  a.src = src->data; a.dst = nullptr; a.ld = src->ld; a.n = src->n;
+  a.c0 = src->fine.d_c0; a.c1 = src->fine.d_c1;
+  a.mode = mode; a.mean = d_mean; a.scale = d_scale; a.rs_out = d_rscale; a.r2_out = d_r2;
+  a.v = d_v; a.alpha = alpha; a.g = d_g;
+  MB_TRY((launch_pass<true, false, true>(ctx, src->fine, a, src->p)));
+  if (mode == MBPLS_SCALE_FIT) {
+    hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)((src->p + 255) / 256)), dim3(256), 0, ctx->stream, src->p,
+                       d_scale, (const double*)a.r2_out, d_rscale, d_g);
+    MB_HIP(hipGetLastError());
+  }
+  return reduce_chunks(ctx, src, a.part_t, a.part_s, d_t, d_ssq_g, nullptr, d_ssq_x, nullptr, 0, nullptr, d_amp);
 }
 
 }  // extern "C"

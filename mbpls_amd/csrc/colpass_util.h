@@ -46,6 +46,11 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// same for a wave-uniform double (per-column statistics fetched through global pointers)
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __longlong_as_double(uniform64(__double_as_longlong(v)));
+}
+
 // X is streamed exactly once per pass: non-temporal loads/stores keep it out of L2/MALL
 // (measured on MI355X: read-only sweep 6.2 -> 6.8 TB/s, read+write pass 5.5 -> 5.7 TB/s).
 // FULL: n == T*R == ld, every pair of every thread is a real sample -> no masks, and (more important) no
@@ -138,7 +143,7 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
 // the per-chunk scalars [ssq_g, ssq_p, ssq_x, -] into the d_ssq_* outputs, lazy-deflation sums into d_d)
 int reduce_chunks(mbpls_ctx* ctx, const mbpls_mat* m, const double* part_t, const double* part_s,
                   double* d_t, double* d_ssq_g, double* d_ssq_p, double* d_ssq_x,
-                  const double* part_d = nullptr, int nd = 0, double* d_d = nullptr);
+                  const double* part_d = nullptr, int nd = 0, double* d_d = nullptr, double* d_amp = nullptr);
 
 
 // colpass_long.hip: the same passes for columns too long to hold in registers (n > ctx->long_columns_from)

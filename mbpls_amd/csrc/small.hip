@@ -78,6 +78,15 @@ __global__ __launch_bounds__(256) void k_right_multiply(int64_t p, const double*
 
 }  // namespace mbpls
 
+namespace mbpls {
+__global__ __launch_bounds__(256) void k_scale_rows(int64_t p, const double* __restrict__ A, int64_t lda,
+                                                    const double* __restrict__ r, double* __restrict__ C,
+                                                    int64_t ldc) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < p) C[(int64_t)blockIdx.y * ldc + j] = A[(int64_t)blockIdx.y * lda + j] * r[j];
+}
+}  // namespace mbpls
+
 using namespace mbpls;
 
 extern "C" {
@@ -113,6 +122,17 @@ int mbpls_hip_right_multiply(mbpls_ctx* ctx, int64_t p, const double* d_A, int64
   const int nwg = (int)std::min<int64_t>((p + 255) / 256, (int64_t)ctx->cus * 8);
   hipLaunchKernelGGL(k_right_multiply, dim3(nwg), dim3(256), 0, ctx->stream, p, d_A, lda, c1, (const double*)dM, c2,
                      d_C, ldc);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+int mbpls_hip_scale_rows(mbpls_ctx* ctx, int64_t p, int c, const double* d_A, int64_t lda, const double* d_r,
+                         double* d_C, int64_t ldc) {
+  MB_ARG(ctx && d_A && d_r && d_C, "NULL argument");
+  MB_ARG(p >= 0 && c >= 1 && lda >= p && ldc >= p, "bad shape");
+  if (p == 0) return MBPLS_OK;
+  hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((p + 255) / 256), (unsigned)c), dim3(256), 0, ctx->stream, p, d_A,
+                     lda, d_r, d_C, ldc);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }

@@ -64,14 +64,18 @@ class HipEngine:
     def load_device(self, dmat, copy=True):
         """Adopt a matrix already resident in HBM.  copy=True keeps the caller's matrix intact
         (the standardise pass writes into a second matrix); copy=False deflates it in place."""
-        if copy:
-            W = _capi.DeviceMatrix(self.ctx, dmat.n, dmat.p, dmat.block_offsets)
-            self._src = dmat
-            self._set_matrix(W, owns=True)
-        else:
-            self._src = None
-            self._set_matrix(dmat, owns=False)
+        # copy=True: the working copy is allocated by prepare() -- and only if the fit writes X at all (with lazy
+        # deflation and implicit standardisation it never does, and the caller's matrix is used as it is)
+        self._src = dmat if copy else None
+        self._set_matrix(dmat, owns=False)
         return self
+
+    def _working_copy(self):
+        """the matrix the standardise pass writes into: X itself when it is ours to overwrite, else a new one"""
+        if self._src is not None:
+            W = _capi.DeviceMatrix(self.ctx, self._src.n, self._src.p, self._src.block_offsets)
+            self.X, self._owns_X = W, True
+        return self.X
 
     def _set_matrix(self, X, owns):
         self.X = X
@@ -87,6 +91,8 @@ class HipEngine:
         self._coef = [self.ctx.empty(self.KD), self.ctx.empty(self.KD)]   # <ts_i, v>, <ts_i, ts>
         self._lazy_ts = []          # score vectors of the components deflated so far (lazy mode)
         self._lazy_pslot = None
+        self._istd = False          # implicit standardisation: X in HBM stays raw (see prepare)
+        self.rs = self.r2 = None
         if not hasattr(self, "_src"):
             self._src = None
 
@@ -199,6 +205,7 @@ class HipEngine:
             mode = "explicit"      # streamed-column passes (csrc/colpass_long.hip) rewrite X
         self._lazy_pslot = pslot if (mode == "lazy" and K < self.KD - 1) else None
         self._lazy_ts = []
+        self._lazy_K = K
         return self._lazy_pslot is not None
 
     def _lazy_coef(self, idx, vec):
@@ -262,6 +269,11 @@ class HipEngine:
         else:
             mode = _capi.SCALE_NONE
         src = self._src if self._src is not None else self.X
+        if self._implicit_ok(v, mean):
+            out = self._prepare_implicit(src, standardize, mode, v, alpha, g_slot)
+            if out is not None:
+                return out
+        self._working_copy()
         dv = self._put_vec(0, v) if v is not None else None
         # row subset (cross-validation fold): excluded samples become zero rows of the working copy and the
         # column statistics are taken over the included ones only
@@ -290,6 +302,52 @@ class HipEngine:
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
         return x, t, g
 
+    # Rounding of the raw dot products is amplified by |mean_j| / scale_j: beyond this the storing pass is used
+    IMPLICIT_STD_MAX_OFFSET = 1.0e4
+
+    def _implicit_ok(self, v, mean):
+        import os
+        return (self._lazy_pslot is not None and v is not None and mean is None and not self.sparse
+                and getattr(self, "rowmask", None) is None and hasattr(self.X, "standardize_stats_sweep")
+                and self.n <= min(8192, getattr(self.ctx, "long_columns_from", 8192))
+                and os.environ.get("MBPLS_IMPLICIT_STD", "1") != "0")
+
+    def _prepare_implicit(self, src, standardize, mode, v, alpha, g_slot):
+        """First pass of a fit that never writes X (lazy deflation + implicit standardisation): statistics and the
+        first sweep only.  Returns None when the data is too badly offset for raw-space dot products."""
+        n, B = self.n, self.nblocks
+        if standardize:
+            self.rs, self.r2 = self.ctx.empty(self.p), self.ctx.empty(self.p)
+        dv = self._put_vec(0, v)
+        src.standardize_stats_sweep(mode, self.mean, self.scale, self.rs, self.r2, self._xptr(n * B + 2 * B),
+                                    self._xptr(n * B + 3 * B), dv, alpha, self._slot_col(g_slot), self._xptr(0),
+                                    self._xptr(n * B))
+        self.run_deferred(2)
+        t, g, _, x = self._finish_pass(True, True, False, True, nd=1)
+        if not np.all(np.isfinite(x)):
+            raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
+        if standardize and float(np.sqrt(np.max(self._last_d))) > self.IMPLICIT_STD_MAX_OFFSET:
+            self.rs.free(); self.r2.free()
+            self.rs = self.r2 = None
+            return None                      # fall back: standardise into a working copy
+        self.X, self._src = src, None        # the raw matrix, never written
+        self._istd = bool(standardize)
+        if self._istd:
+            self.slot("P~raw", self._lazy_K)
+            t = t - t.mean(axis=0)           # raw-space accumulation: remove the column means' share
+        return x, t, g
+
+    def _centre(self, v):
+        """zero-sum copy of an n-vector (the vectors of a fit on standardised data are centred up to rounding)"""
+        v = np.asarray(v, dtype=np.float64)
+        return v - v.mean(axis=0)
+
+    def _scale_col(self, src_spec, dst_spec):
+        """dst[:, k] = src[:, k] / scale: a finished raw-space column (g~, p~) becomes the true g, p"""
+        s, d = self._slot_col(src_spec), self._slot_col(dst_spec)
+        _capi.check(self.ctx.lib.mbpls_hip_scale_rows(self.ctx.handle, self.p, 1, s.ptr, self.p, self.rs.ptr, d.ptr,
+                                                      self.p))
+
     def sweep(self, v, alpha, g_slot, overlap=None):
         """a2+a3: g = alpha X^T v (into the slot column), t~_b = X_b g_b, ||g_b||^2.  One read of X.
         ``overlap``: host work to do while the kernel runs (e.g. fetching finished columns)."""
@@ -298,6 +356,14 @@ class HipEngine:
         k = len(self._lazy_ts) if self._lazy_pslot else 0
         if self.sparse:      # alpha is implied: every column divides by its own masked <u, u>
             self.X.nan_sweep(dv, self._slot_col(g_slot), self._xptr(0), self._xptr(self._d_off), self._xptr(n * B))
+        elif self._istd:
+            v = self._centre(v)
+            dv = self._put_vec(0, v)
+            self.X.sweep_lazy(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B),
+                              self.slots["P~raw"], self.p, k, self._lazy_coef(0, v), self._xptr(n * B + 3 * B),
+                              r2=self.r2)
+            if g_slot is not None:
+                self._scale_col(g_slot, g_slot)
         elif k:
             P = self.slots[self._lazy_pslot]
             self.X.sweep_lazy(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B), P, self.p, k,
@@ -311,6 +377,8 @@ class HipEngine:
         t, g, _, _ = self._finish_pass(True, True, False, False, nd=k)
         if k:
             t = self._lazy_fix(t, self._last_d)
+        if self._istd:
+            t = t - t.mean(axis=0)           # the column means' share of the raw accumulation (scores are centred)
         return t, g
 
     def deflate_sweep(self, ts, inv_tt, deflate, p_slot, v=None, alpha=1.0, g_slot=None, overlap=None):
@@ -333,11 +401,26 @@ class HipEngine:
             assert p_slot is not None and p_slot[0] == self._lazy_pslot and p_slot[1] == len(self._lazy_ts)
             k = len(self._lazy_ts)
             P = self.slots[self._lazy_pslot]
-            self.X.loadings_sweep_lazy(dts, inv_tt, self._slot_col(p_slot), self._xptr(n * B + B), dv, alpha,
+            p_out = self._slot_col(p_slot)
+            if self._istd:
+                # raw-space pass: zero-sum vectors, raw-space loadings in their own slot, true columns afterwards
+                ts = self._centre(ts)
+                dts = self._put_vec(1, ts)
+                if v is not None:
+                    v = self._centre(v)
+                    dv = self._put_vec(0, v)
+                P = self.slots["P~raw"]
+                p_out = P.col(k)
+            self.X.loadings_sweep_lazy(dts, inv_tt, p_out, self._xptr(n * B + B), dv, alpha,
                                        self._slot_col(g_slot), self._xptr(0) if v is not None else None,
                                        self._xptr(n * B) if v is not None else None, P, self.p, k,
                                        self._lazy_coef(0, v) if v is not None else None, self._lazy_coef(1, ts),
-                                       self._xptr(n * B + 3 * B) if v is not None else None)
+                                       self._xptr(n * B + 3 * B) if v is not None else None,
+                                       r2=self.r2 if self._istd else None)
+            if self._istd:
+                self._scale_col(("P~raw", k), p_slot)
+                if v is not None and g_slot is not None:
+                    self._scale_col(g_slot, g_slot)
             if overlap is not None:
                 overlap()
             else:
@@ -345,6 +428,8 @@ class HipEngine:
             t, g, p, _ = self._finish_pass(v is not None, v is not None, True, False, nd=(k + 1) if v is not None else 0)
             if v is not None:
                 t = self._lazy_fix(t, self._last_d, extra_ts=np.asarray(ts))
+                if self._istd:
+                    t = t - t.mean(axis=0)
             if deflate:
                 self._lazy_ts.append(np.array(ts, dtype=np.float64).ravel())
             return p, t, g

@@ -476,3 +476,42 @@ def test_both_deflation_modes(gpu_required, monkeypatch, mode, method, q):
     mdl = MBPLS(n_components=5, method=method).fit(Xs, Y)
     w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} q={q} {mode}")
     assert w < 1e-8, w
+
+
+@pytest.mark.parametrize("offset,expect_implicit", [(0.0, True), (50.0, True), (1.0e6, False)])
+def test_implicit_standardisation_and_its_fallback(gpu_required, monkeypatch, offset, expect_implicit):
+    """One response + lazy deflation: the fit never writes X (statistics-only first pass, raw-space passes after).
+    Offsets amplify the rounding of raw-space sums by |mean|/scale: moderate ones stay inside the tolerance by a wide
+    margin, extreme ones make the engine fall back to the storing standardise pass.  Same numbers either way, the
+    caller's resident matrix is untouched, and MBPLS_IMPLICIT_STD=0 switches the path off."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix
+    from mbpls_amd.engine import HipEngine
+    X, Y = orc.make_latent(1000, 6000, 1, seed=77)
+    X = X + offset * (1.0 + np.arange(X.shape[1]) % 3)       # column offsets 1x..3x
+    ref = orc.fit(X, Y, n_components=4)
+    seen = []
+    real = HipEngine._prepare_implicit
+
+    def spy(self, *a, **k):
+        out = real(self, *a, **k)
+        seen.append(out is not None)
+        return out
+
+    monkeypatch.setattr(HipEngine, "_prepare_implicit", spy)
+    ctx = mbpls_amd.get_context()
+    Xd = DeviceMatrix(ctx, *X.shape)
+    Xd.upload(X)
+    mdl = MBPLS(n_components=4).fit(Xd, Y)
+    assert seen == [expect_implicit]
+    w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"offset {offset}")
+    assert w < (1e-9 if offset == 0.0 else 1e-7), w
+    assert np.array_equal(Xd.download(), X)                  # copy=True: the resident matrix is never written
+    assert util.relerr(np.concatenate([s.mean_ for s in mdl.x_scalers_]), X.mean(axis=0)) < 1e-12
+    assert util.relerr(np.concatenate([s.scale_ for s in mdl.x_scalers_]), X.std(axis=0)) < 1e-9
+    monkeypatch.setenv("MBPLS_IMPLICIT_STD", "0")
+    seen.clear()
+    m2 = MBPLS(n_components=4).fit(Xd, Y)
+    assert seen == []
+    assert util.compare(util.model_to_flat(m2), util.model_to_flat(ref), TOL, what="stored") < 1e-8
+    Xd.close()
