@@ -352,13 +352,13 @@ class HipEngine:
         """a2+a3: g = alpha X^T v (into the slot column), t~_b = X_b g_b, ||g_b||^2.  One read of X.
         ``overlap``: host work to do while the kernel runs (e.g. fetching finished columns)."""
         n, B = self.n, self.nblocks
+        if self._istd:
+            v = self._centre(v)
         dv = self._put_vec(0, v)
         k = len(self._lazy_ts) if self._lazy_pslot else 0
         if self.sparse:      # alpha is implied: every column divides by its own masked <u, u>
             self.X.nan_sweep(dv, self._slot_col(g_slot), self._xptr(0), self._xptr(self._d_off), self._xptr(n * B))
         elif self._istd:
-            v = self._centre(v)
-            dv = self._put_vec(0, v)
             self.X.sweep_lazy(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B),
                               self.slots["P~raw"], self.p, k, self._lazy_coef(0, v), self._xptr(n * B + 3 * B),
                               r2=self.r2)
@@ -384,6 +384,9 @@ class HipEngine:
     def deflate_sweep(self, ts, inv_tt, deflate, p_slot, v=None, alpha=1.0, g_slot=None, overlap=None):
         """a5+a7 (+ next component's first sweep): p = inv_tt X^T ts, X -= ts p^T.  One read + one write."""
         n, B = self.n, self.nblocks
+        if self._istd:       # raw-space pass: zero-sum vectors
+            ts = self._centre(ts)
+            v = self._centre(v) if v is not None else None
         dts = self._put_vec(1, ts)
         dv = self._put_vec(0, v) if v is not None else None
         if self.sparse:      # inv_tt is implied: every column divides by its own masked <ts, ts>
@@ -403,12 +406,7 @@ class HipEngine:
             P = self.slots[self._lazy_pslot]
             p_out = self._slot_col(p_slot)
             if self._istd:
-                # raw-space pass: zero-sum vectors, raw-space loadings in their own slot, true columns afterwards
-                ts = self._centre(ts)
-                dts = self._put_vec(1, ts)
-                if v is not None:
-                    v = self._centre(v)
-                    dv = self._put_vec(0, v)
+                # raw-space pass: raw-space loadings in their own slot, true columns afterwards
                 P = self.slots["P~raw"]
                 p_out = P.col(k)
             self.X.loadings_sweep_lazy(dts, inv_tt, p_out, self._xptr(n * B + B), dv, alpha,
