@@ -75,6 +75,14 @@ def main():
             if method == "NIPALS":
                 # the exit test sits at 1e-14: a different summation order may move it by an iteration
                 assert all(abs(a - b) <= 2 for a, b in zip(mdl.nipals_iterations_, ref.nipals_iterations_))
+        # one response: lazy deflation + implicit standardisation (X never written), sharded
+        Y1, Yn1 = Y[:, :1], Yn[:, :1]
+        for method, K in (("NIPALS", 5), ("UNIPALS", 3)):
+            ref = orc.fit(full, Y1, n_components=K, method=method)
+            mdl = MBPLS(n_components=K, method=method).fit(local, Y1)
+            check(mdl, ref, ranges, full_new, local_new, Yn1, method + " q=1", orc.predict, orc.transform)
+            if method == "NIPALS":
+                assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K
         # explicit deflation and the streamed-column passes through the same exchange
         os.environ["MBPLS_DEFLATION"] = "explicit"
         ref = orc.fit(full, Y, n_components=3, method="NIPALS")
