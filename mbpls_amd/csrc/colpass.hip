@@ -279,6 +279,10 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
       }
 
       double gj = 0.0, pjk = 0.0;
+      // 1/scale_j^2 of the raw-space passes: requested here, ahead of the dot products, so the scalar load is not
+      // waited for behind the reduction
+      double r2c = 1.0;
+      if constexpr (ISTD && !STD) r2c = a.ir2[jj];
       if constexpr (DEFL) {
         // lazy: <x_k, ts> = <x_0, ts> - sum_i P[j,i] <ts_i, ts>, folded into the same reduction
         double ab[2] = {-pp[d] * ce_i, -pp[d] * cu_i};
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
           ab[0] = a1[0];
         }
         const double pj = ab[0] * a.inv_tt;        // ISTD: the raw-space loading p~_j
-        if constexpr (ISTD) ssq_p = fma(pj * pj, a.ir2[jj], ssq_p);
+        if constexpr (ISTD) ssq_p = fma(pj * pj, r2c, ssq_p);
         else ssq_p = fma(pj, pj, ssq_p);
         if (tid == 0 && a.pvec) a.pvec[jj] = pj;
         if (a.deflate) {
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
       if constexpr (SWEEP) {
         if (!handled) {
           double cj = gj;                    // ISTD: gj is g~_j, cj the weight of the RAW column in the scores
-          if constexpr (ISTD && !STD) cj = gj * a.ir2[jj];
+          if constexpr (ISTD && !STD) cj = gj * r2c;
           ssq_g = fma(gj, cj, ssq_g);
           if (tid == 0 && a.g) a.g[jj] = gj;
 #pragma unroll
