@@ -1,0 +1,51 @@
+"""Randomised parity sweep: random shapes / block splits / methods / settings (incl. column offsets and missing
+values), the HIP path against the oracles.  Used by test_gpu_fuzz.py and tools/fuzz_parity.py."""
+import warnings
+
+import numpy as np
+
+from oracle import mbpls_oracle as orc
+from oracle import mbpls_oracle_sparse as ors
+from tests import util
+
+
+def run(cases, seed, verbose=True):
+    from mbpls_amd import MBPLS
+    warnings.filterwarnings("ignore")
+    rng = np.random.RandomState(seed)
+    print_ = print if verbose else (lambda *a, **k: None)
+    worst, bad = 0.0, 0
+    for c in range(cases):
+        n = int(rng.choice([rng.randint(3, 40), rng.randint(40, 700), rng.choice([64, 128, 256, 512, 1024])]))
+        p = int(rng.choice([rng.randint(1, 30), rng.randint(30, 3000)]))
+        q = int(rng.choice([1, 1, 2, 3]))
+        K = int(min(rng.randint(1, 5), max(1, min(n - 1, p))))
+        method = str(rng.choice(["NIPALS", "NIPALS", "UNIPALS", "KERNEL", "SIMPLS"]))
+        std = bool(rng.rand() < 0.7)
+        nb = int(min(p, rng.randint(1, 4)))
+        cuts = np.sort(rng.choice(np.arange(1, p), nb - 1, replace=False)) if nb > 1 else np.array([], dtype=int)
+        X, Y = orc.make_latent(n, p, q, r=min(4, p), seed=1000 + c)
+        X = X + rng.uniform(-3, 3, size=p) * (rng.rand() < 0.5)          # column offsets (implicit standardisation)
+        sp = (lambda A: A) if nb == 1 else (lambda A: [np.ascontiguousarray(b) for b in np.split(A, cuts, axis=1)])
+        sparse = method == "NIPALS" and n >= 20 and p >= 20 and rng.rand() < 0.4
+        if sparse:
+            X[rng.rand(n, p) < rng.choice([0.01, 0.05])] = np.nan
+        tag = f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} blocks={nb} sparse={sparse}"
+        try:
+            if sparse:
+                ref = ors.fit(sp(X), Y, n_components=K, standardize=std)
+            else:
+                ref = orc.fit(sp(X), Y, n_components=K, method=method, standardize=std, full_svd=True)
+        except Exception as e:
+            print_(tag, "oracle failed:", type(e).__name__); continue
+        try:
+            m = MBPLS(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse).fit(sp(X), Y)
+            w = util.compare(util.model_to_flat(m), util.model_to_flat(ref), 1e-6, what=tag)
+            w = max(w, util.relerr(m.predict(sp(X)), (ors if sparse else orc).predict(ref, sp(X))))
+            worst = max(worst, w)
+            if w > 1e-9:
+                print_(tag, f"relerr {w:.2e}")
+        except Exception as e:
+            bad += 1
+            print_(tag, "FAILED:", type(e).__name__, str(e)[:200])
+    return bad, worst

@@ -1,0 +1,13 @@
+"""Randomised parity sweep (tests/fuzz.py) as a GPU test: 150 random problems, every method, block splits, column
+offsets, missing values -- no failure and every attribute within 1e-8 of the oracle (tolerance 1e-6)."""
+import pytest
+
+from tests import fuzz
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_problems(gpu_required):
+    bad, worst = fuzz.run(150, seed=11, verbose=False)
+    assert bad == 0
+    assert worst < 1e-8, worst

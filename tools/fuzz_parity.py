@@ -1,0 +1,10 @@
+"""Randomised parity sweep on the GPU (see tests/fuzz.py):  python tools/fuzz_parity.py [cases] [seed]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import fuzz
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+bad, worst = fuzz.run(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+print(f"{cases} cases, {bad} failures, worst relerr {worst:.2e}")
