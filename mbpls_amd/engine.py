@@ -107,6 +107,11 @@ class HipEngine:
             self.G[0].close()
             self.G[1].free()
             self.G = None
+        if getattr(self, "Gb", None) is not None:
+            self.Gb[0].close()
+            for a in self.Gb[1:]:
+                a.free()
+            self.Gb = None
 
     # ------------------------------------------------------------------ slots (p x K device arrays)
     def slot(self, name, K):
@@ -511,6 +516,32 @@ class HipEngine:
         Gm = _capi.DeviceMatrix(self.ctx, n, n, [0, n], storage=store)
         self.G = (Gm, store)
         return self
+
+    def gram_blocks(self):
+        """Per-block association matrices A_b = X_b X_b^T, side by side in one n x (B n) 'matrix' whose blocks are the
+        B Grams: A_b z for every block is then ONE per-block x_w over B n^2 doubles (multi-response NIPALS iterates
+        on these instead of on X)."""
+        n, B = self.n, self.nblocks
+        ldg = n + (n & 1)
+        store = self.ctx.empty((ldg, n * B), zero=True)
+        for b in range(B):
+            view = _capi.DeviceMatrix(self.ctx, n, self.block_sizes[b], None,
+                                      storage=self.X.data_ptr + 8 * self.X.ld * self.block_offsets[b])
+            view.gram(store.col(b * n, n), ldg)
+            view.close()
+        if self.comm.is_distributed:
+            store.set(self.comm.allreduce_host(store.get()))
+        Gm = _capi.DeviceMatrix(self.ctx, n, n * B, [b * n for b in range(B + 1)], storage=store)
+        self.Gb = (Gm, store, self.ctx.empty(n * B), self.ctx.empty(n * B))
+        return self
+
+    def gram_apply_blocks(self, z):
+        """[A_1 z | ... | A_B z]  (n x B) for a host n-vector z"""
+        Gm, _, dW, buf = self.Gb
+        n, B = self.n, self.nblocks
+        dW.set(np.tile(np.asarray(z, dtype=np.float64).ravel(), B))
+        Gm.x_w(dW, 1, buf, per_block=True, ldw=n * B, ldo=n)
+        return buf.get().reshape(B, n).T.copy()
 
     def gram_apply(self, Z):
         """A @ Z for a host n x c matrix (A symmetric, so the feature-major product X W is A Z)."""

@@ -109,6 +109,91 @@ def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_hos
 
 
 # ----------------------------------------------------------------------------------- NIPALS
+def _nipals_on_grams(eng, q):
+    """Several responses make NIPALS iterate 50-500 times per component, and every iteration is a pass over X.  With
+    p > n the same iterates can be had from the per-block association matrices A_b = X_b X_b^T (n x n each):
+    t_b = X_b w_b = A_b u / sqrt(u^T A_b u), so an iteration touches B n^2 doubles instead of n p.  Worth it once the
+    fit needs more than about n/75 passes (the Gram costs n(n+1)p flop) -- always the case for q > 1 in practice."""
+    import os
+    if (q == 1 or not hasattr(eng, "gram_blocks") or getattr(eng, "sparse", False)
+            or os.environ.get("MBPLS_NIPALS_GRAM", "1") == "0"):
+        return False
+    p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
+    return p_total > eng.n and eng.n <= 16384 and 8.0 * eng.nblocks * eng.n ** 2 <= 16 * 2 ** 30
+
+
+def _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter):
+    """mbpls.py:809-993 with the inner loop (:841-913) on the association matrices.  X is standardised once and never
+    deflated: the deflation X_b <- (I - ts ts^T) X_b (:969) becomes A_b <- P A_b P, P = I - Ts Ts^T, applied to the
+    vectors around each product.  Per component the loop costs B n^2 doubles per iteration; the weights and loadings
+    of the converged component are one pass over X:  w~ = X^T (P u)/(u^T u) (:856),  p = X^T ts (:928)."""
+    n, B = eng.n, eng.nblocks
+    q = Y.shape[1]
+    sizes = _global_sizes(eng)
+    varxb, _, _ = eng.prepare(standardize)
+    eng.gram_blocks()
+    varx = varxb.sum()
+    vary = (Y ** 2).sum()
+    eng.slot("Wn", K); eng.slot("P", K); eng.slot("WP", 2)
+    Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
+    T = [np.empty((n, K)) for _ in range(B)]
+    nu_all = np.empty((B, K))
+    evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
+    for k in range(K):
+        Tp = Ts[:, :k]
+        u = Y[:, 0:1]
+        diff, run, ts_old = 1.0, 1, None
+        while diff > max_tol:
+            uu = u.T.dot(u).item()
+            z = u - Tp.dot(Tp.T.dot(u))                    # P u
+            Az0 = eng.gram_apply_blocks(z)                  # A_b,0 (P u)
+            quad = z.T.dot(Az0).ravel()                     # u^T A_b,k u = ||X_b^T u||^2          (:860)
+            Az = Az0 - Tp.dot(Tp.T.dot(Az0))                # P A_b,0 P u = A_b,k u
+            Tm = Az / np.sqrt(quad)                         # t_b = X_b w_b                          (:875-877)
+            sw = Tm.T.dot(u) / uu                           # (:879)
+            sw = sw / np.linalg.norm(sw)
+            ts = Tm.dot(sw)                                 # (:882)
+            ts = ts / np.linalg.norm(ts)
+            if run > 1:
+                diff = _norm(ts_old - ts, norm)             # (:887)
+            ts_old = ts.copy()
+            z_used, uu_used = z, uu
+            v = Y.T.dot(ts) / ts.T.dot(ts)                  # (:899)
+            u = Y.dot(v) / v.T.dot(v)                       # (:911)
+            u = u / np.linalg.norm(u)
+            run += 1
+            if run - 1 >= max_iter and diff > max_tol:
+                warnings.warn(f"NIPALS component {k}: no convergence to max_tol={max_tol} after {max_iter} "
+                              f"iterations (last diff {diff:.3e}); the reference would loop forever here.")
+                break
+        iters.append(run - 1)
+        # the converged component's p-length vectors: one read of X for both
+        ssq = eng.xt_v(np.hstack((z_used / uu_used, ts - Tp.dot(Tp.T.dot(ts)))), 1.0, "WP", 0, want_ssq=True)
+        eng.right_mul(("WP", 0, 1), np.array([[1.0]]), ("Wn", k))
+        eng.right_mul(("WP", 1, 1), np.array([[1.0]]), ("P", k))
+        nu = np.sqrt(ssq[:, 0])                             # ||w~_b||
+        ssq_p = ssq[:, 1]
+        Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u; V[:, k:k + 1] = v; A[:, k:k + 1] = sw ** 2
+        nu_all[:, k] = nu
+        for b in range(B):
+            T[b][:, k] = Tm[:, b]
+        if calc_all:                                        # (:932-964)
+            tt = ts.T.dot(ts).item()
+            evx.append(tt * ssq_p.sum() / varx)
+            evy.append(tt * v.T.dot(v).item() / vary)
+            evxb[:, k] = tt * ssq_p / varxb
+            Acorr[:, k] = _bip_corrected(sw ** 2, sizes)
+    res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, nipals_iterations_=iters)
+    if calc_all:
+        res.update(explained_var_x_=evx, explained_var_y_=evy, explained_var_xblocks_=evxb, A_corrected_=Acorr)
+    else:
+        res.update(explained_var_x_=[], explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)),
+                   A_corrected_=np.empty((B, 0)))
+    _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V)
+    res.W_non_normal_ = _split(eng.fetch("Wn"), eng.block_offsets)
+    return res
+
+
 def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max_iter=None):
     """mbpls.py:809-993.  Per component: iterate {sweep(u) -> T -> sw, ts -> v -> u} until
     ||ts_old - ts|| <= max_tol (never on the first pass, :884), then p = X^T ts and
@@ -116,6 +201,8 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     max_iter = NIPALS_MAX_ITER if max_iter is None else max_iter
+    if _nipals_on_grams(eng, q):
+        return _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     sizes = _global_sizes(eng)
     u0 = Y[:, 0:1]
     alpha0 = 1.0 / u0.T.dot(u0).item()

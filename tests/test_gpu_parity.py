@@ -515,3 +515,29 @@ def test_implicit_standardisation_and_its_fallback(gpu_required, monkeypatch, of
     assert seen == []
     assert util.compare(util.model_to_flat(m2), util.model_to_flat(ref), TOL, what="stored") < 1e-8
     Xd.close()
+
+
+@pytest.mark.parametrize("gram", ["1", "0"])
+def test_multi_response_nipals_on_association_matrices(gpu_required, monkeypatch, gram):
+    """Several responses: the NIPALS inner loop runs on the per-block association matrices A_b = X_b X_b^T
+    (t_b = A_b u / sqrt(u^T A_b u)) instead of sweeping X every iteration -- same iterates, same results as the
+    X-sweeping loop (MBPLS_NIPALS_GRAM=0) and as the oracle, including row-subset fits."""
+    from mbpls_amd import MBPLS
+    monkeypatch.setenv("MBPLS_NIPALS_GRAM", gram)
+    X, Y = orc.make_latent(333, 4000, 4, seed=90)
+    Xs = [np.ascontiguousarray(X[:, :1500]), np.ascontiguousarray(X[:, 1500:2501]), np.ascontiguousarray(X[:, 2501:])]
+    Xn, Yn = orc.make_latent(40, 4000, 4, seed=91)
+    Xns = [np.ascontiguousarray(Xn[:, :1500]), np.ascontiguousarray(Xn[:, 1500:2501]), np.ascontiguousarray(Xn[:, 2501:])]
+    for std in (True, False):
+        ref = orc.fit(Xs, Y, n_components=4, standardize=std)
+        mdl = MBPLS(n_components=4, standardize=std).fit(Xs, Y)
+        got = _fit_flat(mdl, Xns, Yn)
+        rflat = util.model_to_flat(ref)
+        rflat["predict"] = orc.predict(ref, Xns)
+        rTs, rT, rU = orc.transform(ref, Xns, Yn, return_block_scores=True)
+        for b, blk in enumerate(rT):
+            rflat[f"T_new/{b}"] = blk
+        rflat["Ts_new"], rflat["U_new"] = rTs, rU
+        w = util.compare(got, rflat, TOL, what=f"gram={gram} std={std}")
+        assert w < 1e-8, w
+        assert all(abs(a - b) <= 2 for a, b in zip(mdl.nipals_iterations_, ref.nipals_iterations_))
