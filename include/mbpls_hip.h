@@ -275,6 +275,20 @@ int mbpls_hip_x_w_nan(const mbpls_mat* m, const double* d_W, int64_t ldw, int c,
  * f64 MFMA SYRK; both triangles are written (bitwise symmetric, like numpy's syrk dispatch).      */
 int mbpls_hip_gram(const mbpls_mat* m, double* d_G, int64_t ldg);
 
+/* ---- multi-response NIPALS in association-matrix space ----------------------------------------------------
+ * One iteration of the inner loop (mbpls.py:841-913) given d_a = A z, A = sum_b X_b X_b^T (mbpls_hip_gram per block,
+ * mbpls_hip_x_w on the Grams), z = P u, P = I - Ts Ts^T of the k previous components (d_Tp: n x k, column-major):
+ *   ts = P a/||P a||, diff = ||ts_old - ts|| (:887; norm_kind 0: 2-norm, 1: sum|.|, 2: max|.|, 3: min|.|),
+ *   v = Y^T ts/(ts^T ts) (:899), u = Y v/(v^T v) normalised (:911-913), z_next = P u,
+ * because T sw = P A z for the reference's t_b = X_b w_b and sw ~ T^T u (the per-block products are only needed
+ * once, at convergence).  d_state = [done, iterations, diff]: the step is a no-op once done != 0 (1: diff <= tol on a
+ * pass after the first, :884; 2: max_iter reached), so a batch of steps can be queued without a host round trip and
+ * the state read back is the state at the reference's loop exit.  d_ts holds the previous ts on entry.
+ * k, q <= 16; d_Y: n x q column-major; d_z_next receives ntile copies of z_next, n apart (one per Gram).       */
+int mbpls_hip_nipals_gram_step(mbpls_ctx* ctx, int64_t n, const double* d_a, const double* d_Tp, int k,
+                               const double* d_Y, int q, int norm_kind, double tol, int max_iter, double* d_ts,
+                               double* d_u, double* d_v, double* d_z_next, int ntile, double* d_state);
+
 /* ---- end-of-fit algebra on p x K device arrays (K <= 32), column-major ------------------------
  * h_out (c1 x c2 row-major, HOST) = A^T B for p x c1 / p x c2 device arrays: P_^T W (mbpls.py:988,
  * :569, :737).  Deterministic two-stage reduction; synchronous (the result is on the host on return). */

@@ -112,6 +112,10 @@ class HipEngine:
             for a in self.Gb[1:]:
                 a.free()
             self.Gb = None
+        if getattr(self, "_gp", None) is not None:
+            for a in [self._gp[key] for key in ("Y", "a", "ts", "u", "v", "state")] + self._gp["W"]:
+                a.free()
+            self._gp = None
 
     # ------------------------------------------------------------------ slots (p x K device arrays)
     def slot(self, name, K):
@@ -542,6 +546,42 @@ class HipEngine:
         dW.set(np.tile(np.asarray(z, dtype=np.float64).ravel(), B))
         Gm.x_w(dW, 1, buf, per_block=True, ldw=n * B, ldo=n)
         return buf.get().reshape(B, n).T.copy()
+
+    def gram_power_loop(self, Y, Tp, u0, norm_kind, tol, max_iter, batch=16):
+        """The multi-response NIPALS inner loop (mbpls.py:841-913) on the device: per iteration one product with the
+        Grams and one mbpls_hip_nipals_gram_step, queued ``batch`` at a time; the host only reads the 3-double state
+        between batches.  Returns (iterations, capped, ts, u, v, z_used) with z_used = P u of the LAST iteration's
+        sweep vector (what the weights of the component are taken with)."""
+        Gm = self.Gb[0]
+        n, B, k, q = self.n, self.nblocks, Tp.shape[1], Y.shape[1]
+        ctx = self.ctx
+        if getattr(self, "_gp", None) is None or self._gp["q"] != q:
+            self._gp = dict(q=q, Y=ctx.from_host(Y), W=[ctx.empty(n * B), ctx.empty(n * B)], a=ctx.empty(n),
+                            ts=ctx.empty(n), u=ctx.empty(n), v=ctx.empty(q), state=ctx.empty(3))
+        g = self._gp
+        dTp = ctx.from_host(Tp) if k else None
+        z0 = u0 - Tp.dot(Tp.T.dot(u0))
+        g["W"][0].set(np.tile(z0.ravel(), B))
+        g["ts"].set(np.zeros(n))
+        g["state"].set(np.zeros(3))
+        it = 0
+        while True:
+            for _ in range(batch):
+                Gm.x_w(g["W"][it % 2], 1, g["a"], ldw=n * B, ldo=n)
+                _capi.check(ctx.lib.mbpls_hip_nipals_gram_step(
+                    ctx.handle, n, g["a"].ptr, dTp.ptr if k else None, k, g["Y"].ptr, q, int(norm_kind), float(tol),
+                    int(max_iter), g["ts"].ptr, g["u"].ptr, g["v"].ptr, g["W"][(it + 1) % 2].ptr, B, g["state"].ptr))
+                it += 1
+            st = g["state"].get()
+            if st[0] != 0.0:
+                break
+        iters = int(st[1])
+        z_used = g["W"][(iters - 1) % 2].get()[:n].reshape(-1, 1)
+        out = (iters, st[0] == 2.0, g["ts"].get().reshape(-1, 1), g["u"].get().reshape(-1, 1),
+               g["v"].get().reshape(-1, 1), z_used)
+        if dTp is not None:
+            dTp.free()
+        return out
 
     def gram_apply(self, Z):
         """A @ Z for a host n x c matrix (A symmetric, so the feature-major product X W is A Z)."""

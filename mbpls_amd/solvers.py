@@ -139,10 +139,32 @@ def _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     T = [np.empty((n, K)) for _ in range(B)]
     nu_all = np.empty((B, K))
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
+    # norm of the n x 1 difference as numpy's MATRIX norm (:887): 2, 'fro', 'nuc', -2 -> ||d||_2; 1, -1 -> sum |d|;
+    # inf -> max |d|; -inf -> min |d|; anything else raises exactly as in the reference
+    _norm(np.zeros((2, 1)), norm)
+    kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
+    on_device = (kind is not None and hasattr(eng, "gram_power_loop") and K <= 16 and q <= 16)
+    Yc = np.asfortranarray(Y)
     for k in range(K):
         Tp = Ts[:, :k]
         u = Y[:, 0:1]
         diff, run, ts_old = 1.0, 1, None
+        if on_device:
+            # ts ~ T sw = P (sum_b A_b) P u: the loop needs one product with the summed Grams per iteration and runs
+            # on the device (nipals_step.hip); the per-block quantities of the LAST iteration are taken below
+            n_it, capped, ts, u, v, z = eng.gram_power_loop(Yc, Tp, u, kind, max_tol, max_iter)
+            if capped:
+                warnings.warn(f"NIPALS component {k}: no convergence to max_tol={max_tol} after {max_iter} "
+                              f"iterations; the reference would loop forever here.")
+            uu = Y[:, 0:1].T.dot(Y[:, 0:1]).item() if n_it == 1 else 1.0     # u^T u of the sweep vector used last
+            Az0 = eng.gram_apply_blocks(z)
+            quad = z.T.dot(Az0).ravel()
+            Tm = (Az0 - Tp.dot(Tp.T.dot(Az0))) / np.sqrt(quad)               # t_b (:875-877)
+            sw = np.sqrt(quad).reshape(-1, 1)                                # sw_b ~ t_b^T u = sqrt(u^T A_b u) (:879)
+            sw = sw / np.linalg.norm(sw)
+            z_used, uu_used = z, uu
+            run = n_it + 1
+            diff = 0.0
         while diff > max_tol:
             uu = u.T.dot(u).item()
             z = u - Tp.dot(Tp.T.dot(u))                    # P u

@@ -541,3 +541,37 @@ def test_multi_response_nipals_on_association_matrices(gpu_required, monkeypatch
         w = util.compare(got, rflat, TOL, what=f"gram={gram} std={std}")
         assert w < 1e-8, w
         assert all(abs(a - b) <= 2 for a, b in zip(mdl.nipals_iterations_, ref.nipals_iterations_))
+
+
+@pytest.mark.parametrize("n,k,q,kind", [(257, 0, 1, 0), (1000, 3, 4, 0), (4096, 9, 10, 1), (5000, 16, 16, 2), (300, 2, 3, 3)])
+def test_nipals_gram_step_kernel(ctx, n, k, q, kind):
+    """One device iteration of the association-matrix NIPALS loop against its numpy statement, incl. the done flag."""
+    from mbpls_amd import _capi
+    rng = np.random.RandomState(n + k + q)
+    Tp = np.linalg.qr(rng.standard_normal((n, max(k, 1))))[0][:, :k]
+    Y = rng.standard_normal((n, q))
+    a = rng.standard_normal(n)
+    ts_old = rng.standard_normal(n); ts_old /= np.linalg.norm(ts_old)
+    Pa = a - Tp.dot(Tp.T.dot(a))
+    ts = Pa / np.linalg.norm(Pa)
+    d = ts_old - ts
+    diff = [np.linalg.norm(d), np.abs(d).sum(), np.abs(d).max(), np.abs(d).min()][kind]
+    v = Y.T.dot(ts) / ts.dot(ts)
+    u = Y.dot(v) / v.dot(v); u /= np.linalg.norm(u)
+    z = u - Tp.dot(Tp.T.dot(u))
+    B = 2
+    dts, du, dv, dz, dst = ctx.from_host(ts_old), ctx.empty(n), ctx.empty(q), ctx.empty(n * B), ctx.from_host(np.array([0.0, 4.0, 0.0]))
+    da, dTp, dY = ctx.from_host(a), (ctx.from_host(Tp) if k else None), ctx.from_host(np.asfortranarray(Y))
+
+    def step(tol):
+        _capi.check(ctx.lib.mbpls_hip_nipals_gram_step(ctx.handle, n, da.ptr, dTp.ptr if k else None, k, dY.ptr, q, kind,
+                                                       tol, 100, dts.ptr, du.ptr, dv.ptr, dz.ptr, B, dst.ptr))
+    step(diff * 2)          # converges: 5th iteration, diff below tol
+    st = dst.get()
+    assert st[0] == 1.0 and st[1] == 5.0 and abs(st[2] - diff) <= 1e-12 * max(1.0, diff)
+    assert util.relerr(dts.get(), ts) < 1e-12 and util.relerr(du.get(), u) < 1e-12 and util.relerr(dv.get(), v) < 1e-12
+    zz = dz.get()
+    assert util.relerr(zz[:n], z) < 1e-10 and np.array_equal(zz[:n], zz[n:])
+    da.set(rng.standard_normal(n))
+    step(diff * 2)          # done: a queued step must not change anything
+    assert np.array_equal(dst.get(), st) and util.relerr(dts.get(), ts) < 1e-12
