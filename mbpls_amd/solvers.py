@@ -337,7 +337,10 @@ def fit_unipals(eng, Y, K, standardize):
     eng.slot("S", max(q, 1))
     y0 = Y[:, 0:1]
     if wide and hasattr(eng, "use_lazy_deflation"):
-        eng.use_lazy_deflation(K, "P")      # the n >= p branch mixes in xt_v / x_w on the deflated X: explicit
+        # one response: every pass is a sweep / deflate_sweep, lazy deflation applies.  Several responses: X (X^T Y)
+        # goes through the many-right-hand-side products, which need the deflated matrix itself -> explicit.
+        # (the n >= p branch mixes in xt_v / x_w on the deflated X as well: explicit)
+        eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
     fuse = wide and q == 1
     varxb, m_raw, _ = eng.prepare(standardize, v=y0 if fuse else None, alpha=1.0, g_slot=("S", 0) if fuse else None)
     varx = varxb.sum()
@@ -354,6 +357,10 @@ def fit_unipals(eng, Y, K, standardize):
         if wide:
             if fuse:
                 M = m_raw.sum(axis=1, keepdims=True)        # X (X^T y) = sum_b X_b g_b
+            elif getattr(eng, "_lazy_pslot", None) is None and hasattr(eng, "x_w_slot"):
+                # X (X^T Y) for all q responses in two reads of the (explicitly deflated) X: matrix-core xt_v, x_w
+                eng.xt_v(Y, 1.0, "S", 0)
+                M = eng.x_w_slot("S", 0, q)
             else:
                 M = np.empty((n, q))
                 for c in range(q):

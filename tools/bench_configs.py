@@ -65,5 +65,7 @@ if __name__ == "__main__":
         run("SIMPLS", 4096, 1_000_000, 10, 1, "SIMPLS", [0, 1_000_000], True)
     elif which == "nipals_q10":
         run("NIPALS q=10 (paper protocol)", 4096, 1_000_000, 10, 10, "NIPALS", [0, 500_000, 1_000_000], True, steps=1)
+    elif which == "unipals_q10":
+        run("C3 UNIPALS multiblock q=10", 4096, 1_000_000, 10, 10, "UNIPALS", [0, 300_000, 600_000, 1_000_000], True)
     elif which == "nipals_mb":
         run("NIPALS 4 blocks", 4096, 1_000_000, 10, 1, "NIPALS", [0, 250_000, 500_000, 750_000, 1_000_000], True)
