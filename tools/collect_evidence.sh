@@ -24,7 +24,7 @@ if [ $what = pmc ] || [ $what = all ]; then
 fi
 if [ $what = configs ] || [ $what = all ]; then
   : > $OUT/other_configs.jsonl
-  for c in c3 simpls nipals_mb c4 nipals_q10; do
+  for c in c3 simpls nipals_mb c4 nipals_q10 unipals_q10; do
     python3 $ROOT/tools/bench_configs.py $c 2>> $OUT/configs.err | tail -1 >> $OUT/other_configs.jsonl
   done
   python3 $ROOT/tools/time_sparse.py 250000 0.01 > $OUT/sparse.txt 2>&1
