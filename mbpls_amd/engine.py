@@ -105,12 +105,14 @@ class HipEngine:
         self.X = None
         if self.G is not None:
             self.G[0].close()
-            self.G[1].free()
+            if hasattr(self.G[1], "free"):
+                self.G[1].free()
             self.G = None
         if getattr(self, "Gb", None) is not None:
             self.Gb[0].close()
             for a in self.Gb[1:]:
-                a.free()
+                if hasattr(a, "free"):
+                    a.free()
             self.Gb = None
         if getattr(self, "_gp", None) is not None:
             for a in [self._gp[key] for key in ("Y", "a", "ts", "u", "v", "state")] + self._gp["W"]:
@@ -512,14 +514,19 @@ class HipEngine:
         """A = X X^T on the matrix cores; kept in HBM as an n x n 'matrix' so A @ Z reuses x_w."""
         n = self.n
         ldg = n + (n & 1)
-        store = self.ctx.empty((ldg, n), zero=True)
-        self.X.gram(store, ldg)
-        if self.comm.is_distributed:
-            h = self.comm.allreduce_host(store.get())
-            store.set(h)
-        Gm = _capi.DeviceMatrix(self.ctx, n, n, [0, n], storage=store)
+        store = self._gram_store(ldg * n)
+        self.X.gram(store.ptr, ldg)
+        self.comm.allreduce_device(store)        # partial Grams of the column shards (in place, RCCL when sharded)
+        Gm = _capi.DeviceMatrix(self.ctx, n, n, [0, n], storage=store.ptr)
         self.G = (Gm, store)
         return self
+
+    def _gram_store(self, count):
+        """zeroed device buffer for association matrices: owned by the communicator when sharded (RCCL reduces it in
+        place), by the context otherwise"""
+        if self.comm.is_distributed:
+            return self.comm.exchange_buffer(self.ctx, count)
+        return self.ctx.empty(count, zero=True)
 
     def gram_blocks(self):
         """Per-block association matrices A_b = X_b X_b^T, side by side in one n x (B n) 'matrix' whose blocks are the
@@ -527,15 +534,14 @@ class HipEngine:
         on these instead of on X)."""
         n, B = self.n, self.nblocks
         ldg = n + (n & 1)
-        store = self.ctx.empty((ldg, n * B), zero=True)
+        store = self._gram_store(ldg * n * B)
         for b in range(B):
             view = _capi.DeviceMatrix(self.ctx, n, self.block_sizes[b], None,
                                       storage=self.X.data_ptr + 8 * self.X.ld * self.block_offsets[b])
-            view.gram(store.col(b * n, n), ldg)
+            view.gram(store.ptr + 8 * ldg * n * b, ldg)
             view.close()
-        if self.comm.is_distributed:
-            store.set(self.comm.allreduce_host(store.get()))
-        Gm = _capi.DeviceMatrix(self.ctx, n, n * B, [b * n for b in range(B + 1)], storage=store)
+        self.comm.allreduce_device(store)
+        Gm = _capi.DeviceMatrix(self.ctx, n, n * B, [b * n for b in range(B + 1)], storage=store.ptr)
         self.Gb = (Gm, store, self.ctx.empty(n * B), self.ctx.empty(n * B))
         return self
 
@@ -600,4 +606,5 @@ class HipEngine:
 
     def gram_host(self):
         n = self.n
-        return self.G[1].get()[:n, :n]
+        ldg = n + (n & 1)
+        return np.asarray(self.G[1].get()).reshape(n, ldg).T[:n, :n]
