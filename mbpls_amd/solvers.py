@@ -625,8 +625,11 @@ def fit_simpls(eng, Y, K, standardize):
     inc = None if rm is None else (np.asarray(rm).ravel() != 0)
     Ts = np.empty((n, K)); U = np.empty((n, K)); Q = np.empty((q, K))
     for comp in range(K):
-        StS = eng.cross(("Z", cS, q), ("Z", cS, q))
-        qv = np.array([[1.0]]) if q == 1 else np.linalg.svd(StS, full_matrices=True)[0][:, 0:1]  # (:1001)
+        if q == 1:
+            qv = np.array([[1.0]])                          # the 1 x 1 S^T S has the singular vector [1]
+        else:
+            StS = eng.cross(("Z", cS, q), ("Z", cS, q))
+            qv = np.linalg.svd(StS, full_matrices=True)[0][:, 0:1]  # (:1001)
         eng.right_mul(("Z", cS, q), qv, ("W", comp))        # w = r = S q (:1004-1005)
         t = eng.x_w_slot("W", comp, 1)                      # (:1006)
         t = t - np.mean(t) if inc is None else np.where(inc[:, None], t - t[inc].mean(), 0.0)   # (:1007)
@@ -643,9 +646,11 @@ def fit_simpls(eng, Y, K, standardize):
             coef[:comp] = -eng.cross(("Z", 0, comp), ("Z", K, 1))     # v = p - V_s (V_s^T p) (:1016)
             u = u - Ts[:, :comp].dot(Ts[:, :comp].T.dot(u))            # (:1017)
         eng.right_mul(("Z", 0, nz), coef, ("Z", comp))
-        vv = eng.cross(("Z", comp, 1), ("Z", comp, 1)).item()
+        # one reduction for v^T v and v^T S (columns comp .. end of Z; the columns in between are not used)
+        row = eng.cross(("Z", comp, 1), ("Z", comp, nz - comp))
+        vv = row[0, 0]
         eng.right_mul(("Z", comp, 1), np.array([[1.0 / np.sqrt(vv)]]), ("Z", comp))     # (:1018)
-        vS = eng.cross(("Z", comp, 1), ("Z", cS, q))        # v^T S (1 x q)
+        vS = row[:, cS - comp:] / np.sqrt(vv)               # v^T S of the unit-length v (1 x q)
         M = np.zeros((nz, q))
         M[cS:, :] = np.eye(q)
         M[comp, :] = -vS
