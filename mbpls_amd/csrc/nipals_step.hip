@@ -18,19 +18,29 @@ namespace mbpls {
 
 constexpr int NS_T = 1024;   // one workgroup: the whole step is n x (k + q) L2-resident work, latency-bound -> many waves
 
-// sum the first m of M values over the workgroup, four at a time through block_sum
+// Sum the first m of M values over the workgroup with two barriers per 16 values: every thread parks its partials
+// in LDS, wave g sums value g (16 strided reads + one butterfly), the totals come back through LDS.  Fixed order.
 template <int M>
-__device__ __forceinline__ void reduce_many(double (&v)[M], int m, double* red, int& buf) {
-  static_assert(M % 4 == 0, "groups of four");
+__device__ __forceinline__ void reduce_many(double (&v)[M], int m, double* part /* [16][NS_T] */, double* tot /* [16] */) {
+  const int tid = threadIdx.x, g = tid >> 6, lane = tid & 63;
 #pragma unroll
-  for (int c = 0; c < M; c += 4) {
-    if (c < m) {   // workgroup-uniform
-      double s4[4] = {v[c], v[c + 1], v[c + 2], v[c + 3]};
-      block_sum<4>(s4, red, buf);
-      v[c] = s4[0];
-      v[c + 1] = s4[1];
-      v[c + 2] = s4[2];
-      v[c + 3] = s4[3];
+  for (int base = 0; base < M; base += 16) {
+    if (base < m) {   // workgroup-uniform
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (base + j < M && base + j < m) part[j * NS_T + tid] = v[(base + j < M) ? base + j : 0];
+      __syncthreads();
+      if (base + g < m) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS_T / 64; ++i) s += part[g * NS_T + i * 64 + lane];
+        s = wave_sum(s);
+        if (lane == 0) tot[g] = s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (base + j < M && base + j < m) v[(base + j < M) ? base + j : 0] = tot[j];
     }
   }
 }
@@ -56,9 +66,10 @@ struct StepArgs {
 constexpr int NS_KMAX = 16;   // previous components / responses (register arrays of the workgroup-wide dot products)
 
 __global__ __launch_bounds__(NS_T) void k_nipals_gram_step(StepArgs s) {
-  __shared__ double red[2 * 64];
+  static_assert(NS_T == 1024, "reduce_many maps value g to wave g of 16");
+  __shared__ double part[16 * NS_T];   // 128 KB: one workgroup owns the CU
+  __shared__ double tot[16];
   __shared__ double s_max[NS_T / 64], s_min[NS_T / 64];
-  int buf = 0;
   if (s.state[0] != 0.0) return;   // converged earlier in this batch: keep the state as it is
   const int tid = threadIdx.x;
   const int64_t n = s.n;
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(NS_T) void k_nipals_gram_step(StepArgs s) {
     for (int j = 0; j < NS_KMAX; ++j)
       if (j < k) c[j] = fma(s.Tp[(int64_t)j * n + i], ai, c[j]);
   }
-  reduce_many<NS_KMAX>(c, k, red, buf);
+  reduce_many<NS_KMAX>(c, k, part, tot);
   double nrm[4] = {0.0, 0.0, 0.0, 0.0};
   for (int64_t i = tid; i < n; i += NS_T) {
     double ai = s.a[i];
@@ -85,7 +96,7 @@ __global__ __launch_bounds__(NS_T) void k_nipals_gram_step(StepArgs s) {
     s.z_next[i] = ai;              // scratch: P a (z_next is overwritten at the end)
     nrm[0] = fma(ai, ai, nrm[0]);
   }
-  block_sum<4>(nrm, red, buf);
+  reduce_many<4>(nrm, 1, part, tot);
   const double inv = 1.0 / sqrt(nrm[0]);
 
   // ---- diff = ||ts_old - ts||,  Y^T ts,  ts^T ts
@@ -107,8 +118,8 @@ __global__ __launch_bounds__(NS_T) void k_nipals_gram_step(StepArgs s) {
     for (int j = 0; j < NS_KMAX; ++j)
       if (j < q) yv[j] = fma(s.Y[(int64_t)j * n + i], t, yv[j]);
   }
-  block_sum<4>(d4, red, buf);
-  reduce_many<NS_KMAX>(yv, q, red, buf);
+  reduce_many<4>(d4, 3, part, tot);
+  reduce_many<NS_KMAX>(yv, q, part, tot);
   double diff;
   if (s.norm_kind == 0) diff = sqrt(d4[0]);
   else if (s.norm_kind == 1) diff = d4[1];
@@ -155,8 +166,8 @@ __global__ __launch_bounds__(NS_T) void k_nipals_gram_step(StepArgs s) {
     for (int j = 0; j < NS_KMAX; ++j)
       if (j < k) e[j] = fma(s.Tp[(int64_t)j * n + i], w, e[j]);
   }
-  block_sum<4>(un, red, buf);
-  reduce_many<NS_KMAX>(e, k, red, buf);
+  reduce_many<4>(un, 1, part, tot);
+  reduce_many<NS_KMAX>(e, k, part, tot);
   const double iu = 1.0 / sqrt(un[0]);
   for (int64_t i = tid; i < n; i += NS_T) {
     const double ui = s.u[i] * iu;
