@@ -139,14 +139,27 @@ class HipEngine:
             _capi.check(self.ctx.lib.mbpls_hip_memcpy_d2h_overlap(self.ctx.handle, col.ctypes.data,
                                                                   S.ptr + 8 * self.p * k, 8 * self.p))
 
+    def host_array(self, shape):
+        """F-ordered host array for a p x K attribute.  A refit hands over the previous fit's attribute buffers when
+        nobody else references them (``host_pool``, filled by the estimator): their pages are already mapped, so the
+        device-to-host copy runs at PCIe speed (55 GB/s) instead of page-fault speed (23 GB/s measured into a fresh
+        numpy array) and nothing has to be unmapped."""
+        pool = getattr(self, "host_pool", None)
+        if pool:
+            for i, a in enumerate(pool):
+                if a.shape == tuple(shape):
+                    return pool.pop(i)
+        return np.empty(shape, order="F")
+
     def fetch(self, name, overlapped=False):
         """D2H of a whole slot.  overlapped=True: on the copy stream, not ordered behind the kernels queued on
         the compute stream (the slot must be final); safe to call from a helper thread."""
+        S = self.slots[name]
+        out = self.host_array(S.shape)
         if not overlapped:
             with self._timed("d2h_slots"):
-                return self.slots[name].get()
-        S = self.slots[name]
-        out = np.empty(S.shape, order="F")
+                _capi.check(self.ctx.lib.mbpls_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data, S.ptr, out.nbytes))
+            return out
         _capi.check(self.ctx.lib.mbpls_hip_memcpy_d2h_overlap(self.ctx.handle, out.ctypes.data, S.ptr, out.nbytes))
         return out
 

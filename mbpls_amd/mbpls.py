@@ -84,6 +84,34 @@ def _global_block_sizes(eng):
     return eng.comm.allreduce_host(np.asarray(eng.block_sizes, dtype=np.float64))
 
 
+def _recyclable(stale):
+    """Empties ``stale`` (attributes of the previous fit) and returns the large F-ordered 2-D base arrays behind them
+    that are referenced from nowhere else -- safe to overwrite.  Everything else stays in ``stale``."""
+    import sys
+    roots, keep = {}, []
+    while stale:
+        obj = stale.pop()
+        parts = obj if isinstance(obj, list) else [obj]
+        mine = True
+        for a in parts:
+            r = a
+            while isinstance(r, np.ndarray) and isinstance(r.base, np.ndarray):
+                r = r.base
+            if (isinstance(r, np.ndarray) and r.base is None and r.ndim == 2 and r.flags.f_contiguous
+                    and r.flags.writeable and r.nbytes >= (1 << 20)):
+                roots[id(r)] = r
+            else:
+                mine = False
+        if not mine:
+            keep.append(obj)
+        del obj, parts, a, r
+    stale.extend(keep)
+    del keep
+    roots = list(roots.values())
+    # references to a root now: the list `roots`, the loop variable, getrefcount's argument (+ views someone kept)
+    return [r for r in roots if sys.getrefcount(r) == 3]
+
+
 def _is_block_list(X):
     return isinstance(X, list) and not isinstance(X[0], list)       # mbpls.py:301
 
@@ -182,6 +210,9 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         # one stale object per column pass, right after the launch, while the host would only wait anyway.
         stale = [self.__dict__.pop(k) for k in ("P_", "W_", "W_non_normal_", "R_", "beta_", "W_concat_", "T_")
                  if k in self.__dict__]
+        # ... unless the buffer can simply be used again: the F-ordered p x K arrays behind the old attributes that
+        # nobody else holds go to the engine's host pool (their pages are mapped: copies into them run at PCIe speed)
+        eng.host_pool = _recyclable(stale)
         eng.deferred_host_work = [stale.pop for _ in stale]
         import time as _time
         t_fit0 = _time.perf_counter()

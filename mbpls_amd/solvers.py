@@ -59,6 +59,11 @@ class FitResult(dict):
         self[k] = v
 
 
+def _host_array(eng, shape):
+    """F-ordered host array for a p x K attribute (recycled from the previous fit when the engine can)"""
+    return eng.host_array(shape) if hasattr(eng, "host_array") else np.empty(shape, order="F")
+
+
 def _global_sizes(eng):
     """Block sizes of the WHOLE problem (summed over shards) for the BIP correction."""
     s = np.asarray(eng.block_sizes, dtype=np.float64)
@@ -243,7 +248,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     nu_all = np.empty((B, K))
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
     # host copies of the p x K attributes, filled column by column while later passes run on the GPU
-    Wn_h = np.empty((eng.p, K), order="F"); W_h = np.empty((eng.p, K), order="F"); P_h = np.empty((eng.p, K), order="F")
+    Wn_h, W_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
     import os
     q1_fixed_point = (q == 1 and os.environ.get("MBPLS_NIPALS_Q1_FIXED_POINT", "0") == "1" and not getattr(eng, "sparse", False)
                       and hasattr(eng, "right_mul"))
@@ -351,8 +356,8 @@ def fit_unipals(eng, Y, K, standardize):
     blk_nrm = np.empty((B, K)); tot_nrm = np.empty(K)
     evx, evy, evxb, Acorr = [], [], np.empty((B, K)), np.empty((B, K))
     # p > n: W_ and P_ are streamed to the host column by column while the deflation passes run (as in NIPALS)
-    W_h = np.empty((eng.p, K), order="F") if wide else None
-    P_h = np.empty((eng.p, K), order="F") if wide else None
+    W_h = _host_array(eng, (eng.p, K)) if wide else None
+    P_h = _host_array(eng, (eng.p, K)) if wide else None
     for k in range(K):
         if wide:
             if fuse:

@@ -575,3 +575,21 @@ def test_nipals_gram_step_kernel(ctx, n, k, q, kind):
     da.set(rng.standard_normal(n))
     step(diff * 2)          # done: a queued step must not change anything
     assert np.array_equal(dst.get(), st) and util.relerr(dts.get(), ts) < 1e-12
+
+
+def test_refit_recycles_only_unreferenced_buffers(gpu_required):
+    """A refit reuses the host buffers of the previous fit's p x K attributes -- but never one the caller still holds."""
+    from mbpls_amd import MBPLS
+    X, Y = orc.make_latent(200, 150_000, 1, seed=3)
+    X2, Y2 = orc.make_latent(200, 150_000, 1, seed=4)
+    m = MBPLS(n_components=3).fit(X, Y)
+    held = m.P_[0]                       # a view into the loadings buffer of fit 1
+    held_copy, r_addr = held.copy(), m.R_.ctypes.data
+    beta1 = m.beta_.copy()
+    m.fit(X2, Y2)
+    assert np.array_equal(held, held_copy)                    # still fit 1's loadings
+    assert m.P_[0].ctypes.data != held.ctypes.data            # fit 2 got its own buffer for P_
+    assert r_addr in {a.ctypes.data for a in (m.R_, m.W_[0], m.W_non_normal_[0], m.P_[0])}   # R_'s buffer was recycled
+    ref = orc.fit(X2, Y2, n_components=3)
+    assert util.compare(util.model_to_flat(m), util.model_to_flat(ref), TOL, what="refit") < 1e-9
+    assert not np.array_equal(m.beta_, beta1)
