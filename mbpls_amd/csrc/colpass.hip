@@ -89,8 +89,11 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   // column data; with the lazy-deflation state that no longer fits 128.  Its score vector ts therefore
   // lives in LDS (32 KB, each thread re-reads only its own row pairs: conflict-free ds_read_b128).
   constexpr bool TS_LDS = DEFL && SWEEP && R == 8 && TMAX == 512;
-  __shared__ double2 s_ts[TS_LDS ? (TMAX * R / 2) : 1];
-  __shared__ double2 s_v[TS_LDS ? (TMAX * R / 2) : 1];   // same treatment for the sweep vector there
+  // dynamic LDS sized by the ACTUAL workgroup (2 x T x R/2 double2): a statically TMAX-sized array would cap small
+  // workgroups (n < 4096) at two per CU
+  extern __shared__ double2 s_dyn[];
+  double2* s_ts = s_dyn;
+  double2* s_v = s_dyn + (TS_LDS ? (int)blockDim.x * (R / 2) : 0);   // same treatment for the sweep vector there
   double v[(SWEEP && !TS_LDS) ? R : 1], ts[(DEFL && !TS_LDS) ? R : 1], acc[SWEEP ? R : 1];
   double tsv = 0.0;
   if constexpr (SWEEP) {
@@ -465,7 +468,7 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   ProfScope prof(ctx, kind, 8.0 * (double)a.n * (double)p * (writes ? 2.0 : 1.0));
   Cfg cfg;
   int T = 0;
-  if (!pick_cfg(ctx, a.n, &cfg, &T, STD && a.dst != nullptr)) {
+  if (!pick_cfg(ctx, a.n, &cfg, &T, STD || (DEFL && SWEEP))) {
     set_error("column passes support n <= 65536 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;
   }
@@ -476,19 +479,21 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   const bool full = (a.n == (int64_t)T * cfg.R) && (a.ld == a.n) && cfg.R >= 8 && !(STD && a.rowmask);
   // the ISTD instantiations: implicit standardisation for the lazy passes, statistics-only for the standardise pass
   const bool istd = STD ? (SWEEP && a.dst == nullptr) : (a.lazy && a.ir2 != nullptr);
+  // loadings+sweep at R=8 keeps ts and v in LDS (see TS_LDS in the kernel): T x R/2 double2 each
+  const unsigned dyn_lds = (DEFL && SWEEP && cfg.R == 8 && cfg.TMAX == 512) ? 2u * (unsigned)T * 4u * 16u : 0u;
 #define MB_LAUNCH(R_, TM_, D_)                                                                          \
   do {                                                                                                  \
     constexpr bool F_ = ((R_) >= 8);                                                                    \
     constexpr bool IS_ = !STD || SWEEP;   /* no statistics-only flavour without the fused sweep */      \
     if (istd) {                                                                                         \
       if (full && F_)                                                                                   \
-        hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, F_, IS_>), grid, block, 0, ctx->stream, an);     \
+        hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, F_, IS_>), grid, block, dyn_lds, ctx->stream, an);     \
       else                                                                                              \
-        hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, false, IS_>), grid, block, 0, ctx->stream, an);  \
+        hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, false, IS_>), grid, block, dyn_lds, ctx->stream, an);  \
     } else if (full && F_)                                                                              \
-      hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, F_>), grid, block, 0, ctx->stream, an);           \
+      hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, F_>), grid, block, dyn_lds, ctx->stream, an);           \
     else                                                                                                \
-      hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, false>), grid, block, 0, ctx->stream, an);        \
+      hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, false>), grid, block, dyn_lds, ctx->stream, an);        \
   } while (0)
 #define MB_LAUNCH_D(R_, TM_)            \
   do {                                  \
@@ -506,8 +511,8 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
     set_error("implicit standardisation / statistics-only passes need n <= 8192 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;
   }
-  else if (cfg.R == 32) hipLaunchKernelGGL((k_colpass<32, 1024, 1, STD, DEFL, SWEEP, false>), grid, block, 0, ctx->stream, an);
-  else if (cfg.R == 64) hipLaunchKernelGGL((k_colpass<64, 1024, 1, STD, DEFL, SWEEP, false>), grid, block, 0, ctx->stream, an);
+  else if (cfg.R == 32) hipLaunchKernelGGL((k_colpass<32, 1024, 1, STD, DEFL, SWEEP, false>), grid, block, dyn_lds, ctx->stream, an);
+  else if (cfg.R == 64) hipLaunchKernelGGL((k_colpass<64, 1024, 1, STD, DEFL, SWEEP, false>), grid, block, dyn_lds, ctx->stream, an);
   else {
     set_error("no kernel for R=%d TMAX=%d", cfg.R, cfg.TMAX);
     return MBPLS_ERR_UNSUPPORTED;

@@ -309,6 +309,12 @@ static int launch_nan(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, in
     set_error("the missing-value column passes support n <= 65536 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;
   }
+  if (cfg.R == 8 && cfg.TMAX == 512 && T < 256 && (STD || DEFL)) {
+    // the fused R=8 variants stage u / ts in LDS arrays sized for 512 threads: small workgroups would be capped at two
+    // per CU -- take the register-only R=4 shape instead
+    cfg = Cfg{4, 512};
+    T = (int)((((a.n + 3) / 4) + 63) / 64 * 64);
+  }
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
   const bool full = (a.n == (int64_t)T * cfg.R) && (a.ld == a.n) && cfg.R >= 8;
 #define MB_LAUNCH(R_, TM_)                                                                                       \

@@ -115,14 +115,22 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
     *t = (int)need;
     return true;
   };
-  // the standardise pass has three reductions + divisions per column: fewer, fatter threads win
-  // (measured at n=4096: R=16/T=256 5.46 TB/s vs R=8/T=512 4.77 TB/s)
-  if (std_pass && ctx->rows_per_thread <= 0 && n > 2048) {
-    const Cfg c16 = {16, 512};
-    if (fits(c16, T)) {
-      *cfg = c16;
-      return true;
-    }
+  // Passes that reduce several values per column (standardise: statistics; loadings + sweep: two dot products) are
+  // instruction-issue bound, not bandwidth bound: fewer, fatter threads win -- the per-column reduction overhead is
+  // spread over twice the elements (measured at n=4096, R=16/T=256 vs R=8/T=512: storing standardise 5.46 vs
+  // 4.77 TB/s, statistics-only 5.8 vs 7.9 ms, lazy loadings+sweep 4.73 vs 5.70 ms).  Single-reduction passes
+  // (sweep, loadings only) keep R=8/T=512.
+  // The same holds for the single-reduction passes away from the tuned n = 4096 = 8 x 512 shape (measured, default
+  // table vs R=16: n=2048 sweep 4.99 vs 3.78 ms, n=6000 5.09 vs 4.30 ms; n=4096 loadings-only 4.64 vs 5.05 ms).
+  // Rule: the largest R in {16, 8, 4, 2} that still gives a full wave of real threads.
+  const bool tuned8 = !std_pass && n > 3584 && n <= 4096;
+  if (ctx->rows_per_thread <= 0 && !tuned8) {
+    static const Cfg fat[] = {{16, 512}, {8, 512}, {4, 512}, {2, 256}};
+    for (const Cfg& c : fat)
+      if ((n + c.R - 1) / c.R >= 64 && fits(c, T)) {
+        *cfg = c;
+        return true;
+      }
   }
   if (ctx->rows_per_thread > 0) {
     for (const Cfg& c : table)
