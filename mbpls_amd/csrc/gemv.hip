@@ -164,8 +164,11 @@ struct Cfg {
   int R, TMAX;
 };
 static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T) {
-  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}};
+  // fewer, fatter threads first (the largest R that still fills a wave), as in the column passes: the per-column
+  // reductions are issue-bound
+  static const Cfg table[] = {{16, 512}, {8, 512}, {4, 512}, {2, 256}, {8, 1024}};
   for (const Cfg& c : table) {
+    if (c.TMAX != 1024 && (n + c.R - 1) / c.R < 64 && c.R > 2) continue;
     int64_t need = (n + c.R - 1) / c.R;
     need = (need + 63) / 64 * 64;
     if (need <= c.TMAX) {
