@@ -593,3 +593,35 @@ def test_refit_recycles_only_unreferenced_buffers(gpu_required):
     ref = orc.fit(X2, Y2, n_components=3)
     assert util.compare(util.model_to_flat(m), util.model_to_flat(ref), TOL, what="refit") < 1e-9
     assert not np.array_equal(m.beta_, beta1)
+
+
+def test_no_device_memory_growth(gpu_required):
+    """Every fit / predict / transform returns its device buffers (working copies, slots, association matrices,
+    loop state) to the context pool: free device memory after trimming the pool is the same after many more fits."""
+    import gc
+    import mbpls_amd
+    from mbpls_amd import MBPLS
+    ctx = mbpls_amd.get_context()
+    X, Y = orc.make_latent(300, 6000, 3, seed=1)
+    Xs = [np.ascontiguousarray(X[:, :2500]), np.ascontiguousarray(X[:, 2500:])]
+    Xn = X.copy(); Xn[np.random.RandomState(0).rand(*X.shape) < 0.02] = np.nan
+
+    def one_round():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for method in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+                for q in (1, 3):
+                    m = MBPLS(n_components=3, method=method).fit(Xs, Y[:, :q])
+                    m.predict(Xs); m.transform(Xs, Y[:, :q])
+            MBPLS(n_components=2, sparse_data=True).fit(Xn, Y[:, :1]).predict(Xn)
+
+    def free_bytes():
+        gc.collect()
+        ctx.trim_pool()
+        return ctx.info()["free_bytes"]
+
+    one_round()
+    before = free_bytes()
+    for _ in range(3):
+        one_round()
+    assert before - free_bytes() < (8 << 20)
