@@ -1,0 +1,118 @@
+// OUT = X g for ONE right-hand side (SIMPLS t = X r :1006, predict with one response :1386) as a column pass:
+// full 8n-byte columns are streamed exactly like the sweep kernels do (a workgroup owns a chunk of columns, the
+// column is held in registers, acc += g_j x_j) -- no dot product, hence no workgroup reduction per column at all.
+// The row-slab kernel k_xw reads 4 KB pieces of every column per workgroup and reaches 6.0 TB/s; this one streams
+// at the read-only ceiling of the column passes.  Per-chunk partial n-vectors are summed in fixed order by
+// k_reduce_chunks (colpass.hip).
+#include "colpass_util.h"
+
+namespace mbpls {
+
+template <int R, int TMAX, bool FULL>
+__global__ __launch_bounds__(TMAX) void k_axpy_cols(const double* __restrict__ X, int64_t ld, int64_t n,
+                                                    const int64_t* __restrict__ c0, const int64_t* __restrict__ c1,
+                                                    const double* __restrict__ g, double* __restrict__ part_t,
+                                                    double* __restrict__ part_s) {
+  constexpr int D = 2;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int chunk = blockIdx.x;
+  const int64_t j0 = uniform64(c0[chunk]), j1 = uniform64(c1[chunk]);
+  RowMap<R> rm;
+  rm.init(n, ld, tid, T);
+  double acc[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) acc[k] = 0.0;
+  double x[D][R];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (j0 + d < j1) load_col<R, FULL>(x[d], X + (j0 + d) * ld, rm);
+  // the weights of 64 columns at a time: one coalesced load per wave, then a lane broadcast per column (a global
+  // load of g[j] per column would sit on the critical path of every column)
+  const int lane = tid & 63;
+  double gv = 0.0;
+  for (int64_t j = j0; j < j1; j += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int64_t jj = j + d;
+      if (jj >= j1) break;
+      const int slot = (int)((jj - j0) & 63);
+      if (slot == 0) gv = (jj + lane < j1) ? g[jj + lane] : 0.0;
+      const long long gb = __double_as_longlong(gv);
+      const unsigned glo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(gb & 0xffffffffll), slot);
+      const unsigned ghi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)gb >> 32), slot);
+      const double gj = __longlong_as_double((long long)(((unsigned long long)ghi << 32) | glo));
+#pragma unroll
+      for (int k = 0; k < R; ++k) acc[k] = fma(gj, x[d][k], acc[k]);
+      if (jj + D < j1) load_col<R, FULL>(x[d], X + (jj + D) * ld, rm);
+    }
+    // keep the waves of the workgroup on the same columns: without any reduction they drift apart and the eight
+    // 1 KB pieces of a column stop arriving at HBM together
+    __syncthreads();
+  }
+  double* out = part_t + (int64_t)chunk * n;
+#pragma unroll
+  for (int k = 0; k < R / 2; ++k) {
+    const int64_t r0 = 2 * ((int64_t)k * T + tid);
+    if (FULL || r0 + 1 < n) *reinterpret_cast<double2*>(out + r0) = make_double2(acc[2 * k], acc[2 * k + 1]);
+    else if (r0 < n) out[r0] = acc[2 * k];
+  }
+  if (tid == 0) {
+    double* ps = part_s + (int64_t)chunk * 4;
+    ps[0] = ps[1] = ps[2] = ps[3] = 0.0;
+  }
+}
+
+// out[i] = sum_b in[b * n + i]
+__global__ __launch_bounds__(256) void k_sum_blocks(const double* __restrict__ in, int nblocks, int64_t n,
+                                                    double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s = in[i];
+  for (int b = 1; b < nblocks; ++b) s += in[(int64_t)b * n + i];
+  out[i] = s;
+}
+
+// Returns MBPLS_ERR_UNSUPPORTED (without setting the error text) when the shape is not handled here.
+int axpy_cols(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_g, int per_block, double* d_out) {
+  Cfg cfg;
+  int T = 0;
+  if (long_columns(ctx, m->n) || !pick_cfg(ctx, m->n, &cfg, &T, false) || cfg.R > 16) return MBPLS_ERR_UNSUPPORTED;
+  const ChunkTable& ct = m->fine;
+  const size_t nt = (size_t)ct.nchunks * (size_t)m->n, ns = (size_t)ct.nchunks * 4;
+  const size_t nb = per_block ? 0 : (size_t)m->nblocks * (size_t)m->n;
+  MB_TRY(ensure_ws(ctx, sizeof(double) * (nt + ns + nb)));
+  double* part_t = (double*)ctx->ws;
+  double* part_s = part_t + nt;
+  double* blk = per_block ? d_out : part_s + ns;
+  const bool full = (m->n == (int64_t)T * cfg.R) && (m->ld == m->n) && cfg.R >= 8;
+  dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
+  {
+    ProfScope prof(ctx, MBPLS_K_X_W, 8.0 * (double)m->n * (double)m->p);
+#define MB_AX(R_, TM_)                                                                                              \
+  do {                                                                                                              \
+    if (full && (R_) >= 8)                                                                                          \
+      hipLaunchKernelGGL((k_axpy_cols<R_, TM_, ((R_) >= 8)>), grid, block, 0, ctx->stream, (const double*)m->data,  \
+                         m->ld, m->n, (const int64_t*)ct.d_c0, (const int64_t*)ct.d_c1, d_g, part_t, part_s);       \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_axpy_cols<R_, TM_, false>), grid, block, 0, ctx->stream, (const double*)m->data, m->ld, \
+                         m->n, (const int64_t*)ct.d_c0, (const int64_t*)ct.d_c1, d_g, part_t, part_s);              \
+  } while (0)
+    if (cfg.R == 2) MB_AX(2, 256);
+    else if (cfg.R == 4 && cfg.TMAX == 512) MB_AX(4, 512);
+    else if (cfg.R == 4) MB_AX(4, 1024);
+    else if (cfg.R == 8 && cfg.TMAX == 512) MB_AX(8, 512);
+    else if (cfg.R == 8) MB_AX(8, 1024);
+    else MB_AX(16, 512);
+#undef MB_AX
+  }
+  MB_HIP(hipGetLastError());
+  MB_TRY(reduce_chunks(ctx, m, part_t, part_s, blk, nullptr, nullptr, nullptr));
+  if (!per_block) {
+    hipLaunchKernelGGL(k_sum_blocks, dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)blk,
+                       m->nblocks, m->n, d_out);
+    MB_HIP(hipGetLastError());
+  }
+  return MBPLS_OK;
+}
+
+}  // namespace mbpls

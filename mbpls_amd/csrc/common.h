@@ -109,6 +109,10 @@ int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv,
 int xw_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block,
             const double* d_mean, const double* d_scale, int nanm, double* d_out, int64_t ldo);
 
+// axpy_cols.hip: OUT = X g for one right-hand side as a full-column streaming pass (MBPLS_ERR_UNSUPPORTED when the
+// shape is not handled there and the caller should use the row-slab kernel)
+int axpy_cols(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_g, int per_block, double* d_out);
+
 // RAII bracket: records an event pair around a kernel launch when profiling is on.
 struct ProfScope {
   mbpls_ctx* ctx;
