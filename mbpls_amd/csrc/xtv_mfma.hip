@@ -36,12 +36,17 @@ __global__ __launch_bounds__(256) void k_pack_v(const double* __restrict__ V, in
   Vp[e] = (i < n && k < c) ? V[(int64_t)k * ldv + i] : 0.0;
 }
 
+// feature tiles (of 16) per wave: every wave re-reads the packed V for its features, so more tiles per wave mean
+// proportionally less L2 traffic for V (at c = 40, n = 8192 it exceeded the HBM traffic of X with two tiles);
+// bounded by the 8 FT NT accumulator VGPRs
+__host__ __device__ constexpr int xtv_ft(int NT) { return NT <= 2 ? 4 : (NT == 3 ? 3 : 2); }
+
 template <int NT>
 __global__ __launch_bounds__(256) void k_xtv_mfma(const double* __restrict__ X, int64_t ld, int64_t n, int64_t p,
                                                   const double* __restrict__ Vp, int c, double alpha,
                                                   double* __restrict__ G, int64_t ldg, int64_t ks_per_slice,
                                                   int64_t slice_stride) {
-  constexpr int FT = 2;
+  constexpr int FT = xtv_ft(NT);
   G += (int64_t)blockIdx.y * slice_stride;
   const int64_t ks_begin = (int64_t)blockIdx.y * ks_per_slice;
   const int lane = threadIdx.x & 63;
@@ -152,7 +157,8 @@ int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv,
   const int64_t nk = (m->n + 15) / 16;
   const int64_t total = nk * 4 * NT * 64;
   const size_t off_bytes = sizeof(int64_t) * (size_t)(m->nblocks + 1);
-  const int64_t ntiles = (m->p + 31) / 32;
+  const int ft = xtv_ft(NT);
+  const int64_t ntiles = (m->p + 16 * ft - 1) / (16 * ft);
   const int64_t wgs = (ntiles + 3) / 4;
   // sample slices: only when the feature tiles alone leave most of the chip idle; >= 1024 samples per slice
   int S = 1;
