@@ -347,7 +347,8 @@ def fit_unipals(eng, Y, K, standardize):
         # (the n >= p branch mixes in xt_v / x_w on the deflated X as well: explicit)
         eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
     fuse = wide and q == 1
-    varxb, m_raw, _ = eng.prepare(standardize, v=y0 if fuse else None, alpha=1.0, g_slot=("S", 0) if fuse else None)
+    varxb, m_raw, g_ssq = eng.prepare(standardize, v=y0 if fuse else None, alpha=1.0, g_slot=("S", 0) if fuse else None)
+    yy = y0.T.dot(y0).item()
     varx = varxb.sum()
     vary = (Y ** 2).sum()
     F = _psd_factor(Y.T.dot(Y))
@@ -374,7 +375,15 @@ def fit_unipals(eng, Y, K, standardize):
             ts = _tlsv(M.dot(F))                            # (:489-493)
             v = Y.T.dot(ts) / ts.T.dot(ts)                  # (:496)
             u = Y.dot(v); u = u / np.linalg.norm(u)         # (:499-500)
-            t_raw, ssq = eng.sweep(u, 1.0, ("Wc", k))       # w_raw = X^T u (:503), t~_b = X_b w_raw_b
+            if fuse and hasattr(eng, "right_mul"):
+                # one response: u = Y v / ||Y v|| is c y with a scalar c, so the weights w_raw = X^T u (:503) and the
+                # block scores X_b w_raw_b (:515-517) are c times the X^T y and X_b (X^T y)_b that the fused pass just
+                # produced for M = X (X^T y) -- the same products, not taken twice
+                c = u.T.dot(y0).item() / yy
+                eng.right_mul(("S", 0, 1), np.array([[c]]), ("Wc", k))
+                t_raw, ssq = c * m_raw, c * c * g_ssq
+            else:
+                t_raw, ssq = eng.sweep(u, 1.0, ("Wc", k))   # w_raw = X^T u (:503), t~_b = X_b w_raw_b
         else:
             eng.xt_v(Y, 1.0, "S", 0)
             C = eng.fetch("S")[:, :q]
@@ -405,7 +414,7 @@ def fit_unipals(eng, Y, K, standardize):
             if k > 0:
                 eng.fetch_col("P", k - 1, P_h)
 
-        ssq_p, m_raw, _ = eng.deflate_sweep(ts, 1.0 / tt, not last, ("P", k), y0 if nxt else None, 1.0,
+        ssq_p, m_raw, g_ssq = eng.deflate_sweep(ts, 1.0 / tt, not last, ("P", k), y0 if nxt else None, 1.0,
                                             ("S", 0) if nxt else None,   # p (:520), X - ts p^T (:535)
                                             overlap=stream_out if wide else None)
         Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u; V[:, k:k + 1] = v; A[:, k] = a
