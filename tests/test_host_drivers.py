@@ -77,3 +77,23 @@ def test_q1_fixed_point_option(monkeypatch):
     X, Y = g["in/q1/X"], g["in/q1/Y"]
     res = run_driver(list(np.split(X, splits, axis=1)), Y, "NIPALS", 3)
     util.compare(util.model_to_flat(res), util.sub(g, "ref/q1/multi/NIPALS/std1/ca1"), TOL, skip=FIT_ONLY_SKIP)
+
+
+def test_recyclable_host_buffers_refcount_rule():
+    """mbpls._recyclable: a refit may overwrite the buffer behind an old attribute only if nothing else references
+    it -- directly or through a view -- and only large F-ordered 2-D arrays qualify."""
+    from mbpls_amd.mbpls import _recyclable
+    P = np.empty((200_000, 10), order="F")
+    R = np.empty((200_000, 10), order="F")
+    W = np.empty((200_000, 10), order="F")
+    beta = np.empty((200_000, 1), order="F")
+    T = [np.zeros((5, 2))]
+    p_addr, b_addr, w_addr = P.ctypes.data, beta.ctypes.data, W.ctypes.data
+    held_whole = R                          # the caller kept R_ itself
+    held_view = W[:100]                     # ... and a view into W_'s buffer
+    stale = [[P[:100_000], P[100_000:]], R, [W[:150_000], W[150_000:]], beta, T]
+    del P, R, W, beta, T
+    pool = _recyclable(stale)
+    assert sorted(a.ctypes.data for a in pool) == sorted([p_addr, b_addr])
+    assert w_addr not in [a.ctypes.data for a in pool] and held_view.base is not None and held_whole is not None
+    assert len(stale) == 1 and isinstance(stale[0], list) and stale[0][0].shape == (5, 2)   # small arrays stay
