@@ -57,10 +57,13 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   // per-lane BYTE offsets inside a group of 4 features: (lane>>4) selects the feature, (lane&15) the
   // sample; out-of-range samples are clamped (their rows/columns are never stored).  32-bit offsets +
   // a wave-uniform group base -> global_load with an SGPR base, no 64-bit address VALU work.
-  unsigned oa[4], ob[4];
+  // every lane loads TWO consecutive samples of its feature (16 bytes): half as many load instructions per k-step;
+  // the even samples feed one MFMA sub-tile and the odd ones the next, i.e. sub-tile m covers the samples
+  // base + 32 (m >> 1) + 2 i + (m & 1), i = 0..15 -- the rows / columns of the output are permuted accordingly
+  unsigned oa[2], ob[2];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    int64_t ra = a0 + t * 16 + li, rb = b0 + t * 16 + li;
+  for (int t = 0; t < 2; ++t) {
+    int64_t ra = a0 + t * 32 + 2 * li, rb = b0 + t * 32 + 2 * li;
     if (ra >= a.n) ra = 0;
     if (rb >= a.n) rb = 0;
     oa[t] = (unsigned)((lk * a.ld + ra) * 8);
@@ -76,22 +79,23 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   const int64_t nmain = (nsteps / PD) * PD;
   const char* xb = (const char*)(a.X + jbeg * a.ld);
   const int64_t gstride = 4 * a.ld * 8;               // bytes between consecutive groups
-  double av[PD][4], bv[PD][4];
+  typedef double gv2_t __attribute__((ext_vector_type(2)));
+  gv2_t av[PD][2], bv[PD][2];
   // The ring's loads are inline asm on purpose: hipcc's own waitcnt insertion loses the exact queue depth
   // across the loop back-edge and emits vmcnt(8) -- i.e. it waits for the groups issued one and two steps
   // ago as well, which leaves ONE step of latency cover and 35 % of the requests miss L2 here.  With the
   // loads invisible to that pass the wait is counted by hand: after issuing group g+3 there are 4 groups
-  // (32 loads) in flight and vmcnt(24) retires exactly the oldest one, the group about to be consumed.
+  // (16 16-byte loads) in flight and vmcnt(12) retires exactly the oldest one, the group about to be consumed.
   // Rules kept (cdna_hip_programming.md 5.7): no asm output is read before its wait; sched_barrier pins
   // the order; vmcnt(0) right behind the loop so no late load lands in a re-used register.
 #define MB_GLD(dst, off, base) \
-  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory")
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory")
   if (nmain > 0) {
 #pragma unroll
     for (int s = 0; s < PD - 1; ++s) {
       const char* g = xb + s * gstride;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < 2; ++t) {
         MB_GLD(av[s][t], oa[t], g);
         MB_GLD(bv[s][t], ob[t], g);
       }
@@ -102,14 +106,15 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
     int64_t nx = it + (S) + PD - 1;               /* group to prefetch */                                   \
     nx = nx < nmain ? nx : nmain - 1;             /* clamp: a valid group that is never consumed */         \
     const char* g = xb + nx * gstride;                                                                      \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                         \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                         \
       MB_GLD(av[SL][t], oa[t], g);                                                                          \
       MB_GLD(bv[SL][t], ob[t], g);                                                                          \
     }                                                                                                       \
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                                       \
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)       \
-        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[S][mi], bv[S][ni], acc[mi][ni], 0, 0, 0);     \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[S][mi >> 1][mi & 1], bv[S][ni >> 1][ni & 1],   \
+                                                           acc[mi][ni], 0, 0, 0);                           \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
   }
     for (int64_t it = 0; it < nmain; it += PD) {
@@ -130,10 +135,11 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
     const char* g = (const char*)(a.X + (vj ? j : jbeg) * a.ld);
     double ta[4], tb[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const double xa = vj ? *(const double*)(g + oa[t]) : 0.0, xq = vj ? *(const double*)(g + ob[t]) : 0.0;
-      ta[t] = xa;
-      tb[t] = xq;
+    for (int t = 0; t < 2; ++t) {
+      const double2 xa = vj ? *(const double2*)(g + oa[t]) : make_double2(0.0, 0.0);
+      const double2 xq = vj ? *(const double2*)(g + ob[t]) : make_double2(0.0, 0.0);
+      ta[2 * t] = xa.x; ta[2 * t + 1] = xa.y;
+      tb[2 * t] = xq.x; tb[2 * t + 1] = xq.y;
     }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -149,7 +155,8 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int64_t row = a0 + mi * 16 + lk + 4 * rg, col = b0 + ni * 16 + li;
+        const int64_t row = a0 + 32 * (mi >> 1) + 2 * (lk + 4 * rg) + (mi & 1);
+        const int64_t col = b0 + 32 * (ni >> 1) + 2 * li + (ni & 1);
         if (row < a.n && col < a.n) out[row * a.ldg + col] = acc[mi][ni][rg];
       }
 }
