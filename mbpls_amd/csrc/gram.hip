@@ -208,10 +208,11 @@ extern "C" int mbpls_hip_gram(const mbpls_mat* m, double* d_G, int64_t ldg) {
   // they stream (measured at n=8192: 57 TFLOP/s at p = 2e6 unsliced, 65.7 with 131072-feature slices); cutting the range into
   // slices re-aligns them at every slice boundary.  Partials: nslices x n x ldg doubles (<= 16 GiB).
   // Slices also smooth the launch quantisation: 2080 tiles on 512 resident workgroups are 4.06 rounds, the
-  // last one nearly empty (the 62 TFLOP/s plateau at mid p); aim for >= 16 rounds of >= 2048 features.
+  // last one nearly empty (the 62 TFLOP/s plateau at mid p); aim for >= 48 rounds of >= 2048 features (16 rounds
+  // still leave a quarter-round tail: 68.3 -> 71 TFLOP/s at mid p).
   if (ctx->gram_slice_features > 0) {
     const int64_t by_len = (p + ctx->gram_slice_features - 1) / ctx->gram_slice_features;
-    const int64_t by_rounds = std::min<int64_t>(((int64_t)ctx->cus * 2 * 16 + ntiles - 1) / ntiles, p / 2048);
+    const int64_t by_rounds = std::min<int64_t>(((int64_t)ctx->cus * 2 * 48 + ntiles - 1) / ntiles, p / 2048);
     const int64_t cap = std::max<int64_t>(1, ((int64_t)16 << 30) / std::max<int64_t>(1, n * ldg * 8));
     nslices = (int)std::max<int64_t>(nslices, std::min(std::max(by_len, by_rounds), cap));
   }
