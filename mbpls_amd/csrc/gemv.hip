@@ -141,23 +141,35 @@ __global__ __launch_bounds__(256) void k_xw(const double* __restrict__ X, int64_
 }
 
 // out[(b or 0)][q][i] = sum over chunks (of block b, or all) of part[chunk][q][i], fixed order.
+//   grid (ceil(n/64), cb, blocks), 256 threads: lane = row, wave w takes chunks cs+w, cs+w+4, ... with four independent
+//   accumulators (16 loads in flight per row -- the sum is latency-bound), LDS combine in wave order.
 __global__ __launch_bounds__(256) void k_reduce_xw(const double* __restrict__ part, int CB, int cb, int64_t n,
                                                    const int* __restrict__ blk_start, int nblocks, int per_block,
                                                    double* __restrict__ out, int64_t ldo, int c_total, int k0) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  __shared__ double comb[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   const int q = blockIdx.y;
   const int b = blockIdx.z;
-  if (i >= n || q >= cb) return;
   const int cs = per_block ? blk_start[b] : blk_start[0];
   const int ce = per_block ? blk_start[b + 1] : blk_start[nblocks];
-  double s0 = 0.0, s1 = 0.0;
-  int c = cs;
-  for (; c + 1 < ce; c += 2) {
-    s0 += part[((int64_t)c * CB + q) * n + i];
-    s1 += part[((int64_t)(c + 1) * CB + q) * n + i];
+  double s = 0.0;
+  if (i < n && q < cb) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int c = cs + w;
+    for (; c + 12 < ce; c += 16) {
+      s0 += part[((int64_t)c * CB + q) * n + i];
+      s1 += part[((int64_t)(c + 4) * CB + q) * n + i];
+      s2 += part[((int64_t)(c + 8) * CB + q) * n + i];
+      s3 += part[((int64_t)(c + 12) * CB + q) * n + i];
+    }
+    for (; c < ce; c += 4) s0 += part[((int64_t)c * CB + q) * n + i];
+    s = (s0 + s1) + (s2 + s3);
   }
-  if (c < ce) s0 += part[((int64_t)c * CB + q) * n + i];
-  out[(int64_t)b * ldo * c_total + (int64_t)(k0 + q) * ldo + i] = s0 + s1;
+  comb[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && i < n && q < cb)
+    out[(int64_t)b * ldo * c_total + (int64_t)(k0 + q) * ldo + i] = (comb[0][lane] + comb[1][lane]) + (comb[2][lane] + comb[3][lane]);
 }
 
 struct Cfg {
@@ -244,7 +256,7 @@ int mbpls_hip_xt_v(const mbpls_mat* m, const double* d_V, int64_t ldv, int c, do
 namespace mbpls {
 void launch_reduce_xw(mbpls_ctx* ctx, const mbpls_mat* m, const double* part, int CB, int cb, int per_block,
                       double* d_out, int64_t ldo, int c_total, int k0) {
-  dim3 rgrid((unsigned)((m->n + 255) / 256), (unsigned)cb, per_block ? (unsigned)m->nblocks : 1u);
+  dim3 rgrid((unsigned)((m->n + 63) / 64), (unsigned)cb, per_block ? (unsigned)m->nblocks : 1u);
   hipLaunchKernelGGL(k_reduce_xw, rgrid, dim3(256), 0, ctx->stream, part, CB, cb, m->n,
                      (const int*)m->coarse.d_blk_start, m->nblocks, per_block ? 1 : 0, d_out, ldo, c_total, k0);
 }
@@ -287,9 +299,7 @@ static int x_w_impl(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, i
 #undef MB_XW
     }
     MB_HIP(hipGetLastError());
-    dim3 rgrid((unsigned)((m->n + 255) / 256), (unsigned)cb, per_block ? (unsigned)m->nblocks : 1u);
-    hipLaunchKernelGGL(k_reduce_xw, rgrid, dim3(256), 0, ctx->stream, (const double*)part, CB, cb, m->n,
-                       (const int*)ct.d_blk_start, m->nblocks, per_block ? 1 : 0, d_out, ldo, c, k0);
+    launch_reduce_xw(ctx, m, part, CB, cb, per_block, d_out, ldo, c, k0);
     MB_HIP(hipGetLastError());
   }
   return MBPLS_OK;
