@@ -200,14 +200,15 @@ int mbpls_hip_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double
  * of the accumulated vector (block scores of centred columns are centred): the caller subtracts it, and rescales
  * finished g~ / p~ columns by 1/scale (mbpls_hip_scale_rows).  The first pass only takes the statistics (no store:
  * 8np instead of 16np bytes) and X stays the caller's matrix (copy=True costs no second 8np-byte buffer).
- * Rounding of the raw dot products is amplified by |mean_j|/scale_j; the statistics pass reports its maximum per
- * block so the caller can fall back to the storing pass for badly offset data.  The caller must pass zero-sum
- * vectors (re-centre to rounding).
+ * Every element is shifted in registers before it is used (by the column's first sample in the statistics pass,
+ * by the column mean afterwards), so the rounding of the dot products does not grow with |mean_j|/scale_j; the
+ * shifted one-pass variance is amplified by ((x_0j - mean_j)/scale_j)^2 <= n, which the statistics pass reports
+ * per block.  The caller must pass zero-sum vectors (re-centre to rounding).
  *
  * StandardScaler statistics (MBPLS_SCALE_FIT; MBPLS_SCALE_NONE: sums of squares only) + the first sweep on the
  * raw columns held in registers; nothing is written to X.  d_rscale / d_r2 (required with MBPLS_SCALE_FIT):
  * 1/scale_j and 1/scale_j^2 (0 for a constant column); d_amp[nblocks] (optional) = the SQUARE of
- * max_j max(|mean_j|/scale_j, ((x_0j - mean_j)/scale_j)^2), the rounding amplification of the raw-space sums.    */
+ * max_j ((x_0j - mean_j)/scale_j)^2, the rounding amplification of the shifted sums.                             */
 int mbpls_hip_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_mean, double* d_scale,
                                       double* d_rscale, double* d_r2, double* d_ssq_x, double* d_amp,
                                       const double* d_v, double alpha, double* d_g, double* d_t,
@@ -215,15 +216,17 @@ int mbpls_hip_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_
 /* mbpls_hip_sweep_lazy / mbpls_hip_loadings_sweep_lazy on a RAW matrix with implicit standardisation (d_r2: p
  * values 1/scale_j^2; NULL = the plain lazy passes).  d_g / d_p receive and d_P holds the RAW-SPACE columns g~,
  * p~; d_ssq_g / d_ssq_p are the squared norms of the TRUE g_b, p_b; d_d as in the plain variants with c_j in
- * place of g_j.                                                                                                */
+ * place of g_j.  d_mean (p values, required with d_r2): the column means, subtracted from every element in
+ * registers before the dot products and the accumulation -- a raw-space dot product would carry rounding noise
+ * of |mean_j|/scale_j ulps, which keeps offset data from ever meeting the NIPALS stop rule (mbpls.py:841).     */
 int mbpls_hip_sweep_lazy_scaled(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t,
                                 double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
-                                double* d_d, const double* d_r2);
+                                double* d_d, const double* d_r2, const double* d_mean);
 int mbpls_hip_loadings_sweep_lazy_scaled(const mbpls_mat* m, const double* d_ts, double inv_tt, double* d_p,
                                          double* d_ssq_p, const double* d_v, double alpha, double* d_g,
                                          double* d_t, double* d_ssq_g, const double* d_P, int64_t ldp, int kprev,
                                          const double* d_cu, const double* d_ce, double* d_d,
-                                         const double* d_r2);
+                                         const double* d_r2, const double* d_mean);
 /* d_C[j, k] = d_A[j, k] * d_r[j] for a p x c column-major array (row scaling; raw-space -> true loadings).      */
 int mbpls_hip_scale_rows(mbpls_ctx* ctx, int64_t p, int c, const double* d_A, int64_t lda, const double* d_r,
                          double* d_C, int64_t ldc);
@@ -289,7 +292,7 @@ int mbpls_hip_nipals_gram_step(mbpls_ctx* ctx, int64_t n, const double* d_a, con
                                const double* d_Y, int q, int norm_kind, double tol, int max_iter, double* d_ts,
                                double* d_u, double* d_v, double* d_z_next, int ntile, double* d_state);
 
-/* ---- end-of-fit algebra on p x K device arrays (K <= 32), column-major ------------------------
+/* ---- end-of-fit algebra on p x K device arrays (any K; 32-column tiles inside), column-major ---
  * h_out (c1 x c2 row-major, HOST) = A^T B for p x c1 / p x c2 device arrays: P_^T W (mbpls.py:988,
  * :569, :737).  Deterministic two-stage reduction; synchronous (the result is on the host on return). */
 int mbpls_hip_cross_product(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1,

@@ -60,9 +60,9 @@ SIGNATURES = {
     "mbpls_hip_nipals_gram_step": (_int, [_vp, _i64, _vp, _vp, _int, _vp, _int, _int, _dbl, _int, _vp, _vp, _vp, _vp, _int,
                                           _vp]),
     "mbpls_hip_scale_rows": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _vp, _i64]),
-    "mbpls_hip_sweep_lazy_scaled": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp]),
+    "mbpls_hip_sweep_lazy_scaled": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "mbpls_hip_loadings_sweep_lazy_scaled": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int,
-                                                    _vp, _vp, _vp, _vp]),
+                                                    _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_loadings_sweep_lazy": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int,
                                              _vp, _vp, _vp]),
     "mbpls_hip_xt_v": (_int, [_vp, _vp, _i64, _int, _dbl, _vp, _i64, _vp]),
@@ -391,21 +391,21 @@ class DeviceMatrix:
                                                              _ptr(rscale), _ptr(r2), _ptr(ssq_x), _ptr(amp), _ptr(v),
                                                              float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g)))
 
-    def sweep_lazy(self, v, alpha, g, t, ssq_g, P, ldp, kprev, cu, d, r2=None):
+    def sweep_lazy(self, v, alpha, g, t, ssq_g, P, ldp, kprev, cu, d, r2=None, mean=None):
         if r2 is not None:
             check(self.ctx.lib.mbpls_hip_sweep_lazy_scaled(self.handle, _ptr(v), float(alpha), _ptr(g), _ptr(t),
                                                            _ptr(ssq_g), _ptr(P), int(ldp), int(kprev), _ptr(cu),
-                                                           _ptr(d), _ptr(r2)))
+                                                           _ptr(d), _ptr(r2), _ptr(mean)))
             return
         check(self.ctx.lib.mbpls_hip_sweep_lazy(self.handle, _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g),
                                                 _ptr(P), int(ldp), int(kprev), _ptr(cu), _ptr(d)))
 
     def loadings_sweep_lazy(self, ts, inv_tt, p, ssq_p, v, alpha, g, t, ssq_g, P, ldp, kprev, cu, ce, d,
-                            r2=None):
+                            r2=None, mean=None):
         if r2 is not None:
             check(self.ctx.lib.mbpls_hip_loadings_sweep_lazy_scaled(
                 self.handle, _ptr(ts), float(inv_tt), _ptr(p), _ptr(ssq_p), _ptr(v), float(alpha), _ptr(g), _ptr(t),
-                _ptr(ssq_g), _ptr(P), int(ldp), int(kprev), _ptr(cu), _ptr(ce), _ptr(d), _ptr(r2)))
+                _ptr(ssq_g), _ptr(P), int(ldp), int(kprev), _ptr(cu), _ptr(ce), _ptr(d), _ptr(r2), _ptr(mean)))
             return
         check(self.ctx.lib.mbpls_hip_loadings_sweep_lazy(self.handle, _ptr(ts), float(inv_tt), _ptr(p), _ptr(ssq_p),
                                                          _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g),

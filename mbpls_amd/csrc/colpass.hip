@@ -65,6 +65,11 @@ struct PassArgs {
   // (||g_b||^2 = sum g~_j c_j, ||p_b||^2 = sum p~_j^2 ir2_j); the constant is the mean of the accumulated vector
   // (scores are centred), removed by the caller, who also rescales finished g~ / p~ columns by 1/scale.
   const double* ir2;
+  // ... and the dot products / accumulations run on x_j - mean_j 1 (one subtraction per element in registers): the
+  // rounding of a raw-space dot product would otherwise be amplified by |mean_j| / scale_j, enough to keep the
+  // NIPALS stop rule ||ts_old - ts|| <= 1e-14 (mbpls.py:841) out of reach for offset data.  The statistics-only
+  // pass, which does not know the mean yet, shifts by the column's first sample instead.
+  const double* mu;
   double* rs_out;      // standardise pass: 1 / scale_j   (optional)
   double* r2_out;      // standardise pass: 1 / scale_j^2 (optional)
 };
@@ -183,9 +188,10 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
           for (int k = 0; k < R; ++k) {
             const bool real = FULL || ((((k & 1) ? rm.in_n1 : rm.in_n0) >> (k >> 1)) & 1u);
             const double e = real ? xc[k] - K0 : 0.0;
+            xc[k] = e;                       // the shifted column serves the dot product and the accumulation too
             s3[0] += e;
             s3[1] = fma(e, e, s3[1]);
-            s3[2] = fma(xc[k], v[k], s3[2]);
+            s3[2] = fma(e, v[k], s3[2]);
           }
           block_sum<3>(s3, red, buf);
           // every thread needs only c_j = g~_j / var (one division); sqrt and the outputs are thread 0's business --
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
             const int slot = (int)((jj - j0) & 63);
             if (tid == 0) {
               const double m2 = m1 * m1 * r2;
-              amp = fmax(amp, fmax(mean * mean * r2, m2 * m2));   // SQUARED offsets |mean|/scale, ((K-mean)/scale)^2
+              amp = fmax(amp, m2 * m2);      // SQUARE of ((K - mean)/scale)^2, the amplification of the shifted sums
               ssq_x = fma(dn * var, r2, ssq_x);                   // sum z^2 of the column
               s_out[0][slot] = mean;
               s_out[1][slot] = var;
@@ -285,7 +291,12 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
       // 1/scale_j^2 of the raw-space passes: requested here, ahead of the dot products, so the scalar load is not
       // waited for behind the reduction
       double r2c = 1.0;
-      if constexpr (ISTD && !STD) r2c = a.ir2[jj];
+      if constexpr (ISTD && !STD) {
+        r2c = a.ir2[jj];
+        const double muj = a.mu[jj];
+#pragma unroll
+        for (int k = 0; k < R; ++k) xc[k] -= muj;   // rows beyond n become -mean: their v / ts entries are 0, never stored
+      }
       if constexpr (DEFL) {
         // lazy: <x_k, ts> = <x_0, ts> - sum_i P[j,i] <ts_i, ts>, folded into the same reduction
         double ab[2] = {-pp[d] * ce_i, -pp[d] * cu_i};
@@ -589,13 +600,14 @@ int mbpls_hip_deflate_sweep(mbpls_mat* m, const double* d_ts, double inv_tt, int
 int mbpls_hip_sweep_lazy(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t,
                          double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
                          double* d_d) {
-  return mbpls_hip_sweep_lazy_scaled(m, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu, d_d, nullptr);
+  return mbpls_hip_sweep_lazy_scaled(m, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu, d_d, nullptr, nullptr);
 }
 
 int mbpls_hip_sweep_lazy_scaled(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t,
                                 double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
-                                double* d_d, const double* d_r2) {
+                                double* d_d, const double* d_r2, const double* d_mean) {
   MB_ARG(m && d_v, "NULL argument");
+  MB_ARG((d_r2 == nullptr) == (d_mean == nullptr), "d_r2 and d_mean must be given together");
   MB_ARG(kprev >= 0 && kprev < KD && (kprev == 0 || (d_P && d_cu && d_d)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   mbpls_ctx* ctx = m->ctx;
   if (long_columns(ctx, m->n)) {
@@ -608,7 +620,7 @@ int mbpls_hip_sweep_lazy_scaled(const mbpls_mat* m, const double* d_v, double al
   a.c0 = m->fine.d_c0; a.c1 = m->fine.d_c1;
   a.v = d_v; a.alpha = alpha; a.g = d_g;
   a.lazy = 1; a.kprev = kprev; a.Pm = d_P; a.ldp = ldp; a.cu = d_cu; a.ce = nullptr;
-  a.ir2 = d_r2;
+  a.ir2 = d_r2; a.mu = d_mean;
   MB_TRY((launch_pass<false, false, true>(ctx, m->fine, a, m->p)));
   return reduce_chunks(ctx, m, a.part_t, a.part_s, d_t, d_ssq_g, nullptr, nullptr, a.part_d, kprev, kprev ? d_d : nullptr);
 }
@@ -618,15 +630,16 @@ int mbpls_hip_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double
                                   double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
                                   const double* d_ce, double* d_d) {
   return mbpls_hip_loadings_sweep_lazy_scaled(m, d_ts, inv_tt, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp,
-                                              kprev, d_cu, d_ce, d_d, nullptr);
+                                              kprev, d_cu, d_ce, d_d, nullptr, nullptr);
 }
 
 int mbpls_hip_loadings_sweep_lazy_scaled(const mbpls_mat* m, const double* d_ts, double inv_tt, double* d_p,
                                          double* d_ssq_p, const double* d_v, double alpha, double* d_g, double* d_t,
                                          double* d_ssq_g, const double* d_P, int64_t ldp, int kprev,
                                          const double* d_cu, const double* d_ce, double* d_d,
-                                         const double* d_r2) {
+                                         const double* d_r2, const double* d_mean) {
   MB_ARG(m && d_ts, "NULL argument");
+  MB_ARG((d_r2 == nullptr) == (d_mean == nullptr), "d_r2 and d_mean must be given together");
   MB_ARG(kprev >= 0 && kprev < KD - 1 && (kprev == 0 || (d_P && d_ce)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   MB_ARG(!d_v || (d_d && (kprev == 0 || d_cu)), "sweep part needs d_cu / d_d");
   mbpls_ctx* ctx = m->ctx;
@@ -641,7 +654,7 @@ int mbpls_hip_loadings_sweep_lazy_scaled(const mbpls_mat* m, const double* d_ts,
   a.ts = d_ts; a.inv_tt = inv_tt; a.deflate = d_v ? 1 : 0; a.pvec = d_p;   // deflate=1: the fused sweep sees X_{k+1}
   a.v = d_v; a.alpha = alpha; a.g = d_g;
   a.lazy = 1; a.kprev = kprev; a.Pm = d_P; a.ldp = ldp; a.cu = d_cu; a.ce = d_ce;
-  a.ir2 = d_r2;
+  a.ir2 = d_r2; a.mu = d_mean;
   if (d_v) {
     MB_TRY((launch_pass<false, true, true>(ctx, m->fine, a, m->p)));
     return reduce_chunks(ctx, m, a.part_t, a.part_s, d_t, d_ssq_g, d_ssq_p, nullptr, a.part_d, kprev + 1, d_d);

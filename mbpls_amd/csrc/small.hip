@@ -55,10 +55,10 @@ __global__ __launch_bounds__(64) void k_cross_final(const double* __restrict__ p
   if (threadIdx.x == 0) out[e] = s;
 }
 
-// C[r, j] = sum_i A[r, i] * M[i, j]   (M: c1 x c2 row-major in device memory)
+// C[r, j] (+)= sum_i A[r, i] * M[i, j]   (M: c1 x c2 row-major in device memory)
 __global__ __launch_bounds__(256) void k_right_multiply(int64_t p, const double* __restrict__ A, int64_t lda, int c1,
                                                         const double* __restrict__ M, int c2,
-                                                        double* __restrict__ Cm, int64_t ldc) {
+                                                        double* __restrict__ Cm, int64_t ldc, int accumulate) {
   __shared__ double sM[CMAX * CMAX];
   for (int e = threadIdx.x; e < c1 * c2; e += blockDim.x) sM[e] = M[e];
   __syncthreads();
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_right_multiply(int64_t p, const double*
 #pragma unroll
     for (int i = 0; i < CMAX; ++i) a[i] = (i < c1) ? A[(int64_t)i * lda + r] : 0.0;
     for (int j = 0; j < c2; ++j) {
-      double s = 0.0;
+      double s = accumulate ? Cm[(int64_t)j * ldc + r] : 0.0;
 #pragma unroll
       for (int i = 0; i < CMAX; ++i)
         if (i < c1) s = fma(a[i], sM[i * c2 + j], s);
@@ -94,35 +94,64 @@ extern "C" {
 int mbpls_hip_cross_product(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1, const double* d_B,
                             int64_t ldb, int c2, double* h_out) {
   MB_ARG(ctx && d_A && d_B && h_out, "NULL argument");
-  MB_ARG(p >= 1 && c1 >= 1 && c2 >= 1 && c1 <= CMAX && c2 <= CMAX, "need 1 <= c1, c2 <= %d", CMAX);
+  MB_ARG(p >= 1 && c1 >= 1 && c2 >= 1, "need p, c1, c2 >= 1");
   MB_ARG(lda >= p && ldb >= p, "leading dimension < p");
   const int nwg = (int)std::min<int64_t>((p + 255) / 256, (int64_t)ctx->cus * 4);
-  const int cc = c1 * c2;
-  MB_TRY(ensure_ws(ctx, sizeof(double) * ((size_t)nwg * cc + cc)));
-  double* partial = (double*)ctx->ws;
-  double* d_out = partial + (size_t)nwg * cc;
-  hipLaunchKernelGGL(k_cross_partial, dim3(nwg), dim3(256), 0, ctx->stream, p, d_A, lda, c1, d_B, ldb, c2, partial);
-  MB_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_cross_final, dim3(cc), dim3(64), 0, ctx->stream, (const double*)partial, nwg, cc, d_out);
-  MB_HIP(hipGetLastError());
-  MB_HIP(hipMemcpyAsync(h_out, d_out, sizeof(double) * cc, hipMemcpyDeviceToHost, ctx->stream));
-  MB_HIP(hipStreamSynchronize(ctx->stream));
+  // any number of columns: CMAX x CMAX tiles of the result, one pair of launches each
+  std::vector<double> tile((size_t)CMAX * CMAX);
+  for (int i0 = 0; i0 < c1; i0 += CMAX)
+    for (int j0 = 0; j0 < c2; j0 += CMAX) {
+      const int t1 = std::min(CMAX, c1 - i0), t2 = std::min(CMAX, c2 - j0), cc = t1 * t2;
+      MB_TRY(ensure_ws(ctx, sizeof(double) * ((size_t)nwg * cc + cc)));
+      double* partial = (double*)ctx->ws;
+      double* d_out = partial + (size_t)nwg * cc;
+      hipLaunchKernelGGL(k_cross_partial, dim3(nwg), dim3(256), 0, ctx->stream, p, d_A + (int64_t)i0 * lda, lda, t1,
+                         d_B + (int64_t)j0 * ldb, ldb, t2, partial);
+      MB_HIP(hipGetLastError());
+      hipLaunchKernelGGL(k_cross_final, dim3(cc), dim3(64), 0, ctx->stream, (const double*)partial, nwg, cc, d_out);
+      MB_HIP(hipGetLastError());
+      double* dst = (c1 <= CMAX && c2 <= CMAX) ? h_out : tile.data();
+      MB_HIP(hipMemcpyAsync(dst, d_out, sizeof(double) * cc, hipMemcpyDeviceToHost, ctx->stream));
+      MB_HIP(hipStreamSynchronize(ctx->stream));
+      if (dst != h_out)
+        for (int i = 0; i < t1; ++i)
+          for (int j = 0; j < t2; ++j) h_out[(size_t)(i0 + i) * c2 + (j0 + j)] = tile[(size_t)i * t2 + j];
+    }
   return MBPLS_OK;
 }
 
 int mbpls_hip_right_multiply(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1, const double* h_M,
                              int c2, double* d_C, int64_t ldc) {
   MB_ARG(ctx && d_A && h_M && d_C, "NULL argument");
-  MB_ARG(p >= 1 && c1 >= 1 && c2 >= 1 && c1 <= CMAX && c2 <= CMAX, "need 1 <= c1, c2 <= %d", CMAX);
+  MB_ARG(p >= 1 && c1 >= 1 && c2 >= 1, "need p, c1, c2 >= 1");
   MB_ARG(lda >= p && ldc >= p, "leading dimension < p");
-  // M travels through a small dedicated device buffer (not the workspace: calls may be queued back to back)
-  if (!ctx->small_m) MB_HIP(hipMalloc(&ctx->small_m, sizeof(double) * CMAX * CMAX * 16));
-  double* dM = (double*)ctx->small_m + (size_t)(ctx->small_m_slot++ % 16) * CMAX * CMAX;
-  MB_HIP(hipMemcpyAsync(dM, h_M, sizeof(double) * c1 * c2, hipMemcpyHostToDevice, ctx->stream));
+  // M travels through a small dedicated device buffer (not the workspace: calls may be queued back to back; the
+  // copies are ordered on the stream behind the kernels that still read a slot of the ring)
+  constexpr int RING = 16;
+  if (!ctx->small_m) MB_HIP(hipMalloc(&ctx->small_m, sizeof(double) * CMAX * CMAX * RING));
   const int nwg = (int)std::min<int64_t>((p + 255) / 256, (int64_t)ctx->cus * 8);
-  hipLaunchKernelGGL(k_right_multiply, dim3(nwg), dim3(256), 0, ctx->stream, p, d_A, lda, c1, (const double*)dM, c2,
-                     d_C, ldc);
-  MB_HIP(hipGetLastError());
+  // any c1, c2: CMAX x CMAX tiles of M; the tiles along c1 accumulate into C (so with c1 > CMAX the output must not
+  // alias the input columns)
+  const bool tiled = c1 > CMAX || c2 > CMAX;
+  std::vector<std::vector<double>> tiles;     // packed sub-blocks of M: alive until the copies have run (sync below)
+  for (int j0 = 0; j0 < c2; j0 += CMAX)
+    for (int i0 = 0; i0 < c1; i0 += CMAX) {
+      const int t1 = std::min(CMAX, c1 - i0), t2 = std::min(CMAX, c2 - j0);
+      const double* hM = h_M;
+      if (tiled) {
+        tiles.emplace_back((size_t)t1 * t2);
+        std::vector<double>& tile = tiles.back();
+        for (int i = 0; i < t1; ++i)
+          for (int j = 0; j < t2; ++j) tile[(size_t)i * t2 + j] = h_M[(size_t)(i0 + i) * c2 + (j0 + j)];
+        hM = tile.data();
+      }
+      double* dM = (double*)ctx->small_m + (size_t)(ctx->small_m_slot++ % RING) * CMAX * CMAX;
+      MB_HIP(hipMemcpyAsync(dM, hM, sizeof(double) * t1 * t2, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_right_multiply, dim3(nwg), dim3(256), 0, ctx->stream, p, d_A + (int64_t)i0 * lda, lda, t1,
+                         (const double*)dM, t2, d_C + (int64_t)j0 * ldc, ldc, i0 > 0 ? 1 : 0);
+      MB_HIP(hipGetLastError());
+    }
+  if (tiled) MB_HIP(hipStreamSynchronize(ctx->stream));
   return MBPLS_OK;
 }
 

@@ -326,7 +326,9 @@ class HipEngine:
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
         return x, t, g
 
-    # Rounding of the raw dot products is amplified by |mean_j| / scale_j: beyond this the storing pass is used
+    # The shifted one-pass variance of the statistics pass is amplified by ((x_0j - mean_j) / scale_j)^2 (<= n, a
+    # single sample cannot lie further out); beyond this value the storing two-pass standardisation is used.  The dot
+    # products themselves run on mean-shifted elements and do not depend on the offset of the data.
     IMPLICIT_STD_MAX_OFFSET = 1.0e4
 
     def _implicit_ok(self, v, mean):
@@ -385,7 +387,7 @@ class HipEngine:
         elif self._istd:
             self.X.sweep_lazy(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B),
                               self.slots["P~raw"], self.p, k, self._lazy_coef(0, v), self._xptr(n * B + 3 * B),
-                              r2=self.r2)
+                              r2=self.r2, mean=self.mean)
             if g_slot is not None:
                 self._scale_col(g_slot, g_slot)
         elif k:
@@ -438,7 +440,8 @@ class HipEngine:
                                        self._xptr(n * B) if v is not None else None, P, self.p, k,
                                        self._lazy_coef(0, v) if v is not None else None, self._lazy_coef(1, ts),
                                        self._xptr(n * B + 3 * B) if v is not None else None,
-                                       r2=self.r2 if self._istd else None)
+                                       r2=self.r2 if self._istd else None,
+                                       mean=self.mean if self._istd else None)
             if self._istd:
                 self._scale_col(("P~raw", k), p_slot)
                 if v is not None and g_slot is not None:

@@ -518,7 +518,7 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
             Ts = np.hstack((Ts, ts)); U = np.hstack((U, u))
         eng.slot("UT", 2 * K)
         ssq = eng.xt_v(np.hstack((U, Ts)), 1.0, "UT", 0, want_ssq=True)   # X^T [U Ts] in one call (:731, :734)
-        if K <= 32 and hasattr(eng, "right_mul"):
+        if hasattr(eng, "right_mul"):
             # post-processing on the device: only K x K matrices visit the host, every p x K attribute is
             # fetched once
             wnorm2 = ssq[:, :K]                             # per-block ||(X^T U)_b||^2, all shards

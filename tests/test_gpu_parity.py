@@ -478,18 +478,24 @@ def test_both_deflation_modes(gpu_required, monkeypatch, mode, method, q):
     assert w < 1e-8, w
 
 
-@pytest.mark.parametrize("offset,expect_implicit", [(0.0, True), (50.0, True), (1.0e6, False)])
-def test_implicit_standardisation_and_its_fallback(gpu_required, monkeypatch, offset, expect_implicit):
+@pytest.mark.parametrize("offset,n,p,force_fallback", [(0.0, 1000, 6000, False), (50.0, 1000, 6000, False),
+                                                       (1.0e3, 1000, 6000, False), (1.0e3, 300, 40, False),
+                                                       (5.0e3, 64, 7, False), (1.0e6, 1000, 6000, False),
+                                                       (50.0, 1000, 6000, True)])
+def test_implicit_standardisation_and_its_fallback(gpu_required, monkeypatch, offset, n, p, force_fallback):
     """One response + lazy deflation: the fit never writes X (statistics-only first pass, raw-space passes after).
-    Offsets amplify the rounding of raw-space sums by |mean|/scale: moderate ones stay inside the tolerance by a wide
-    margin, extreme ones make the engine fall back to the storing standardise pass.  Same numbers either way, the
-    caller's resident matrix is untouched, and MBPLS_IMPLICIT_STD=0 switches the path off."""
+    Every element is shifted in registers before it is used (first sample in the statistics pass, column mean
+    afterwards), so column offsets of 10^3..10^6 scale units neither cost accuracy nor keep ||ts_old - ts|| from
+    reaching 1e-14: the iteration counts equal the reference's ([2]*K).  The storing standardise pass remains as a
+    fallback (forced here through the threshold) and behind MBPLS_IMPLICIT_STD=0.  Same numbers every way, and the
+    caller's resident matrix is untouched."""
     import mbpls_amd
     from mbpls_amd import MBPLS, DeviceMatrix
     from mbpls_amd.engine import HipEngine
-    X, Y = orc.make_latent(1000, 6000, 1, seed=77)
+    K = 4
+    X, Y = orc.make_latent(n, p, 1, seed=77)
     X = X + offset * (1.0 + np.arange(X.shape[1]) % 3)       # column offsets 1x..3x
-    ref = orc.fit(X, Y, n_components=4)
+    ref = orc.fit(X, Y, n_components=K)
     seen = []
     real = HipEngine._prepare_implicit
 
@@ -499,22 +505,50 @@ def test_implicit_standardisation_and_its_fallback(gpu_required, monkeypatch, of
         return out
 
     monkeypatch.setattr(HipEngine, "_prepare_implicit", spy)
+    if force_fallback:
+        monkeypatch.setattr(HipEngine, "IMPLICIT_STD_MAX_OFFSET", -1.0)
     ctx = mbpls_amd.get_context()
     Xd = DeviceMatrix(ctx, *X.shape)
     Xd.upload(X)
-    mdl = MBPLS(n_components=4).fit(Xd, Y)
-    assert seen == [expect_implicit]
+    mdl = MBPLS(n_components=K).fit(Xd, Y)
+    assert seen == [not force_fallback]
+    assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K, (mdl.nipals_iterations_, ref.nipals_iterations_)
     w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"offset {offset}")
-    assert w < (1e-9 if offset == 0.0 else 1e-7), w
+    # the input itself is only known to offset * eps scale units: that, not the arithmetic, bounds the agreement
+    assert w < max(1e-9, 1e3 * offset * np.finfo(float).eps), w
     assert np.array_equal(Xd.download(), X)                  # copy=True: the resident matrix is never written
     assert util.relerr(np.concatenate([s.mean_ for s in mdl.x_scalers_]), X.mean(axis=0)) < 1e-12
-    assert util.relerr(np.concatenate([s.scale_ for s in mdl.x_scalers_]), X.std(axis=0)) < 1e-9
+    assert util.relerr(np.concatenate([s.scale_ for s in mdl.x_scalers_]), X.std(axis=0)) < max(1e-9, 1e2 * offset * 2.3e-16)
     monkeypatch.setenv("MBPLS_IMPLICIT_STD", "0")
     seen.clear()
-    m2 = MBPLS(n_components=4).fit(Xd, Y)
+    m2 = MBPLS(n_components=K).fit(Xd, Y)
     assert seen == []
-    assert util.compare(util.model_to_flat(m2), util.model_to_flat(ref), TOL, what="stored") < 1e-8
+    assert m2.nipals_iterations_ == [2] * K
+    assert util.compare(util.model_to_flat(m2), util.model_to_flat(ref), TOL, what="stored") < max(1e-8, 1e3 * offset * 2.3e-16)
     Xd.close()
+
+
+@pytest.mark.parametrize("method,K,q,n,p", [("NIPALS", 40, 1, 1200, 900), ("NIPALS", 38, 1, 1200, 900),
+                                            ("NIPALS", 33, 2, 1200, 900), ("UNIPALS", 40, 1, 300, 2400),
+                                            ("UNIPALS", 35, 3, 300, 2400), ("KERNEL", 40, 2, 300, 2400),
+                                            ("SIMPLS", 40, 1, 300, 2400)])
+def test_many_components(gpu_required, method, K, q, n, p):
+    """More components than one 32-column tile of the device helpers (cross products / right-multiplications are tiled)
+    and than the lazy-deflation correction registers hold (K >= 39 takes the stored, explicitly deflated path): any K
+    works, as in the reference.  (NIPALS on tall data: with p > n the response is fitted exactly after ~30 components
+    and the stop rule of mbpls.py:841 is then out of reach for the reference as well.)"""
+    from mbpls_amd import MBPLS
+    X, Y = orc.make_latent(n, p, q, r=60, seed=5 + K, decay=0.97, noise_y=1.0)
+    h = p // 2 - 50
+    Xs = [np.ascontiguousarray(X[:, :h]), np.ascontiguousarray(X[:, h:])]
+    ref = orc.fit(Xs, Y, n_components=K, method=method)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mdl = MBPLS(n_components=K, method=method).fit(Xs, Y)
+    w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} K={K} q={q}")
+    assert w < 1e-8, w
+    if method == "NIPALS" and q == 1:
+        assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K
 
 
 @pytest.mark.parametrize("gram", ["1", "0"])
