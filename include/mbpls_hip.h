@@ -292,6 +292,62 @@ int mbpls_hip_nipals_gram_step(mbpls_ctx* ctx, int64_t n, const double* d_a, con
                                const double* d_Y, int q, int norm_kind, double tol, int max_iter, double* d_ts,
                                double* d_u, double* d_v, double* d_z_next, int ntile, double* d_state);
 
+/* ---- device-resident NIPALS: a whole one-response fit queued without a host round trip -----------------------
+ * Between two passes over X the reference does n x (B + q) algebra on the host (mbpls.py:860-913: norms of the
+ * block weights, block scores t_b, super weights sw, super score ts, the stop rule ||ts_old - ts|| <= max_tol,
+ * Y loadings v, next u).  mbpls_hip_nipals_step does exactly that on the device, reading the exchange buffer the
+ * pass (mbpls_hip_sweep*, mbpls_hip_loadings_sweep_lazy*, mbpls_hip_standardize_*sweep) left behind -- layout
+ * [t~: nblocks x n | ssq_g: nblocks | ssq_p: nblocks | ssq_x: nblocks | d: nblocks x nd] -- after it was all-reduced
+ * over the column shards, and writing the inputs of the next pass: the n-vectors vpass / tspass (centred copies when
+ * `centre`), the lazy-deflation coefficients cu / ce (kc doubles each) and par[0] = alpha, par[1] = inv_tt.
+ * With mbpls_hip_set_pass_params(ctx, par) the passes take alpha / inv_tt from par instead of their host arguments
+ * and turn into no-ops once par[2] != 0.
+ *
+ * run == 1: the pass was the first sweep of component kc (start vector Y[:, 0], :838): no stop test (:884), the next
+ * pass is a sweep with the new u.  run >= 2: stop test; converged -> component kc is recorded (Ts, U, V, Tb, scal,
+ * iters) and the next pass is loadings (+ lazy deflation) + first sweep of component kc + 1; not converged -> the
+ * queue was built for exactly `run` iterations, so par[2] = 1 (everything queued behind becomes a no-op),
+ * par[3] = kc, par[4] = the difference, and the caller resumes component kc with its own loop.
+ * Shapes: nblocks <= MBPLS_STEP_MAX_BLOCKS, q <= MBPLS_STEP_MAX_RESPONSES, kc < 39; nd = number of lazily deflated
+ * components the pass corrected for (0 or kc).  All arrays column-major.                                          */
+#define MBPLS_STEP_MAX_BLOCKS 16
+#define MBPLS_STEP_MAX_RESPONSES 16
+typedef struct mbpls_nipals_step {
+  int64_t n;
+  int nblocks, q, kc, run, nd, centre, norm_kind;   /* norm_kind: 0 ||.||_2, 1 sum|.|, 2 max|.|, 3 min|.| (:887) */
+  double tol;              /* max_tol (:841)                                                                       */
+  const double* xchg;      /* exchange buffer of the pass that just finished                                       */
+  const double* Y;         /* n x q standardised responses                                                         */
+  double* Ts;              /* n x K  super scores (column kc written at convergence)                               */
+  double* Tsc;             /* n x K  the same, re-centred when `centre` (what the lazy corrections are taken with)   */
+  double* U;               /* n x K                                                                                */
+  double* V;               /* q x K                                                                                */
+  double* Tb;              /* n x nblocks x K: block scores, block b of component k at ((k * nblocks) + b) * n       */
+  double* scal;            /* K x 4 x nblocks: [||w~_b||^2 | a_b = sw_b^2 | ||p_b||^2 | -]                           */
+  double* ssq_x;           /* nblocks: sums of squares of the standardised blocks (run 1 of component 0)           */
+  double* iters;           /* K: NIPALS iterations per component                                                   */
+  double* u_cur;           /* n: the sweep vector the finished pass was taken with (in), the next one (out)        */
+  double* ts_old;          /* n: super score of the previous iteration (in/out)                                    */
+  double* vpass;           /* n: sweep vector of the next pass (out)                                               */
+  double* tspass;          /* n: score vector of the next loadings pass (out)                                      */
+  double* cu;              /* >= kc: <ts_i, vpass>                                                                 */
+  double* ce;              /* >= kc: <ts_i, tspass>                                                                */
+  double* par;             /* >= 8: [alpha, inv_tt, skip flag, failed component, last diff, ...]                   */
+} mbpls_nipals_step;
+int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s);
+/* d_par != NULL: every column pass on this context reads alpha = d_par[0], inv_tt = d_par[1] from the device and
+ * does nothing when d_par[2] != 0.  NULL restores the host-scalar behaviour.                                        */
+int mbpls_hip_set_pass_params(mbpls_ctx* ctx, const double* d_par);
+/* d_dst[j] = d_src[j] / sqrt(d_nu2[block of j]): block weights w_b = w~_b / ||w~_b|| (mbpls.py:860) with the norms
+ * still on the device (d_nu2: nblocks squared norms).                                                              */
+int mbpls_hip_block_unit_col(const mbpls_mat* m, const double* d_src, double* d_dst, const double* d_nu2);
+/* Ordered device-to-host copies for finished columns: record an event behind the kernels queued so far; a HELPER
+ * thread then waits for that event only (not for the stream) and copies on the copy stream, so the queueing thread
+ * never blocks.                                                                                                   */
+int mbpls_hip_event_record(mbpls_ctx* ctx, void** event);
+int mbpls_hip_memcpy_d2h_after(mbpls_ctx* ctx, void* event, void* h_dst, const void* d_src, size_t bytes);
+int mbpls_hip_event_destroy(mbpls_ctx* ctx, void* event);
+
 /* ---- end-of-fit algebra on p x K device arrays (any K; 32-column tiles inside), column-major ---
  * h_out (c1 x c2 row-major, HOST) = A^T B for p x c1 / p x c2 device arrays: P_^T W (mbpls.py:988,
  * :569, :737).  Deterministic two-stage reduction; synchronous (the result is on the host on return). */

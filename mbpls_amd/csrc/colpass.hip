@@ -70,6 +70,9 @@ struct PassArgs {
   // NIPALS stop rule ||ts_old - ts|| <= 1e-14 (mbpls.py:841) out of reach for offset data.  The statistics-only
   // pass, which does not know the mean yet, shifts by the column's first sample instead.
   const double* mu;
+  // device-resident parameters (ctx->dpar): when given, alpha = dpar[0], inv_tt = dpar[1] and the whole pass is a
+  // no-op when dpar[2] != 0 (a speculatively queued fit that turned out to need more NIPALS iterations)
+  const double* dpar;
   double* rs_out;      // standardise pass: 1 / scale_j   (optional)
   double* r2_out;      // standardise pass: 1 / scale_j^2 (optional)
 };
@@ -83,6 +86,11 @@ template <int R, int TMAX, int D, bool STD, bool DEFL, bool SWEEP, bool FULL, bo
 __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpass(PassArgs a) {
   __shared__ double red[2 * 64];
   int buf = 0;
+  if (a.dpar) {
+    if (a.dpar[2] != 0.0) return;
+    a.alpha = uniform_f64(a.dpar[0]);
+    a.inv_tt = uniform_f64(a.dpar[1]);
+  }
   const int tid = threadIdx.x, T = blockDim.x;
   const int64_t n = a.n, ld = a.ld;
   const int chunk = blockIdx.x;
@@ -418,8 +426,10 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const double* __restrict_
                                                        double* __restrict__ out_ssq_p, double* __restrict__ out_ssq_x,
                                                        const double* __restrict__ part_d, int nd,
                                                        double* __restrict__ out_d /* [nblocks][nd] */,
-                                                       double* __restrict__ out_amp /* [nblocks] max of slot 3 */) {
+                                                       double* __restrict__ out_amp /* [nblocks] max of slot 3 */,
+                                                       const double* __restrict__ dpar) {
   __shared__ double comb[4][64];
+  if (dpar && dpar[2] != 0.0) return;
   const int b = blockIdx.y;
   const int cs = blk_start[b], ce = blk_start[b + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -483,7 +493,8 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
     set_error("column passes support n <= 65536 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;
   }
-  const PassArgs& an = a;
+  PassArgs an = a;
+  an.dpar = ctx->dpar;
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
   const int D = ctx->prefetch >= 1 && ctx->prefetch <= 3 ? ctx->prefetch : 2;
   // FULL: every thread's every row pair is a real sample and columns are unpadded (n=4096, 8192, ...)
@@ -539,7 +550,8 @@ int reduce_chunks(mbpls_ctx* ctx, const mbpls_mat* m, const double* part_t, cons
                   const double* part_d, int nd, double* d_d, double* d_amp) {
   dim3 grid(d_t ? (unsigned)((m->n + 63) / 64) : 1u, (unsigned)m->nblocks);
   hipLaunchKernelGGL(k_reduce_chunks, grid, dim3(256), 0, ctx->stream, part_t, part_s,
-                     (const int*)m->fine.d_blk_start, m->n, d_t, d_ssq_g, d_ssq_p, d_ssq_x, part_d, nd, d_d, d_amp);
+                     (const int*)m->fine.d_blk_start, m->n, d_t, d_ssq_g, d_ssq_p, d_ssq_x, part_d, nd, d_d, d_amp,
+                     ctx->dpar);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }

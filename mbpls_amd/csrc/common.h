@@ -75,6 +75,11 @@ struct mbpls_ctx {
   // ring of small K x K matrices for right_multiply
   void* small_m = nullptr;
   unsigned small_m_slot = 0;
+  // device-resident pass parameters (mbpls_hip_set_pass_params): [0] alpha, [1] inv_tt, [2] skip flag -- the
+  // column passes read them from HBM instead of taking host scalars, so a whole fit can be queued without a host
+  // round trip (resident.hip writes them between the passes)
+  const double* dpar = nullptr;
+  void* rccl = nullptr;      // RcclState* (rccl_comm.hip) when a communicator was initialised on this context
   // per-kernel profile (HIP events around the main kernel of every hot-path call)
   bool prof = false;
   struct Pending { hipEvent_t a, b; int kind; double bytes; };
@@ -154,6 +159,35 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* red, int& buf
     v[k] = s;
   }
   buf ^= 1;
+}
+
+// Sum the first m of M values over a 1024-thread workgroup with two barriers per 16 values: every thread parks its
+// partials in LDS, wave g sums value g (16 strided reads + one butterfly), the totals come back through LDS.  Fixed
+// order (deterministic).  part: double[16][1024], tot: double[16].
+constexpr int WG1024 = 1024;
+template <int M>
+__device__ __forceinline__ void reduce_many(double (&v)[M], int m, double* part, double* tot) {
+  const int tid = threadIdx.x, g = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int base = 0; base < M; base += 16) {
+    if (base < m) {   // workgroup-uniform
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (base + j < M && base + j < m) part[j * WG1024 + tid] = v[(base + j < M) ? base + j : 0];
+      __syncthreads();
+      if (base + g < m) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < WG1024 / 64; ++i) s += part[g * WG1024 + i * 64 + lane];
+        s = wave_sum(s);
+        if (lane == 0) tot[g] = s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (base + j < M && base + j < m) v[(base + j < M) ? base + j : 0] = tot[j];
+    }
+  }
 }
 #endif
 

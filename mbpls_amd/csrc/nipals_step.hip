@@ -16,34 +16,7 @@
 
 namespace mbpls {
 
-constexpr int NS_T = 1024;   // one workgroup: the whole step is n x (k + q) L2-resident work, latency-bound -> many waves
-
-// Sum the first m of M values over the workgroup with two barriers per 16 values: every thread parks its partials
-// in LDS, wave g sums value g (16 strided reads + one butterfly), the totals come back through LDS.  Fixed order.
-template <int M>
-__device__ __forceinline__ void reduce_many(double (&v)[M], int m, double* part /* [16][NS_T] */, double* tot /* [16] */) {
-  const int tid = threadIdx.x, g = tid >> 6, lane = tid & 63;
-#pragma unroll
-  for (int base = 0; base < M; base += 16) {
-    if (base < m) {   // workgroup-uniform
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (base + j < M && base + j < m) part[j * NS_T + tid] = v[(base + j < M) ? base + j : 0];
-      __syncthreads();
-      if (base + g < m) {
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < NS_T / 64; ++i) s += part[g * NS_T + i * 64 + lane];
-        s = wave_sum(s);
-        if (lane == 0) tot[g] = s;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (base + j < M && base + j < m) v[(base + j < M) ? base + j : 0] = tot[j];
-    }
-  }
-}
+constexpr int NS_T = WG1024;   // one workgroup: the whole step is n x (k + q) L2-resident work, latency-bound -> many waves
 
 struct StepArgs {
   int64_t n;

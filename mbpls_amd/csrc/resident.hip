@@ -1,0 +1,341 @@
+// Device-resident NIPALS step: everything the reference does between two passes over X (mbpls.py:860-913 -- block
+// weights' norms, block scores, super weights, super score, the stop rule, Y loadings, next u) plus the bookkeeping of
+// lazy deflation and implicit standardisation, in ONE small kernel that reads the exchange buffer of the pass that
+// just finished and writes the inputs of the pass that follows.  With it a one-response fit is queued as
+//   stats+sweep, step, [sweep, step, loadings+sweep, step] x K
+// without a single host round trip (the passes take alpha / inv_tt / a skip flag from the same device block,
+// ctx->dpar): the host reads the results once, at the end.  When the column shards of several GPUs take part, the
+// all-reduce of the exchange buffer (rccl_comm.hip) sits on the same stream between the pass and the step.
+//
+// One response converges in exactly two iterations per component (u = Y v / ||Y v|| does not depend on ts), so the
+// queue is built SPECULATIVELY for two; a step that finds ||ts_old - ts|| above the tolerance raises the skip flag,
+// everything queued behind it becomes a no-op, and the host resumes that component with its ordinary loop.
+//
+// All of it is n x (B + q + k) work in one 1024-thread workgroup, L2-resident, latency-bound: ~20 us against the
+// ~170 us a blocking D2H + numpy + H2D round trip costs per pass.
+#include "common.h"
+
+namespace mbpls {
+
+constexpr int RS_BMAX = MBPLS_STEP_MAX_BLOCKS;
+constexpr int RS_QMAX = MBPLS_STEP_MAX_RESPONSES;
+constexpr int RS_KMAX = 40;   // == KD of colpass.hip (lazily deflated components + 1)
+
+__global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
+  __shared__ double part[16 * WG1024];   // 128 KB: the workgroup owns its CU
+  __shared__ double tot[16];
+  __shared__ double s_mx[WG1024 / 64], s_mn[WG1024 / 64];
+  double* par = s.par;
+  if (par[2] != 0.0) return;             // an earlier component needed more iterations than were queued
+  const int tid = threadIdx.x;
+  const int64_t n = s.n;
+  const int B = s.nblocks, q = s.q, kc = s.kc, nd = s.nd;
+  const bool istd = s.centre != 0;
+  const double* tr = s.xchg;             // [B][n] raw accumulations of the pass
+  const double* ssq_g = s.xchg + n * B;
+  const double* ssq_p = ssq_g + B;
+  const double* ssq_x = ssq_g + 2 * B;
+  const double* dd = ssq_g + 3 * B;      // [B][nd] lazy-deflation sums
+  double* tb = s.Tb + (int64_t)kc * B * n;   // block scores of this component: scratch now, final at convergence
+
+  if (s.run == 1 && tid < B) {
+    if (kc == 0) s.ssq_x[tid] = ssq_x[tid];
+    else s.scal[(int64_t)(kc - 1) * 4 * B + 2 * B + tid] = ssq_p[tid];   // ||p_b||^2 of the component just deflated
+  }
+
+  // ---- t~_b = A_b - Ts d_b (lazy deflation), its mean (implicit standardisation), t~_b^T u, u^T u
+  double sum_t[RS_BMAX], tu[RS_BMAX], mu[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int b = 0; b < RS_BMAX; ++b) sum_t[b] = tu[b] = 0.0;
+  for (int64_t i = tid; i < n; i += WG1024) {
+    const double ui = s.u_cur[i];
+    mu[0] = fma(ui, ui, mu[0]);
+    mu[1] += ui;
+#pragma unroll
+    for (int b = 0; b < RS_BMAX; ++b)
+      if (b < B) {
+        double t = tr[(int64_t)b * n + i];
+        for (int j = 0; j < nd; ++j) t = fma(-s.Tsc[(int64_t)j * n + i], dd[b * nd + j], t);
+        tb[(int64_t)b * n + i] = t;
+        sum_t[b] += t;
+        tu[b] = fma(t, ui, tu[b]);
+      }
+  }
+  if (istd) reduce_many<RS_BMAX>(sum_t, B, part, tot);
+  reduce_many<RS_BMAX>(tu, B, part, tot);
+  reduce_many<4>(mu, 2, part, tot);
+  const double uu = mu[0], su = mu[1];
+
+  // ---- t_b = t~_b / ||w~_b|| (:860, :875-877);  sw = T^T u / u^T u, unit length (:879-880)
+  double sw[RS_BMAX], mean_t[RS_BMAX], nu[RS_BMAX];
+  double sw2 = 0.0;
+#pragma unroll
+  for (int b = 0; b < RS_BMAX; ++b) {
+    sw[b] = mean_t[b] = 0.0;
+    nu[b] = 1.0;
+    if (b < B) {
+      mean_t[b] = istd ? sum_t[b] / (double)n : 0.0;
+      nu[b] = sqrt(ssq_g[b]);
+      sw[b] = (tu[b] - mean_t[b] * su) / nu[b] / uu;
+      sw2 = fma(sw[b], sw[b], sw2);
+    }
+  }
+  const double swn = sqrt(sw2);
+#pragma unroll
+  for (int b = 0; b < RS_BMAX; ++b) sw[b] = sw[b] / swn;
+
+  // ---- ts = T sw, unit length (:882-883); scratch in vpass (the pass that read it has finished)
+  double m2[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = tid; i < n; i += WG1024) {
+    double acc = 0.0;
+#pragma unroll
+    for (int b = 0; b < RS_BMAX; ++b)
+      if (b < B) {
+        const double tm = (tb[(int64_t)b * n + i] - mean_t[b]) / nu[b];
+        tb[(int64_t)b * n + i] = tm;
+        acc = fma(tm, sw[b], acc);
+      }
+    s.vpass[i] = acc;
+    m2[0] = fma(acc, acc, m2[0]);
+  }
+  reduce_many<4>(m2, 1, part, tot);
+  const double tsn = sqrt(m2[0]);
+
+  // ---- diff = ||ts_old - ts|| (:887), Y^T ts, ts^T ts
+  double d4[4] = {0.0, 0.0, 0.0, 0.0};
+  double dmax = 0.0, dmin = 1.0e300;
+  double yv[RS_QMAX];
+#pragma unroll
+  for (int j = 0; j < RS_QMAX; ++j) yv[j] = 0.0;
+  for (int64_t i = tid; i < n; i += WG1024) {
+    const double t = s.vpass[i] / tsn;
+    const double d = s.ts_old[i] - t;
+    s.ts_old[i] = t;
+    d4[0] = fma(d, d, d4[0]);
+    d4[1] += fabs(d);
+    d4[2] = fma(t, t, d4[2]);
+    d4[3] += t;
+    dmax = fmax(dmax, fabs(d));
+    dmin = fmin(dmin, fabs(d));
+#pragma unroll
+    for (int j = 0; j < RS_QMAX; ++j)
+      if (j < q) yv[j] = fma(s.Y[(int64_t)j * n + i], t, yv[j]);
+  }
+  reduce_many<4>(d4, 4, part, tot);
+  reduce_many<RS_QMAX>(yv, q, part, tot);
+  double diff;
+  if (s.norm_kind == 0) diff = sqrt(d4[0]);
+  else if (s.norm_kind == 1) diff = d4[1];
+  else {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+      dmin = fmin(dmin, __shfl_xor(dmin, off, 64));
+    }
+    if ((tid & 63) == 0) {
+      s_mx[tid >> 6] = dmax;
+      s_mn[tid >> 6] = dmin;
+    }
+    __syncthreads();
+    for (int w = 0; w < WG1024 / 64; ++w) {
+      dmax = fmax(dmax, s_mx[w]);
+      dmin = fmin(dmin, s_mn[w]);
+    }
+    diff = (s.norm_kind == 2) ? dmax : dmin;
+  }
+  const bool converged = s.run > 1 && diff <= s.tol;
+  if (s.run > 1 && !converged) {
+    // the speculation (two iterations per component) does not hold: stop here, the host takes over at component kc
+    if (tid == 0) {
+      par[2] = 1.0;
+      par[3] = (double)kc;
+      par[4] = diff;
+    }
+    return;
+  }
+
+  // ---- v = Y^T ts / ts^T ts (:899);  u = Y v / v^T v, unit length (:911-913); scratch in tspass
+  double vv = 0.0;
+#pragma unroll
+  for (int j = 0; j < RS_QMAX; ++j)
+    if (j < q) {
+      yv[j] = yv[j] / d4[2];
+      vv = fma(yv[j], yv[j], vv);
+    }
+  double un[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = tid; i < n; i += WG1024) {
+    double w = 0.0;
+#pragma unroll
+    for (int j = 0; j < RS_QMAX; ++j)
+      if (j < q) w = fma(s.Y[(int64_t)j * n + i], yv[j], w);
+    w = w / vv;
+    s.tspass[i] = w;
+    un[0] = fma(w, w, un[0]);
+  }
+  reduce_many<4>(un, 1, part, tot);
+  const double unrm = sqrt(un[0]);
+
+  // out[j] = <Tsc_j, vec> for j < kc, 16 at a time (register budget: 1024 threads leave 128 VGPRs each)
+  auto dots = [&](const double* vec, double* out) {
+    for (int j0 = 0; j0 < kc; j0 += 16) {
+      double c[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) c[jj] = 0.0;
+      for (int64_t i = tid; i < n; i += WG1024) {
+        const double vi = vec[i];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj)
+          if (j0 + jj < kc) c[jj] = fma(s.Tsc[(int64_t)(j0 + jj) * n + i], vi, c[jj]);
+      }
+      reduce_many<16>(c, min(16, kc - j0), part, tot);
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj)
+        if (j0 + jj < kc && tid == 0) out[j0 + jj] = c[jj];
+    }
+  };
+
+  if (!converged) {
+    // ---- next pass: sweep with the new u (centred copy for the raw-space passes), alpha = 1 / u^T u, cu_j = <ts_j, u>
+    double a4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = tid; i < n; i += WG1024) {
+      const double ui = s.tspass[i] / unrm;
+      s.u_cur[i] = ui;
+      a4[0] += ui;
+      a4[1] = fma(ui, ui, a4[1]);
+    }
+    reduce_many<4>(a4, 2, part, tot);
+    const double mean_u = istd ? a4[0] / (double)n : 0.0;
+    for (int64_t i = tid; i < n; i += WG1024) s.vpass[i] = s.u_cur[i] - mean_u;   // each thread re-reads its own rows
+    dots(s.vpass, s.cu);
+    if (tid == 0) {
+      par[0] = 1.0 / a4[1];
+      par[4] = diff;
+    }
+    return;
+  }
+
+  // ---- converged: record component kc, then prepare loadings (+ lazy deflation) + first sweep of component kc+1
+  const double* u0 = s.Y;                      // start vector of every component: Y[:, 0] (:838)
+  double a4[4] = {0.0, 0.0, 0.0, 0.0};         // sum u0, u0^T u0
+  for (int64_t i = tid; i < n; i += WG1024) {
+    const double ui = s.tspass[i] / unrm;
+    s.U[(int64_t)kc * n + i] = ui;
+    s.Ts[(int64_t)kc * n + i] = s.ts_old[i];
+    const double y0 = u0[i];
+    s.u_cur[i] = y0;
+    a4[0] += y0;
+    a4[1] = fma(y0, y0, a4[1]);
+  }
+  reduce_many<4>(a4, 2, part, tot);
+  const double mean_ts = istd ? d4[3] / (double)n : 0.0, mean_u0 = istd ? a4[0] / (double)n : 0.0;
+  for (int64_t i = tid; i < n; i += WG1024) {
+    const double ti = s.ts_old[i] - mean_ts, vi = u0[i] - mean_u0;
+    s.tspass[i] = ti;
+    s.Tsc[(int64_t)kc * n + i] = ti;
+    s.vpass[i] = vi;
+  }
+  dots(s.vpass, s.cu);     // j < kc only: the component being deflated is handled inside the pass (its <ts, v>)
+  dots(s.tspass, s.ce);
+#pragma unroll
+  for (int j = 0; j < RS_QMAX; ++j)
+    if (j < q && tid == 0) s.V[(int64_t)kc * q + j] = yv[j];
+#pragma unroll
+  for (int b = 0; b < RS_BMAX; ++b)
+    if (b < B && tid == 0) {
+      s.scal[(int64_t)kc * 4 * B + b] = ssq_g[b];               // ||w~_b||^2 of the last iteration
+      s.scal[(int64_t)kc * 4 * B + B + b] = sw[b] * sw[b];      // a_b (:949)
+    }
+  if (tid == 0) {
+    s.iters[kc] = (double)s.run;
+    par[0] = 1.0 / a4[1];     // alpha of the fused first sweep of the next component
+    par[1] = 1.0;             // inv_tt: ts is unit length (:928 has no division)
+    par[4] = diff;
+  }
+}
+
+// dst[j] = src[j] / sqrt(nu2[b(j)]) for one p-length column: the block weights w_b = w~_b / ||w~_b|| (:860) with the
+// norms still on the device
+__global__ __launch_bounds__(256) void k_block_unit_col(int64_t p, const double* __restrict__ src, double* __restrict__ dst,
+                                                        const int64_t* __restrict__ offs, int nblocks,
+                                                        const double* __restrict__ nu2, const double* __restrict__ dpar) {
+  if (dpar && dpar[2] != 0.0) return;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  int b = 0;
+  while (b + 1 < nblocks && j >= offs[b + 1]) ++b;
+  dst[j] = src[j] / sqrt(nu2[b]);
+}
+
+}  // namespace mbpls
+
+using namespace mbpls;
+
+extern "C" {
+
+int mbpls_hip_set_pass_params(mbpls_ctx* ctx, const double* d_par) {
+  MB_ARG(ctx, "ctx is NULL");
+  ctx->dpar = d_par;
+  return MBPLS_OK;
+}
+
+int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
+  MB_ARG(ctx && s, "NULL argument");
+  MB_ARG(s->n >= 1 && s->nblocks >= 1 && s->nblocks <= RS_BMAX && s->q >= 1 && s->q <= RS_QMAX,
+         "step kernel covers nblocks <= %d, q <= %d (got %d, %d)", RS_BMAX, RS_QMAX, s->nblocks, s->q);
+  MB_ARG(s->kc >= 0 && s->kc < RS_KMAX - 1 && s->nd >= 0 && s->nd <= s->kc && s->run >= 1, "bad component / run");
+  MB_ARG(s->norm_kind >= 0 && s->norm_kind <= 3, "bad norm kind %d", s->norm_kind);
+  MB_ARG(s->xchg && s->Y && s->Ts && s->Tsc && s->U && s->V && s->Tb && s->scal && s->ssq_x && s->iters && s->u_cur &&
+             s->ts_old && s->vpass && s->tspass && s->cu && s->ce && s->par,
+         "NULL pointer in mbpls_nipals_step");
+  hipLaunchKernelGGL(k_nipals_step, dim3(1), dim3(WG1024), 0, ctx->stream, *s);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+int mbpls_hip_block_unit_col(const mbpls_mat* m, const double* d_src, double* d_dst, const double* d_nu2) {
+  MB_ARG(m && d_src && d_dst && d_nu2, "NULL argument");
+  mbpls_ctx* ctx = m->ctx;
+  // block offsets on the device: the coarse chunk table does not hold them, so keep a small copy per call site --
+  // they travel through the workspace-independent small buffer of the context
+  const int B = m->nblocks;
+  if (!ctx->small_m) MB_HIP(hipMalloc(&ctx->small_m, sizeof(double) * 32 * 32 * 16));
+  MB_ARG((size_t)(B + 1) * sizeof(int64_t) <= sizeof(double) * 32 * 32, "too many blocks");
+  int64_t* d_offs = (int64_t*)((double*)ctx->small_m + (size_t)(ctx->small_m_slot++ % 16) * 32 * 32);
+  MB_HIP(hipMemcpyAsync(d_offs, m->block_offsets.data(), sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_block_unit_col, dim3((unsigned)((m->p + 255) / 256)), dim3(256), 0, ctx->stream, m->p, d_src,
+                     d_dst, (const int64_t*)d_offs, B, d_nu2, ctx->dpar);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+/* ---- ordered device-to-host copies: the copy waits (on the copy stream / in the calling thread) for an event
+ * recorded on the compute stream, not for the whole stream -- finished columns leave while later passes run, and
+ * the thread that queues the passes never blocks. */
+int mbpls_hip_event_record(mbpls_ctx* ctx, void** event) {
+  MB_ARG(ctx && event, "NULL argument");
+  hipEvent_t e = nullptr;
+  if (!ctx->copy_stream) MB_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  MB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  MB_HIP(hipEventRecord(e, ctx->stream));
+  *event = (void*)e;
+  return MBPLS_OK;
+}
+
+int mbpls_hip_memcpy_d2h_after(mbpls_ctx* ctx, void* event, void* h_dst, const void* d_src, size_t bytes) {
+  MB_ARG(ctx && event, "NULL argument");
+  MB_HIP(hipSetDevice(ctx->device));   // called from a helper thread (the current device is per thread)
+  MB_HIP(hipEventSynchronize((hipEvent_t)event));
+  if (bytes == 0) return MBPLS_OK;
+  MB_ARG(h_dst && d_src && ctx->copy_stream, "NULL argument");
+  MB_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+  MB_HIP(hipStreamSynchronize(ctx->copy_stream));
+  return MBPLS_OK;
+}
+
+int mbpls_hip_event_destroy(mbpls_ctx* ctx, void* event) {
+  MB_ARG(ctx, "ctx is NULL");
+  if (event) MB_HIP(hipEventDestroy((hipEvent_t)event));
+  return MBPLS_OK;
+}
+
+}  // extern "C"

@@ -365,7 +365,14 @@ def test_medium_vs_oracle(gpu_required, method, n, p, q, K, blocks):
     w = util.compare(got, rflat, TOL, what=f"{method} n={n} p={p}")
     assert w < 1e-8, w
     if method == "NIPALS" and q == 1:
-        assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K
+        assert ref.nipals_iterations_ == [2] * K
+        # Lazy deflation (K < 39) applies X_k = X_0 - sum ts_i p_i^T algebraically: its rounding is relative to X_0, not
+        # to the (much smaller) deflated X_k, so deep components can miss ||ts_old - ts|| <= 1e-14 by a hair on the
+        # second iteration and take a third -- same numbers (asserted above), one more pass.
+        assert mdl.nipals_iterations_[:20] == [2] * 20
+        assert all(i in (2, 3) for i in mdl.nipals_iterations_), mdl.nipals_iterations_
+        if K >= 39:
+            assert mdl.nipals_iterations_ == [2] * K
 
 
 @pytest.mark.parametrize("p,c1,c2", [(70, 2, 2), (1001, 3, 1), (50000, 10, 10), (300001, 20, 7), (4097, 32, 32)])
@@ -548,7 +555,14 @@ def test_many_components(gpu_required, method, K, q, n, p):
     w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} K={K} q={q}")
     assert w < 1e-8, w
     if method == "NIPALS" and q == 1:
-        assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K
+        assert ref.nipals_iterations_ == [2] * K
+        # Lazy deflation (K < 39) applies X_k = X_0 - sum ts_i p_i^T algebraically: its rounding is relative to X_0, not
+        # to the (much smaller) deflated X_k, so deep components can miss ||ts_old - ts|| <= 1e-14 by a hair on the
+        # second iteration and take a third -- same numbers (asserted above), one more pass.
+        assert mdl.nipals_iterations_[:20] == [2] * 20
+        assert all(i in (2, 3) for i in mdl.nipals_iterations_), mdl.nipals_iterations_
+        if K >= 39:
+            assert mdl.nipals_iterations_ == [2] * K
 
 
 @pytest.mark.parametrize("gram", ["1", "0"])
