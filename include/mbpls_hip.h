@@ -348,6 +348,22 @@ int mbpls_hip_event_record(mbpls_ctx* ctx, void** event);
 int mbpls_hip_memcpy_d2h_after(mbpls_ctx* ctx, void* event, void* h_dst, const void* d_src, size_t bytes);
 int mbpls_hip_event_destroy(mbpls_ctx* ctx, void* event);
 
+/* ---- exchange step of the column-sharded fit: RCCL over xGMI, inside the C ABI ---------------------
+ * Feature columns are split over one process per GPU; every per-iteration quantity that is a sum over features (the
+ * exchange buffer of a pass: block scores t~ (n x B), ||w~_b||^2, ||p_b||^2, lazy-deflation sums; X W products; the
+ * K x K P^T W; the n x n association matrix of the KERNEL method) is summed over the ranks by ONE ncclAllReduce
+ * (float64, in place) enqueued on the context's stream -- between the chunk reduction of the pass and the step kernel
+ * that consumes it, no host synchronisation.  The reference has no counterpart (single process, numpy).
+ * Bootstrap: rank 0 calls mbpls_hip_comm_unique_id, ships the MBPLS_COMM_ID_BYTES bytes to the other ranks by any
+ * means (bench.py: torch.distributed's store), then every rank calls mbpls_hip_comm_init_rank (collective).
+ * librccl.so is loaded with dlopen on first use.                                                                    */
+#define MBPLS_COMM_ID_BYTES 128
+int mbpls_hip_comm_unique_id(void* id_out);
+int mbpls_hip_comm_init_rank(mbpls_ctx* ctx, int world_size, int rank, const void* id_in);
+int mbpls_hip_comm_info(mbpls_ctx* ctx, int* world_size, int* rank, int* rccl_version);
+int mbpls_hip_comm_destroy(mbpls_ctx* ctx);
+int mbpls_hip_allreduce(mbpls_ctx* ctx, double* d_buf, size_t count);   /* sum, in place, asynchronous */
+
 /* ---- end-of-fit algebra on p x K device arrays (any K; 32-column tiles inside), column-major ---
  * h_out (c1 x c2 row-major, HOST) = A^T B for p x c1 / p x c2 device arrays: P_^T W (mbpls.py:988,
  * :569, :737).  Deterministic two-stage reduction; synchronous (the result is on the host on return). */

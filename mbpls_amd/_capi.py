@@ -15,11 +15,26 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmbpls_hip.so")
 
 ROW_MAJOR, COL_MAJOR = 0, 1
+COMM_ID_BYTES = 128
 SCALE_FIT, SCALE_APPLY, SCALE_NONE = 0, 1, 2
 ABI_VERSION = 1
 
 _vp, _i64, _dbl, _int, _sz = C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
+
+
+
+class NipalsStep(C.Structure):
+    """``mbpls_nipals_step`` of include/mbpls_hip.h (device-resident NIPALS step)."""
+    _fields_ = [("n", _i64), ("nblocks", _int), ("q", _int), ("kc", _int), ("run", _int), ("nd", _int),
+                ("centre", _int), ("norm_kind", _int), ("tol", _dbl),
+                ("xchg", _vp), ("Y", _vp), ("Ts", _vp), ("Tsc", _vp), ("U", _vp), ("V", _vp), ("Tb", _vp),
+                ("scal", _vp), ("ssq_x", _vp), ("iters", _vp), ("u_cur", _vp), ("ts_old", _vp), ("vpass", _vp),
+                ("tspass", _vp), ("cu", _vp), ("ce", _vp), ("par", _vp)]
+
+
+STEP_MAX_BLOCKS = 16
+STEP_MAX_RESPONSES = 16
 
 # name -> (restype, argtypes); must list every symbol of include/mbpls_hip.h
 SIGNATURES = {
@@ -72,6 +87,17 @@ SIGNATURES = {
     "mbpls_hip_nan_deflate_sweep": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_x_w_nan": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _int, _vp, _i64]),
     "mbpls_hip_gram": (_int, [_vp, _vp, _i64]),
+    "mbpls_hip_comm_unique_id": (_int, [_vp]),
+    "mbpls_hip_comm_init_rank": (_int, [_vp, _int, _int, _vp]),
+    "mbpls_hip_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
+    "mbpls_hip_comm_destroy": (_int, [_vp]),
+    "mbpls_hip_allreduce": (_int, [_vp, _vp, _sz]),
+    "mbpls_hip_nipals_step": (_int, [_vp, C.POINTER(NipalsStep)]),
+    "mbpls_hip_set_pass_params": (_int, [_vp, _vp]),
+    "mbpls_hip_block_unit_col": (_int, [_vp, _vp, _vp, _vp]),
+    "mbpls_hip_event_record": (_int, [_vp, _pp]),
+    "mbpls_hip_memcpy_d2h_after": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "mbpls_hip_event_destroy": (_int, [_vp, _vp]),
     "mbpls_hip_cross_product": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp]),
     "mbpls_hip_right_multiply": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _int, _vp, _i64]),
 }

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmbpls_hip.so")
-SOURCES = ["ctx.hip", "colpass.hip", "colpass_nan.hip", "colpass_long.hip", "gemv.hip", "gram.hip", "gen.hip", "small.hip", "xtv_mfma.hip", "xw_mfma.hip", "nipals_step.hip", "axpy_cols.hip", "resident.hip"]
+SOURCES = ["ctx.hip", "colpass.hip", "colpass_nan.hip", "colpass_long.hip", "gemv.hip", "gram.hip", "gen.hip", "small.hip", "xtv_mfma.hip", "xw_mfma.hip", "nipals_step.hip", "axpy_cols.hip", "resident.hip", "rccl_comm.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
@@ -59,7 +59,7 @@ def build(force=False, save_temps=False, verbose=True):
                 raise RuntimeError(f"hipcc failed on {name}")
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             sys.stderr.write(r.stderr)

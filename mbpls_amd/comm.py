@@ -3,8 +3,9 @@
 Feature columns are split over ranks; every per-iteration quantity that is a sum over
 features (un-normalised block scores t~, ||w~_b||^2, ||p_b||^2, X-sized sums of squares,
 X W products, the Gram matrix) is all-reduced.  One process per GPU; the collective is
-``torch.distributed`` (backend "nccl" == RCCL over xGMI on ROCm, "gloo" for CPU tests).
-torch is plumbing here: it owns the exchange buffer and the communicator, nothing else.
+the C ABI's own RCCL communicator (``RcclComm``: ncclAllReduce on the context's stream, no host
+synchronisation), or ``torch.distributed`` (``TorchDistComm``: backend "nccl" == RCCL on ROCm, "gloo" for the
+CPU tests), where torch owns the exchange buffer and the communicator, nothing else.
 """
 from __future__ import annotations
 
@@ -90,6 +91,80 @@ class TorchDistComm:
             t = t.to(self.device)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy().reshape(a.shape)
+
+
+class RcclComm:
+    """All-reduce through the C ABI's own RCCL communicator (csrc/rccl_comm.hip): the collective is enqueued on the
+    context's stream, in place on library-owned device memory -- no torch tensor, no host synchronisation.  This is
+    what lets a column-sharded one-response fit run as ONE device queue (pass, all-reduce, step kernel, pass, ...).
+
+    ``bootstrap(payload)``: a callable that returns rank 0's ``payload`` (bytes) on every rank -- e.g. a broadcast
+    over torch.distributed's store, MPI, or a file.  ``RcclComm.from_torch`` builds one from an initialised
+    torch.distributed process group (any backend; only the 128-byte id goes through it)."""
+    is_distributed = True
+
+    def __init__(self, ctx, rank, world_size, bootstrap):
+        import ctypes as C
+        from . import _capi
+        self.ctx, self.rank, self.world_size = ctx, int(rank), int(world_size)
+        buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
+        if self.rank == 0:
+            _capi.check(ctx.lib.mbpls_hip_comm_unique_id(buf))
+        payload = bootstrap(bytes(buf.raw) if self.rank == 0 else None)
+        assert isinstance(payload, (bytes, bytearray)) and len(payload) == _capi.COMM_ID_BYTES
+        idbuf = C.create_string_buffer(bytes(payload), _capi.COMM_ID_BYTES)
+        _capi.check(ctx.lib.mbpls_hip_comm_init_rank(ctx.handle, self.world_size, self.rank, idbuf))
+        self._small = None
+
+    @classmethod
+    def from_torch(cls, ctx, group=None):
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def bootstrap(payload):
+            box = [payload]
+            dist.broadcast_object_list(box, src=0, group=group)
+            return box[0]
+
+        return cls(ctx, rank, world, bootstrap)
+
+    def info(self):
+        import ctypes as C
+        w, r, v = C.c_int(0), C.c_int(0), C.c_int(0)
+        from . import _capi
+        _capi.check(self.ctx.lib.mbpls_hip_comm_info(self.ctx.handle, C.byref(w), C.byref(r), C.byref(v)))
+        return dict(world_size=w.value, rank=r.value, rccl_version=v.value)
+
+    def close(self):
+        if self.ctx is not None and self.ctx.handle:
+            self.ctx.lib.mbpls_hip_comm_destroy(self.ctx.handle)
+        self.ctx = None
+
+    def exchange_buffer(self, ctx, count):
+        from ._capi import DeviceArray
+        return DeviceArray(ctx, (int(count),), zero=True)
+
+    def allreduce_device(self, buf):
+        from . import _capi
+        _capi.check(self.ctx.lib.mbpls_hip_allreduce(self.ctx.handle, buf.ptr, buf.size))
+        return buf
+
+    def allreduce_host(self, arr):
+        """small host arrays (block sizes, K x K cross products): staged through a device buffer"""
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        if a.size == 0:
+            return a
+        if self._small is None or self._small.size < a.size:
+            if self._small is not None:
+                self._small.free()
+            self._small = self.ctx.empty(max(a.size, 4096))
+        d = self._small
+        from . import _capi
+        _capi.check(self.ctx.lib.mbpls_hip_memcpy_h2d(self.ctx.handle, d.ptr, a.ctypes.data, a.nbytes))
+        _capi.check(self.ctx.lib.mbpls_hip_allreduce(self.ctx.handle, d.ptr, a.size))
+        out = np.empty_like(a)
+        _capi.check(self.ctx.lib.mbpls_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data, d.ptr, a.nbytes))
+        return out
 
 
 def shard_columns(block_sizes, rank, world_size):

@@ -228,6 +228,7 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
   if (!ctx) return MBPLS_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->rccl) (void)mbpls_hip_comm_destroy(ctx);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->small_m) (void)hipFree(ctx->small_m);

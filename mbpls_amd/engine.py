@@ -278,9 +278,10 @@ class HipEngine:
         return d
 
     # ------------------------------------------------------------------ hot path
-    def prepare(self, standardize, v=None, alpha=1.0, g_slot=None, mean=None, scale=None):
+    def prepare(self, standardize, v=None, alpha=1.0, g_slot=None, mean=None, scale=None, defer=False):
         """a1 (+ first sweep): standardise X (or just take its sums of squares) and optionally run the
-        first sweep of component 0 in the same pass.  Returns (ssq_x[B], t[n,B] or None, ssq_g[B] or None)."""
+        first sweep of component 0 in the same pass.  Returns (ssq_x[B], t[n,B] or None, ssq_g[B] or None).
+        defer=True only queues the pass (device-resident fit: the exchange buffer is consumed on the device)."""
         n, B = self.n, self.nblocks
         if standardize:
             self.mean = self.ctx.empty(self.p)
@@ -294,8 +295,8 @@ class HipEngine:
             mode = _capi.SCALE_NONE
         src = self._src if self._src is not None else self.X
         if self._implicit_ok(v, mean):
-            out = self._prepare_implicit(src, standardize, mode, v, alpha, g_slot)
-            if out is not None:
+            out = self._prepare_implicit(src, standardize, mode, v, alpha, g_slot, defer)
+            if out is not None or defer:
                 return out
         self._working_copy()
         dv = self._put_vec(0, v) if v is not None else None
@@ -319,6 +320,8 @@ class HipEngine:
                                   self._slot_col(g_slot), self._xptr(0) if v is not None else None,
                                   self._xptr(n * B) if v is not None else None, rowmask=dm, n_eff=n_eff)
         self._src = None
+        if defer:
+            return None
         self.run_deferred(2)        # the standardise pass is the longest of the fit
         t, g, _, x = self._finish_pass(v is not None, v is not None, False, True)
         if not np.all(np.isfinite(x)):
@@ -338,9 +341,10 @@ class HipEngine:
                 and self.n <= min(8192, getattr(self.ctx, "long_columns_from", 8192))
                 and os.environ.get("MBPLS_IMPLICIT_STD", "1") != "0")
 
-    def _prepare_implicit(self, src, standardize, mode, v, alpha, g_slot):
+    def _prepare_implicit(self, src, standardize, mode, v, alpha, g_slot, defer=False):
         """First pass of a fit that never writes X (lazy deflation + implicit standardisation): statistics and the
-        first sweep only.  Returns None when the data is too badly offset for raw-space dot products."""
+        first sweep only.  Returns None when the shifted one-pass variance would be too inaccurate (cannot happen for
+        n <= 8192, see IMPLICIT_STD_MAX_OFFSET; not looked at when the pass is only queued, defer=True)."""
         n, B = self.n, self.nblocks
         if standardize:
             self.rs, self.r2 = self.ctx.empty(self.p), self.ctx.empty(self.p)
@@ -348,6 +352,12 @@ class HipEngine:
         src.standardize_stats_sweep(mode, self.mean, self.scale, self.rs, self.r2, self._xptr(n * B + 2 * B),
                                     self._xptr(n * B + 3 * B), dv, alpha, self._slot_col(g_slot), self._xptr(0),
                                     self._xptr(n * B))
+        if defer:
+            self.X, self._src = src, None
+            self._istd = bool(standardize)
+            if self._istd:
+                self.slot("P~raw", self._lazy_K)
+            return None
         self.run_deferred(2)
         t, g, _, x = self._finish_pass(True, True, False, True, nd=1)
         if not np.all(np.isfinite(x)):
@@ -467,6 +477,153 @@ class HipEngine:
             self.run_deferred()
         t, g, p, _ = self._finish_pass(v is not None, v is not None, True, False)
         return p, t, g
+
+    # ------------------------------------------------------------------ device-resident NIPALS (one response)
+    def resident_supported(self, q, K, norm_kind):
+        """The whole fit can be queued without a host round trip: lazy deflation (X is never written, so a wrong
+        speculation costs nothing but the skipped launches), one response, shapes the step kernel covers."""
+        import os
+        return (self._lazy_pslot is not None and not self.sparse and norm_kind is not None and q == 1
+                and self.nblocks <= _capi.STEP_MAX_BLOCKS and K < self.KD - 1
+                and os.environ.get("MBPLS_RESIDENT", "1") != "0")
+
+    def _res_sweep(self, k, g_slot):
+        """sweep with the device-resident vector / coefficients (written by the step kernel); alpha comes from par"""
+        n, B = self.n, self.nblocks
+        dv, g = self._vec_n[0], self._slot_col(g_slot)
+        if self._istd:
+            self.X.sweep_lazy(dv, 1.0, g, self._xptr(0), self._xptr(n * B), self.slots["P~raw"], self.p, k,
+                              self._coef[0], self._xptr(n * B + 3 * B), r2=self.r2, mean=self.mean)
+            self._scale_col(g_slot, g_slot)
+        elif k:
+            self.X.sweep_lazy(dv, 1.0, g, self._xptr(0), self._xptr(n * B), self.slots[self._lazy_pslot], self.p, k,
+                              self._coef[0], self._xptr(n * B + 3 * B))
+        else:
+            self.X.sweep(dv, 1.0, g, self._xptr(0), self._xptr(n * B))
+
+    def _res_loadings(self, k, last, g_slot):
+        """loadings of component k (+ lazy deflation + first sweep of component k+1 unless last), device-resident
+        operands"""
+        n, B = self.n, self.nblocks
+        pslot = self._lazy_pslot
+        P = self.slots["P~raw"] if self._istd else self.slots[pslot]
+        dv = None if last else self._vec_n[0]
+        self.X.loadings_sweep_lazy(self._vec_n[1], 1.0, P.col(k), self._xptr(n * B + B), dv, 1.0,
+                                   None if last else self._slot_col(g_slot), None if last else self._xptr(0),
+                                   None if last else self._xptr(n * B), P, self.p, k, self._coef[0], self._coef[1],
+                                   self._xptr(n * B + 3 * B), r2=self.r2 if self._istd else None,
+                                   mean=self.mean if self._istd else None)
+        if self._istd:
+            self._scale_col(("P~raw", k), (pslot, k))
+            if not last:
+                self._scale_col(g_slot, g_slot)
+
+    def nipals_resident(self, Y, K, norm_kind, tol, wslot, Wn_h, W_h, P_h):
+        """Queue a complete one-response NIPALS fit (mbpls.py:836-969 for every component) on the device: the first
+        pass must already be queued (prepare(..., defer=True)).  Per component: step, sweep, step, loadings (+ lazy
+        deflation + next first sweep); the step kernel (csrc/resident.hip) does the n x B algebra and the stop test
+        between the passes, RCCL all-reduces the exchange buffer on the same stream when the columns are sharded.
+        Finished columns of W~, W and P are copied to the host by a helper thread behind events.  The queue is
+        speculative (two iterations per component, which is what one response takes); returns the results of the
+        components that converged that way (``k_done`` of them -- the caller resumes from there when k_done < K)."""
+        import queue
+        import threading
+        n, B, q = self.n, self.nblocks, Y.shape[1]
+        ctx, lib = self.ctx, self.ctx.lib
+        pslot = self._lazy_pslot
+        Ts = ctx.empty((n, K))
+        bufs = dict(Y=ctx.from_host(np.asfortranarray(Y)), Ts=Ts, Tsc=ctx.empty((n, K)) if self._istd else Ts,
+                    U=ctx.empty((n, K)), V=ctx.empty((q, K)), Tb=ctx.empty(n * B * K), scal=ctx.empty(K * 4 * B, zero=True),
+                    ssqx=ctx.empty(B), iters=ctx.empty(K, zero=True), u_cur=ctx.from_host(np.ascontiguousarray(Y[:, 0])),
+                    ts_old=ctx.empty(n, zero=True), par=ctx.from_host(np.zeros(8)))
+        self.slot("Wblk", K)
+        st = _capi.NipalsStep(n=n, nblocks=B, q=q, centre=int(self._istd), norm_kind=int(norm_kind), tol=float(tol),
+                              xchg=self._xchg.ptr, Y=bufs["Y"].ptr, Ts=Ts.ptr, Tsc=bufs["Tsc"].ptr, U=bufs["U"].ptr,
+                              V=bufs["V"].ptr, Tb=bufs["Tb"].ptr, scal=bufs["scal"].ptr, ssq_x=bufs["ssqx"].ptr,
+                              iters=bufs["iters"].ptr, u_cur=bufs["u_cur"].ptr, ts_old=bufs["ts_old"].ptr,
+                              vpass=self._vec_n[0].ptr, tspass=self._vec_n[1].ptr, cu=self._coef[0].ptr,
+                              ce=self._coef[1].ptr, par=bufs["par"].ptr)
+
+        def step(kc, run, nd):
+            if self.comm.is_distributed:
+                self.comm.allreduce_device(self._xchg)
+            st.kc, st.run, st.nd = kc, run, nd
+            _capi.check(lib.mbpls_hip_nipals_step(ctx.handle, st))
+
+        jobs, errors = queue.Queue(), []
+
+        def copier():
+            while True:
+                job = jobs.get()
+                if job is None:
+                    return
+                ev, copies = job
+                try:
+                    for i, (dst, src) in enumerate(copies):
+                        _capi.check(lib.mbpls_hip_memcpy_d2h_after(ctx.handle, ev, dst.ctypes.data, src, dst.nbytes))
+                except BaseException as e:      # re-raised on the calling thread
+                    errors.append(e)
+                finally:
+                    lib.mbpls_hip_event_destroy(ctx.handle, ev)
+
+        def stream_out(copies):
+            ev = _capi._vp()
+            _capi.check(lib.mbpls_hip_event_record(ctx.handle, _capi.C.byref(ev)))
+            jobs.put((ev, copies))
+
+        def col(arr, k):
+            c = arr[:, k]
+            assert c.flags.c_contiguous
+            return c
+
+        th = threading.Thread(target=copier, daemon=True)
+        th.start()
+        Wn, Wb, Pm = self.slots[wslot], self.slots["Wblk"], self.slots[pslot]
+        p8 = 8 * self.p
+        _capi.check(lib.mbpls_hip_set_pass_params(ctx.handle, bufs["par"].ptr))
+        try:
+            with self._timed("queue_passes"):
+                step(0, 1, 0)
+                for k in range(K):
+                    last = k == K - 1
+                    self._res_sweep(k, (wslot, k))                   # second iteration (:856, :875)
+                    step(k, 2, k)
+                    # w_b = w~_b / ||w~_b|| (:860) with the norms the step just recorded
+                    _capi.check(lib.mbpls_hip_block_unit_col(self.X.handle, Wn.ptr + p8 * k, Wb.ptr + p8 * k,
+                                                             bufs["scal"].ptr + 8 * 4 * B * k))
+                    stream_out([(col(Wn_h, k), Wn.ptr + p8 * k), (col(W_h, k), Wb.ptr + p8 * k)]
+                               + ([(col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []))
+                    self._res_loadings(k, last, None if last else (wslot, k + 1))   # (:928, :969) + next first sweep
+                    if not last:
+                        step(k + 1, 1, k + 1)
+                    elif self.comm.is_distributed:
+                        self.comm.allreduce_device(self._xchg)
+                stream_out([(col(P_h, K - 1), Pm.ptr + p8 * (K - 1))])
+            self.run_deferred(all_of_it=True)          # host chores while the GPU works through the queue
+            with self._timed("wait_kernel+d2h_small"):
+                par = bufs["par"].get()
+        finally:
+            lib.mbpls_hip_set_pass_params(ctx.handle, None)
+            jobs.put(None)
+            th.join()
+        if errors:
+            raise errors[0]
+        k_done = K if par[2] == 0.0 else int(par[3])
+        h = self._xchg.get()
+        scal = bufs["scal"].get().reshape(K, 4, B)
+        if k_done == K:
+            scal[K - 1, 2] = h[n * B + B:n * B + 2 * B]     # ||p_b||^2 of the last (loadings-only) pass
+        out = dict(k_done=k_done, Ts=Ts.get(), U=bufs["U"].get(), V=bufs["V"].get(),
+                   Tb=bufs["Tb"].get().reshape(K, B, n), scal=scal, ssq_x=bufs["ssqx"].get(),
+                   iters=bufs["iters"].get(), last_diff=float(par[4]))
+        if k_done < K:
+            # hand the lazy-deflation state to the host-driven loop
+            Tc = bufs["Tsc"].get()
+            self._lazy_ts = [np.ascontiguousarray(Tc[:, i]) for i in range(k_done)]
+        for key, b in bufs.items():
+            if key != "Tsc" or self._istd:
+                b.free()
+        return out
 
     def xt_v(self, V, alpha, slot, k0=0, want_ssq=False):
         """slot[:, k0:k0+c] = alpha X^T V  (V: n x c host).  Optional per-block column norms^2 (B x c)."""

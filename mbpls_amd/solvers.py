@@ -240,19 +240,52 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
         # responses iterate 50-500 times per component (paper protocol, q = 10): every sweep then pays the lazy
         # correction (~6 %), far more than one rewrite of X per component (measured 7.05 s -> 6.72 s).
         eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
-    varxb, t_raw, ssq = eng.prepare(standardize, v=u0, alpha=alpha0, g_slot=("Wn", 0))
-    varx = varxb.sum()
-    vary = (Y ** 2).sum()
+    import os
+    q1_fixed_point = (q == 1 and os.environ.get("MBPLS_NIPALS_Q1_FIXED_POINT", "0") == "1" and not getattr(eng, "sparse", False)
+                      and hasattr(eng, "right_mul"))
     Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
     T = [np.empty((n, K)) for _ in range(B)]
     nu_all = np.empty((B, K))
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
     # host copies of the p x K attributes, filled column by column while later passes run on the GPU
     Wn_h, W_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
-    import os
-    q1_fixed_point = (q == 1 and os.environ.get("MBPLS_NIPALS_Q1_FIXED_POINT", "0") == "1" and not getattr(eng, "sparse", False)
-                      and hasattr(eng, "right_mul"))
-    for k in range(K):
+    vary = (Y ** 2).sum()
+    # norm of the n x 1 difference as numpy's MATRIX norm (:887), see _fit_nipals_grams
+    _norm(np.zeros((2, 1)), norm)
+    kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
+    k_start = 0
+    if (not q1_fixed_point and max_iter >= 2 and hasattr(eng, "resident_supported")
+            and eng.resident_supported(q, K, kind)):
+        # One response: the whole fit is queued on the device (two iterations per component -- what one response takes),
+        # the host reads the results once.  Components the speculation did not hold for are resumed below.
+        eng.prepare(standardize, v=u0, alpha=alpha0, g_slot=("Wn", 0), defer=True)
+        out = eng.nipals_resident(Y, K, kind, max_tol, "Wn", Wn_h, W_h, P_h)
+        varxb = out["ssq_x"]                                # summed over the column shards on the device already
+        if not np.all(np.isfinite(varxb)):
+            raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
+        varx = varxb.sum()
+        k_start = out["k_done"]
+        for k in range(k_start):
+            ts, v = out["Ts"][:, k:k + 1], out["V"][:, k:k + 1]
+            Ts[:, k:k + 1] = ts; U[:, k] = out["U"][:, k]; V[:, k:k + 1] = v
+            A[:, k] = out["scal"][k, 1]
+            nu_all[:, k] = np.sqrt(out["scal"][k, 0])
+            for b in range(B):
+                T[b][:, k] = out["Tb"][k, b]
+            iters.append(int(out["iters"][k]))
+            if calc_all:                                    # (:932-964), analytic (ts^T ts)(p^T p)
+                ssq_p = out["scal"][k, 2]
+                tt = ts.T.dot(ts).item()
+                evx.append(tt * ssq_p.sum() / varx)
+                evy.append(tt * v.T.dot(v).item() / vary)
+                evxb[:, k] = tt * ssq_p / varxb
+                Acorr[:, k] = _bip_corrected(A[:, k], sizes)
+        if k_start < K:
+            t_raw, ssq = eng.sweep(u0, alpha0, ("Wn", k_start))     # first sweep of the component to resume with
+    else:
+        varxb, t_raw, ssq = eng.prepare(standardize, v=u0, alpha=alpha0, g_slot=("Wn", 0))
+        varx = varxb.sum()
+    for k in range(k_start, K):
         u = u0
         diff, run, ts_old = 1.0, 1, None
         while diff > max_tol:

@@ -26,8 +26,16 @@ def main():
     dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     rank, world = dist.get_rank(), dist.get_world_size()
     mbpls_amd.set_device(local_rank)
-    comm = mbpls_amd.TorchDistComm(device=f"cuda:{local_rank}")
-    X, Y = orc.make_latent(512, 6000, 2, r=8, seed=5)
+    which = os.environ.get("MBPLS_TEST_COMM", "torch")
+    if which == "rccl":
+        # the C ABI's own communicator: ncclAllReduce on the context's stream, bootstrapped through torch's store
+        comm = mbpls_amd.RcclComm.from_torch(mbpls_amd.get_context())
+        info = comm.info()
+        assert info["world_size"] == world and info["rank"] == rank and info["rccl_version"] > 0, info
+    else:
+        comm = mbpls_amd.TorchDistComm(device=f"cuda:{local_rank}")
+    q = int(os.environ.get("MBPLS_TEST_Q", "2"))
+    X, Y = orc.make_latent(512, 6000, q, r=8, seed=5)
     sizes = [1500, 2500, 2000]
     full = list(np.split(X, np.cumsum(sizes)[:-1], axis=1))
     ranges = shard_columns(sizes, rank, world)
@@ -42,7 +50,9 @@ def main():
         for b, (lo, hi) in enumerate(ranges):
             assert util.relerr(mdl.P_[b] * s, ref.P_[b][lo:hi]) < 1e-8, method
         assert util.relerr(yh, orc.predict(ref, full)) < 1e-8, method
-    print(f"rank {rank}/{world}: RCCL-sharded fit == oracle", flush=True)
+        if method == "NIPALS" and q == 1:
+            assert mdl.nipals_iterations_ == ref.nipals_iterations_
+    print(f"rank {rank}/{world}: RCCL-sharded fit == oracle ({which}, q={q})", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -565,6 +565,75 @@ def test_many_components(gpu_required, method, K, q, n, p):
             assert mdl.nipals_iterations_ == [2] * K
 
 
+@pytest.mark.parametrize("blocks,standardize,norm,implicit", [(1, True, 2, "1"), (3, True, 2, "1"), (3, False, 1, "1"),
+                                                              (2, True, np.inf, "0"), (1, True, -np.inf, "1"),
+                                                              (16, True, "fro", "1")])
+def test_device_resident_nipals(gpu_required, monkeypatch, blocks, standardize, norm, implicit):
+    """One response: the whole NIPALS fit is queued on the device (csrc/resident.hip does the n x B algebra and the
+    stop test between the passes; no host round trip per pass).  Same numbers as the host-driven loop
+    (MBPLS_RESIDENT=0) and as the oracle, for every variant of the passes (implicit / stored standardisation, no
+    standardisation, several blocks, every norm of the stop rule)."""
+    from mbpls_amd import MBPLS
+    from mbpls_amd.engine import HipEngine
+    monkeypatch.setenv("MBPLS_IMPLICIT_STD", implicit)
+    K = 6
+    X, Y = orc.make_latent(900, 4800, 1, seed=31 + blocks)
+    Xs = [np.ascontiguousarray(b) for b in np.array_split(X, blocks, axis=1)] if blocks > 1 else X
+    ref = orc.fit(Xs, Y, n_components=K, standardize=standardize, nipals_convergence_norm=norm)
+    calls = []
+    real = HipEngine.nipals_resident
+
+    def spy(self, *a, **k):
+        out = real(self, *a, **k)
+        calls.append(out["k_done"])
+        return out
+
+    monkeypatch.setattr(HipEngine, "nipals_resident", spy)
+    mdl = MBPLS(n_components=K, standardize=standardize, nipals_convergence_norm=norm).fit(Xs, Y)
+    assert calls == [K]                                      # the whole fit ran on the device queue
+    assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K
+    assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="resident") < 1e-9
+    monkeypatch.setenv("MBPLS_RESIDENT", "0")
+    calls.clear()
+    m0 = MBPLS(n_components=K, standardize=standardize, nipals_convergence_norm=norm).fit(Xs, Y)
+    assert calls == []
+    assert util.compare(util.model_to_flat(mdl), util.model_to_flat(m0), TOL, what="resident vs host loop") < 1e-11
+    assert util.relerr(mdl.predict(Xs), orc.predict(ref, Xs)) < 1e-9
+
+
+@pytest.mark.parametrize("resume_at", [0, 3])
+def test_device_resident_nipals_resumes_on_the_host(gpu_required, monkeypatch, resume_at):
+    """The device queue is speculative (two iterations per component).  When a component does not meet the stop rule
+    on its second iteration the queued launches behind it turn into no-ops and the host-driven loop resumes at that
+    component: forced here at component 0 (impossible tolerance on the device) and emulated at component 3."""
+    from mbpls_amd import MBPLS
+    from mbpls_amd.engine import HipEngine
+    K = 6
+    X, Y = orc.make_latent(700, 3000, 1, seed=8)
+    Xs = [np.ascontiguousarray(X[:, :1300]), np.ascontiguousarray(X[:, 1300:])]
+    ref = orc.fit(Xs, Y, n_components=K)
+    real = HipEngine.nipals_resident
+    seen = []
+
+    def wrapped(self, Y_, K_, kind, tol, *a):
+        if resume_at == 0:
+            out = real(self, Y_, K_, kind, -1.0, *a)         # ||ts_old - ts|| <= -1 never holds
+        else:
+            out = real(self, Y_, K_, kind, tol, *a)
+            assert out["k_done"] == K_
+            out["k_done"] = resume_at                        # pretend component 3 needed a third iteration
+            cols = [np.ascontiguousarray(out["Ts"][:, i]) for i in range(resume_at)]
+            self._lazy_ts = [c - c.mean() for c in cols] if self._istd else cols
+        seen.append(out["k_done"])
+        return out
+
+    monkeypatch.setattr(HipEngine, "nipals_resident", wrapped)
+    mdl = MBPLS(n_components=K).fit(Xs, Y)
+    assert seen == [resume_at]
+    assert mdl.nipals_iterations_ == [2] * K
+    assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="resumed") < 1e-9
+
+
 @pytest.mark.parametrize("gram", ["1", "0"])
 def test_multi_response_nipals_on_association_matrices(gpu_required, monkeypatch, gram):
     """Several responses: the NIPALS inner loop runs on the per-block association matrices A_b = X_b X_b^T

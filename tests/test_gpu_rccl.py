@@ -10,13 +10,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_rccl_sharded_fit(gpu_required):
+@pytest.mark.parametrize("which,q", [("torch", 2), ("torch", 1), ("rccl", 2), ("rccl", 1)])
+def test_rccl_sharded_fit(gpu_required, which, q):
+    """All four methods column-sharded over the visible GPUs, the exchange through torch.distributed ("nccl" = RCCL)
+    or through the C ABI's own RCCL communicator (ncclAllReduce on the context's stream; with one response the whole
+    NIPALS fit is then a single device queue).  One GPU here: world_size 1, every piece of plumbing is the one the
+    8-GPU run uses."""
     from mbpls_amd import _capi
     n = max(1, min(_capi.device_count(), 2))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MBPLS_TEST_COMM=which, MBPLS_TEST_Q=str(q))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_nccl_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
