@@ -1,25 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- MBPLS.fit() on device-resident synthetic wide matrices (BASELINE.json metric).
+"""bench.py -- MBPLS.fit() on device-resident synthetic wide matrices (BASELINE.json metric:
+"fit() wall-time + achieved HBM GB/s, n=4096 p=1e6 K=10; 1/2/4/8 GPU").
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one complete ``MBPLS(n_components=10, method='NIPALS').fit(X, Y)`` on a matrix that is
-already resident in HBM (feature-major): standardise + all components + fetching the fitted
-attributes to the host.  X is generated on the device (planted latent structure) and is
-NOT modified by fit (copy=True -> the standardise pass writes a working copy), so every step does
-identical work.
+One "step" = one complete ``MBPLS(n_components=10, method='NIPALS').fit(X, Y)`` on a matrix that is already
+resident in HBM (feature-major): statistics + all components + the fitted attributes fetched to the host.
+X is generated on the device (planted latent structure), is NOT modified by fit (copy=True; with one
+response the fit never writes X at all), so every step does identical work.
 
-N = 1 : BASELINE config[1]  single-block NIPALS n=4096 p=1,000,000 K=10 float64.
-N > 1 : BASELINE config[4]  multiblock (4 blocks) NIPALS, n=4096, p = N x 1,000,000, feature columns of
-        every block split evenly over the ranks (weak scaling: 32.8 GB of X per GPU), one RCCL
-        all-reduce of [t~ (n x B), ||w~_b||^2] per NIPALS iteration via torch.distributed.
+N = 1 : BASELINE config[1]  single-block NIPALS n=4096 p=1,000,000 K=10 q=1 float64.
+N > 1 : BASELINE config[4]  multiblock (4 blocks) NIPALS, n=4096, p = N x 1,000,000: the feature columns of every
+        block are split evenly over the ranks (weak scaling, 32.8 GB of X per GPU), one RCCL all-reduce of the
+        exchange buffer [t~ (n x B), ||w~_b||^2, ...] per pass, enqueued on the kernels' stream by the C ABI's own
+        communicator (mbpls_hip_allreduce).  Before timing every rank checks a small sharded fit against the same fit
+        done unsharded on its own GPU and exits non-zero on a mismatch; the strong-scaling figure (config[1] split
+        over the N GPUs) is reported beside the weak-scaling one.
 
-value  = reference-algorithm X traffic of the fit / wall time  [GB/s], whole job:
-         units = sum_k (2 I_k + 3) + 1 (varx) + 3 (StandardScaler passes), 1 unit = 8 n p bytes
-         (SURVEY 8d "algorithmic bytes per fit"; I_k = NIPALS iterations actually run).  The fused
-         HIP path moves fewer bytes than that (reported as fused_units); the per-kernel roofline
-         uses the kernel's own algorithmic bytes.
+value = ACHIEVED HBM traffic of the whole job / wall time [GB/s]: the X bytes the kernels of one fit really move
+        (sum of their algorithmic bytes, 8np per read-only pass -- PMC-measured traffic is 1.003x that,
+        profiles/) x ranks / time per fit.  fit_wall_s and fits_per_s are printed beside it; the reference
+        algorithm's un-fused byte count ("effective" GB/s) is an extra key, never `value`.
 """
 import argparse
 import json
@@ -32,7 +34,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E (MI355X_MICROARCH.md); the guide's measured copy ceiling is ~6290 GB/s
 
 
 def planted(n, q, r, seed, decay=0.85, noise_y=0.5):
@@ -43,31 +45,48 @@ def planted(n, q, r, seed, decay=0.85, noise_y=0.5):
     return T * decay ** np.arange(r), Y
 
 
+def fill_blocks(ctx, X, dT, r, offs, rank, world, pb_global):
+    """rank `rank` owns columns [rank*pb_loc, (rank+1)*pb_loc) of each global block"""
+    from mbpls_amd import DeviceMatrix
+    for b in range(len(offs) - 1):
+        w = offs[b + 1] - offs[b]
+        view = DeviceMatrix(ctx, X.n, w, None, storage=X.data_ptr + 8 * X.ld * offs[b])
+        view.fill_latent(dT, r, 0.5, 1234, b * pb_global + rank * w)
+        view.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--p", type=int, default=1_000_000, help="feature columns PER GPU")
     ap.add_argument("--K", type=int, default=10)
     ap.add_argument("--q", type=int, default=1)
     ap.add_argument("--method", default="NIPALS")
     ap.add_argument("--dist", action="store_true",
-                    help="use the torch.distributed/RCCL exchange path and the N>1 block layout even at world size 1")
-    ap.add_argument("--cpu-cols", type=int, default=65536, help="columns of the CPU-baseline sample (0 = skip)")
+                    help="use the sharded exchange path and the N>1 block layout even at world size 1")
+    ap.add_argument("--comm", default=os.environ.get("MBPLS_BENCH_COMM", "rccl"), choices=["rccl", "torch"],
+                    help="N>1 exchange: the C ABI's RCCL communicator (default) or torch.distributed all_reduce")
+    ap.add_argument("--cpu-cols", type=int, default=32768,
+                    help="largest column count of the CPU-baseline samples (three sizes: /4, /2, /1; 0 = skip)")
+    ap.add_argument("--e2e-cols", type=int, default=-1,
+                    help="columns of the end-to-end (host numpy in) leg; -1 = all when host RAM allows, 0 = skip")
+    ap.add_argument("--no-extras", action="store_true", help="skip the explicit-deflation / fixed-point extras")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import mbpls_amd
     from mbpls_amd import MBPLS, DeviceMatrix
 
     dist = None
+    comm_info = None
+    shared_gpu = os.environ.get("MBPLS_BENCH_SHARED_GPU") == "1"
     if world > 1 or a.dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -78,7 +97,7 @@ def main():
         import torch
         import torch.distributed as dist
         torch.set_num_threads(1)
-        if os.environ.get("MBPLS_BENCH_SHARED_GPU") == "1":
+        if shared_gpu:
             # dry run of the N>1 code path on a single-GPU box: all ranks drive cuda:0, exchange host-staged
             # over gloo (RCCL refuses duplicate devices).  Not a measurement configuration.
             local_rank = 0
@@ -88,7 +107,15 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         mbpls_amd.set_device(local_rank)
-        mbpls_amd.set_comm(mbpls_amd.TorchDistComm(device=f"cuda:{local_rank}"))
+        ctx = mbpls_amd.get_context()
+        if shared_gpu or a.comm == "torch":
+            comm = mbpls_amd.TorchDistComm(device=f"cuda:{local_rank}")
+            comm_info = {"backend": "torch.distributed/" + str(dist.get_backend()), "world_size": comm.world_size}
+        else:
+            comm = mbpls_amd.RcclComm.from_torch(ctx)
+            comm_info = dict(comm.info(), backend="rccl (C ABI, mbpls_hip_allreduce on the kernels' stream)")
+            assert comm_info["world_size"] == world, comm_info
+        mbpls_amd.set_comm(comm)
     ctx = mbpls_amd.get_context()
 
     def barrier_sync():
@@ -100,24 +127,33 @@ def main():
             torch.cuda.synchronize()
         ctx.sync()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        import torch
+        dev = "cpu" if shared_gpu else f"cuda:{local_rank}"
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     n, p, K, q = a.n, a.p, a.K, a.q
     r = 32
     Ts, Y = planted(n, q, r, seed=0)
+    dT = ctx.from_host(Ts)
+
+    check = None
+    if dist is not None:
+        check = sharded_self_check(ctx, mbpls_amd, dT, Y, r, rank, world)      # exits non-zero on a mismatch
+
     # global matrix: world*p columns; N>1 = 4 equal blocks, every block split evenly over ranks
     B = 1 if dist is None else 4
     pb = p // B
     offs = [b * pb for b in range(B)] + [p]
     X = DeviceMatrix(ctx, n, p, offs)
-    dT = ctx.from_host(Ts)
     if dist is None:
         X.fill_latent(dT, r, 0.5, 1234, 0)
     else:
-        # rank r owns columns [r*pb_loc, (r+1)*pb_loc) of each global block (global block size world*pb)
-        from mbpls_amd import _capi
-        for b in range(B):
-            view = DeviceMatrix(ctx, n, offs[b + 1] - offs[b], None, storage=X.data_ptr + 8 * X.ld * offs[b])
-            view.fill_latent(dT, r, 0.5, 1234, (b * world + rank) * pb)
-            view.close()
+        fill_blocks(ctx, X, dT, r, offs, rank, world, world * pb)
     ctx.sync()
 
     mdl = MBPLS(n_components=K, method=a.method, standardize=True, calc_all=True, copy=True)
@@ -125,58 +161,49 @@ def main():
         mdl.fit(X, Y)
     ctx.profile(True)
     ctx.profile_reset()
+    per_fit = []
     barrier_sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        mdl.fit(X, Y)
+        t1 = time.perf_counter()
+        mdl.fit(X, Y)                      # returns with the fitted attributes on the host
+        per_fit.append(time.perf_counter() - t1)
     barrier_sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
     prof = ctx.profile_get()
     ctx.profile(False)
-    # Informational only, OUTSIDE the timed region and never part of `value`: the opt-in q=1 fixed-point mode
-    # (MBPLS_NIPALS_Q1_FIXED_POINT=1) that skips the provably redundant second NIPALS pass per component.
-    q1_opt = None
-    if q == 1 and a.method == "NIPALS":
-        os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "1"
-        try:
-            mdl.fit(X, Y)
-            barrier_sync()
-            t1 = time.perf_counter()
-            mdl.fit(X, Y)
-            barrier_sync()
-            q1_opt = {"fit_wall_s": round(time.perf_counter() - t1, 5), "nipals_iterations": list(mdl.nipals_iterations_),
-                      "note": "opt-in mode, default off, not used for value/roofline"}
-        finally:
-            os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0"
-            mdl.fit(X, Y)       # leave the estimator in its default state for the fields below
+    iters = list(getattr(mdl, "nipals_iterations_", [2] * K))
+    phases = {k: round(1e3 * v, 2) for k, v in getattr(mdl, "fit_timings_", {}).items()}
 
-    iters = getattr(mdl, "nipals_iterations_", [2] * K)
+    extras = {}
+    if not a.no_extras and a.method == "NIPALS" and q == 1:
+        extras = nipals_extras(ctx, mdl, X, Y, n, p, barrier_sync)
+    if dist is not None and not a.no_extras:
+        extras["allreduce"] = time_allreduce(ctx, mbpls_amd.get_comm(), n * B + 3 * B + B * 40)
+        extras["strong_scaling_c2"] = strong_scaling(ctx, mbpls_amd, dT, Y, r, rank, world, n, a.p, K, a.method,
+                                                     barrier_sync, max_over_ranks)
+
     ref_units = sum(2 * i + 3 for i in iters) + 1 + 3
     # X traffic the HIP path really generates per fit = sum of the kernels' algorithmic bytes (HIP-event
-    # profile of the timed region); with lazy deflation every pass after the standardisation is read-only
+    # profile of the timed region); with lazy deflation every pass is read-only
     fused_units = round(sum(v["bytes_per_launch"] * v["launches"] for v in prof.values()) / a.steps / (8.0 * n * p), 2)
     unit_bytes = 8.0 * n * p * world
     per_step = dt / a.steps
-    value = ref_units * unit_bytes / per_step / 1e9
+    achieved = fused_units * unit_bytes / per_step / 1e9
 
-    out = None
     if rank == 0:
         dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"]) if prof else (None, None)
         roof = None
         if dom[0]:
             k = dom[1]
-            traffic = pmc_traffic(dom[0], n, p)
+            traffic, src = pmc_traffic(dom[0], n, p)
             roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(k["GBps"], 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(k["GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "bytes_per_launch": k["bytes_per_launch"], "avg_ms": round(k["avg_ms"], 4),
-                    "launches": k["launches"]}
+                    "traffic_source": src, "bytes_per_launch": k["bytes_per_launch"], "avg_ms": round(k["avg_ms"], 4),
+                    "launches": k["launches"],
+                    "timing": "HIP events on the launch stream around every launch of the timed region"}
         out = {
-            "metric": "mbpls_fit_effective_hbm_GBps", "value": round(value, 1), "unit": "GB/s",
+            "metric": "mbpls_fit_achieved_hbm_GBps", "value": round(achieved, 1), "unit": "GB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(per_step * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (planted latent structure, generated on device)",
@@ -186,15 +213,26 @@ def main():
                                     f"feature columns sharded over {world} GPUs (BASELINE config[4])"),
                        "method": a.method, "standardize": True, "calc_all": True, "nipals_iterations": iters},
             "fit_wall_s": round(per_step, 5), "fits_per_s": round(1.0 / per_step, 4),
-            "ref_units_per_fit": ref_units, "fused_units_per_fit": fused_units,
-            "fused_hbm_GBps": round(fused_units * unit_bytes / per_step / 1e9, 1),
+            "fit_wall_s_median": round(float(np.median(per_fit)), 5),
+            "fit_wall_s_each": [round(t, 5) for t in per_fit],
+            "units_moved_per_fit": fused_units, "unit_bytes": unit_bytes,
+            "frac_of_hbm_peak_whole_fit": round(achieved / (HBM_PEAK_GBPS * world), 4),
+            "effective_GBps_reference_algorithm_bytes": round(ref_units * unit_bytes / per_step / 1e9, 1),
+            "ref_units_per_fit": ref_units,
             "roofline": roof,
             "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4), "GBps": round(v["GBps"], 1)}
                         for k, v in prof.items()},
-            "optional_q1_fixed_point": q1_opt,
+            "host_phases_ms_last_fit": phases,
+            "comm": comm_info, "sharded_self_check": check,
         }
+        out.update(extras)
+    if dist is None and a.e2e_cols != 0:
+        e2e = end_to_end(ctx, X, Y, n, p if a.e2e_cols < 0 else min(a.e2e_cols, p), K, a.method)
+        if rank == 0:
+            out["end_to_end_host_numpy"] = e2e
+    if rank == 0:
         if dist is None and a.cpu_cols > 0:
-            out["cpu_baseline"] = cpu_baseline(ctx, X, Y, n, min(a.cpu_cols, p), K, a.method)
+            out["cpu_baseline"] = cpu_baseline(ctx, X, Y, n, p, min(a.cpu_cols, p), K, a.method, per_step)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
@@ -204,25 +242,200 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel, n, p):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
-    separate runs, gfx950 x2 read correction) -- only when they were taken on this exact shape, else None."""
+# ------------------------------------------------------------------------------------------------ N > 1 helpers
+def sharded_self_check(ctx, mbpls_amd, dT, Y, r, rank, world):
+    """A small 3-block problem fitted (a) column-sharded over all ranks through the communicator and (b) unsharded on
+    this rank's own GPU: every rank compares its shard of (a) with (b).  Both are the product path -- this checks the
+    exchange, not the kernels.  Exits the process non-zero on a mismatch, before anything is timed."""
+    from mbpls_amd import MBPLS, DeviceMatrix, LocalComm
+    from mbpls_amd.comm import shard_columns
+    n = Y.shape[0]
+    sizes = [3000 * world, 2000 * world + 3, 4000 * world + 1]       # ragged: the shards differ in width
+    goffs = np.concatenate(([0], np.cumsum(sizes)))
+    full = DeviceMatrix(ctx, n, int(goffs[-1]), [int(o) for o in goffs])
+    full.fill_latent(dT, r, 0.5, 99, 0)
+    ranges = shard_columns(sizes, rank, world)
+    loffs = np.concatenate(([0], np.cumsum([hi - lo for lo, hi in ranges])))
+    local = DeviceMatrix(ctx, n, int(loffs[-1]), [int(o) for o in loffs])
+    for b, (lo, hi) in enumerate(ranges):
+        view = DeviceMatrix(ctx, n, hi - lo, None, storage=local.data_ptr + 8 * local.ld * int(loffs[b]))
+        view.fill_latent(dT, r, 0.5, 99, int(goffs[b]) + lo)
+        view.close()
+    ctx.sync()
+    worst = 0.0
+    comm = mbpls_amd.get_comm()
+    for method in ("NIPALS", "UNIPALS"):
+        sharded = MBPLS(n_components=4, method=method).fit(local, Y)
+        mbpls_amd.set_comm(LocalComm())
+        try:
+            ref = MBPLS(n_components=4, method=method).fit(full, Y)
+        finally:
+            mbpls_amd.set_comm(comm)
+        s = np.sign(np.sum(ref.Ts_ * sharded.Ts_, axis=0))
+        errs = [np.max(np.abs(sharded.Ts_ * s - ref.Ts_)) / np.max(np.abs(ref.Ts_))]
+        for b, (lo, hi) in enumerate(ranges):
+            errs.append(np.max(np.abs(sharded.P_[b] * s - ref.P_[b][lo:hi])) / np.max(np.abs(ref.P_[b])))
+        glob = np.concatenate([np.arange(int(goffs[b]) + lo, int(goffs[b]) + hi) for b, (lo, hi) in enumerate(ranges)])
+        errs.append(np.max(np.abs(sharded.beta_ - ref.beta_[glob])) / np.max(np.abs(ref.beta_)))
+        if method == "NIPALS" and sharded.nipals_iterations_ != ref.nipals_iterations_:
+            errs.append(1.0)
+        worst = max(worst, float(max(errs)))
+    full.close(); local.close()
+    ok = np.isfinite(worst) and worst < 1e-8
+    print(f"[bench] rank {rank}/{world}: sharded fit vs unsharded fit, worst rel. error {worst:.2e} "
+          f"({'ok' if ok else 'MISMATCH'})", file=sys.stderr, flush=True)
+    if not ok:
+        os._exit(3)
+    return {"worst_rel_err": worst, "methods": ["NIPALS", "UNIPALS"], "blocks": sizes}
+
+
+def time_allreduce(ctx, comm, count, reps=200):
+    """mean time of one all-reduce of the exchange buffer (the per-pass collective), back to back on the stream"""
+    buf = comm.exchange_buffer(ctx, count)
+    for _ in range(10):
+        comm.allreduce_device(buf)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        comm.allreduce_device(buf)
+    if hasattr(buf, "tensor"):
+        import torch
+        torch.cuda.synchronize()
+    ctx.sync()
+    us = (time.perf_counter() - t0) / reps * 1e6
+    if hasattr(buf, "free"):
+        buf.free()
+    return {"doubles": int(count), "mean_us": round(us, 1), "per_fit": "one per pass (21 per fit)"}
+
+
+def strong_scaling(ctx, mbpls_amd, dT, Y, r, rank, world, n, p_total, K, method, barrier_sync, max_over_ranks):
+    """BASELINE config[1] (ONE block of p_total columns) split over the ranks: the same problem as the 1-GPU line"""
+    from mbpls_amd import MBPLS, DeviceMatrix
+    from mbpls_amd.comm import shard_columns
+    (lo, hi), = shard_columns([p_total], rank, world)
+    Xs = DeviceMatrix(ctx, n, hi - lo, [0, hi - lo])
+    Xs.fill_latent(dT, r, 0.5, 1234, lo)
+    ctx.sync()
+    mdl = MBPLS(n_components=K, method=method)
+    for _ in range(2):
+        mdl.fit(Xs, Y)
+    barrier_sync()
+    t0 = time.perf_counter()
+    steps = 5
+    for _ in range(steps):
+        mdl.fit(Xs, Y)
+    barrier_sync()
+    dt = max_over_ranks(time.perf_counter() - t0) / steps
+    Xs.close()
+    return {"workload": f"single-block NIPALS n={n} p={p_total} K={K} split over {world} GPUs", "fit_wall_s": round(dt, 5),
+            "fits_per_s": round(1.0 / dt, 3), "nipals_iterations": list(getattr(mdl, "nipals_iterations_", []))}
+
+
+# ------------------------------------------------------------------------------------------------ extras (N = 1)
+def nipals_extras(ctx, mdl, X, Y, n, p, barrier_sync):
+    """Outside the timed region, never part of `value`:
+    * explicit deflation (MBPLS_DEFLATION=explicit): X is standardised into a working copy and rewritten in place by
+      every deflation -- the read+write deflation pass north_star sets its >= 60 % target on;
+    * the opt-in q=1 fixed-point mode (skips the provably redundant second NIPALS pass per component)."""
+    from mbpls_amd import MBPLS
+    out = {}
+    os.environ["MBPLS_DEFLATION"] = "explicit"
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_c2.json")) as f:
-            d = json.load(f)
-        if d["config"]["n"] == n and d["config"]["p"] == p:
-            return d["kernels"][kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+        m2 = MBPLS(n_components=mdl.n_components, method="NIPALS")
+        m2.fit(X, Y)
+        ctx.profile(True); ctx.profile_reset()
+        barrier_sync()
+        t1 = time.perf_counter()
+        m2.fit(X, Y)
+        barrier_sync()
+        wall = time.perf_counter() - t1
+        pr = ctx.profile_get(); ctx.profile(False)
+        d = pr.get("deflate_sweep")
+        out["explicit_deflation"] = {
+            "fit_wall_s": round(wall, 5),
+            "deflate_sweep_read_write": None if d is None else {
+                "avg_ms": round(d["avg_ms"], 4), "bytes_per_launch": d["bytes_per_launch"], "GBps": round(d["GBps"], 1),
+                "frac_of_hbm_peak": round(d["GBps"] / HBM_PEAK_GBPS, 4), "launches": d["launches"]},
+            "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4), "GBps": round(v["GBps"], 1)}
+                        for k, v in pr.items()},
+            "note": "loadings + in-place rank-1 deflation + next sweep, 16np bytes per launch (mbpls.py:928+:969+:856)"}
+    finally:
+        del os.environ["MBPLS_DEFLATION"]
+    os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "1"
+    try:
+        mdl.fit(X, Y)
+        barrier_sync()
+        t1 = time.perf_counter()
+        mdl.fit(X, Y)
+        barrier_sync()
+        out["optional_q1_fixed_point"] = {"fit_wall_s": round(time.perf_counter() - t1, 5),
+                                          "nipals_iterations": list(mdl.nipals_iterations_),
+                                          "note": "opt-in mode, default off, not used for value/roofline"}
+    finally:
+        os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0"
+        mdl.fit(X, Y)       # leave the estimator in its default state
+    return out
 
 
-def cpu_baseline(ctx, X, Y, n, cols, K, method):
-    """The oracle in faithful mode (= the reference's numpy op sequence, temporaries included) on a bounded
-    column sample of the SAME device-generated matrix; also checks the GPU fit of that sample against it."""
+def end_to_end(ctx, X, Y, n, cols, K, method):
+    """fit() from a HOST numpy array (C-order, what a user of the reference holds): chunked H2D with the
+    transpose to feature-major on the GPU, fit, attributes back on the host.  PCIe-inclusive, never `value`."""
+    from mbpls_amd import MBPLS
+    try:
+        avail = None
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable"):
+                    avail = int(line.split()[1]) * 1024
+        need = 8.0 * n * cols
+        if avail is not None and need * 1.5 > avail:
+            cols = int(avail / 1.5 / (8.0 * n)) // 1024 * 1024
+            if cols < 1024:
+                return {"skipped": "not enough host memory"}
+        t0 = time.perf_counter()
+        Xh = X.download(0, cols)                      # C-order n x cols host array (the generator's output)
+        t_down = time.perf_counter() - t0
+        m = MBPLS(n_components=K, method=method)
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            m.fit(Xh, Y)
+            times.append(time.perf_counter() - t0)
+        ph = {k: round(1e3 * v, 1) for k, v in m.fit_timings_.items()}
+        gb = 8.0 * n * cols / 1e9
+        return {"fit_wall_s": round(min(times), 4), "fit_wall_s_each": [round(t, 4) for t in times], "p": cols, "host_GB": round(gb, 2),
+                "includes": "H2D (chunked, pageable host memory) + GPU transpose to feature-major + fit + D2H of the attributes",
+                "upload_GBps": round(gb / (ph.get("load", 0.0) / 1e3), 1) if ph.get("load") else None,
+                "host_phases_ms": ph, "setup_download_s": round(t_down, 2)}
+    except MemoryError:
+        return {"skipped": "not enough host memory"}
+
+
+def pmc_traffic(kernel, n, p):
+    """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate
+    runs, gfx950 x2 read correction) -- taken on the builder's lease, not in this run -- and only when they were taken
+    on this exact shape, else None."""
+    for name in ("r02_pmc_traffic_c2.json", "r01_pmc_traffic_c2.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            if d["config"]["n"] == n and d["config"]["p"] == p:
+                return d["kernels"][kernel]["hbm_bytes_per_launch"], f"profiles/{name} (PMC passes of an earlier run of this command, not measured in this run)"
+        except Exception:
+            continue
+    return None, None
+
+
+def cpu_baseline(ctx, X, Y, n, p, cols, K, method, gpu_fit_s):
+    """BASELINE.md section 3 protocol on the GPU box's host cores: the oracle in FAITHFUL mode (= the reference's numpy
+    op sequence, n x p temporaries included) and in LEAN mode (the GPU's algorithm on the CPU) at three widths of the
+    SAME device-generated matrix, after one warm-up fit; a line fitted in p gives the labelled extrapolation to the
+    full width (the full size needs ~5x X of host RAM and ~4 minutes).  BLAS threads = the cgroup CPU quota.
+    Also checks the GPU fit of the largest sample against the faithful oracle."""
     from mbpls_amd import MBPLS
     from oracle import mbpls_oracle as orc
     from mbpls_amd.runtime import cpu_quota
+    sizes = sorted({max(1024, cols // 4), max(2048, cols // 2), cols})
     Xs = X.download(0, cols)
     thr = cpu_quota()      # CPUs this container may really use (cgroup quota), not the visible count
     try:
@@ -230,23 +443,47 @@ def cpu_baseline(ctx, X, Y, n, cols, K, method):
         limiter = threadpoolctl.threadpool_limits(limits=thr)
     except Exception:
         limiter = None
-    t0 = time.perf_counter()
-    ref = orc.fit(Xs, Y, n_components=K, method=method, standardize=True, calc_all=True, faithful=True)
-    t_cpu = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.restore_original_limits()
+    runs = []
+    ref = None
+    try:
+        orc.fit(np.ascontiguousarray(Xs[:, :sizes[0]]), Y, n_components=K, method=method, faithful=True)   # warm-up
+        for c in sizes:
+            Xc = np.ascontiguousarray(Xs[:, :c])
+            rec = {"p": c}
+            for mode, faithful in (("faithful", True), ("lean", False)):
+                t0 = time.perf_counter()
+                mdl = orc.fit(Xc, Y, n_components=K, method=method, standardize=True, calc_all=True, faithful=faithful)
+                rec[mode + "_s"] = round(time.perf_counter() - t0, 3)
+                if faithful:
+                    ref = mdl
+            runs.append(rec)
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits()
     iters = ref.get("nipals_iterations_", [2] * K)
     units = sum(2 * i + 3 for i in iters) + 1 + 3
+    t_cpu = runs[-1]["faithful_s"]
     gbps = units * 8.0 * n * cols / t_cpu / 1e9
+    fit = {}
+    pp = np.array([r["p"] for r in runs], dtype=float)
+    for mode in ("faithful", "lean"):
+        tt = np.array([r[mode + "_s"] for r in runs])
+        slope, icpt = np.polyfit(pp, tt, 1) if len(runs) > 1 else (tt[0] / pp[0], 0.0)
+        full = float(slope * p + icpt)
+        fit[mode] = {"s_per_1e6_columns": round(float(slope) * 1e6, 2), "extrapolated_full_size_fit_s": round(full, 1),
+                     "extrapolated_fits_per_s": round(1.0 / full, 6), "gpu_speedup_fits_per_s": round(full / gpu_fit_s, 1)}
     mdl = MBPLS(n_components=K, method=method).fit(Xs, Y)
     s = np.sign(np.sum(ref.Ts_ * mdl.Ts_, axis=0))
     err = max(np.max(np.abs(mdl.Ts_ * s - ref.Ts_)) / np.max(np.abs(ref.Ts_)),
               np.max(np.abs(mdl.beta_ - ref.beta_)) / np.max(np.abs(ref.beta_)),
               np.max(np.abs(mdl.P_[0] * s - ref.P_[0])) / np.max(np.abs(ref.P_[0])))
     return {"value": round(gbps, 3), "unit": "GB/s", "cores": thr, "kind": "port",
-            "sample": f"oracle faithful mode (reference numpy op sequence), first {cols} columns of the same matrix, "
-                      f"n={n} K={K}, {t_cpu:.1f} s wall; BLAS threads = CPU quota = {thr} ({os.cpu_count()} logical CPUs visible)",
-            "fit_wall_s": round(t_cpu, 3), "gpu_vs_oracle_relerr_on_sample": float(err)}
+            "sample": f"oracle faithful mode (reference numpy op sequence) on the first {cols} columns of the same matrix, "
+                      f"n={n} K={K}: {t_cpu:.1f} s wall = {units} reference-algorithm units of 8np bytes / wall; "
+                      f"BLAS threads = CPU quota = {thr} ({os.cpu_count()} logical CPUs visible); after one warm-up fit",
+            "fit_wall_s": t_cpu, "runs": runs, "linear_fit_in_p": fit,
+            "extrapolation": f"EXTRAPOLATED to p={p} from {len(runs)} sizes (linear in p); not measured at full size",
+            "gpu_vs_oracle_relerr_on_sample": float(err)}
 
 
 if __name__ == "__main__":

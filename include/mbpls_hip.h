@@ -200,15 +200,15 @@ int mbpls_hip_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double
  * of the accumulated vector (block scores of centred columns are centred): the caller subtracts it, and rescales
  * finished g~ / p~ columns by 1/scale (mbpls_hip_scale_rows).  The first pass only takes the statistics (no store:
  * 8np instead of 16np bytes) and X stays the caller's matrix (copy=True costs no second 8np-byte buffer).
- * Every element is shifted in registers before it is used (by the column's first sample in the statistics pass,
- * by the column mean afterwards), so the rounding of the dot products does not grow with |mean_j|/scale_j; the
- * shifted one-pass variance is amplified by ((x_0j - mean_j)/scale_j)^2 <= n, which the statistics pass reports
- * per block.  The caller must pass zero-sum vectors (re-centre to rounding).
+ * The statistics pass shifts every element by the column's first sample before it is used, so neither its variance
+ * (amplification ((x_0j - mean_j)/scale_j)^2 <= n) nor its dot products suffer from offsets, and it reports
+ * max_j |mean_j|/scale_j per block: above a few units the later passes should be given d_mean (see below).
+ * The caller must pass zero-sum vectors (re-centre to rounding).
  *
  * StandardScaler statistics (MBPLS_SCALE_FIT; MBPLS_SCALE_NONE: sums of squares only) + the first sweep on the
  * raw columns held in registers; nothing is written to X.  d_rscale / d_r2 (required with MBPLS_SCALE_FIT):
  * 1/scale_j and 1/scale_j^2 (0 for a constant column); d_amp[nblocks] (optional) = the SQUARE of
- * max_j ((x_0j - mean_j)/scale_j)^2, the rounding amplification of the shifted sums.                             */
+ * max_j |mean_j|/scale_j, the rounding amplification of un-centred raw-space dot products.                       */
 int mbpls_hip_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_mean, double* d_scale,
                                       double* d_rscale, double* d_r2, double* d_ssq_x, double* d_amp,
                                       const double* d_v, double alpha, double* d_g, double* d_t,
@@ -216,9 +216,11 @@ int mbpls_hip_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_
 /* mbpls_hip_sweep_lazy / mbpls_hip_loadings_sweep_lazy on a RAW matrix with implicit standardisation (d_r2: p
  * values 1/scale_j^2; NULL = the plain lazy passes).  d_g / d_p receive and d_P holds the RAW-SPACE columns g~,
  * p~; d_ssq_g / d_ssq_p are the squared norms of the TRUE g_b, p_b; d_d as in the plain variants with c_j in
- * place of g_j.  d_mean (p values, required with d_r2): the column means, subtracted from every element in
- * registers before the dot products and the accumulation -- a raw-space dot product would carry rounding noise
- * of |mean_j|/scale_j ulps, which keeps offset data from ever meeting the NIPALS stop rule (mbpls.py:841).     */
+ * place of g_j.  d_mean (p values, optional, needs d_r2): the column means, subtracted from every element in
+ * registers before the dot products and the accumulation -- a raw-space dot product carries rounding noise of
+ * |mean_j|/scale_j ulps, which keeps badly offset data from ever meeting the NIPALS stop rule (mbpls.py:841).
+ * The subtraction costs 8-13 % of the pass, so callers give d_mean only when the statistics pass reported
+ * max_j |mean_j|/scale_j above a few units.                                                                     */
 int mbpls_hip_sweep_lazy_scaled(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t,
                                 double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
                                 double* d_d, const double* d_r2, const double* d_mean);
@@ -316,6 +318,9 @@ typedef struct mbpls_nipals_step {
   int64_t n;
   int nblocks, q, kc, run, nd, centre, norm_kind;   /* norm_kind: 0 ||.||_2, 1 sum|.|, 2 max|.|, 3 min|.| (:887) */
   double tol;              /* max_tol (:841)                                                                       */
+  double amp2_max;         /* > 0, component 0 / run 1 only: the statistics pass left max_j (mean_j/scale_j)^2 per block
+                              in the d area; above this value the step stops the queue with par[5] = 1 (the caller
+                              queues again with the centring flavour of the passes, d_mean given)                   */
   const double* xchg;      /* exchange buffer of the pass that just finished                                       */
   const double* Y;         /* n x q standardised responses                                                         */
   double* Ts;              /* n x K  super scores (column kc written at convergence)                               */
@@ -332,7 +337,8 @@ typedef struct mbpls_nipals_step {
   double* tspass;          /* n: score vector of the next loadings pass (out)                                      */
   double* cu;              /* >= kc: <ts_i, vpass>                                                                 */
   double* ce;              /* >= kc: <ts_i, tspass>                                                                */
-  double* par;             /* >= 8: [alpha, inv_tt, skip flag, failed component, last diff, ...]                   */
+  double* par;             /* >= 8: [alpha, inv_tt, skip flag, failed component, last diff, reason (1 = offset data),
+                              offset measure, -]                                                                    */
 } mbpls_nipals_step;
 int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s);
 /* d_par != NULL: every column pass on this context reads alpha = d_par[0], inv_tt = d_par[1] from the device and

@@ -27,7 +27,7 @@ _pp = C.POINTER(C.c_void_p)
 class NipalsStep(C.Structure):
     """``mbpls_nipals_step`` of include/mbpls_hip.h (device-resident NIPALS step)."""
     _fields_ = [("n", _i64), ("nblocks", _int), ("q", _int), ("kc", _int), ("run", _int), ("nd", _int),
-                ("centre", _int), ("norm_kind", _int), ("tol", _dbl),
+                ("centre", _int), ("norm_kind", _int), ("tol", _dbl), ("amp2_max", _dbl),
                 ("xchg", _vp), ("Y", _vp), ("Ts", _vp), ("Tsc", _vp), ("U", _vp), ("V", _vp), ("Tb", _vp),
                 ("scal", _vp), ("ssq_x", _vp), ("iters", _vp), ("u_cur", _vp), ("ts_old", _vp), ("vpass", _vp),
                 ("tspass", _vp), ("cu", _vp), ("ce", _vp), ("par", _vp)]

@@ -65,10 +65,12 @@ struct PassArgs {
   // (||g_b||^2 = sum g~_j c_j, ||p_b||^2 = sum p~_j^2 ir2_j); the constant is the mean of the accumulated vector
   // (scores are centred), removed by the caller, who also rescales finished g~ / p~ columns by 1/scale.
   const double* ir2;
-  // ... and the dot products / accumulations run on x_j - mean_j 1 (one subtraction per element in registers): the
-  // rounding of a raw-space dot product would otherwise be amplified by |mean_j| / scale_j, enough to keep the
-  // NIPALS stop rule ||ts_old - ts|| <= 1e-14 (mbpls.py:841) out of reach for offset data.  The statistics-only
-  // pass, which does not know the mean yet, shifts by the column's first sample instead.
+  // ... and for OFFSET data (mu != NULL, template flag CEN) the dot products / accumulations run on x_j - mean_j 1
+  // (one subtraction per element in registers): the rounding of a raw-space dot product is amplified by
+  // |mean_j| / scale_j, enough to keep the NIPALS stop rule ||ts_old - ts|| <= 1e-14 (mbpls.py:841) out of reach
+  // once that ratio is in the hundreds.  The passes are partly issue-bound (8 % / 13 % slower with the subtraction),
+  // so it is a separate instantiation, chosen from the offset measure of the statistics pass -- which itself, not
+  // knowing the mean yet, always shifts by the column's first sample.
   const double* mu;
   // device-resident parameters (ctx->dpar): when given, alpha = dpar[0], inv_tt = dpar[1] and the whole pass is a
   // no-op when dpar[2] != 0 (a speculatively queued fit that turned out to need more NIPALS iterations)
@@ -82,7 +84,7 @@ constexpr int KD = 40;
 // The n=4096 workhorse (R=8, 512 threads = 8 waves) must stay at <= 128 VGPRs: 4 waves/SIMD = two
 // workgroups per CU.  At 129+ VGPRs only ONE 8-wave workgroup fits a CU and the pass runs ~2x slower
 // (measured: the lazy loadings+sweep variant at 157 VGPRs took 9.3 ms instead of 4.8 ms).
-template <int R, int TMAX, int D, bool STD, bool DEFL, bool SWEEP, bool FULL, bool ISTD = false>
+template <int R, int TMAX, int D, bool STD, bool DEFL, bool SWEEP, bool FULL, bool ISTD = false, bool CEN = false>
 __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpass(PassArgs a) {
   __shared__ double red[2 * 64];
   int buf = 0;
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   __shared__ double s_out[(STD && ISTD) ? 4 : 1][64];   // statistics-only pass: per-column outputs of 64 columns
   double pp[D];   // P[column, tid] of the column held in slot d (0 for threads >= kprev)
   double k0v[(STD && ISTD) ? D : 1];   // statistics-only pass: first sample of the column in slot d (the shift)
+  double muv[CEN ? D : 1];  // raw-space passes on offset data: mean of the column in slot d, requested with the column
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     pp[d] = 0.0;
@@ -171,6 +174,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
       load_col<R, FULL>(x[d], a.src + (j0 + d) * ld, rm);
       if (mine) pp[d] = prow[j0 + d];
       if constexpr (STD && ISTD) k0v[d] = a.src[(j0 + d) * ld];
+      if constexpr (CEN) muv[d] = a.mu[j0 + d];
     }
   }
 
@@ -223,7 +227,8 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
             const int slot = (int)((jj - j0) & 63);
             if (tid == 0) {
               const double m2 = m1 * m1 * r2;
-              amp = fmax(amp, m2 * m2);      // SQUARE of ((K - mean)/scale)^2, the amplification of the shifted sums
+              amp = fmax(amp, mean * mean * r2);   // SQUARED offset |mean|/scale: decides whether the later passes centre
+              (void)m2;                            // (((K - mean)/scale)^2 <= n bounds the error of the shifted variance)
               ssq_x = fma(dn * var, r2, ssq_x);                   // sum z^2 of the column
               s_out[0][slot] = mean;
               s_out[1][slot] = var;
@@ -301,9 +306,11 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
       double r2c = 1.0;
       if constexpr (ISTD && !STD) {
         r2c = a.ir2[jj];
-        const double muj = a.mu[jj];
+        if constexpr (CEN) {
+          const double muj = muv[d];
 #pragma unroll
-        for (int k = 0; k < R; ++k) xc[k] -= muj;   // rows beyond n become -mean: their v / ts entries are 0, never stored
+          for (int k = 0; k < R; ++k) xc[k] -= muj;   // rows beyond n become -mean: their v / ts entries are 0, never stored
+        }
       }
       if constexpr (DEFL) {
         // lazy: <x_k, ts> = <x_0, ts> - sum_i P[j,i] <ts_i, ts>, folded into the same reduction
@@ -370,6 +377,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
         load_col<R, FULL>(xc, a.src + (jj + D) * ld, rm);
         if (mine) pp[d] = prow[jj + D];
         if constexpr (STD && ISTD) k0v[d] = a.src[(jj + D) * ld];
+        if constexpr (CEN) muv[d] = a.mu[jj + D];
       }
     }
   }
@@ -501,13 +509,20 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   const bool full = (a.n == (int64_t)T * cfg.R) && (a.ld == a.n) && cfg.R >= 8 && !(STD && a.rowmask);
   // the ISTD instantiations: implicit standardisation for the lazy passes, statistics-only for the standardise pass
   const bool istd = STD ? (SWEEP && a.dst == nullptr) : (a.lazy && a.ir2 != nullptr);
+  const bool cen = !STD && istd && a.mu != nullptr;   // offset data: subtract the column mean in registers
   // loadings+sweep at R=8 keeps ts and v in LDS (see TS_LDS in the kernel): T x R/2 double2 each
   const unsigned dyn_lds = (DEFL && SWEEP && cfg.R == 8 && cfg.TMAX == 512) ? 2u * (unsigned)T * 4u * 16u : 0u;
 #define MB_LAUNCH(R_, TM_, D_)                                                                          \
   do {                                                                                                  \
     constexpr bool F_ = ((R_) >= 8);                                                                    \
     constexpr bool IS_ = !STD || SWEEP;   /* no statistics-only flavour without the fused sweep */      \
-    if (istd) {                                                                                         \
+    constexpr bool CE_ = !STD;             /* centring flavour: raw-space lazy passes only */             \
+    if (cen) {                                                                                          \
+      if (full && F_)                                                                                   \
+        hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, F_, IS_, CE_>), grid, block, dyn_lds, ctx->stream, an);     \
+      else                                                                                              \
+        hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, false, IS_, CE_>), grid, block, dyn_lds, ctx->stream, an);  \
+    } else if (istd) {                                                                                  \
       if (full && F_)                                                                                   \
         hipLaunchKernelGGL((k_colpass<R_, TM_, D_, STD, DEFL, SWEEP, F_, IS_>), grid, block, dyn_lds, ctx->stream, an);     \
       else                                                                                              \
@@ -619,7 +634,7 @@ int mbpls_hip_sweep_lazy_scaled(const mbpls_mat* m, const double* d_v, double al
                                 double* d_ssq_g, const double* d_P, int64_t ldp, int kprev, const double* d_cu,
                                 double* d_d, const double* d_r2, const double* d_mean) {
   MB_ARG(m && d_v, "NULL argument");
-  MB_ARG((d_r2 == nullptr) == (d_mean == nullptr), "d_r2 and d_mean must be given together");
+  MB_ARG(!d_mean || d_r2, "d_mean needs d_r2");
   MB_ARG(kprev >= 0 && kprev < KD && (kprev == 0 || (d_P && d_cu && d_d)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   mbpls_ctx* ctx = m->ctx;
   if (long_columns(ctx, m->n)) {
@@ -651,7 +666,7 @@ int mbpls_hip_loadings_sweep_lazy_scaled(const mbpls_mat* m, const double* d_ts,
                                          const double* d_cu, const double* d_ce, double* d_d,
                                          const double* d_r2, const double* d_mean) {
   MB_ARG(m && d_ts, "NULL argument");
-  MB_ARG((d_r2 == nullptr) == (d_mean == nullptr), "d_r2 and d_mean must be given together");
+  MB_ARG(!d_mean || d_r2, "d_mean needs d_r2");
   MB_ARG(kprev >= 0 && kprev < KD - 1 && (kprev == 0 || (d_P && d_ce)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   MB_ARG(!d_v || (d_d && (kprev == 0 || d_cu)), "sweep part needs d_cu / d_d");
   mbpls_ctx* ctx = m->ctx;

@@ -38,6 +38,21 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
   const double* dd = ssq_g + 3 * B;      // [B][nd] lazy-deflation sums
   double* tb = s.Tb + (int64_t)kc * B * n;   // block scores of this component: scratch now, final at convergence
 
+  if (s.run == 1 && kc == 0 && s.amp2_max > 0.0) {
+    // the statistics pass left max_j (mean_j/scale_j)^2 per block where the lazy sums of later passes go: raw-space
+    // dot products without centring are only good for modestly offset data -- hand back to the caller otherwise
+    double worst = 0.0;
+    for (int b = 0; b < B; ++b) worst = fmax(worst, dd[b]);
+    if (!(worst <= s.amp2_max)) {
+      if (tid == 0) {
+        par[2] = 1.0;
+        par[3] = 0.0;
+        par[5] = 1.0;      // reason: offset data, queue again with the centring passes
+        par[6] = worst;
+      }
+      return;
+    }
+  }
   if (s.run == 1 && tid < B) {
     if (kc == 0) s.ssq_x[tid] = ssq_x[tid];
     else s.scal[(int64_t)(kc - 1) * 4 * B + 2 * B + tid] = ssq_p[tid];   // ||p_b||^2 of the component just deflated

@@ -92,6 +92,7 @@ class HipEngine:
         self._lazy_ts = []          # score vectors of the components deflated so far (lazy mode)
         self._lazy_pslot = None
         self._istd = False          # implicit standardisation: X in HBM stays raw (see prepare)
+        self._cen = False           # ... and the raw-space passes subtract the column means (offset data)
         self.rs = self.r2 = None
         if not hasattr(self, "_src"):
             self._src = None
@@ -296,8 +297,7 @@ class HipEngine:
         src = self._src if self._src is not None else self.X
         if self._implicit_ok(v, mean):
             out = self._prepare_implicit(src, standardize, mode, v, alpha, g_slot, defer)
-            if out is not None or defer:
-                return out
+            return None if defer else out
         self._working_copy()
         dv = self._put_vec(0, v) if v is not None else None
         # row subset (cross-validation fold): excluded samples become zero rows of the working copy and the
@@ -329,10 +329,11 @@ class HipEngine:
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
         return x, t, g
 
-    # The shifted one-pass variance of the statistics pass is amplified by ((x_0j - mean_j) / scale_j)^2 (<= n, a
-    # single sample cannot lie further out); beyond this value the storing two-pass standardisation is used.  The dot
-    # products themselves run on mean-shifted elements and do not depend on the offset of the data.
-    IMPLICIT_STD_MAX_OFFSET = 1.0e4
+    # Raw-space dot products carry rounding noise of max_j |mean_j| / scale_j ulps.  Above this offset ratio the
+    # raw-space passes subtract the column mean from every element in registers first (template flag CEN of
+    # csrc/colpass.hip; 8-13 % slower, the passes are partly issue-bound) -- which is what keeps the NIPALS stop rule
+    # ||ts_old - ts|| <= 1e-14 reachable for offset data.  The statistics pass itself always shifts (by the first sample).
+    CENTRE_FROM_OFFSET = 8.0
 
     def _implicit_ok(self, v, mean):
         import os
@@ -343,8 +344,9 @@ class HipEngine:
 
     def _prepare_implicit(self, src, standardize, mode, v, alpha, g_slot, defer=False):
         """First pass of a fit that never writes X (lazy deflation + implicit standardisation): statistics and the
-        first sweep only.  Returns None when the shifted one-pass variance would be too inaccurate (cannot happen for
-        n <= 8192, see IMPLICIT_STD_MAX_OFFSET; not looked at when the pass is only queued, defer=True)."""
+        first sweep only.  Its offset measure max_j |mean_j|/scale_j decides whether the later raw-space passes centre
+        the columns in registers (CENTRE_FROM_OFFSET); with defer=True the pass is only queued and the step kernel
+        looks at the measure (nipals_resident)."""
         n, B = self.n, self.nblocks
         if standardize:
             self.rs, self.r2 = self.ctx.empty(self.p), self.ctx.empty(self.p)
@@ -357,17 +359,14 @@ class HipEngine:
             self._istd = bool(standardize)
             if self._istd:
                 self.slot("P~raw", self._lazy_K)
-            return None
+            return "queued"
         self.run_deferred(2)
         t, g, _, x = self._finish_pass(True, True, False, True, nd=1)
         if not np.all(np.isfinite(x)):
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
-        if standardize and float(np.sqrt(np.max(self._last_d))) > self.IMPLICIT_STD_MAX_OFFSET:
-            self.rs.free(); self.r2.free()
-            self.rs = self.r2 = None
-            return None                      # fall back: standardise into a working copy
         self.X, self._src = src, None        # the raw matrix, never written
         self._istd = bool(standardize)
+        self._cen = self._istd and float(np.sqrt(np.max(self._last_d))) > self.CENTRE_FROM_OFFSET
         if self._istd:
             self.slot("P~raw", self._lazy_K)
             t = t - t.mean(axis=0)           # raw-space accumulation: remove the column means' share
@@ -397,7 +396,7 @@ class HipEngine:
         elif self._istd:
             self.X.sweep_lazy(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B),
                               self.slots["P~raw"], self.p, k, self._lazy_coef(0, v), self._xptr(n * B + 3 * B),
-                              r2=self.r2, mean=self.mean)
+                              r2=self.r2, mean=self.mean if self._cen else None)
             if g_slot is not None:
                 self._scale_col(g_slot, g_slot)
         elif k:
@@ -451,7 +450,7 @@ class HipEngine:
                                        self._lazy_coef(0, v) if v is not None else None, self._lazy_coef(1, ts),
                                        self._xptr(n * B + 3 * B) if v is not None else None,
                                        r2=self.r2 if self._istd else None,
-                                       mean=self.mean if self._istd else None)
+                                       mean=self.mean if self._cen else None)
             if self._istd:
                 self._scale_col(("P~raw", k), p_slot)
                 if v is not None and g_slot is not None:
@@ -493,7 +492,8 @@ class HipEngine:
         dv, g = self._vec_n[0], self._slot_col(g_slot)
         if self._istd:
             self.X.sweep_lazy(dv, 1.0, g, self._xptr(0), self._xptr(n * B), self.slots["P~raw"], self.p, k,
-                              self._coef[0], self._xptr(n * B + 3 * B), r2=self.r2, mean=self.mean)
+                              self._coef[0], self._xptr(n * B + 3 * B), r2=self.r2,
+                              mean=self.mean if self._cen else None)
             self._scale_col(g_slot, g_slot)
         elif k:
             self.X.sweep_lazy(dv, 1.0, g, self._xptr(0), self._xptr(n * B), self.slots[self._lazy_pslot], self.p, k,
@@ -512,7 +512,7 @@ class HipEngine:
                                    None if last else self._slot_col(g_slot), None if last else self._xptr(0),
                                    None if last else self._xptr(n * B), P, self.p, k, self._coef[0], self._coef[1],
                                    self._xptr(n * B + 3 * B), r2=self.r2 if self._istd else None,
-                                   mean=self.mean if self._istd else None)
+                                   mean=self.mean if self._cen else None)
         if self._istd:
             self._scale_col(("P~raw", k), (pslot, k))
             if not last:
@@ -537,7 +537,11 @@ class HipEngine:
                     ssqx=ctx.empty(B), iters=ctx.empty(K, zero=True), u_cur=ctx.from_host(np.ascontiguousarray(Y[:, 0])),
                     ts_old=ctx.empty(n, zero=True), par=ctx.from_host(np.zeros(8)))
         self.slot("Wblk", K)
+        # raw-space passes without centring are only good for modestly offset data: the first step checks the measure
+        # the statistics pass left behind and stops the queue when the centring flavour is needed
+        amp2 = self.CENTRE_FROM_OFFSET ** 2 if (self._istd and not self._cen) else 0.0
         st = _capi.NipalsStep(n=n, nblocks=B, q=q, centre=int(self._istd), norm_kind=int(norm_kind), tol=float(tol),
+                              amp2_max=amp2,
                               xchg=self._xchg.ptr, Y=bufs["Y"].ptr, Ts=Ts.ptr, Tsc=bufs["Tsc"].ptr, U=bufs["U"].ptr,
                               V=bufs["V"].ptr, Tb=bufs["Tb"].ptr, scal=bufs["scal"].ptr, ssq_x=bufs["ssqx"].ptr,
                               iters=bufs["iters"].ptr, u_cur=bufs["u_cur"].ptr, ts_old=bufs["ts_old"].ptr,
@@ -608,6 +612,13 @@ class HipEngine:
             th.join()
         if errors:
             raise errors[0]
+        if par[2] != 0.0 and par[5] == 1.0:
+            # offset data (max |mean|/scale = sqrt(par[6])): the caller queues again, now with centring passes
+            self._cen = True
+            for key, b in bufs.items():
+                if key != "Tsc" or self._istd:
+                    b.free()
+            return dict(k_done=0, reason="offset", offset=float(np.sqrt(par[6])))
         k_done = K if par[2] == 0.0 else int(par[3])
         h = self._xchg.get()
         scal = bufs["scal"].get().reshape(K, 4, B)

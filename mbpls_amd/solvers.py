@@ -260,6 +260,11 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
         # the host reads the results once.  Components the speculation did not hold for are resumed below.
         eng.prepare(standardize, v=u0, alpha=alpha0, g_slot=("Wn", 0), defer=True)
         out = eng.nipals_resident(Y, K, kind, max_tol, "Wn", Wn_h, W_h, P_h)
+        if out.get("reason") == "offset":
+            # badly offset columns: the same queue again with the passes that centre in registers (the first pass is
+            # repeated because a sharded run has already summed its exchange buffer once more)
+            eng.prepare(standardize, v=u0, alpha=alpha0, g_slot=("Wn", 0), defer=True)
+            out = eng.nipals_resident(Y, K, kind, max_tol, "Wn", Wn_h, W_h, P_h)
         varxb = out["ssq_x"]                                # summed over the column shards on the device already
         if not np.all(np.isfinite(varxb)):
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")

@@ -369,7 +369,7 @@ def test_medium_vs_oracle(gpu_required, method, n, p, q, K, blocks):
         # Lazy deflation (K < 39) applies X_k = X_0 - sum ts_i p_i^T algebraically: its rounding is relative to X_0, not
         # to the (much smaller) deflated X_k, so deep components can miss ||ts_old - ts|| <= 1e-14 by a hair on the
         # second iteration and take a third -- same numbers (asserted above), one more pass.
-        assert mdl.nipals_iterations_[:20] == [2] * 20
+        assert mdl.nipals_iterations_[:20] == [2] * min(K, 20)
         assert all(i in (2, 3) for i in mdl.nipals_iterations_), mdl.nipals_iterations_
         if K >= 39:
             assert mdl.nipals_iterations_ == [2] * K
@@ -485,40 +485,46 @@ def test_both_deflation_modes(gpu_required, monkeypatch, mode, method, q):
     assert w < 1e-8, w
 
 
-@pytest.mark.parametrize("offset,n,p,force_fallback", [(0.0, 1000, 6000, False), (50.0, 1000, 6000, False),
-                                                       (1.0e3, 1000, 6000, False), (1.0e3, 300, 40, False),
-                                                       (5.0e3, 64, 7, False), (1.0e6, 1000, 6000, False),
-                                                       (50.0, 1000, 6000, True)])
-def test_implicit_standardisation_and_its_fallback(gpu_required, monkeypatch, offset, n, p, force_fallback):
+@pytest.mark.parametrize("offset,n,p", [(0.0, 1000, 6000), (3.0, 1000, 6000), (50.0, 1000, 6000), (1.0e3, 1000, 6000),
+                                        (1.0e3, 300, 40), (5.0e3, 64, 7), (1.0e6, 1000, 6000)])
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_implicit_standardisation_of_offset_data(gpu_required, monkeypatch, offset, n, p, resident):
     """One response + lazy deflation: the fit never writes X (statistics-only first pass, raw-space passes after).
-    Every element is shifted in registers before it is used (first sample in the statistics pass, column mean
-    afterwards), so column offsets of 10^3..10^6 scale units neither cost accuracy nor keep ||ts_old - ts|| from
-    reaching 1e-14: the iteration counts equal the reference's ([2]*K).  The storing standardise pass remains as a
-    fallback (forced here through the threshold) and behind MBPLS_IMPLICIT_STD=0.  Same numbers every way, and the
-    caller's resident matrix is untouched."""
+    The statistics pass shifts every element by the column's first sample and reports max |mean|/scale; above
+    HipEngine.CENTRE_FROM_OFFSET the later passes subtract the column mean in registers before every dot product and
+    accumulation, so column offsets of 10^3..10^6 scale units neither cost accuracy nor keep ||ts_old - ts|| from
+    reaching 1e-14: the iteration counts equal the reference's ([2]*K), with the device-resident queue (which finds
+    out on the device and is queued again with centring passes) and with the host-driven loop.  The storing
+    standardise pass remains behind MBPLS_IMPLICIT_STD=0.  The caller's resident matrix is untouched."""
     import mbpls_amd
     from mbpls_amd import MBPLS, DeviceMatrix
     from mbpls_amd.engine import HipEngine
+    monkeypatch.setenv("MBPLS_RESIDENT", resident)
     K = 4
     X, Y = orc.make_latent(n, p, 1, seed=77)
     X = X + offset * (1.0 + np.arange(X.shape[1]) % 3)       # column offsets 1x..3x
     ref = orc.fit(X, Y, n_components=K)
-    seen = []
+    seen, cen = [], []
     real = HipEngine._prepare_implicit
+    real_close = HipEngine.close
 
     def spy(self, *a, **k):
-        out = real(self, *a, **k)
-        seen.append(out is not None)
-        return out
+        seen.append(True)
+        return real(self, *a, **k)
+
+    def spy_close(self):
+        cen.append(self._cen)
+        return real_close(self)
 
     monkeypatch.setattr(HipEngine, "_prepare_implicit", spy)
-    if force_fallback:
-        monkeypatch.setattr(HipEngine, "IMPLICIT_STD_MAX_OFFSET", -1.0)
+    monkeypatch.setattr(HipEngine, "close", spy_close)
     ctx = mbpls_amd.get_context()
     Xd = DeviceMatrix(ctx, *X.shape)
     Xd.upload(X)
     mdl = MBPLS(n_components=K).fit(Xd, Y)
-    assert seen == [not force_fallback]
+    centred = offset > HipEngine.CENTRE_FROM_OFFSET
+    assert cen == [centred]
+    assert len(seen) == (2 if centred and resident == "1" else 1)      # queued twice when the device finds offset data
     assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K, (mdl.nipals_iterations_, ref.nipals_iterations_)
     w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"offset {offset}")
     # the input itself is only known to offset * eps scale units: that, not the arithmetic, bounds the agreement
@@ -559,7 +565,7 @@ def test_many_components(gpu_required, method, K, q, n, p):
         # Lazy deflation (K < 39) applies X_k = X_0 - sum ts_i p_i^T algebraically: its rounding is relative to X_0, not
         # to the (much smaller) deflated X_k, so deep components can miss ||ts_old - ts|| <= 1e-14 by a hair on the
         # second iteration and take a third -- same numbers (asserted above), one more pass.
-        assert mdl.nipals_iterations_[:20] == [2] * 20
+        assert mdl.nipals_iterations_[:20] == [2] * min(K, 20)
         assert all(i in (2, 3) for i in mdl.nipals_iterations_), mdl.nipals_iterations_
         if K >= 39:
             assert mdl.nipals_iterations_ == [2] * K
