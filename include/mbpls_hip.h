@@ -152,6 +152,10 @@ int mbpls_hip_standardize_sweep_masked(const mbpls_mat* src, mbpls_mat* dst, int
                                        const double* d_v, double alpha,
                                        double* d_g, double* d_t, double* d_ssq_g);
 
+/* d_var != NULL: every MBPLS_SCALE_FIT standardise pass on this context also writes the per-column variance
+ * (sklearn StandardScaler.var_, mbpls.py:307,:316; 0 for a constant column, whose scale_ is 1).  NULL switches it off. */
+int mbpls_hip_set_variance_output(mbpls_ctx* ctx, double* d_var);
+
 /* One NIPALS inner iteration over X in ONE read (mbpls.py:856 + :875, a2+a3 of SURVEY 8a):
  *   g = alpha * X^T v                (w~_b = X_b^T u / (u^T u), all blocks at once)
  *   t_b = X_b g_b                    (UN-normalised block scores; caller divides by ||g_b||)

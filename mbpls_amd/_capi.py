@@ -94,6 +94,7 @@ SIGNATURES = {
     "mbpls_hip_allreduce": (_int, [_vp, _vp, _sz]),
     "mbpls_hip_nipals_step": (_int, [_vp, C.POINTER(NipalsStep)]),
     "mbpls_hip_set_pass_params": (_int, [_vp, _vp]),
+    "mbpls_hip_set_variance_output": (_int, [_vp, _vp]),
     "mbpls_hip_block_unit_col": (_int, [_vp, _vp, _vp, _vp]),
     "mbpls_hip_event_record": (_int, [_vp, _pp]),
     "mbpls_hip_memcpy_d2h_after": (_int, [_vp, _vp, _vp, _vp, _sz]),

@@ -75,6 +75,7 @@ struct PassArgs {
   // device-resident parameters (ctx->dpar): when given, alpha = dpar[0], inv_tt = dpar[1] and the whole pass is a
   // no-op when dpar[2] != 0 (a speculatively queued fit that turned out to need more NIPALS iterations)
   const double* dpar;
+  double* var_out;     // standardise passes, MBPLS_SCALE_FIT: per-column variance (optional; ctx->var_out)
   double* rs_out;      // standardise pass: 1 / scale_j   (optional)
   double* r2_out;      // standardise pass: 1 / scale_j^2 (optional)
 };
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
             if (tid == 0) {
               a.mean[jj] = mean;
               a.scale[jj] = scale;
+              if (a.var_out) a.var_out[jj] = (var <= bound) ? 0.0 : var;
             }
           } else {
             mean = a.mean[jj];
@@ -413,10 +415,12 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
 // After the statistics-only pass: scale[] holds var -> scale, rs = 1/scale (0 for a constant column, flagged by
 // r2 == 0), g~ -> g = g~ rs.
 __global__ __launch_bounds__(256) void k_finish_stats(int64_t p, double* __restrict__ scale, const double* __restrict__ r2,
-                                                      double* __restrict__ rs, double* __restrict__ g) {
+                                                      double* __restrict__ rs, double* __restrict__ g,
+                                                      double* __restrict__ var_out) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= p) return;
   const bool constant = r2[j] == 0.0;
+  if (var_out) var_out[j] = constant ? 0.0 : scale[j];
   const double sc = constant ? 1.0 : sqrt(scale[j]);
   const double r = constant ? 0.0 : 1.0 / sc;
   scale[j] = sc;
@@ -503,6 +507,7 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   }
   PassArgs an = a;
   an.dpar = ctx->dpar;
+  an.var_out = ctx->var_out;
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
   const int D = ctx->prefetch >= 1 && ctx->prefetch <= 3 ? ctx->prefetch : 2;
   // FULL: every thread's every row pair is a real sample and columns are unpadded (n=4096, 8192, ...)
@@ -748,7 +753,7 @@ int mbpls_hip_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_
   MB_TRY((launch_pass<true, false, true>(ctx, src->fine, a, src->p)));
   if (mode == MBPLS_SCALE_FIT) {
     hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)((src->p + 255) / 256)), dim3(256), 0, ctx->stream, src->p,
-                       d_scale, (const double*)a.r2_out, d_rscale, d_g);
+                       d_scale, (const double*)a.r2_out, d_rscale, d_g, ctx->var_out);
     MB_HIP(hipGetLastError());
   }
   return reduce_chunks(ctx, src, a.part_t, a.part_s, d_t, d_ssq_g, nullptr, d_ssq_x, nullptr, 0, nullptr, d_amp);

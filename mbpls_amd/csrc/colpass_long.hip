@@ -18,6 +18,7 @@
 namespace mbpls {
 
 struct LongArgs {
+  double* var_out;
   const double* src;
   double* dst;
   int64_t ld, n;
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void k_colpass_long(LongArgs a) {
         if (tid == 0) {
           a.mean[j] = mean;
           a.scale[j] = scale;
+          if (a.var_out) a.var_out[j] = (var <= bound) ? 0.0 : var;
         }
       } else if (a.mode == MBPLS_SCALE_APPLY) {
         mean = a.mean[j];
@@ -268,6 +270,7 @@ int long_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode, const
   a.src = src->data; a.dst = dst->data; a.ld = dst->ld; a.n = dst->n;
   a.c0 = dst->fine.d_c0; a.c1 = dst->fine.d_c1;
   a.mode = mode; a.mean = d_mean; a.scale = d_scale; a.rowmask = d_rowmask; a.n_eff = n_eff;
+  a.var_out = ctx->var_out;
   a.v = d_v; a.alpha = alpha; a.g = g;
   dim3 grid((unsigned)dst->fine.nchunks), block(256);
   {

@@ -20,6 +20,7 @@
 namespace mbpls {
 
 struct NanArgs {
+  double* var_out;
   const double* src;
   double* dst;
   int64_t ld, n;
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
               a.mean[jj] = mean;
               a.scale[jj] = scale;
               if (a.count) a.count[jj] = cnt;
+              if (a.var_out) a.var_out[jj] = (var <= bound) ? 0.0 : var;
             }
           } else {
             mean = a.mean[jj];
@@ -382,6 +384,7 @@ int mbpls_hip_nan_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mo
   a.src = src->data; a.dst = dst->data; a.ld = dst->ld; a.n = dst->n;
   a.c0 = dst->fine.d_c0; a.c1 = dst->fine.d_c1;
   a.mode = mode; a.mean = d_mean; a.scale = d_scale; a.count = d_count;
+  a.var_out = ctx->var_out;
   a.v = d_v; a.g = d_g;
   if (d_v) MB_TRY((launch_nan<true, false, true>(ctx, dst->fine, a, dst->p)));
   else MB_TRY((launch_nan<true, false, false>(ctx, dst->fine, a, dst->p)));

@@ -79,6 +79,9 @@ struct mbpls_ctx {
   // column passes read them from HBM instead of taking host scalars, so a whole fit can be queued without a host
   // round trip (resident.hip writes them between the passes)
   const double* dpar = nullptr;
+  // optional per-column variance output of the standardise passes (mbpls_hip_set_variance_output): sklearn's
+  // StandardScaler.var_ (0 for a constant column, whose scale_ is 1)
+  double* var_out = nullptr;
   void* rccl = nullptr;      // RcclState* (rccl_comm.hip) when a communicator was initialised on this context
   // per-kernel profile (HIP events around the main kernel of every hot-path call)
   bool prof = false;

@@ -293,6 +293,12 @@ int mbpls_hip_set_pass_params(mbpls_ctx* ctx, const double* d_par) {
   return MBPLS_OK;
 }
 
+int mbpls_hip_set_variance_output(mbpls_ctx* ctx, double* d_var) {
+  MB_ARG(ctx, "ctx is NULL");
+  ctx->var_out = d_var;
+  return MBPLS_OK;
+}
+
 int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
   MB_ARG(ctx && s, "NULL argument");
   MB_ARG(s->n >= 1 && s->nblocks >= 1 && s->nblocks <= RS_BMAX && s->q >= 1 && s->q <= RS_QMAX,

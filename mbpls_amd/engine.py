@@ -284,10 +284,13 @@ class HipEngine:
         first sweep of component 0 in the same pass.  Returns (ssq_x[B], t[n,B] or None, ssq_g[B] or None).
         defer=True only queues the pass (device-resident fit: the exchange buffer is consumed on the device)."""
         n, B = self.n, self.nblocks
+        self.var = None
         if standardize:
             self.mean = self.ctx.empty(self.p)
             self.scale = self.ctx.empty(self.p)
             mode = _capi.SCALE_FIT
+            if mean is None:
+                self.var = self.ctx.empty(self.p)      # StandardScaler.var_ of the fitted scalers
             if mean is not None:
                 self.mean.set(mean)
                 self.scale.set(scale)
@@ -295,6 +298,14 @@ class HipEngine:
         else:
             mode = _capi.SCALE_NONE
         src = self._src if self._src is not None else self.X
+        _capi.check(self.ctx.lib.mbpls_hip_set_variance_output(self.ctx.handle, _capi._ptr(self.var)))
+        try:
+            return self._prepare_passes(src, standardize, mode, v, alpha, g_slot, mean, defer)
+        finally:
+            self.ctx.lib.mbpls_hip_set_variance_output(self.ctx.handle, None)
+
+    def _prepare_passes(self, src, standardize, mode, v, alpha, g_slot, mean, defer):
+        n, B = self.n, self.nblocks
         if self._implicit_ok(v, mean):
             out = self._prepare_implicit(src, standardize, mode, v, alpha, g_slot, defer)
             return None if defer else out

@@ -7,8 +7,9 @@ the HIP library or a GPU every method raises.
 
 Deliberate deviations from the reference (documented in DESIGN.md):
 * ``sparse_data=True`` (NaN-aware NIPALS, per-row/column Python loops in the reference, mbpls.py:846-926)
-  runs on masked column passes (csrc/colpass_nan.hip) for missing values in X; missing values in Y are not
-  supported (``NotImplementedError``).
+  runs on masked column passes (csrc/colpass_nan.hip) for missing values in X; missing responses are handled on the
+  host (n x q) for EVERY row, where the reference only patches the sparse rows of the last X block and fails on any
+  other (mbpls.py:903): same numbers wherever the reference produces any.
 * NIPALS has an iteration cap (``solvers.NIPALS_MAX_ITER``) with a warning; the reference loops
   forever on data without latent structure (mbpls.py:841).
 * SIMPLS with one response and ``full_svd=False`` works (the reference raises inside scipy ``svds``).
@@ -167,10 +168,10 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
                           "The method will be set to 'NIPALS'")
             self.method = 'NIPALS'
         if sparse:
+            # missing values are allowed in Y as well (:293, force_all_finite=not sparse_data); inf is not
             Y = _check_array_no_scan(np.asarray(Y, dtype=np.float64).reshape(len(Y), -1))
-            if np.isnan(Y).any():
-                raise NotImplementedError("sparse_data=True is accelerated for missing values in X only; "
-                                          "Y must be complete")
+            if np.isinf(Y).any():
+                raise ValueError("Input Y contains infinity or a value too large for dtype('float64').")
             if row_mask is not None:
                 raise NotImplementedError("row-subset fits are not available with sparse_data=True")
             Y = np.array(Y, copy=True) if self.copy else Y
@@ -297,8 +298,12 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         self._block_offsets = list(eng.block_offsets)
         if self.standardize:
             mean, scale = eng.mean.get(), eng.scale.get()
+            var = eng.var.get() if getattr(eng, "var", None) is not None else None
             seen = eng.count.get().astype(np.int64) if eng.sparse else None    # per-column present samples
-            self.x_scalers_ = [ColumnScaler(mean[s:e], scale[s:e], eng.n if seen is None else seen[s:e])
+            rm = getattr(eng, "rowmask", None)
+            n_seen = eng.n if rm is None else int(np.count_nonzero(rm))        # row-subset fit: the included samples
+            self.x_scalers_ = [ColumnScaler(mean[s:e], scale[s:e], n_seen if seen is None else seen[s:e],
+                                            None if var is None else var[s:e])
                                for s, e in zip(eng.block_offsets[:-1], eng.block_offsets[1:])]
         # containers exactly as the reference leaves them (mbpls.py:359-382)
         self.W_non_normal_ = [np.empty((sz, 0)) for sz in sizes]
@@ -395,11 +400,18 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         if T is not None:
             out.append(T)
         if Y is not None:
-            Y = check_array(Y, dtype=np.float64, ensure_2d=False, copy=copy)       # :1120
+            if self.sparse_data is True:                                            # :1120, NaN allowed
+                Y = np.array(Y, dtype=np.float64, copy=copy)
+                if np.isinf(Y).any():
+                    raise ValueError("Input Y contains infinity or a value too large for dtype('float64').")
+            else:
+                Y = check_array(Y, dtype=np.float64, ensure_2d=False, copy=copy)   # :1120
             if Y.ndim == 1:
                 Y = Y.reshape(-1, 1)
             if self.standardize:
                 Y = self.y_scaler_.transform(Y)                                     # :1125
+            if self.sparse_data is True:
+                Y = np.where(np.isnan(Y), 0.0, Y)           # :1157-1163: missing responses do not contribute
             YV = Y.dot(self.V_)
             out.append(YV / np.linalg.norm(YV, axis=0))                             # :1166
         return out[0] if len(out) == 1 else tuple(out)

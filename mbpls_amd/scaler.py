@@ -15,27 +15,40 @@ class ColumnScaler:
     with_mean = True
     with_std = True
 
-    def __init__(self, mean=None, scale=None, n_samples=None):
+    copy = True
+
+    def __init__(self, mean=None, scale=None, n_samples=None, var=None):
+        """the fitted attributes of sklearn's StandardScaler: ``mean_``, ``scale_``, ``var_`` (0 for a constant
+        column, whose ``scale_`` is 1), ``n_samples_seen_`` (an int, or one count per column when the data had
+        missing values), ``n_features_in_``"""
         if mean is not None:
             self.mean_ = np.asarray(mean, dtype=np.float64)
             self.scale_ = np.asarray(scale, dtype=np.float64)
+            if var is not None:
+                self.var_ = np.asarray(var, dtype=np.float64)
             self.n_samples_seen_ = n_samples
             self.n_features_in_ = self.mean_.size
 
     def fit(self, X):
+        """mean, then corrected two-pass variance (sklearn ``_incremental_mean_and_var``); NaN entries are ignored, as
+        sklearn does (the statistics of a column are taken over its present samples)."""
         X = np.asarray(X, dtype=np.float64)
-        n = X.shape[0]
-        self.mean_ = np.sum(X, axis=0) / n
+        miss = np.isnan(X)
+        has_nan = bool(miss.any())
+        cnt = (X.shape[0] - miss.sum(axis=0)).astype(np.float64) if has_nan else float(X.shape[0])
+        self.mean_ = (np.nansum(X, axis=0) if has_nan else np.sum(X, axis=0)) / cnt
         d = X - self.mean_
+        if has_nan:
+            d[miss] = 0.0
         corr = np.sum(d, axis=0)
         d **= 2
         ssq = np.sum(d, axis=0)
-        ssq -= corr ** 2 / n
-        self.var_ = ssq / n
-        bound = n * _EPS * self.var_ + (n * self.mean_ * _EPS) ** 2
+        ssq -= corr ** 2 / cnt
+        self.var_ = ssq / cnt
+        bound = cnt * _EPS * self.var_ + (cnt * self.mean_ * _EPS) ** 2
         self.scale_ = np.sqrt(self.var_)
         self.scale_[self.var_ <= bound] = 1.0
-        self.n_samples_seen_ = n
+        self.n_samples_seen_ = cnt.astype(np.int64) if has_nan else X.shape[0]
         self.n_features_in_ = X.shape[1]
         return self
 

@@ -52,6 +52,53 @@ def _split(arr, offsets):
     return [arr[offsets[b]:offsets[b + 1]] for b in range(len(offsets) - 1)]
 
 
+class _Responses:
+    """Y side of the NIPALS iteration (mbpls.py:890-913), also for responses with missing values
+    (``sparse_data=True``, :832-836 and :891-906): the Y loadings of a column are regressed over its present rows,
+    the Y scores of a row over its present responses.  The reference patches the rows it finds in
+    ``sparse_X_info_[block][0]`` -- the sparse rows of the LAST X block, a loop variable left over from the X side
+    (:903) -- and fails (LinAlgError) on a missing response anywhere else; here every row with a missing response is
+    regressed over what is present, which is the same numbers wherever the reference produces any."""
+
+    def __init__(self, Y):
+        self.miss = np.isnan(Y)
+        self.sparse = bool(self.miss.any())
+        self.Y = np.where(self.miss, 0.0, Y) if self.sparse else Y
+        if self.sparse:
+            self.present = (~self.miss).astype(np.float64)
+            self.col_sparse = self.miss.any(axis=0)
+            self.row_sparse = self.miss.any(axis=1)
+        self.ssq = float((self.Y ** 2).sum())                    # nansum(Y**2) (:827)
+
+    def start(self):
+        """u of a new component: Y[:, 0] (:838); with missing responses the first complete column (:836), a uniform
+        random vector when there is none (:833-834)"""
+        if not self.sparse:
+            return self.Y[:, 0:1]
+        dense = np.where(~self.col_sparse)[0]
+        if dense.size == 0:
+            return np.random.rand(self.Y.shape[0], 1)
+        return self.Y[:, dense[0]:dense[0] + 1]
+
+    def loadings(self, ts):
+        """v = Y^T ts / ts^T ts (:899 / :891-897)"""
+        num = self.Y.T.dot(ts)
+        v = num / ts.T.dot(ts)
+        if self.sparse:
+            den = self.present.T.dot(ts ** 2)
+            v = np.where(self.col_sparse[:, None], num / np.where(den == 0.0, 1.0, den), v)
+        return v
+
+    def scores(self, v):
+        """u = Y v / v^T v, unit length (:911-913 / :900-907)"""
+        num = self.Y.dot(v)
+        u = num / v.T.dot(v)
+        if self.sparse:
+            den = self.present.dot(v ** 2)
+            u = np.where(self.row_sparse[:, None], num / np.where(den == 0.0, 1.0, den), u)
+        return u / np.linalg.norm(u)
+
+
 class FitResult(dict):
     __getattr__ = dict.__getitem__
 
@@ -231,7 +278,9 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     if _nipals_on_grams(eng, q):
         return _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     sizes = _global_sizes(eng)
-    u0 = Y[:, 0:1]
+    resp = _Responses(Y)
+    Y = resp.Y                                              # missing responses (sparse_data=True) as zeros + masks
+    u0 = resp.start()
     alpha0 = 1.0 / u0.T.dot(u0).item()
     eng.slot("Wn", K)
     eng.slot("P", K)
@@ -249,12 +298,12 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
     # host copies of the p x K attributes, filled column by column while later passes run on the GPU
     Wn_h, W_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
-    vary = (Y ** 2).sum()
+    vary = resp.ssq
     # norm of the n x 1 difference as numpy's MATRIX norm (:887), see _fit_nipals_grams
     _norm(np.zeros((2, 1)), norm)
     kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
     k_start = 0
-    if (not q1_fixed_point and max_iter >= 2 and hasattr(eng, "resident_supported")
+    if (not q1_fixed_point and not resp.sparse and max_iter >= 2 and hasattr(eng, "resident_supported")
             and eng.resident_supported(q, K, kind)):
         # One response: the whole fit is queued on the device (two iterations per component -- what one response takes),
         # the host reads the results once.  Components the speculation did not hold for are resumed below.
@@ -306,9 +355,8 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
             if run > 1:
                 diff = _norm(ts_old - ts, norm)             # (:887)
             ts_old = ts.copy()
-            v = Y.T.dot(ts) / ts.T.dot(ts)                  # (:899)
-            u = Y.dot(v) / v.T.dot(v)                       # (:911)
-            u = u / np.linalg.norm(u)
+            v = resp.loadings(ts)                           # (:899)
+            u = resp.scores(v)                              # (:911-913)
             run += 1
             if q1_fixed_point and run == 2:
                 # OPT-IN (off by default).  One response: u after the first pass is sign(v) Y/||Y|| whatever ts

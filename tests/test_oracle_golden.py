@@ -153,3 +153,39 @@ def test_sparse_oracle_vs_reference_fixture():
                 util.compare(flat, ref, 1e-8, what=f"sparse q{q} {blocks} std{std}")
                 n_cases += 1
     assert n_cases == 8
+
+
+def test_sparse_oracle_with_missing_responses_vs_reference_fixture():
+    """sparse_data=True with NaN in Y as well (mbpls.py:832-836, :890-909; transform :1156-1166): the oracle against
+    attributes captured from the imported reference on patterns the reference handles (missing responses only in
+    sparse rows of the last X block)."""
+    from oracle import mbpls_oracle_sparse as ors
+    g = util.load("sparse_y")
+    n_cases = 0
+    for q in (2, 3):
+        X, Y = g[f"in/q{q}/X"], g[f"in/q{q}/Y"]
+        Xn, Yn = g[f"in/q{q}/Xnew"], g[f"in/q{q}/Ynew"]
+        assert np.isnan(Y[:, 0]).any() and np.isnan(Yn).any()
+        for blocks in ("single", "multi"):
+            sp = (lambda A: A) if blocks == "single" else (lambda A: [A[:, :40], A[:, 40:]])
+            for std in (True, False):
+                ref = util.sub(g, f"ref/q{q}/{blocks}/std{int(std)}")
+                mdl = ors.fit(sp(X), Y, n_components=3, standardize=std)
+                flat = util.model_to_flat(mdl)
+                flat["predict"] = ors.predict(mdl, sp(Xn))
+                Ts, T, U = ors.transform(mdl, sp(Xn), Yn, return_block_scores=True)
+                flat["Ts_new"], flat["U_new"] = Ts, U
+                for b, blk in enumerate(T):
+                    flat[f"T_new/{b}"] = blk
+                util.compare(flat, ref, 1e-8, what=f"sparse_y q{q} {blocks} std{std}")
+                if std:
+                    assert util.relerr(mdl.y_scaler_.mean_, ref["y_mean"]) < 1e-13
+                    assert util.relerr(mdl.y_scaler_.scale_, ref["y_scale"]) < 1e-13
+                n_cases += 1
+    assert n_cases == 8
+    # a missing response in a row the reference does not patch: nothing to restate
+    Yb = g["in/q2/Y"].copy()
+    dense_rows = np.where(~np.isnan(g["in/q2/X"]).any(axis=1))[0]
+    Yb[dense_rows[0], 1] = np.nan
+    with pytest.raises(ValueError):
+        ors.fit(g["in/q2/X"], Yb, n_components=2)
