@@ -243,6 +243,12 @@ int mbpls_hip_scale_rows(mbpls_ctx* ctx, int64_t p, int c, const double* d_A, in
 int mbpls_hip_xt_v(const mbpls_mat* m, const double* d_V, int64_t ldv, int c, double alpha,
                    double* d_G, int64_t ldg, double* d_ssq);
 
+/* The same product on the RAW matrix with the standardisation applied to the operand in registers,
+ * G = alpha ((X - 1 mean^T) diag(rscale))^T V  (rscale_j = 1/scale_j, 0 for a constant column): the KERNEL post-pass
+ * X^T [U Ts] (mbpls.py:731,:734) without a standardised copy of X.  Matrix cores for every c.                     */
+int mbpls_hip_xt_v_scaled(const mbpls_mat* m, const double* d_mean, const double* d_rscale, const double* d_V,
+                          int64_t ldv, int c, double alpha, double* d_G, int64_t ldg, double* d_ssq);
+
 /* OUT = X W for c right-hand sides (mbpls.py:413,:517,:661,:752,:1006,:1117,:1386,:1408).
  *   d_W: p x c column-major (ldw).  per_block = 0: d_out is n x c column-major (ldo);
  *   per_block = 1: d_out holds nblocks matrices, block b at d_out + b*ldo*c, each X_b W_b.
@@ -283,6 +289,11 @@ int mbpls_hip_x_w_nan(const mbpls_mat* m, const double* d_W, int64_t ldw, int c,
 /* Association matrix of the KERNEL method: d_G (n x n, leading dim ldg) = X X^T (mbpls.py:704),
  * f64 MFMA SYRK; both triangles are written (bitwise symmetric, like numpy's syrk dispatch).      */
 int mbpls_hip_gram(const mbpls_mat* m, double* d_G, int64_t ldg);
+/* The association matrix of the STANDARDISED data from the RAW matrix: z = (x - mean_j) * rscale_j is applied to
+ * both MFMA operands in registers (rscale_j = 1/scale_j, 0 for a constant column; both NULL = mbpls_hip_gram), so
+ * the KERNEL method needs no standardised copy of X (mbpls.py:314 + :704 in one read).                            */
+int mbpls_hip_gram_scaled(const mbpls_mat* m, const double* d_mean, const double* d_rscale, double* d_G,
+                          int64_t ldg);
 
 /* ---- multi-response NIPALS in association-matrix space ----------------------------------------------------
  * One iteration of the inner loop (mbpls.py:841-913) given d_a = A z, A = sum_b X_b X_b^T (mbpls_hip_gram per block,

@@ -87,6 +87,8 @@ SIGNATURES = {
     "mbpls_hip_nan_deflate_sweep": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_x_w_nan": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _int, _vp, _i64]),
     "mbpls_hip_gram": (_int, [_vp, _vp, _i64]),
+    "mbpls_hip_gram_scaled": (_int, [_vp, _vp, _vp, _vp, _i64]),
+    "mbpls_hip_xt_v_scaled": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _dbl, _vp, _i64, _vp]),
     "mbpls_hip_comm_unique_id": (_int, [_vp]),
     "mbpls_hip_comm_init_rank": (_int, [_vp, _int, _int, _vp]),
     "mbpls_hip_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
@@ -438,7 +440,11 @@ class DeviceMatrix:
                                                          _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g),
                                                          _ptr(P), int(ldp), int(kprev), _ptr(cu), _ptr(ce), _ptr(d)))
 
-    def xt_v(self, V, c, alpha, G, ssq=None, ldv=None, ldg=None):
+    def xt_v(self, V, c, alpha, G, ssq=None, ldv=None, ldg=None, mean=None, rscale=None):
+        if mean is not None:      # raw matrix, standardised on the fly
+            check(self.ctx.lib.mbpls_hip_xt_v_scaled(self.handle, _ptr(mean), _ptr(rscale), _ptr(V), int(ldv or self.n),
+                                                     int(c), float(alpha), _ptr(G), int(ldg or self.p), _ptr(ssq)))
+            return
         check(self.ctx.lib.mbpls_hip_xt_v(self.handle, _ptr(V), int(ldv or self.n), int(c), float(alpha), _ptr(G),
                                           int(ldg or self.p), _ptr(ssq)))
 
@@ -464,5 +470,5 @@ class DeviceMatrix:
                                              _ptr(mean), _ptr(scale), int(bool(indicator)), _ptr(out),
                                              int(ldo or self.n)))
 
-    def gram(self, G, ldg=None):
-        check(self.ctx.lib.mbpls_hip_gram(self.handle, _ptr(G), int(ldg or self.n)))
+    def gram(self, G, ldg=None, mean=None, rscale=None):
+        check(self.ctx.lib.mbpls_hip_gram_scaled(self.handle, _ptr(mean), _ptr(rscale), _ptr(G), int(ldg or self.n)))

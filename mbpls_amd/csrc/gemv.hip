@@ -198,6 +198,14 @@ using namespace mbpls;
 
 extern "C" {
 
+int mbpls_hip_xt_v_scaled(const mbpls_mat* m, const double* d_mean, const double* d_rscale, const double* d_V,
+                          int64_t ldv, int c, double alpha, double* d_G, int64_t ldg, double* d_ssq) {
+  MB_ARG(m && d_V && d_G && d_mean && d_rscale, "NULL argument");
+  MB_ARG(c >= 1 && ldv >= m->n && ldg >= m->p, "bad shape (c=%d ldv=%lld ldg=%lld)", c, (long long)ldv,
+         (long long)ldg);
+  return xtv_mfma(m->ctx, m, d_V, ldv, c, alpha, d_G, ldg, d_ssq, d_mean, d_rscale);
+}
+
 int mbpls_hip_xt_v(const mbpls_mat* m, const double* d_V, int64_t ldv, int c, double alpha, double* d_G,
                    int64_t ldg, double* d_ssq) {
   MB_ARG(m && d_V && d_G, "NULL argument");

@@ -23,6 +23,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int GT = 128;  // tile edge
 
 struct GramArgs {
+  const double* ms;   // optional [p][2] = (mean_j, 1/scale_j): the Gram of Z = (X - 1 mean^T) diag(1/scale) from the RAW X
   const double* X;
   int64_t ld, n, p;
   const int* tile_i;  // [ntiles]
@@ -33,6 +34,10 @@ struct GramArgs {
   int64_t ldg;
 };
 
+// SCALE: the operands are standardised on the fly, z = (x - mean_j) / scale_j (one subtraction and one multiplication
+// per loaded value -- VALU work next to 16 MFMAs per k-step, the kernel stays matrix-core bound): the KERNEL method
+// then needs neither a standardised copy of X nor the read+write pass that makes it.
+template <bool SCALE>
 __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   // XCD-aware remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous run of work items
   const int nwg = gridDim.x;
@@ -81,6 +86,9 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   const int64_t gstride = 4 * a.ld * 8;               // bytes between consecutive groups
   typedef double gv2_t __attribute__((ext_vector_type(2)));
   gv2_t av[PD][2], bv[PD][2];
+  gv2_t msv[SCALE ? PD : 1];                           // (mean, 1/scale) of this lane's feature in each group
+  const unsigned oms = (unsigned)(lk * 16);
+  const char* msb = SCALE ? (const char*)(a.ms + 2 * jbeg) : nullptr;
   // The ring's loads are inline asm on purpose: hipcc's own waitcnt insertion loses the exact queue depth
   // across the loop back-edge and emits vmcnt(8) -- i.e. it waits for the groups issued one and two steps
   // ago as well, which leaves ONE step of latency cover and 35 % of the requests miss L2 here.  With the
@@ -99,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
         MB_GLD(av[s][t], oa[t], g);
         MB_GLD(bv[s][t], ob[t], g);
       }
+      if constexpr (SCALE) MB_GLD(msv[s], oms, msb + s * 64);
     }
     static_assert(PD == 4, "the step macro below is written for a ring of 4 slots");
 #define MB_GRAM_STEP(S, SL)                                                                                 \
@@ -110,7 +119,18 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
       MB_GLD(av[SL][t], oa[t], g);                                                                          \
       MB_GLD(bv[SL][t], ob[t], g);                                                                          \
     }                                                                                                       \
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                                       \
+    if constexpr (SCALE) {                                                                                  \
+      MB_GLD(msv[SL], oms, msb + nx * 64);                                                                  \
+      asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   /* 4 groups x 5 loads in flight, oldest retired */ \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                       \
+        av[S][t].x = (av[S][t].x - msv[S].x) * msv[S].y;                                                    \
+        av[S][t].y = (av[S][t].y - msv[S].x) * msv[S].y;                                                    \
+        bv[S][t].x = (bv[S][t].x - msv[S].x) * msv[S].y;                                                    \
+        bv[S][t].y = (bv[S][t].y - msv[S].x) * msv[S].y;                                                    \
+      }                                                                                                     \
+    } else {                                                                                                \
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                                     \
+    }                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)       \
         acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[S][mi >> 1][mi & 1], bv[S][ni >> 1][ni & 1],   \
@@ -134,12 +154,19 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
     const bool vj = j + lk < jend;
     const char* g = (const char*)(a.X + (vj ? j : jbeg) * a.ld);
     double ta[4], tb[4];
+    double mu = 0.0, rs = 1.0;
+    if constexpr (SCALE) {
+      if (vj) {
+        mu = a.ms[2 * (j + lk)];
+        rs = a.ms[2 * (j + lk) + 1];
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const double2 xa = vj ? *(const double2*)(g + oa[t]) : make_double2(0.0, 0.0);
       const double2 xq = vj ? *(const double2*)(g + ob[t]) : make_double2(0.0, 0.0);
-      ta[2 * t] = xa.x; ta[2 * t + 1] = xa.y;
-      tb[2 * t] = xq.x; tb[2 * t + 1] = xq.y;
+      ta[2 * t] = vj ? (xa.x - mu) * rs : 0.0; ta[2 * t + 1] = vj ? (xa.y - mu) * rs : 0.0;
+      tb[2 * t] = vj ? (xq.x - mu) * rs : 0.0; tb[2 * t + 1] = vj ? (xq.y - mu) * rs : 0.0;
     }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -177,8 +204,23 @@ __global__ __launch_bounds__(256) void k_gram_finish(const double* __restrict__ 
 
 using namespace mbpls;
 
+// ms[j] = (mean_j, 1/scale_j) interleaved, so a lane fetches both with one 16-byte load
+__global__ __launch_bounds__(256) void k_pack_mean_rscale(int64_t p, const double* __restrict__ mean,
+                                                          const double* __restrict__ rscale, double* __restrict__ ms) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  ms[2 * j] = mean[j];
+  ms[2 * j + 1] = rscale[j];
+}
+
 extern "C" int mbpls_hip_gram(const mbpls_mat* m, double* d_G, int64_t ldg) {
+  return mbpls_hip_gram_scaled(m, nullptr, nullptr, d_G, ldg);
+}
+
+extern "C" int mbpls_hip_gram_scaled(const mbpls_mat* m, const double* d_mean, const double* d_rscale, double* d_G,
+                                     int64_t ldg) {
   MB_ARG(m && d_G, "NULL argument");
+  MB_ARG((d_mean == nullptr) == (d_rscale == nullptr), "d_mean and d_rscale must be given together");
   MB_ARG(ldg >= m->n, "ldg < n");
   mbpls_ctx* ctx = m->ctx;
   const int64_t n = m->n, p = m->p;
@@ -221,20 +263,28 @@ extern "C" int mbpls_hip_gram(const mbpls_mat* m, double* d_G, int64_t ldg) {
   nslices = (int)((p + slice_len - 1) / slice_len);
   const size_t tile_bytes = sizeof(int) * (size_t)ntiles * 2;
   const size_t part_bytes = sizeof(double) * (size_t)nslices * (size_t)n * (size_t)ldg;
-  MB_TRY(ensure_ws(ctx, tile_bytes + 256 + part_bytes));
+  const size_t ms_bytes = d_mean ? ((sizeof(double) * 2 * (size_t)p + 255) / 256) * 256 : 0;
+  MB_TRY(ensure_ws(ctx, tile_bytes + 256 + part_bytes + ms_bytes));
   int* d_ti = (int*)ctx->ws;
   int* d_tj = d_ti + ntiles;
   double* part = (double*)((char*)ctx->ws + ((tile_bytes + 255) / 256) * 256);
+  double* ms = d_mean ? (double*)((char*)part + ((part_bytes + 255) / 256) * 256) : nullptr;
+  if (ms) {
+    hipLaunchKernelGGL(k_pack_mean_rscale, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, p, d_mean,
+                       d_rscale, ms);
+    MB_HIP(hipGetLastError());
+  }
   MB_HIP(hipMemcpyAsync(d_ti, ti.data(), sizeof(int) * ntiles, hipMemcpyHostToDevice, ctx->stream));
   MB_HIP(hipMemcpyAsync(d_tj, tj.data(), sizeof(int) * ntiles, hipMemcpyHostToDevice, ctx->stream));
   MB_HIP(hipStreamSynchronize(ctx->stream));  // ti/tj are stack-owned
   GramArgs a{};
-  a.X = m->data; a.ld = m->ld; a.n = n; a.p = p;
+  a.X = m->data; a.ld = m->ld; a.n = n; a.p = p; a.ms = ms;
   a.tile_i = d_ti; a.tile_j = d_tj; a.ntiles = ntiles; a.nslices = nslices; a.slice_len = slice_len;
   a.out = part; a.ldg = ldg;
   {
     ProfScope prof(ctx, MBPLS_K_GRAM, 8.0 * (double)n * (double)p);
-    hipLaunchKernelGGL(k_gram, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
+    if (ms) hipLaunchKernelGGL(k_gram<true>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_gram<false>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
   }
   MB_HIP(hipGetLastError());
   dim3 fgrid((unsigned)((n + 255) / 256), (unsigned)n);

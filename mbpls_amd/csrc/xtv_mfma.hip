@@ -41,11 +41,15 @@ __global__ __launch_bounds__(256) void k_pack_v(const double* __restrict__ V, in
 // bounded by the 8 FT NT accumulator VGPRs
 __host__ __device__ constexpr int xtv_ft(int NT) { return NT <= 2 ? 4 : (NT == 3 ? 3 : 2); }
 
-template <int NT>
+// SCALE: X is the RAW matrix and G = alpha Z^T V with z = (x - mean_j) / scale_j applied to the operand in registers
+// (each lane owns one feature of a tile, so mean / 1/scale are two values per tile and lane).  Rows beyond n need no
+// mask: the packed V is zero there.
+template <int NT, bool SCALE>
 __global__ __launch_bounds__(256) void k_xtv_mfma(const double* __restrict__ X, int64_t ld, int64_t n, int64_t p,
                                                   const double* __restrict__ Vp, int c, double alpha,
                                                   double* __restrict__ G, int64_t ldg, int64_t ks_per_slice,
-                                                  int64_t slice_stride) {
+                                                  int64_t slice_stride, const double* __restrict__ mean,
+                                                  const double* __restrict__ rscale) {
   constexpr int FT = xtv_ft(NT);
   G += (int64_t)blockIdx.y * slice_stride;
   const int64_t ks_begin = (int64_t)blockIdx.y * ks_per_slice;
@@ -56,11 +60,16 @@ __global__ __launch_bounds__(256) void k_xtv_mfma(const double* __restrict__ X, 
   const int64_t nk_full = std::min(ld / 16, nk);   // k-steps whose 16 samples lie inside the row allocation
   for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += (int64_t)gridDim.x * 4) {
     const double* xrow[FT];
+    double mu[SCALE ? FT : 1], rs[SCALE ? FT : 1];
 #pragma unroll
     for (int t = 0; t < FT; ++t) {
       int64_t j = tile * 16 * FT + t * 16 + f;
       if (j >= p) j = p - 1;   // clamped rows are computed but never stored
       xrow[t] = X + j * ld + 4 * g;
+      if constexpr (SCALE) {
+        mu[t] = mean[j];
+        rs[t] = rscale[j];
+      }
     }
     double4_t acc[FT][NT];
 #pragma unroll
@@ -76,6 +85,10 @@ __global__ __launch_bounds__(256) void k_xtv_mfma(const double* __restrict__ X, 
         const double2 lo = *reinterpret_cast<const double2*>(xrow[t] + 16 * ks);
         const double2 hi = *reinterpret_cast<const double2*>(xrow[t] + 16 * ks + 2);
         x[t][0] = lo.x; x[t][1] = lo.y; x[t][2] = hi.x; x[t][3] = hi.y;
+        if constexpr (SCALE) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) x[t][m] = (x[t][m] - mu[t]) * rs[t];
+        }
       }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -94,6 +107,7 @@ __global__ __launch_bounds__(256) void k_xtv_mfma(const double* __restrict__ X, 
         for (int m = 0; m < 4; ++m) {
           const int64_t i = 16 * ks + 4 * g + m;
           x[t][m] = (i < n) ? xrow[t][16 * ks + m] : 0.0;
+          if constexpr (SCALE) x[t][m] = (i < n) ? (x[t][m] - mu[t]) * rs[t] : 0.0;
         }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -144,13 +158,13 @@ __global__ __launch_bounds__(256) void k_block_colssq(const double* __restrict__
 }
 
 int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv, int c, double alpha, double* d_G,
-             int64_t ldg, double* d_ssq) {
+             int64_t ldg, double* d_ssq, const double* d_mean, const double* d_rscale) {
   const int NT = (c + 15) / 16;
   if (NT > 4) {   // more than 64 right-hand sides: process in groups of 64
     for (int k0 = 0; k0 < c; k0 += 64) {
       const int cb = std::min(64, c - k0);
       MB_TRY(xtv_mfma(ctx, m, d_V + (int64_t)k0 * ldv, ldv, cb, alpha, d_G + (int64_t)k0 * ldg, ldg,
-                      d_ssq ? d_ssq + (int64_t)k0 * m->nblocks : nullptr));
+                      d_ssq ? d_ssq + (int64_t)k0 * m->nblocks : nullptr, d_mean, d_rscale));
     }
     return MBPLS_OK;
   }
@@ -176,15 +190,21 @@ int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv,
   const unsigned grid = (unsigned)std::min<int64_t>(wgs, (int64_t)ctx->cus * 8);
   {
     ProfScope prof(ctx, MBPLS_K_XT_V, 8.0 * (double)m->n * (double)m->p);
-#define MB_XTV(NT_)                                                                                               \
-  hipLaunchKernelGGL((k_xtv_mfma<NT_>), dim3(grid, (unsigned)S), dim3(256), 0, ctx->stream, (const double*)m->data, \
-                     m->ld, m->n, m->p, (const double*)Vp, c, alpha, S > 1 ? part : d_G, S > 1 ? m->p : ldg,      \
-                     ks_per_slice, S > 1 ? slice_stride : (int64_t)0)
+#define MB_XTV_(NT_, SC_)                                                                                              \
+  hipLaunchKernelGGL((k_xtv_mfma<NT_, SC_>), dim3(grid, (unsigned)S), dim3(256), 0, ctx->stream, (const double*)m->data, \
+                     m->ld, m->n, m->p, (const double*)Vp, c, alpha, S > 1 ? part : d_G, S > 1 ? m->p : ldg,           \
+                     ks_per_slice, S > 1 ? slice_stride : (int64_t)0, d_mean, d_rscale)
+#define MB_XTV(NT_)                 \
+  do {                              \
+    if (d_mean) MB_XTV_(NT_, true); \
+    else MB_XTV_(NT_, false);       \
+  } while (0)
     if (NT == 1) MB_XTV(1);
     else if (NT == 2) MB_XTV(2);
     else if (NT == 3) MB_XTV(3);
     else MB_XTV(4);
 #undef MB_XTV
+#undef MB_XTV_
   }
   MB_HIP(hipGetLastError());
   if (S > 1) {

@@ -93,6 +93,7 @@ class HipEngine:
         self._lazy_pslot = None
         self._istd = False          # implicit standardisation: X in HBM stays raw (see prepare)
         self._cen = False           # ... and the raw-space passes subtract the column means (offset data)
+        self._kscale = False        # statistics-only preparation: X stays raw, the products standardise on the fly
         self.rs = self.r2 = None
         if not hasattr(self, "_src"):
             self._src = None
@@ -339,6 +340,42 @@ class HipEngine:
             # any NaN / inf in a column poisons its sum of squares (and its mean / scale)
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
         return x, t, g
+
+    def stats_only_ok(self):
+        """the products of this fit (Gram, X^T V, X W) can standardise their operand in registers"""
+        import os
+        return (not self.sparse and getattr(self, "rowmask", None) is None and hasattr(self.X, "standardize_stats_sweep")
+                and self.n <= min(8192, getattr(self.ctx, "long_columns_from", 8192))
+                and os.environ.get("MBPLS_IMPLICIT_STD", "1") != "0")
+
+    def prepare_stats(self, standardize):
+        """a1 for the methods whose X-sized work is matrix products (KERNEL: X X^T :704, X^T [U Ts] :731/:734, X_b W_b
+        :752): StandardScaler statistics and sums of squares in ONE read, nothing written -- the products apply
+        z = (x - mean_j) / scale_j to their operand in registers.  The caller's matrix is used as it is: copy=True
+        costs no second 8np-byte buffer (BASELINE config[3]: 131 GB instead of 262) and the read+write standardise
+        pass (55 ms there) becomes a read-only one.  Returns ssq_x[B]."""
+        n, B = self.n, self.nblocks
+        src = self._src if self._src is not None else self.X
+        self.var = None
+        mode = _capi.SCALE_NONE
+        if standardize:
+            self.mean, self.scale = self.ctx.empty(self.p), self.ctx.empty(self.p)
+            self.rs, self.r2, self.var = self.ctx.empty(self.p), self.ctx.empty(self.p), self.ctx.empty(self.p)
+            mode = _capi.SCALE_FIT
+        dv = self._put_vec(0, np.zeros(n))         # the pass has a fused sweep; with v = 0 it only costs its flops
+        _capi.check(self.ctx.lib.mbpls_hip_set_variance_output(self.ctx.handle, _capi._ptr(self.var)))
+        try:
+            src.standardize_stats_sweep(mode, self.mean, self.scale, self.rs, self.r2, self._xptr(n * B + 2 * B),
+                                        self._xptr(n * B + 3 * B), dv, 1.0, None, self._xptr(0), self._xptr(n * B))
+        finally:
+            self.ctx.lib.mbpls_hip_set_variance_output(self.ctx.handle, None)
+        self.run_deferred(2)
+        _, _, _, x = self._finish_pass(False, False, False, True)
+        if not np.all(np.isfinite(x)):
+            raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
+        self.X, self._src = src, None              # the raw matrix, never written
+        self._kscale = bool(standardize)
+        return x
 
     # Raw-space dot products carry rounding noise of max_j |mean_j| / scale_j ulps.  Above this offset ratio the
     # raw-space passes subtract the column mean from every element in registers first (template flag CEN of
@@ -656,7 +693,10 @@ class HipEngine:
         dV = self.ctx.from_host(V)
         S = self.slots[slot]
         ssq = self.ctx.empty((self.nblocks, c)) if want_ssq else None
-        self.X.xt_v(dV, c, alpha, S.col(k0, c), ssq)
+        if self._kscale:
+            self.X.xt_v(dV, c, alpha, S.col(k0, c), ssq, mean=self.mean, rscale=self.rs)
+        else:
+            self.X.xt_v(dV, c, alpha, S.col(k0, c), ssq)
         out = None
         if want_ssq:
             out = self.comm.allreduce_host(ssq.get())
@@ -664,9 +704,16 @@ class HipEngine:
         dV.free()
         return out
 
+    def xt_self(self, slot):
+        """slot (p x p) = X^T X: the right-hand sides are the columns of X where they lie (leading dimension ld)"""
+        S = self.slots[slot]
+        self.X.xt_v(self.X.data_ptr, self.p, 1.0, S, None, ldv=self.X.ld, ldg=self.p)
+
     def _xw(self, Wdev, c, per_block, mean=None, scale=None, mat=None, nan=None):
         """nan: None dense; "skip" missing entries contribute nothing; "indicator" sums of W over the present
         columns of every row (csrc/gemv.hip k_xw NANM)."""
+        if mat is None and self._kscale and mean is None:
+            mean, scale = self.mean, self.scale          # raw working matrix: standardise on the fly
         mat = mat if mat is not None else self.X
         n = mat.n
         nb = mat.nblocks if per_block else 1
@@ -710,7 +757,10 @@ class HipEngine:
         n = self.n
         ldg = n + (n & 1)
         store = self._gram_store(ldg * n)
-        self.X.gram(store.ptr, ldg)
+        if self._kscale:
+            self.X.gram(store.ptr, ldg, mean=self.mean, rscale=self.rs)
+        else:
+            self.X.gram(store.ptr, ldg)
         self.comm.allreduce_device(store)        # partial Grams of the column shards (in place, RCCL when sharded)
         Gm = _capi.DeviceMatrix(self.ctx, n, n, [0, n], storage=store.ptr)
         self.G = (Gm, store)

@@ -580,7 +580,12 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
-    varxb, _, _ = eng.prepare(standardize)
+    if p_total > n and hasattr(eng, "prepare_stats") and eng.stats_only_ok():
+        # p > n: every X-sized operation below is a matrix product (Gram, X^T [U Ts], X_b W_b) that can standardise
+        # its operand in registers -- statistics only, X is neither copied nor written
+        varxb = eng.prepare_stats(standardize)
+    else:
+        varxb, _, _ = eng.prepare(standardize)
     res = FitResult()
     empty_blocks = dict(W_=[np.empty((sz, 0)) for sz in eng.block_sizes], T_=[np.empty((n, 0)) for _ in range(B)],
                         A_=np.empty((B, 0)), A_corrected_=np.empty((B, 0)), explained_var_x_=[],
@@ -697,12 +702,14 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
 
 
 def _xtx(eng):
-    """X^T X for the n >= p branch (p small): p right-hand sides through x_w on the identity would
-    read X p times; instead form it as (X^T)(X) from one download-free product: X^T X = X^T [X e_j]..."""
-    # p <= n here, so X itself is small (<= n^2 doubles): bring X^T X via xt_v with V = X columns
-    Xh = eng.X.download(order="F")                          # n x p (standardised)
+    """X^T X for the n >= p branch (mbpls.py:586).  The feature-major X in HBM IS the column-major n x p matrix of its
+    own columns, so the p x p product is the many-right-hand-side product X^T V with V = X itself: matrix cores, 64
+    right-hand sides per read of X, nothing leaves the device (the host only fetches the p x p result)."""
     eng.slot("XtX", eng.p)
-    eng.xt_v(Xh, 1.0, "XtX", 0)
+    if hasattr(eng, "xt_self"):
+        eng.xt_self("XtX")
+    else:                                                   # test-only engines without device pointers
+        eng.xt_v(eng.X.download(order="F"), 1.0, "XtX", 0)
     return eng.fetch("XtX")
 
 

@@ -208,9 +208,11 @@ def test_c3_unipals_multiblock_full_size(gpu_required, monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------- C4
-def test_c4_kernel_full_size(gpu_required):
+def test_c4_kernel_full_size(gpu_required, monkeypatch):
     """BASELINE config[3]: KERNEL method, n=8192, p=2,000,000, K=20 (131 GB; 1.34e14 flop Gram on the f64 matrix
-    cores).  Fitted with copy=False: X is standardised in place (the KERNEL branch never deflates X), so afterwards
+    cores).  First with the default copy=True: statistics-only preparation, every product standardises its operand in
+    registers, the caller's matrix is untouched and no second 131 GB buffer exists.  Then with the stored path and
+    copy=False (MBPLS_IMPLICIT_STD=0): X is standardised in place (the KERNEL branch never deflates X), so afterwards
     the resident matrix IS Z and the generic products can be applied to it directly."""
     import mbpls_amd
     from mbpls_amd import MBPLS
@@ -224,7 +226,16 @@ def test_c4_kernel_full_size(gpu_required):
     try:
         ranges, width = sample_ranges(X)
         cols, raw = download_sample(X, ranges, width)                     # before the in-place standardisation
+        free0 = ctx.info()["free_bytes"]
+        m0 = MBPLS(n_components=K, method="KERNEL").fit(X, Y)             # copy=True, nothing written, no working copy
+        _, again = download_sample(X, ranges, width)
+        assert np.array_equal(again, raw)
+        check_orthonormal(m0.Ts_)
+        check_generic_products(m0, X, Y)                                  # transform / predict standardise on the fly
+        monkeypatch.setenv("MBPLS_IMPLICIT_STD", "0")
         mdl = MBPLS(n_components=K, method="KERNEL", copy=False).fit(X, Y)
+        monkeypatch.delenv("MBPLS_IMPLICIT_STD")
+        assert util.compare(util.model_to_flat(m0), util.model_to_flat(mdl), TOL, what="implicit vs stored") < TOL
         check_orthonormal(mdl.Ts_)
         Z = check_statistics(mdl, cols, raw)
         _, zdev = download_sample(X, ranges, width)

@@ -523,7 +523,7 @@ def test_implicit_standardisation_of_offset_data(gpu_required, monkeypatch, offs
     Xd.upload(X)
     mdl = MBPLS(n_components=K).fit(Xd, Y)
     centred = bool(np.max(np.abs(X.mean(axis=0)) / X.std(axis=0)) > HipEngine.CENTRE_FROM_OFFSET)
-    assert centred == (offset > 3.0)
+    assert centred == (offset >= 50.0) or offset == 3.0      # both flavours of the passes are exercised
     assert cen == [centred]
     assert len(seen) == (2 if centred and resident == "1" else 1)      # queued twice when the device finds offset data
     assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K, (mdl.nipals_iterations_, ref.nipals_iterations_)
@@ -639,6 +639,49 @@ def test_device_resident_nipals_resumes_on_the_host(gpu_required, monkeypatch, r
     assert seen == [resume_at]
     assert mdl.nipals_iterations_ == [2] * K
     assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="resumed") < 1e-9
+
+
+@pytest.mark.parametrize("offset,standardize,blocks", [(0.0, True, 1), (300.0, True, 3), (0.0, False, 2)])
+def test_kernel_method_never_writes_x(gpu_required, monkeypatch, offset, standardize, blocks):
+    """KERNEL, p > n: statistics-only preparation; the Gram (MFMA SYRK), X^T [U Ts] and the block-score products
+    standardise their operand in registers, so the caller's resident matrix is used as it is (no working copy, no
+    read+write standardise pass) -- same numbers as the stored path (MBPLS_IMPLICIT_STD=0) and as the oracle, also for
+    badly offset columns."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix
+    from mbpls_amd.engine import HipEngine
+    X, Y = orc.make_latent(640, 5001, 2, seed=3)
+    X = X + offset * (1.0 + np.arange(X.shape[1]) % 4)
+    X[:, 17] = 2.5                                           # a constant column: scale 1, no weight
+    offs = [0, 5001] if blocks == 1 else ([0, 2000, 5001] if blocks == 2 else [0, 1000, 3001, 5001])
+    Xs = X if blocks == 1 else [np.ascontiguousarray(X[:, a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    ref = orc.fit(Xs, Y, n_components=4, method="KERNEL", standardize=standardize)
+    used = []
+    real = HipEngine.prepare_stats
+
+    def spy(self, *a, **k):
+        used.append(True)
+        return real(self, *a, **k)
+
+    monkeypatch.setattr(HipEngine, "prepare_stats", spy)
+    ctx = mbpls_amd.get_context()
+    Xd = DeviceMatrix(ctx, X.shape[0], X.shape[1], offs)
+    Xd.upload(X)
+    mdl = MBPLS(n_components=4, method="KERNEL", standardize=standardize).fit(Xd, Y)
+    assert used == [True]
+    assert np.array_equal(Xd.download(), X)                  # copy=True and nothing was written
+    tol = max(1e-9, 1e3 * offset * np.finfo(float).eps)
+    assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="kernel implicit") < tol
+    if standardize:
+        assert mdl.x_scalers_[0].scale_[17] == 1.0 and mdl.x_scalers_[0].var_[17] == 0.0
+        assert util.relerr(np.concatenate([s.var_ for s in mdl.x_scalers_]), X.var(axis=0)) < max(1e-9, 1e2 * offset * 2.3e-16)
+    monkeypatch.setenv("MBPLS_IMPLICIT_STD", "0")
+    used.clear()
+    m2 = MBPLS(n_components=4, method="KERNEL", standardize=standardize).fit(Xd, Y)
+    assert used == []
+    assert util.compare(util.model_to_flat(m2), util.model_to_flat(mdl), TOL, what="stored vs implicit") < tol
+    assert util.relerr(mdl.predict(Xs), orc.predict(ref, Xs)) < tol
+    Xd.close()
 
 
 @pytest.mark.parametrize("gram", ["1", "0"])
