@@ -235,11 +235,22 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ctx, X, Y, n, p, min(a.cpu_cols, p), K, a.method, per_step)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
     X.close()
     if dist is not None:
         dist.barrier()
+        comm = mbpls_amd.get_comm()
+        if hasattr(comm, "close"):
+            comm.close()
         dist.destroy_process_group()
+    # the ONE JSON line is the last thing on stdout: librccl writes a version banner through C stdio, which would
+    # otherwise be flushed behind it at exit
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------ N > 1 helpers

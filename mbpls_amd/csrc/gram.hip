@@ -122,20 +122,32 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
     if constexpr (SCALE) {                                                                                  \
       MB_GLD(msv[SL], oms, msb + nx * 64);                                                                  \
       asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   /* 4 groups x 5 loads in flight, oldest retired */ \
-      _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                       \
-        av[S][t].x = (av[S][t].x - msv[S].x) * msv[S].y;                                                    \
-        av[S][t].y = (av[S][t].y - msv[S].x) * msv[S].y;                                                    \
-        bv[S][t].x = (bv[S][t].x - msv[S].x) * msv[S].y;                                                    \
-        bv[S][t].y = (bv[S][t].y - msv[S].x) * msv[S].y;                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      /* z = (x - mean) * rscale on the 8 operand values, INTERLEAVED with the 16 MFMAs: an MFMA occupies the */ \
+      /* matrix pipe for 16 cycles but the issue port for 4, so two VALU ops ride along with each one        */ \
+      const double mu_ = msv[S].x, rs_ = msv[S].y;                                                          \
+      double za[4], zb[4];                                                                                  \
+      za[0] = (av[S][0].x - mu_) * rs_;                                                                     \
+      zb[0] = (bv[S][0].x - mu_) * rs_;                                                                     \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) {   \
+        /* operands needed by a later MFMA are prepared while this one runs */                              \
+        if (mi == 0 && ni < 3) zb[ni + 1] = (bv[S][(ni + 1) >> 1][(ni + 1) & 1] - mu_) * rs_;               \
+        if (ni == 3 && mi < 3) za[mi + 1] = (av[S][(mi + 1) >> 1][(mi + 1) & 1] - mu_) * rs_;               \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(za[mi], zb[ni], acc[mi][ni], 0, 0, 0);           \
       }                                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   /* 2 VALU */                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA */                                   \
+      }                                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
     } else {                                                                                                \
       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)     \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[S][mi >> 1][mi & 1], bv[S][ni >> 1][ni & 1], \
+                                                             acc[mi][ni], 0, 0, 0);                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
     }                                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                      \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)       \
-        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[S][mi >> 1][mi & 1], bv[S][ni >> 1][ni & 1],   \
-                                                           acc[mi][ni], 0, 0, 0);                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                      \
   }
     for (int64_t it = 0; it < nmain; it += PD) {
       MB_GRAM_STEP(0, 3)

@@ -41,30 +41,49 @@ __global__ __launch_bounds__(256) void k_pack_v(const double* __restrict__ V, in
 // bounded by the 8 FT NT accumulator VGPRs
 __host__ __device__ constexpr int xtv_ft(int NT) { return NT <= 2 ? 4 : (NT == 3 ? 3 : 2); }
 
+// k-steps (16 samples each) of the packed V staged in LDS at a time: the four waves of a workgroup work on different
+// feature tiles but on the SAME samples, so they share every B fragment.  Staging cuts the L2 -> L1 traffic of V by
+// four (it equalled the HBM traffic of X at c = 40) and turns 12 global loads per k-step and wave into LDS reads.
+constexpr int XTV_KC = 4;
+
 // SCALE: X is the RAW matrix and G = alpha Z^T V with z = (x - mean_j) / scale_j applied to the operand in registers
 // (each lane owns one feature of a tile, so mean / 1/scale are two values per tile and lane).  Rows beyond n need no
 // mask: the packed V is zero there.
+//
+// Pipeline per workgroup: V chunk c+1 travels global -> registers while chunk c (in LDS) is consumed; the X operand
+// of k-step s+1 is loaded (two 16-byte loads per tile and lane) before the MFMAs of k-step s issue.
 template <int NT, bool SCALE>
-__global__ __launch_bounds__(256) void k_xtv_mfma(const double* __restrict__ X, int64_t ld, int64_t n, int64_t p,
+__global__ __launch_bounds__(256, 2) void k_xtv_mfma(const double* __restrict__ X, int64_t ld, int64_t n, int64_t p,
                                                   const double* __restrict__ Vp, int c, double alpha,
                                                   double* __restrict__ G, int64_t ldg, int64_t ks_per_slice,
                                                   int64_t slice_stride, const double* __restrict__ mean,
                                                   const double* __restrict__ rscale) {
   constexpr int FT = xtv_ft(NT);
+  constexpr int CH = XTV_KC * 4 * NT * 64;      // doubles of V per chunk
+  constexpr int NV2 = CH / 2 / 256;             // double2 per thread and chunk
+  static_assert(CH % 512 == 0, "chunk must split evenly over 256 threads x 16 bytes");
+  __shared__ double s_v[CH];
   G += (int64_t)blockIdx.y * slice_stride;
   const int64_t ks_begin = (int64_t)blockIdx.y * ks_per_slice;
-  const int lane = threadIdx.x & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int f = lane & 15, g = lane >> 4;
   const int64_t ntiles = (p + 16 * FT - 1) / (16 * FT);
-  const int64_t nk = std::min((n + 15) / 16, ks_begin + ks_per_slice);
+  const int64_t nsuper = (ntiles + 3) / 4;
+  const int64_t nk_all = (n + 15) / 16;
+  const int64_t nk = std::min(nk_all, ks_begin + ks_per_slice);
   const int64_t nk_full = std::min(ld / 16, nk);   // k-steps whose 16 samples lie inside the row allocation
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  const int64_t vtotal2 = nk_all * 4 * NT * 32;    // packed V, in double2 units
+  const double2* Vp2 = reinterpret_cast<const double2*>(Vp);
+  double2* s_v2 = reinterpret_cast<double2*>(s_v);
+
+  for (int64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
+    const int64_t tile = st * 4 + wave;            // beyond ntiles: clamped rows, computed but never stored
     const double* xrow[FT];
     double mu[SCALE ? FT : 1], rs[SCALE ? FT : 1];
 #pragma unroll
     for (int t = 0; t < FT; ++t) {
       int64_t j = tile * 16 * FT + t * 16 + f;
-      if (j >= p) j = p - 1;   // clamped rows are computed but never stored
+      if (j >= p) j = p - 1;
       xrow[t] = X + j * ld + 4 * g;
       if constexpr (SCALE) {
         mu[t] = mean[j];
@@ -76,47 +95,78 @@ __global__ __launch_bounds__(256) void k_xtv_mfma(const double* __restrict__ X, 
     for (int t = 0; t < FT; ++t)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    const double* vp = Vp + lane;
 
-    for (int64_t ks = ks_begin; ks < nk_full; ++ks) {
-      double x[FT][4];
+    double2 vreg[NV2];
+    auto fetch_chunk = [&](int64_t kc0) {          // global -> registers
+      const int64_t base2 = kc0 * 4 * NT * 32;
 #pragma unroll
-      for (int t = 0; t < FT; ++t) {
-        const double2 lo = *reinterpret_cast<const double2*>(xrow[t] + 16 * ks);
-        const double2 hi = *reinterpret_cast<const double2*>(xrow[t] + 16 * ks + 2);
-        x[t][0] = lo.x; x[t][1] = lo.y; x[t][2] = hi.x; x[t][3] = hi.y;
-        if constexpr (SCALE) {
+      for (int i = 0; i < NV2; ++i) {
+        const int64_t e = base2 + i * 256 + tid;
+        vreg[i] = e < vtotal2 ? Vp2[e] : make_double2(0.0, 0.0);
+      }
+    };
+    auto park_chunk = [&]() {                      // registers -> LDS
 #pragma unroll
-          for (int m = 0; m < 4; ++m) x[t][m] = (x[t][m] - mu[t]) * rs[t];
+      for (int i = 0; i < NV2; ++i) s_v2[i * 256 + tid] = vreg[i];
+    };
+    auto load_x = [&](double (&x)[FT][4], int64_t ks) {
+      if (ks < nk_full) {
+#pragma unroll
+        for (int t = 0; t < FT; ++t) {
+          const double2 lo = *reinterpret_cast<const double2*>(xrow[t] + 16 * ks);
+          const double2 hi = *reinterpret_cast<const double2*>(xrow[t] + 16 * ks + 2);
+          x[t][0] = lo.x; x[t][1] = lo.y; x[t][2] = hi.x; x[t][3] = hi.y;
         }
+      } else {                                     // ragged end of the rows: guarded scalar loads
+#pragma unroll
+        for (int t = 0; t < FT; ++t)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int64_t i = 16 * ks + 4 * g + m;
+            x[t][m] = (i < n) ? xrow[t][16 * ks + m] : 0.0;
+          }
+      }
+    };
+    auto step = [&](double (&cur)[FT][4], double (&nxt)[FT][4], int64_t ks, int lk) {
+      if (ks + 1 < nk) load_x(nxt, ks + 1);
+      if constexpr (SCALE) {
+#pragma unroll
+        for (int t = 0; t < FT; ++t)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) cur[t][m] = (cur[t][m] - mu[t]) * rs[t];
       }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const double b = vp[((ks * 4 + m) * NT + nt) * 64];
+          const double b = s_v[((lk * 4 + m) * NT + nt) * 64 + lane];
 #pragma unroll
-          for (int t = 0; t < FT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[t][m], b, acc[t][nt], 0, 0, 0);
+          for (int t = 0; t < FT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[t][m], b, acc[t][nt], 0, 0, 0);
         }
+    };
+
+    double xa[FT][4], xb[FT][4];
+    __syncthreads();                               // the previous super tile's last chunk is no longer read
+    if (ks_begin < nk) {
+      fetch_chunk(ks_begin);
+      load_x(xa, ks_begin);
+      park_chunk();
     }
-    for (int64_t ks = std::max(nk_full, ks_begin); ks < nk; ++ks) {   // ragged end of the rows: guarded scalar loads
-      double x[FT][4];
+    __syncthreads();
+    for (int64_t kc0 = ks_begin; kc0 < nk; kc0 += XTV_KC) {
+      const bool more = kc0 + XTV_KC < nk;
+      if (more) fetch_chunk(kc0 + XTV_KC);
+      static_assert(XTV_KC % 2 == 0, "the operand double buffer alternates per k-step");
 #pragma unroll
-      for (int t = 0; t < FT; ++t)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int64_t i = 16 * ks + 4 * g + m;
-          x[t][m] = (i < n) ? xrow[t][16 * ks + m] : 0.0;
-          if constexpr (SCALE) x[t][m] = (i < n) ? (x[t][m] - mu[t]) * rs[t] : 0.0;
-        }
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const double b = vp[((ks * 4 + m) * NT + nt) * 64];
-#pragma unroll
-          for (int t = 0; t < FT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[t][m], b, acc[t][nt], 0, 0, 0);
-        }
+      for (int lk = 0; lk < XTV_KC; lk += 2) {
+        if (kc0 + lk < nk) step(xa, xb, kc0 + lk, lk);
+        if (kc0 + lk + 1 < nk) step(xb, xa, kc0 + lk + 1, lk + 1);
+      }
+      __syncthreads();                             // every wave has consumed this chunk
+      if (more) {
+        park_chunk();
+        __syncthreads();
+      }
     }
     // D layout (f64 16x16x4): column (rhs) = lane & 15, row (feature) = (lane >> 4) + 4 * reg
 #pragma unroll

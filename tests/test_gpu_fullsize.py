@@ -93,14 +93,15 @@ def recurrence(Z, Ts, U, weights_from_u=True):
     return Wn, P
 
 
-def check_generic_products(mdl, X, Y, blocks=True):
+def check_generic_products(mdl, X, Y, blocks=True, check_u=True):
     """(a): the fitted model through transform / predict (generic x_w kernels, on-the-fly standardisation)"""
     out = mdl.transform(X, Y, return_block_scores=True) if blocks else mdl.transform(X, Y)
     Ts_new, U_new = out[0], out[-1]
     s = np.sign(np.sum(Ts_new * mdl.Ts_, axis=0))
     assert np.all(s == 1.0)                                # same model, same data: no sign freedom
     assert util.relerr(Ts_new, mdl.Ts_) < TOL, util.relerr(Ts_new, mdl.Ts_)
-    assert util.relerr(U_new, mdl.U_) < TOL
+    if check_u:     # (KERNEL takes U_ from the deflated Y, transform from Y itself: not comparable there)
+        assert util.relerr(U_new, mdl.U_) < TOL
     if blocks:
         for b, Tb in enumerate(out[1]):
             assert util.relerr(Tb, mdl.T_[b]) < TOL, (b, util.relerr(Tb, mdl.T_[b]))
@@ -226,12 +227,11 @@ def test_c4_kernel_full_size(gpu_required, monkeypatch):
     try:
         ranges, width = sample_ranges(X)
         cols, raw = download_sample(X, ranges, width)                     # before the in-place standardisation
-        free0 = ctx.info()["free_bytes"]
         m0 = MBPLS(n_components=K, method="KERNEL").fit(X, Y)             # copy=True, nothing written, no working copy
         _, again = download_sample(X, ranges, width)
         assert np.array_equal(again, raw)
         check_orthonormal(m0.Ts_)
-        check_generic_products(m0, X, Y)                                  # transform / predict standardise on the fly
+        check_generic_products(m0, X, Y, check_u=False)                   # transform / predict standardise on the fly
         monkeypatch.setenv("MBPLS_IMPLICIT_STD", "0")
         mdl = MBPLS(n_components=K, method="KERNEL", copy=False).fit(X, Y)
         monkeypatch.delenv("MBPLS_IMPLICIT_STD")

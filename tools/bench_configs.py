@@ -60,7 +60,8 @@ if __name__ == "__main__":
         run("C3 UNIPALS multiblock", 4096, 1_000_000, 10, 1, "UNIPALS", [0, 300_000, 600_000, 1_000_000], True)
     elif which == "c4":
         p = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
-        run("C4 KERNEL Gram", 8192, p, 20, 1, "KERNEL", [0, p], False)
+        # default copy=True: statistics-only preparation, the products standardise on the fly (no second 131 GB buffer)
+        run("C4 KERNEL Gram", 8192, p, 20, 1, "KERNEL", [0, p], os.environ.get("MBPLS_IMPLICIT_STD", "1") != "0")
     elif which == "simpls":
         run("SIMPLS", 4096, 1_000_000, 10, 1, "SIMPLS", [0, 1_000_000], True)
     elif which == "nipals_q10":
