@@ -291,9 +291,11 @@ int mbpls_hip_x_w_nan(const mbpls_mat* m, const double* d_W, int64_t ldw, int c,
 int mbpls_hip_gram(const mbpls_mat* m, double* d_G, int64_t ldg);
 /* The association matrix of the STANDARDISED data from the RAW matrix: z = (x - mean_j) * rscale_j is applied to
  * both MFMA operands in registers (rscale_j = 1/scale_j, 0 for a constant column; both NULL = mbpls_hip_gram), so
- * the KERNEL method needs no standardised copy of X (mbpls.py:314 + :704 in one read).                            */
-int mbpls_hip_gram_scaled(const mbpls_mat* m, const double* d_mean, const double* d_rscale, double* d_G,
-                          int64_t ldg);
+ * the KERNEL method needs no standardised copy of X (mbpls.py:314 + :704 in one read).  centre_first = 1: subtract,
+ * then multiply (any offset); 0: one fma(x, rscale, -mean rscale) per value -- its rounding grows with
+ * |mean_j|/scale_j, for data whose offset measure (mbpls_hip_standardize_stats_sweep d_amp) is small.             */
+int mbpls_hip_gram_scaled(const mbpls_mat* m, const double* d_mean, const double* d_rscale, int centre_first,
+                          double* d_G, int64_t ldg);
 
 /* ---- multi-response NIPALS in association-matrix space ----------------------------------------------------
  * One iteration of the inner loop (mbpls.py:841-913) given d_a = A z, A = sum_b X_b X_b^T (mbpls_hip_gram per block,

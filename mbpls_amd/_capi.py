@@ -87,7 +87,7 @@ SIGNATURES = {
     "mbpls_hip_nan_deflate_sweep": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_x_w_nan": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _int, _vp, _i64]),
     "mbpls_hip_gram": (_int, [_vp, _vp, _i64]),
-    "mbpls_hip_gram_scaled": (_int, [_vp, _vp, _vp, _vp, _i64]),
+    "mbpls_hip_gram_scaled": (_int, [_vp, _vp, _vp, _int, _vp, _i64]),
     "mbpls_hip_xt_v_scaled": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _dbl, _vp, _i64, _vp]),
     "mbpls_hip_comm_unique_id": (_int, [_vp]),
     "mbpls_hip_comm_init_rank": (_int, [_vp, _int, _int, _vp]),
@@ -470,5 +470,6 @@ class DeviceMatrix:
                                              _ptr(mean), _ptr(scale), int(bool(indicator)), _ptr(out),
                                              int(ldo or self.n)))
 
-    def gram(self, G, ldg=None, mean=None, rscale=None):
-        check(self.ctx.lib.mbpls_hip_gram_scaled(self.handle, _ptr(mean), _ptr(rscale), _ptr(G), int(ldg or self.n)))
+    def gram(self, G, ldg=None, mean=None, rscale=None, centre_first=True):
+        check(self.ctx.lib.mbpls_hip_gram_scaled(self.handle, _ptr(mean), _ptr(rscale), int(bool(centre_first)), _ptr(G),
+                                                 int(ldg or self.n)))

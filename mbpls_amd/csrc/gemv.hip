@@ -114,9 +114,9 @@ __global__ __launch_bounds__(256) void k_xw(const double* __restrict__ X, int64_
     if (inld) t = *reinterpret_cast<const double2*>(col);
     double x0 = in0 ? t.x : 0.0, x1 = in1 ? t.y : 0.0;
     if constexpr (SCALE) {
-      const double mu = mean[j], sc = scale[j];
-      x0 = in0 ? (x0 - mu) / sc : 0.0;
-      x1 = in1 ? (x1 - mu) / sc : 0.0;
+      const double mu = mean[j], rsc = scale[j];     // `scale` holds the RECIPROCALS here (k_recip, x_w_impl)
+      x0 = in0 ? (x0 - mu) * rsc : 0.0;
+      x1 = in1 ? (x1 - mu) * rsc : 0.0;
     }
     if constexpr (NANM == 1) {
       x0 = (x0 == x0) ? x0 : 0.0;
@@ -270,6 +270,12 @@ void launch_reduce_xw(mbpls_ctx* ctx, const mbpls_mat* m, const double* part, in
 }
 }  // namespace mbpls
 
+// r[j] = 1 / s[j]: the on-the-fly standardisation multiplies (a division per element cost more than the loads)
+__global__ __launch_bounds__(256) void k_recip(int64_t p, const double* __restrict__ s, double* __restrict__ r) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < p) r[j] = 1.0 / s[j];
+}
+
 static int x_w_impl(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block, const double* d_mean,
                     const double* d_scale, int nanm, double* d_out, int64_t ldo) {
   MB_ARG(m && d_W && d_out, "NULL argument");
@@ -287,8 +293,15 @@ static int x_w_impl(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, i
   }
   const ChunkTable& ct = m->coarse;
   constexpr int CB = 8;
-  MB_TRY(ensure_ws(ctx, sizeof(double) * (size_t)ct.nchunks * CB * (size_t)m->n));
+  const size_t part_bytes = ((sizeof(double) * (size_t)ct.nchunks * CB * (size_t)m->n + 255) / 256) * 256;
+  MB_TRY(ensure_ws(ctx, part_bytes + (d_scale ? sizeof(double) * (size_t)m->p : 0)));
   double* part = (double*)ctx->ws;
+  if (d_scale && nanm != 2) {
+    double* rs = (double*)((char*)ctx->ws + part_bytes);
+    hipLaunchKernelGGL(k_recip, dim3((unsigned)((m->p + 255) / 256)), dim3(256), 0, ctx->stream, m->p, d_scale, rs);
+    MB_HIP(hipGetLastError());
+    d_scale = rs;
+  }
   const unsigned slabs = (unsigned)((m->n + 511) / 512);
   for (int k0 = 0; k0 < c; k0 += CB) {
     const int cb = std::min(CB, c - k0);

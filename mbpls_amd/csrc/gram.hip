@@ -37,7 +37,10 @@ struct GramArgs {
 // SCALE: the operands are standardised on the fly, z = (x - mean_j) / scale_j (one subtraction and one multiplication
 // per loaded value -- VALU work next to 16 MFMAs per k-step, the kernel stays matrix-core bound): the KERNEL method
 // then needs neither a standardised copy of X nor the read+write pass that makes it.
-template <bool SCALE>
+// SCALE 1: z = (x - mean) * rscale (two operations per value, safe for any column offset); SCALE 2: z = fma(x, rscale,
+// -mean * rscale) (one operation; its rounding is amplified by |mean_j|/scale_j, so callers use it when the
+// statistics pass reported a small offset measure).
+template <int SCALE>
 __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   // XCD-aware remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous run of work items
   const int nwg = gridDim.x;
@@ -86,9 +89,9 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   const int64_t gstride = 4 * a.ld * 8;               // bytes between consecutive groups
   typedef double gv2_t __attribute__((ext_vector_type(2)));
   gv2_t av[PD][2], bv[PD][2];
-  gv2_t msv[SCALE ? PD : 1];                           // (mean, 1/scale) of this lane's feature in each group
+  gv2_t msv[SCALE != 0 ? PD : 1];                           // (mean, 1/scale) of this lane's feature in each group
   const unsigned oms = (unsigned)(lk * 16);
-  const char* msb = SCALE ? (const char*)(a.ms + 2 * jbeg) : nullptr;
+  const char* msb = SCALE != 0 ? (const char*)(a.ms + 2 * jbeg) : nullptr;
   // The ring's loads are inline asm on purpose: hipcc's own waitcnt insertion loses the exact queue depth
   // across the loop back-edge and emits vmcnt(8) -- i.e. it waits for the groups issued one and two steps
   // ago as well, which leaves ONE step of latency cover and 35 % of the requests miss L2 here.  With the
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
         MB_GLD(av[s][t], oa[t], g);
         MB_GLD(bv[s][t], ob[t], g);
       }
-      if constexpr (SCALE) MB_GLD(msv[s], oms, msb + s * 64);
+      if constexpr (SCALE != 0) MB_GLD(msv[s], oms, msb + s * 64);
     }
     static_assert(PD == 4, "the step macro below is written for a ring of 4 slots");
 #define MB_GRAM_STEP(S, SL)                                                                                 \
@@ -119,25 +122,26 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
       MB_GLD(av[SL][t], oa[t], g);                                                                          \
       MB_GLD(bv[SL][t], ob[t], g);                                                                          \
     }                                                                                                       \
-    if constexpr (SCALE) {                                                                                  \
+    if constexpr (SCALE != 0) {                                                                             \
       MB_GLD(msv[SL], oms, msb + nx * 64);                                                                  \
       asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   /* 4 groups x 5 loads in flight, oldest retired */ \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
       /* z = (x - mean) * rscale on the 8 operand values, INTERLEAVED with the 16 MFMAs: an MFMA occupies the */ \
       /* matrix pipe for 16 cycles but the issue port for 4, so two VALU ops ride along with each one        */ \
       const double mu_ = msv[S].x, rs_ = msv[S].y;                                                          \
+      auto Z_ = [&](double x) { return SCALE == 2 ? fma(x, rs_, mu_) : (x - mu_) * rs_; };                  \
       double za[4], zb[4];                                                                                  \
-      za[0] = (av[S][0].x - mu_) * rs_;                                                                     \
-      zb[0] = (bv[S][0].x - mu_) * rs_;                                                                     \
+      za[0] = Z_(av[S][0].x);                                                                               \
+      zb[0] = Z_(bv[S][0].x);                                                                               \
       _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) {   \
         /* operands needed by a later MFMA are prepared while this one runs */                              \
-        if (mi == 0 && ni < 3) zb[ni + 1] = (bv[S][(ni + 1) >> 1][(ni + 1) & 1] - mu_) * rs_;               \
-        if (ni == 3 && mi < 3) za[mi + 1] = (av[S][(mi + 1) >> 1][(mi + 1) & 1] - mu_) * rs_;               \
+        if (mi == 0 && ni < 3) zb[ni + 1] = Z_(bv[S][(ni + 1) >> 1][(ni + 1) & 1]);                         \
+        if (ni == 3 && mi < 3) za[mi + 1] = Z_(av[S][(mi + 1) >> 1][(mi + 1) & 1]);                         \
         acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(za[mi], zb[ni], acc[mi][ni], 0, 0, 0);           \
       }                                                                                                     \
       _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                      \
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   /* 2 VALU */                                   \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA */                                   \
+        __builtin_amdgcn_sched_group_barrier(0x002, SCALE == 2 ? 1 : 2, 0);   /* VALU */                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    /* 1 MFMA */                  \
       }                                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
     } else {                                                                                                \
@@ -167,18 +171,19 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
     const char* g = (const char*)(a.X + (vj ? j : jbeg) * a.ld);
     double ta[4], tb[4];
     double mu = 0.0, rs = 1.0;
-    if constexpr (SCALE) {
+    if constexpr (SCALE != 0) {
       if (vj) {
         mu = a.ms[2 * (j + lk)];
         rs = a.ms[2 * (j + lk) + 1];
       }
     }
+    auto Zt = [&](double x) { return SCALE == 2 ? fma(x, rs, mu) : (x - mu) * rs; };
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const double2 xa = vj ? *(const double2*)(g + oa[t]) : make_double2(0.0, 0.0);
       const double2 xq = vj ? *(const double2*)(g + ob[t]) : make_double2(0.0, 0.0);
-      ta[2 * t] = vj ? (xa.x - mu) * rs : 0.0; ta[2 * t + 1] = vj ? (xa.y - mu) * rs : 0.0;
-      tb[2 * t] = vj ? (xq.x - mu) * rs : 0.0; tb[2 * t + 1] = vj ? (xq.y - mu) * rs : 0.0;
+      ta[2 * t] = vj ? Zt(xa.x) : 0.0; ta[2 * t + 1] = vj ? Zt(xa.y) : 0.0;
+      tb[2 * t] = vj ? Zt(xq.x) : 0.0; tb[2 * t + 1] = vj ? Zt(xq.y) : 0.0;
     }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -216,21 +221,23 @@ __global__ __launch_bounds__(256) void k_gram_finish(const double* __restrict__ 
 
 using namespace mbpls;
 
-// ms[j] = (mean_j, 1/scale_j) interleaved, so a lane fetches both with one 16-byte load
+// ms[j] = (mean_j, 1/scale_j) -- or (-mean_j/scale_j, 1/scale_j) for the one-fma form -- interleaved, so a lane
+// fetches both with one 16-byte load
 __global__ __launch_bounds__(256) void k_pack_mean_rscale(int64_t p, const double* __restrict__ mean,
-                                                          const double* __restrict__ rscale, double* __restrict__ ms) {
+                                                          const double* __restrict__ rscale, double* __restrict__ ms,
+                                                          int fused) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= p) return;
-  ms[2 * j] = mean[j];
+  ms[2 * j] = fused ? -mean[j] * rscale[j] : mean[j];
   ms[2 * j + 1] = rscale[j];
 }
 
 extern "C" int mbpls_hip_gram(const mbpls_mat* m, double* d_G, int64_t ldg) {
-  return mbpls_hip_gram_scaled(m, nullptr, nullptr, d_G, ldg);
+  return mbpls_hip_gram_scaled(m, nullptr, nullptr, 1, d_G, ldg);
 }
 
-extern "C" int mbpls_hip_gram_scaled(const mbpls_mat* m, const double* d_mean, const double* d_rscale, double* d_G,
-                                     int64_t ldg) {
+extern "C" int mbpls_hip_gram_scaled(const mbpls_mat* m, const double* d_mean, const double* d_rscale, int centre_first,
+                                     double* d_G, int64_t ldg) {
   MB_ARG(m && d_G, "NULL argument");
   MB_ARG((d_mean == nullptr) == (d_rscale == nullptr), "d_mean and d_rscale must be given together");
   MB_ARG(ldg >= m->n, "ldg < n");
@@ -283,7 +290,7 @@ extern "C" int mbpls_hip_gram_scaled(const mbpls_mat* m, const double* d_mean, c
   double* ms = d_mean ? (double*)((char*)part + ((part_bytes + 255) / 256) * 256) : nullptr;
   if (ms) {
     hipLaunchKernelGGL(k_pack_mean_rscale, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, p, d_mean,
-                       d_rscale, ms);
+                       d_rscale, ms, centre_first ? 0 : 1);
     MB_HIP(hipGetLastError());
   }
   MB_HIP(hipMemcpyAsync(d_ti, ti.data(), sizeof(int) * ntiles, hipMemcpyHostToDevice, ctx->stream));
@@ -295,8 +302,9 @@ extern "C" int mbpls_hip_gram_scaled(const mbpls_mat* m, const double* d_mean, c
   a.out = part; a.ldg = ldg;
   {
     ProfScope prof(ctx, MBPLS_K_GRAM, 8.0 * (double)n * (double)p);
-    if (ms) hipLaunchKernelGGL(k_gram<true>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(k_gram<false>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
+    if (ms && centre_first) hipLaunchKernelGGL(k_gram<1>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
+    else if (ms) hipLaunchKernelGGL(k_gram<2>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_gram<0>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
   }
   MB_HIP(hipGetLastError());
   dim3 fgrid((unsigned)((n + 255) / 256), (unsigned)n);

@@ -370,11 +370,12 @@ class HipEngine:
         finally:
             self.ctx.lib.mbpls_hip_set_variance_output(self.ctx.handle, None)
         self.run_deferred(2)
-        _, _, _, x = self._finish_pass(False, False, False, True)
+        _, _, _, x = self._finish_pass(False, False, False, True, nd=1)
         if not np.all(np.isfinite(x)):
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
         self.X, self._src = src, None              # the raw matrix, never written
         self._kscale = bool(standardize)
+        self._cen = self._kscale and float(np.sqrt(np.max(self._last_d))) > self.CENTRE_FROM_OFFSET
         return x
 
     # Raw-space dot products carry rounding noise of max_j |mean_j| / scale_j ulps.  Above this offset ratio the
@@ -758,7 +759,7 @@ class HipEngine:
         ldg = n + (n & 1)
         store = self._gram_store(ldg * n)
         if self._kscale:
-            self.X.gram(store.ptr, ldg, mean=self.mean, rscale=self.rs)
+            self.X.gram(store.ptr, ldg, mean=self.mean, rscale=self.rs, centre_first=self._cen)
         else:
             self.X.gram(store.ptr, ldg)
         self.comm.allreduce_device(store)        # partial Grams of the column shards (in place, RCCL when sharded)
