@@ -197,8 +197,11 @@ def main():
         if dom[0]:
             k = dom[1]
             traffic, src = pmc_traffic(dom[0], n, p)
+            ceiling = X.probe_read_bandwidth(3)      # best pure-read kernel on this box, same buffer (after the timed region)
             roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(k["GBps"], 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(k["GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "measured_read_ceiling_GBps": round(ceiling, 1),
+                    "frac_of_measured_read_ceiling": round(k["GBps"] / ceiling, 4) if ceiling > 0 else None,
                     "traffic_source": src, "bytes_per_launch": k["bytes_per_launch"], "avg_ms": round(k["avg_ms"], 4),
                     "launches": k["launches"],
                     "timing": "HIP events on the launch stream around every launch of the timed region"}

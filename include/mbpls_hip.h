@@ -124,6 +124,11 @@ int mbpls_hip_mat_copy(mbpls_mat* dst, const mbpls_mat* src);
 int mbpls_hip_mat_fill_latent(mbpls_mat* m, const double* d_T, int r, double noise, uint64_t seed,
                               int64_t col_base);
 
+/* Measurement aid (bench.py): the best read-only bandwidth a kernel reaches on THIS device over this matrix's
+ * storage -- slab-wise non-temporal 16-byte loads, nothing stored; best of `reps` launches, GB/s.  The HBM-bound
+ * passes are priced against the nominal 8 TB/s AND against this measured ceiling.                                */
+int mbpls_hip_probe_read_bandwidth(const mbpls_mat* m, int reps, double* best_gbps);
+
 /* ---- the hot path -----------------------------------------------------------------------------
  * Common conventions: d_v / d_ts are n-vectors; d_g / d_p are p-vectors (may point into a column
  * of a p x K device array); d_t is n*nblocks (block b at d_t + b*n); d_ssq_* are nblocks doubles.
@@ -334,6 +339,9 @@ int mbpls_hip_nipals_gram_step(mbpls_ctx* ctx, int64_t n, const double* d_a, con
 typedef struct mbpls_nipals_step {
   int64_t n;
   int nblocks, q, kc, run, nd, centre, norm_kind;   /* norm_kind: 0 ||.||_2, 1 sum|.|, 2 max|.|, 3 min|.| (:887) */
+  int mode;                /* 0 NIPALS; 1 UNIPALS p > n with one response (:481-572): the pass delivered X_b (X_b^T y),
+                              one step per component (run = 1) forms ts, v, u, c (w = c X^T y, scal[kc][3][0]), the
+                              block norms and scores and prepares the loadings pass; no iteration                   */
   double tol;              /* max_tol (:841)                                                                       */
   double amp2_max;         /* > 0, component 0 / run 1 only: the statistics pass left max_j (mean_j/scale_j)^2 per block
                               in the d area; above this value the step stops the queue with par[5] = 1 (the caller
@@ -364,6 +372,8 @@ int mbpls_hip_set_pass_params(mbpls_ctx* ctx, const double* d_par);
 /* d_dst[j] = d_src[j] / sqrt(d_nu2[block of j]): block weights w_b = w~_b / ||w~_b|| (mbpls.py:860) with the norms
  * still on the device (d_nu2: nblocks squared norms).                                                              */
 int mbpls_hip_block_unit_col(const mbpls_mat* m, const double* d_src, double* d_dst, const double* d_nu2);
+/* d_dst[j] = d_src[j] * d_scalar[0] for a p-length column (UNIPALS: w = X^T u = c X^T y, mbpls.py:503).              */
+int mbpls_hip_scale_col_by(mbpls_ctx* ctx, int64_t p, const double* d_src, double* d_dst, const double* d_scalar);
 /* Ordered device-to-host copies for finished columns: record an event behind the kernels queued so far; a HELPER
  * thread then waits for that event only (not for the stream) and copies on the copy stream, so the queueing thread
  * never blocks.                                                                                                   */

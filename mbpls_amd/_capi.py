@@ -27,7 +27,7 @@ _pp = C.POINTER(C.c_void_p)
 class NipalsStep(C.Structure):
     """``mbpls_nipals_step`` of include/mbpls_hip.h (device-resident NIPALS step)."""
     _fields_ = [("n", _i64), ("nblocks", _int), ("q", _int), ("kc", _int), ("run", _int), ("nd", _int),
-                ("centre", _int), ("norm_kind", _int), ("tol", _dbl), ("amp2_max", _dbl),
+                ("centre", _int), ("norm_kind", _int), ("mode", _int), ("tol", _dbl), ("amp2_max", _dbl),
                 ("xchg", _vp), ("Y", _vp), ("Ts", _vp), ("Tsc", _vp), ("U", _vp), ("V", _vp), ("Tb", _vp),
                 ("scal", _vp), ("ssq_x", _vp), ("iters", _vp), ("u_cur", _vp), ("ts_old", _vp), ("vpass", _vp),
                 ("tspass", _vp), ("cu", _vp), ("ce", _vp), ("par", _vp)]
@@ -66,6 +66,7 @@ SIGNATURES = {
     "mbpls_hip_mat_download": (_int, [_vp, _vp, _i64, _int, _i64, _i64]),
     "mbpls_hip_mat_copy": (_int, [_vp, _vp]),
     "mbpls_hip_mat_fill_latent": (_int, [_vp, _vp, _int, _dbl, C.c_uint64, _i64]),
+    "mbpls_hip_probe_read_bandwidth": (_int, [_vp, _int, C.POINTER(_dbl)]),
     "mbpls_hip_standardize_sweep": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
     "mbpls_hip_standardize_sweep_masked": (_int, [_vp, _vp, _int, _vp, _dbl, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
     "mbpls_hip_sweep": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "mbpls_hip_set_pass_params": (_int, [_vp, _vp]),
     "mbpls_hip_set_variance_output": (_int, [_vp, _vp]),
     "mbpls_hip_block_unit_col": (_int, [_vp, _vp, _vp, _vp]),
+    "mbpls_hip_scale_col_by": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "mbpls_hip_event_record": (_int, [_vp, _pp]),
     "mbpls_hip_memcpy_d2h_after": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "mbpls_hip_event_destroy": (_int, [_vp, _vp]),
@@ -397,6 +399,12 @@ class DeviceMatrix:
 
     def copy_from(self, other):
         check(self.ctx.lib.mbpls_hip_mat_copy(self.handle, other.handle))
+
+    def probe_read_bandwidth(self, reps=3):
+        """best read-only GB/s over this matrix's storage (measured ceiling of the HBM-bound passes)"""
+        g = _dbl(0)
+        check(self.ctx.lib.mbpls_hip_probe_read_bandwidth(self.handle, int(reps), C.byref(g)))
+        return g.value
 
     def fill_latent(self, Ts_dev, r, noise, seed, col_base=0):
         check(self.ctx.lib.mbpls_hip_mat_fill_latent(self.handle, Ts_dev.ptr, int(r), float(noise), int(seed), int(col_base)))

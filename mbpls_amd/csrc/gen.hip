@@ -3,6 +3,8 @@
 // Ts (n x r, column-major) is the score matrix already scaled by the decay; L and the noise come
 // from a counter-based generator (splitmix64 of (seed, stream, index) + Box-Muller), so any
 // column range of the same global matrix can be produced independently on any rank.
+#include <algorithm>
+
 #include "common.h"
 
 namespace mbpls {
@@ -60,9 +62,58 @@ __global__ __launch_bounds__(256) void k_fill_latent(double* __restrict__ X, int
   }
 }
 
+// Measured read ceiling of this GPU (bench.py reports it beside the 8 TB/s nominal peak): every workgroup streams a
+// contiguous slab with non-temporal 16-byte loads, U of them in flight per lane, one add per value, nothing stored.
+typedef double v2d_probe __attribute__((ext_vector_type(2)));
+template <int U>
+__global__ __launch_bounds__(512) void k_read_probe(const v2d_probe* __restrict__ x, int64_t n2, double* __restrict__ out) {
+  const int64_t per = (n2 + gridDim.x - 1) / gridDim.x;
+  const int64_t b0 = (int64_t)blockIdx.x * per, b1 = b0 + per < n2 ? b0 + per : n2;
+  double s0 = 0.0, s1 = 0.0;
+  int64_t i = b0 + threadIdx.x;
+  for (; i + (int64_t)(U - 1) * blockDim.x < b1; i += (int64_t)U * blockDim.x) {
+    v2d_probe v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(x + i + (int64_t)u * blockDim.x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s0 += v[u].x;
+      s1 += v[u].y;
+    }
+  }
+  for (; i < b1; i += blockDim.x) {
+    const v2d_probe v = __builtin_nontemporal_load(x + i);
+    s0 += v.x;
+    s1 += v.y;
+  }
+  if (s0 + s1 == 1.2345e-300) out[blockIdx.x] = s0;   // never true for real data: keeps the loads alive
+}
+
 }  // namespace mbpls
 
 using namespace mbpls;
+
+extern "C" int mbpls_hip_probe_read_bandwidth(const mbpls_mat* m, int reps, double* best_gbps) {
+  MB_ARG(m && best_gbps && reps >= 1, "bad argument");
+  mbpls_ctx* ctx = m->ctx;
+  const int64_t n2 = m->ld * m->p / 2;
+  const unsigned grid = (unsigned)ctx->cus * 8;
+  MB_TRY(ensure_ws(ctx, sizeof(double) * grid));
+  double best = 0.0;
+  for (int r = 0; r <= reps; ++r) {      // first launch is a warm-up
+    MB_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_read_probe<4>, dim3(grid), dim3(512), 0, ctx->stream, (const v2d_probe*)m->data, n2,
+                       (double*)ctx->ws);
+    MB_HIP(hipGetLastError());
+    MB_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    MB_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    MB_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (r > 0 && ms > 0.f) best = std::max(best, 16.0 * (double)n2 / 1e9 / ((double)ms / 1e3));
+  }
+  *best_gbps = best;
+  return MBPLS_OK;
+}
 
 extern "C" int mbpls_hip_mat_fill_latent(mbpls_mat* m, const double* d_T, int r, double noise, uint64_t seed,
                                          int64_t col_base) {

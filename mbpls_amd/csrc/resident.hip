@@ -31,6 +31,9 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
   const int64_t n = s.n;
   const int B = s.nblocks, q = s.q, kc = s.kc, nd = s.nd;
   const bool istd = s.centre != 0;
+  // mode 1: UNIPALS, p > n, one response (mbpls.py:481-572): the pass delivered X_b (X_b^T y) and ||X_b^T y||^2; a
+  // component needs no iteration: ts = X (X^T y) / ||.|| (:489-493 with one response), w = X^T u = c X^T y (:503)
+  const bool uni = s.mode == 1;
   const double* tr = s.xchg;             // [B][n] raw accumulations of the pass
   const double* ssq_g = s.xchg + n * B;
   const double* ssq_p = ssq_g + B;
@@ -100,15 +103,20 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
   for (int b = 0; b < RS_BMAX; ++b) sw[b] = sw[b] / swn;
 
   // ---- ts = T sw, unit length (:882-883); scratch in vpass (the pass that read it has finished)
+  //      UNIPALS: ts = sum_b X_b (X_b^T y), unit length; the block scores are scaled once c is known
   double m2[4] = {0.0, 0.0, 0.0, 0.0};
   for (int64_t i = tid; i < n; i += WG1024) {
     double acc = 0.0;
 #pragma unroll
     for (int b = 0; b < RS_BMAX; ++b)
       if (b < B) {
-        const double tm = (tb[(int64_t)b * n + i] - mean_t[b]) / nu[b];
-        tb[(int64_t)b * n + i] = tm;
-        acc = fma(tm, sw[b], acc);
+        if (uni) {
+          acc += tb[(int64_t)b * n + i] - mean_t[b];
+        } else {
+          const double tm = (tb[(int64_t)b * n + i] - mean_t[b]) / nu[b];
+          tb[(int64_t)b * n + i] = tm;
+          acc = fma(tm, sw[b], acc);
+        }
       }
     s.vpass[i] = acc;
     m2[0] = fma(acc, acc, m2[0]);
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
     }
     diff = (s.norm_kind == 2) ? dmax : dmin;
   }
-  const bool converged = s.run > 1 && diff <= s.tol;
+  const bool converged = uni || (s.run > 1 && diff <= s.tol);
   if (s.run > 1 && !converged) {
     // the speculation (two iterations per component) does not hold: stop here, the host takes over at component kc
     if (tid == 0) {
@@ -186,8 +194,9 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
     w = w / vv;
     s.tspass[i] = w;
     un[0] = fma(w, w, un[0]);
+    un[1] = fma(w, s.u_cur[i], un[1]);     // UNIPALS: u^T y (u_cur is y, the start vector)
   }
-  reduce_many<4>(un, 1, part, tot);
+  reduce_many<4>(un, 2, part, tot);
   const double unrm = sqrt(un[0]);
 
   // out[j] = <Tsc_j, vec> for j < kc, 16 at a time (register budget: 1024 threads leave 128 VGPRs each)
@@ -229,6 +238,16 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
     return;
   }
 
+  // ---- UNIPALS: w_raw = X^T u = c X^T y with c = u^T y / y^T y, so ||w_raw_b||^2 = c^2 ||X_b^T y||^2 and
+  //      t_b = X_b w_raw_b / ||w_raw_b|| = c t~_b / sqrt(c^2 ||g_b||^2)                         (:503-517)
+  const double c_uni = uni ? (un[1] / unrm) / uu : 1.0;
+  if (uni) {
+    for (int64_t i = tid; i < n; i += WG1024)
+#pragma unroll
+      for (int b = 0; b < RS_BMAX; ++b)
+        if (b < B) tb[(int64_t)b * n + i] = c_uni * (tb[(int64_t)b * n + i] - mean_t[b]) / sqrt(c_uni * c_uni * ssq_g[b]);
+  }
+
   // ---- converged: record component kc, then prepare loadings (+ lazy deflation) + first sweep of component kc+1
   const double* u0 = s.Y;                      // start vector of every component: Y[:, 0] (:838)
   double a4[4] = {0.0, 0.0, 0.0, 0.0};         // sum u0, u0^T u0
@@ -257,13 +276,26 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
 #pragma unroll
   for (int b = 0; b < RS_BMAX; ++b)
     if (b < B && tid == 0) {
-      s.scal[(int64_t)kc * 4 * B + b] = ssq_g[b];               // ||w~_b||^2 of the last iteration
-      s.scal[(int64_t)kc * 4 * B + B + b] = sw[b] * sw[b];      // a_b (:949)
+      if (uni) {
+        double tot_w = 0.0;
+        for (int bb = 0; bb < B; ++bb) tot_w += c_uni * c_uni * ssq_g[bb];
+        s.scal[(int64_t)kc * 4 * B + b] = c_uni * c_uni * ssq_g[b];                // ||w_raw_b||^2
+        s.scal[(int64_t)kc * 4 * B + B + b] = c_uni * c_uni * ssq_g[b] / tot_w;    // a_b (:512)
+      } else {
+        s.scal[(int64_t)kc * 4 * B + b] = ssq_g[b];               // ||w~_b||^2 of the last iteration
+        s.scal[(int64_t)kc * 4 * B + B + b] = sw[b] * sw[b];      // a_b (:949)
+      }
     }
   if (tid == 0) {
     s.iters[kc] = (double)s.run;
-    par[0] = 1.0 / a4[1];     // alpha of the fused first sweep of the next component
-    par[1] = 1.0;             // inv_tt: ts is unit length (:928 has no division)
+    if (uni) {
+      s.scal[(int64_t)kc * 4 * B + 3 * B] = c_uni;   // w_raw = c X^T y: the caller scales the column the pass left
+      par[0] = 1.0;               // the fused products of the next component are taken with y itself (:489)
+      par[1] = 1.0 / d4[2];       // p = X^T ts / ts^T ts (:520)
+    } else {
+      par[0] = 1.0 / a4[1];     // alpha of the fused first sweep of the next component
+      par[1] = 1.0;             // inv_tt: ts is unit length (:928 has no division)
+    }
     par[4] = diff;
   }
 }
@@ -279,6 +311,14 @@ __global__ __launch_bounds__(256) void k_block_unit_col(int64_t p, const double*
   int b = 0;
   while (b + 1 < nblocks && j >= offs[b + 1]) ++b;
   dst[j] = src[j] / sqrt(nu2[b]);
+}
+
+// dst[j] = src[j] * (*scalar): a p-length column times a scalar that lives on the device
+__global__ __launch_bounds__(256) void k_scale_col_by(int64_t p, const double* __restrict__ src, double* __restrict__ dst,
+                                                      const double* __restrict__ scalar, const double* __restrict__ dpar) {
+  if (dpar && dpar[2] != 0.0) return;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < p) dst[j] = src[j] * scalar[0];
 }
 
 }  // namespace mbpls
@@ -305,6 +345,7 @@ int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
          "step kernel covers nblocks <= %d, q <= %d (got %d, %d)", RS_BMAX, RS_QMAX, s->nblocks, s->q);
   MB_ARG(s->kc >= 0 && s->kc < RS_KMAX - 1 && s->nd >= 0 && s->nd <= s->kc && s->run >= 1, "bad component / run");
   MB_ARG(s->norm_kind >= 0 && s->norm_kind <= 3, "bad norm kind %d", s->norm_kind);
+  MB_ARG(s->mode == 0 || (s->mode == 1 && s->q == 1 && s->run == 1), "mode 1 (UNIPALS) is one response, one step per component");
   MB_ARG(s->xchg && s->Y && s->Ts && s->Tsc && s->U && s->V && s->Tb && s->scal && s->ssq_x && s->iters && s->u_cur &&
              s->ts_old && s->vpass && s->tspass && s->cu && s->ce && s->par,
          "NULL pointer in mbpls_nipals_step");
@@ -325,6 +366,14 @@ int mbpls_hip_block_unit_col(const mbpls_mat* m, const double* d_src, double* d_
   MB_HIP(hipMemcpyAsync(d_offs, m->block_offsets.data(), sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_block_unit_col, dim3((unsigned)((m->p + 255) / 256)), dim3(256), 0, ctx->stream, m->p, d_src,
                      d_dst, (const int64_t*)d_offs, B, d_nu2, ctx->dpar);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+int mbpls_hip_scale_col_by(mbpls_ctx* ctx, int64_t p, const double* d_src, double* d_dst, const double* d_scalar) {
+  MB_ARG(ctx && d_src && d_dst && d_scalar && p >= 1, "bad argument");
+  hipLaunchKernelGGL(k_scale_col_by, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, p, d_src, d_dst,
+                     d_scalar, ctx->dpar);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }

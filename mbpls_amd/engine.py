@@ -342,11 +342,25 @@ class HipEngine:
         return x, t, g
 
     def stats_only_ok(self):
-        """the products of this fit (Gram, X^T V, X W) can standardise their operand in registers"""
+        """The products of this fit (Gram, X^T V, X W) can standardise their operand in registers -- and should: the
+        Gram pays ~6 % for it (a fifth load per k-step plus the operand arithmetic: 2.00 s instead of 1.88 s at
+        BASELINE config[3]), more than the read-only statistics pass saves (27 ms instead of 57 ms), so the stored path
+        is kept whenever a standardised working copy comfortably fits beside the caller's matrix (or copy=False lets
+        the matrix itself be overwritten) and the never-writes-X path takes over when it does not (config[3]: 131 GB
+        of X on a 288 GB device).  MBPLS_KERNEL_IMPLICIT=1/0 forces either."""
         import os
-        return (not self.sparse and getattr(self, "rowmask", None) is None and hasattr(self.X, "standardize_stats_sweep")
-                and self.n <= min(8192, getattr(self.ctx, "long_columns_from", 8192))
-                and os.environ.get("MBPLS_IMPLICIT_STD", "1") != "0")
+        if (self.sparse or getattr(self, "rowmask", None) is not None or not hasattr(self.X, "standardize_stats_sweep")
+                or self.n > min(8192, getattr(self.ctx, "long_columns_from", 8192))
+                or os.environ.get("MBPLS_IMPLICIT_STD", "1") == "0"):
+            return False
+        force = os.environ.get("MBPLS_KERNEL_IMPLICIT")
+        if force in ("0", "1"):
+            return force == "1"
+        if self._src is None:
+            return False                              # the matrix is ours to overwrite: standardise in place
+        need = self.X.nbytes + 8 * self.n * self.n * 3 + (17 << 30)     # working copy + Gram + its split-K slices
+        free = self.ctx.info()["free_bytes"] + self.ctx._pool_bytes      # pooled buffers are reusable
+        return free < 1.1 * need
 
     def prepare_stats(self, standardize):
         """a1 for the methods whose X-sized work is matrix products (KERNEL: X X^T :704, X^T [U Ts] :731/:734, X_b W_b
@@ -575,115 +589,52 @@ class HipEngine:
         Finished columns of W~, W and P are copied to the host by a helper thread behind events.  The queue is
         speculative (two iterations per component, which is what one response takes); returns the results of the
         components that converged that way (``k_done`` of them -- the caller resumes from there when k_done < K)."""
-        import queue
-        import threading
-        n, B, q = self.n, self.nblocks, Y.shape[1]
-        ctx, lib = self.ctx, self.ctx.lib
-        pslot = self._lazy_pslot
-        Ts = ctx.empty((n, K))
-        bufs = dict(Y=ctx.from_host(np.asfortranarray(Y)), Ts=Ts, Tsc=ctx.empty((n, K)) if self._istd else Ts,
-                    U=ctx.empty((n, K)), V=ctx.empty((q, K)), Tb=ctx.empty(n * B * K), scal=ctx.empty(K * 4 * B, zero=True),
-                    ssqx=ctx.empty(B), iters=ctx.empty(K, zero=True), u_cur=ctx.from_host(np.ascontiguousarray(Y[:, 0])),
-                    ts_old=ctx.empty(n, zero=True), par=ctx.from_host(np.zeros(8)))
-        self.slot("Wblk", K)
-        # raw-space passes without centring are only good for modestly offset data: the first step checks the measure
-        # the statistics pass left behind and stops the queue when the centring flavour is needed
-        amp2 = self.CENTRE_FROM_OFFSET ** 2 if (self._istd and not self._cen) else 0.0
-        st = _capi.NipalsStep(n=n, nblocks=B, q=q, centre=int(self._istd), norm_kind=int(norm_kind), tol=float(tol),
-                              amp2_max=amp2,
-                              xchg=self._xchg.ptr, Y=bufs["Y"].ptr, Ts=Ts.ptr, Tsc=bufs["Tsc"].ptr, U=bufs["U"].ptr,
-                              V=bufs["V"].ptr, Tb=bufs["Tb"].ptr, scal=bufs["scal"].ptr, ssq_x=bufs["ssqx"].ptr,
-                              iters=bufs["iters"].ptr, u_cur=bufs["u_cur"].ptr, ts_old=bufs["ts_old"].ptr,
-                              vpass=self._vec_n[0].ptr, tspass=self._vec_n[1].ptr, cu=self._coef[0].ptr,
-                              ce=self._coef[1].ptr, par=bufs["par"].ptr)
-
-        def step(kc, run, nd):
-            if self.comm.is_distributed:
-                self.comm.allreduce_device(self._xchg)
-            st.kc, st.run, st.nd = kc, run, nd
-            _capi.check(lib.mbpls_hip_nipals_step(ctx.handle, st))
-
-        jobs, errors = queue.Queue(), []
-
-        def copier():
-            while True:
-                job = jobs.get()
-                if job is None:
-                    return
-                ev, copies = job
-                try:
-                    for i, (dst, src) in enumerate(copies):
-                        _capi.check(lib.mbpls_hip_memcpy_d2h_after(ctx.handle, ev, dst.ctypes.data, src, dst.nbytes))
-                except BaseException as e:      # re-raised on the calling thread
-                    errors.append(e)
-                finally:
-                    lib.mbpls_hip_event_destroy(ctx.handle, ev)
-
-        def stream_out(copies):
-            ev = _capi._vp()
-            _capi.check(lib.mbpls_hip_event_record(ctx.handle, _capi.C.byref(ev)))
-            jobs.put((ev, copies))
-
-        def col(arr, k):
-            c = arr[:, k]
-            assert c.flags.c_contiguous
-            return c
-
-        th = threading.Thread(target=copier, daemon=True)
-        th.start()
-        Wn, Wb, Pm = self.slots[wslot], self.slots["Wblk"], self.slots[pslot]
-        p8 = 8 * self.p
-        _capi.check(lib.mbpls_hip_set_pass_params(ctx.handle, bufs["par"].ptr))
-        try:
+        with _ResidentQueue(self, Y, K, norm_kind, tol, mode=0) as rq:
+            Wn, Wb, Pm = self.slots[wslot], self.slot("Wblk", K), self.slots[self._lazy_pslot]
+            p8, B = 8 * self.p, self.nblocks
             with self._timed("queue_passes"):
-                step(0, 1, 0)
+                rq.step(0, 1, 0)
                 for k in range(K):
                     last = k == K - 1
                     self._res_sweep(k, (wslot, k))                   # second iteration (:856, :875)
-                    step(k, 2, k)
+                    rq.step(k, 2, k)
                     # w_b = w~_b / ||w~_b|| (:860) with the norms the step just recorded
-                    _capi.check(lib.mbpls_hip_block_unit_col(self.X.handle, Wn.ptr + p8 * k, Wb.ptr + p8 * k,
-                                                             bufs["scal"].ptr + 8 * 4 * B * k))
-                    stream_out([(col(Wn_h, k), Wn.ptr + p8 * k), (col(W_h, k), Wb.ptr + p8 * k)]
-                               + ([(col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []))
+                    rq.block_unit_col(Wn.ptr + p8 * k, Wb.ptr + p8 * k, k)
+                    rq.stream_out([(rq.col(Wn_h, k), Wn.ptr + p8 * k), (rq.col(W_h, k), Wb.ptr + p8 * k)]
+                                  + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []))
                     self._res_loadings(k, last, None if last else (wslot, k + 1))   # (:928, :969) + next first sweep
                     if not last:
-                        step(k + 1, 1, k + 1)
-                    elif self.comm.is_distributed:
-                        self.comm.allreduce_device(self._xchg)
-                stream_out([(col(P_h, K - 1), Pm.ptr + p8 * (K - 1))])
-            self.run_deferred(all_of_it=True)          # host chores while the GPU works through the queue
-            with self._timed("wait_kernel+d2h_small"):
-                par = bufs["par"].get()
-        finally:
-            lib.mbpls_hip_set_pass_params(ctx.handle, None)
-            jobs.put(None)
-            th.join()
-        if errors:
-            raise errors[0]
-        if par[2] != 0.0 and par[5] == 1.0:
-            # offset data (max |mean|/scale = sqrt(par[6])): the caller queues again, now with centring passes
-            self._cen = True
-            for key, b in bufs.items():
-                if key != "Tsc" or self._istd:
-                    b.free()
-            return dict(k_done=0, reason="offset", offset=float(np.sqrt(par[6])))
-        k_done = K if par[2] == 0.0 else int(par[3])
-        h = self._xchg.get()
-        scal = bufs["scal"].get().reshape(K, 4, B)
-        if k_done == K:
-            scal[K - 1, 2] = h[n * B + B:n * B + 2 * B]     # ||p_b||^2 of the last (loadings-only) pass
-        out = dict(k_done=k_done, Ts=Ts.get(), U=bufs["U"].get(), V=bufs["V"].get(),
-                   Tb=bufs["Tb"].get().reshape(K, B, n), scal=scal, ssq_x=bufs["ssqx"].get(),
-                   iters=bufs["iters"].get(), last_diff=float(par[4]))
-        if k_done < K:
-            # hand the lazy-deflation state to the host-driven loop
-            Tc = bufs["Tsc"].get()
-            self._lazy_ts = [np.ascontiguousarray(Tc[:, i]) for i in range(k_done)]
-        for key, b in bufs.items():
-            if key != "Tsc" or self._istd:
-                b.free()
-        return out
+                        rq.step(k + 1, 1, k + 1)
+                    else:
+                        rq.allreduce()
+                rq.stream_out([(rq.col(P_h, K - 1), Pm.ptr + p8 * (K - 1))])
+        return rq.result
+
+    def unipals_resident(self, Y, K, wslot, gslot, W_h, P_h):
+        """The p > n branch of UNIPALS with one response (mbpls.py:481-572) as one device queue: a component costs ONE
+        pass (loadings + lazy deflation + the products X^T y, X_b (X^T y)_b of the next component, see
+        solvers.fit_unipals); the step kernel forms ts = X (X^T y) / ||.||, v, u, the scalar c with w = c X^T y, the block
+        norms and scores between the passes.  No iteration, so nothing is speculative; the offset check of the first
+        step is the same as for NIPALS."""
+        with _ResidentQueue(self, Y, K, 0, 0.0, mode=1) as rq:
+            S, Wc, Wb, Pm = self.slots[gslot], self.slots[wslot], self.slot("Wblk", K), self.slots[self._lazy_pslot]
+            p8 = 8 * self.p
+            with self._timed("queue_passes"):
+                rq.step(0, 1, 0)
+                for k in range(K):
+                    last = k == K - 1
+                    # w_raw = X^T u = c X^T y (:503): the column the pass left in S times the scalar the step recorded
+                    rq.scale_col(S.ptr, Wc.ptr + p8 * k, k)
+                    rq.block_unit_col(Wc.ptr + p8 * k, Wb.ptr + p8 * k, k)           # w_b / ||w_b|| (:510-512)
+                    rq.stream_out([(rq.col(W_h, k), Wb.ptr + p8 * k)]
+                                  + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []))
+                    self._res_loadings(k, last, None if last else (gslot, 0))        # p (:520), deflation (:535)
+                    if not last:
+                        rq.step(k + 1, 1, k + 1)
+                    else:
+                        rq.allreduce()
+                rq.stream_out([(rq.col(P_h, K - 1), Pm.ptr + p8 * (K - 1))])
+        return rq.result
 
     def xt_v(self, V, alpha, slot, k0=0, want_ssq=False):
         """slot[:, k0:k0+c] = alpha X^T V  (V: n x c host).  Optional per-block column norms^2 (B x c)."""
@@ -759,7 +710,8 @@ class HipEngine:
         ldg = n + (n & 1)
         store = self._gram_store(ldg * n)
         if self._kscale:
-            self.X.gram(store.ptr, ldg, mean=self.mean, rscale=self.rs, centre_first=self._cen)
+            # (the one-fma form, centre_first=False, measured no faster: the cost is the fifth load per k-step)
+            self.X.gram(store.ptr, ldg, mean=self.mean, rscale=self.rs, centre_first=True)
         else:
             self.X.gram(store.ptr, ldg)
         self.comm.allreduce_device(store)        # partial Grams of the column shards (in place, RCCL when sharded)
@@ -854,3 +806,131 @@ class HipEngine:
         n = self.n
         ldg = n + (n & 1)
         return np.asarray(self.G[1].get()).reshape(n, ldg).T[:n, :n]
+
+
+class _ResidentQueue:
+    """State of one device-resident fit (csrc/resident.hip): the device buffers the step kernel works on, the helper
+    thread that copies finished columns to the host behind events, and the read-back of the results.  Used as a context
+    manager around the queueing of the passes; ``result`` is available afterwards."""
+
+    def __init__(self, eng, Y, K, norm_kind, tol, mode):
+        import queue
+        import threading
+        self.eng, self.K, self.mode = eng, K, mode
+        n, B, q = eng.n, eng.nblocks, Y.shape[1]
+        ctx = self.ctx = eng.ctx
+        self.lib = ctx.lib
+        Ts = ctx.empty((n, K))
+        self.bufs = dict(Y=ctx.from_host(np.asfortranarray(Y)), Ts=Ts, Tsc=ctx.empty((n, K)) if eng._istd else Ts,
+                         U=ctx.empty((n, K)), V=ctx.empty((q, K)), Tb=ctx.empty(n * B * K),
+                         scal=ctx.empty(K * 4 * B, zero=True), ssqx=ctx.empty(B), iters=ctx.empty(K, zero=True),
+                         u_cur=ctx.from_host(np.ascontiguousarray(Y[:, 0])), ts_old=ctx.empty(n, zero=True),
+                         par=ctx.from_host(np.zeros(8)))
+        b = self.bufs
+        # raw-space passes without centring are only good for modestly offset data: the first step checks the measure
+        # the statistics pass left behind and stops the queue when the centring flavour is needed
+        amp2 = eng.CENTRE_FROM_OFFSET ** 2 if (eng._istd and not eng._cen) else 0.0
+        self.st = _capi.NipalsStep(n=n, nblocks=B, q=q, centre=int(eng._istd), norm_kind=int(norm_kind), tol=float(tol),
+                                   amp2_max=amp2, mode=int(mode), xchg=eng._xchg.ptr, Y=b["Y"].ptr, Ts=Ts.ptr,
+                                   Tsc=b["Tsc"].ptr, U=b["U"].ptr, V=b["V"].ptr, Tb=b["Tb"].ptr, scal=b["scal"].ptr,
+                                   ssq_x=b["ssqx"].ptr, iters=b["iters"].ptr, u_cur=b["u_cur"].ptr,
+                                   ts_old=b["ts_old"].ptr, vpass=eng._vec_n[0].ptr, tspass=eng._vec_n[1].ptr,
+                                   cu=eng._coef[0].ptr, ce=eng._coef[1].ptr, par=b["par"].ptr)
+        self.jobs, self.errors = queue.Queue(), []
+        self.thread = threading.Thread(target=self._copier, daemon=True)
+        self.result = None
+
+    # ---- helper thread: device-to-host copies ordered behind events
+    def _copier(self):
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            ev, copies = job
+            try:
+                for dst, src in copies:
+                    _capi.check(self.lib.mbpls_hip_memcpy_d2h_after(self.ctx.handle, ev, dst.ctypes.data, src, dst.nbytes))
+            except BaseException as e:      # re-raised on the calling thread
+                self.errors.append(e)
+            finally:
+                self.lib.mbpls_hip_event_destroy(self.ctx.handle, ev)
+
+    @staticmethod
+    def col(arr, k):
+        c = arr[:, k]
+        assert c.flags.c_contiguous
+        return c
+
+    def stream_out(self, copies):
+        ev = _capi._vp()
+        _capi.check(self.lib.mbpls_hip_event_record(self.ctx.handle, _capi.C.byref(ev)))
+        self.jobs.put((ev, copies))
+
+    # ---- launches
+    def allreduce(self):
+        if self.eng.comm.is_distributed:
+            self.eng.comm.allreduce_device(self.eng._xchg)
+
+    def step(self, kc, run, nd):
+        self.allreduce()
+        self.st.kc, self.st.run, self.st.nd = kc, run, nd
+        _capi.check(self.lib.mbpls_hip_nipals_step(self.ctx.handle, self.st))
+
+    def block_unit_col(self, src, dst, k):
+        B = self.eng.nblocks
+        _capi.check(self.lib.mbpls_hip_block_unit_col(self.eng.X.handle, src, dst, self.bufs["scal"].ptr + 8 * 4 * B * k))
+
+    def scale_col(self, src, dst, k):
+        """dst = src * c_k with the scalar the step of component k left at scal[k][3][0]"""
+        B = self.eng.nblocks
+        _capi.check(self.lib.mbpls_hip_scale_col_by(self.ctx.handle, self.eng.p, src, dst,
+                                                    self.bufs["scal"].ptr + 8 * (4 * B * k + 3 * B)))
+
+    # ---- context manager
+    def __enter__(self):
+        self.thread.start()
+        _capi.check(self.lib.mbpls_hip_set_pass_params(self.ctx.handle, self.bufs["par"].ptr))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        eng, bufs, K = self.eng, self.bufs, self.K
+        n, B = eng.n, eng.nblocks
+        try:
+            if et is None:
+                eng.run_deferred(all_of_it=True)          # host chores while the GPU works through the queue
+                with eng._timed("wait_kernel+d2h_small"):
+                    par = bufs["par"].get()
+        finally:
+            self.lib.mbpls_hip_set_pass_params(self.ctx.handle, None)
+            self.jobs.put(None)
+            self.thread.join()
+        if et is not None:
+            return False
+        if self.errors:
+            raise self.errors[0]
+
+        def free_all():
+            for key, b in bufs.items():
+                if key != "Tsc" or eng._istd:
+                    b.free()
+
+        if par[2] != 0.0 and par[5] == 1.0:
+            # offset data (max |mean|/scale = sqrt(par[6])): the caller queues again, now with centring passes
+            eng._cen = True
+            free_all()
+            self.result = dict(k_done=0, reason="offset", offset=float(np.sqrt(par[6])))
+            return False
+        k_done = K if par[2] == 0.0 else int(par[3])
+        h = eng._xchg.get()
+        scal = bufs["scal"].get().reshape(K, 4, B)
+        if k_done == K:
+            scal[K - 1, 2] = h[n * B + B:n * B + 2 * B]     # ||p_b||^2 of the last (loadings-only) pass
+        self.result = dict(k_done=k_done, Ts=bufs["Ts"].get(), U=bufs["U"].get(), V=bufs["V"].get(),
+                           Tb=bufs["Tb"].get().reshape(K, B, n), scal=scal, ssq_x=bufs["ssqx"].get(),
+                           iters=bufs["iters"].get(), last_diff=float(par[4]))
+        if k_done < K:
+            # hand the lazy-deflation state to the host-driven loop
+            Tc = bufs["Tsc"].get()
+            eng._lazy_ts = [np.ascontiguousarray(Tc[:, i]) for i in range(k_done)]
+        free_all()
+        return False

@@ -373,6 +373,15 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
                 warnings.warn(f"NIPALS component {k}: no convergence to max_tol={max_tol} after {max_iter} "
                               f"iterations (last diff {diff:.3e}); the reference would loop forever here.")
                 break
+            if q == 1 and not resp.sparse and run - 1 >= 4 and diff > max_tol:
+                # One complete response: u = Y v / ||Y v|| = +-y/||y|| whatever ts was, so the iteration sits at its
+                # fixed point after the first pass and successive ts differ by rounding only.  A difference that is
+                # still above max_tol now is the noise floor of this component (deep components of a nearly exhausted
+                # X), not a lack of iterations: more passes would only re-roll the rounding.
+                if diff > 1e4 * max_tol:
+                    warnings.warn(f"NIPALS component {k}: ||ts_old - ts|| = {diff:.3e} stays above max_tol={max_tol} "
+                                  f"(rounding noise of a nearly exhausted X); stopped after {run - 1} iterations.")
+                break
         iters.append(run - 1)
         last = (k == K - 1)
 
@@ -433,11 +442,7 @@ def fit_unipals(eng, Y, K, standardize):
         # (the n >= p branch mixes in xt_v / x_w on the deflated X as well: explicit)
         eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
     fuse = wide and q == 1
-    varxb, m_raw, g_ssq = eng.prepare(standardize, v=y0 if fuse else None, alpha=1.0, g_slot=("S", 0) if fuse else None)
-    yy = y0.T.dot(y0).item()
-    varx = varxb.sum()
     vary = (Y ** 2).sum()
-    F = _psd_factor(Y.T.dot(Y))
     Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
     T = [np.empty((n, K)) for _ in range(B)]
     blk_nrm = np.empty((B, K)); tot_nrm = np.empty(K)
@@ -445,6 +450,40 @@ def fit_unipals(eng, Y, K, standardize):
     # p > n: W_ and P_ are streamed to the host column by column while the deflation passes run (as in NIPALS)
     W_h = _host_array(eng, (eng.p, K)) if wide else None
     P_h = _host_array(eng, (eng.p, K)) if wide else None
+    if fuse and hasattr(eng, "unipals_resident") and eng.resident_supported(q, K, 0):
+        # one response: a component is ONE pass and everything between two passes is n x B algebra -- the whole fit
+        # is queued on the device (engine.unipals_resident), the host reads the results once
+        for attempt in range(2):
+            eng.prepare(standardize, v=y0, alpha=1.0, g_slot=("S", 0), defer=True)
+            out = eng.unipals_resident(Y, K, "Wc", "S", W_h, P_h)
+            if out.get("reason") != "offset":
+                break                                       # (offset data: queued again with centring passes)
+        varxb = out["ssq_x"]
+        if not np.all(np.isfinite(varxb)):
+            raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
+        varx = varxb.sum()
+        for k in range(K):
+            ts, v = out["Ts"][:, k:k + 1], out["V"][:, k:k + 1]
+            Ts[:, k:k + 1] = ts; U[:, k] = out["U"][:, k]; V[:, k:k + 1] = v
+            ssq = out["scal"][k, 0]
+            A[:, k] = out["scal"][k, 1]
+            blk_nrm[:, k] = np.sqrt(ssq); tot_nrm[k] = np.sqrt(ssq.sum())
+            for b in range(B):
+                T[b][:, k] = out["Tb"][k, b]
+            ssq_p = out["scal"][k, 2]
+            tt = ts.T.dot(ts).item()
+            evx.append(tt * ssq_p.sum() / varx)             # (:521-533)
+            evxb[:, k] = tt * ssq_p / varxb
+            evy.append(tt * v.T.dot(v).item() / vary)       # (:538-540)
+            Acorr[:, k] = _bip_corrected(A[:, k], sizes)    # (:542-553)
+        res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, explained_var_x_=evx, explained_var_y_=evy,
+                        explained_var_xblocks_=evxb, A_corrected_=Acorr)
+        _finalise_device(eng, res, "Wc", K, tot_nrm, blk_nrm, V, W_host=W_h, P_host=P_h)   # (:569-572)
+        return res
+    varxb, m_raw, g_ssq = eng.prepare(standardize, v=y0 if fuse else None, alpha=1.0, g_slot=("S", 0) if fuse else None)
+    yy = y0.T.dot(y0).item()
+    varx = varxb.sum()
+    F = _psd_factor(Y.T.dot(Y))
     for k in range(K):
         if wide:
             if fuse:
