@@ -161,13 +161,14 @@ def main():
         mdl.fit(X, Y)
     ctx.profile(True)
     ctx.profile_reset()
-    per_fit = []
+    per_fit, per_fit_phases = [], []
     barrier_sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         t1 = time.perf_counter()
         mdl.fit(X, Y)                      # returns with the fitted attributes on the host
         per_fit.append(time.perf_counter() - t1)
+        per_fit_phases.append(mdl.fit_timings_)
     barrier_sync()
     dt = max_over_ranks(time.perf_counter() - t0)
     prof = ctx.profile_get()
@@ -226,6 +227,8 @@ def main():
             "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4), "GBps": round(v["GBps"], 1)}
                         for k, v in prof.items()},
             "host_phases_ms_last_fit": phases,
+            "host_phases_ms_slowest_fit": {k: round(1e3 * v, 2)
+                                           for k, v in per_fit_phases[int(np.argmax(per_fit))].items()},
             "comm": comm_info, "sharded_self_check": check,
         }
         out.update(extras)

@@ -189,12 +189,21 @@ class Context:
     def _raw_free(self, ptr, nbytes):
         nbytes = max(int(nbytes), 8)
         if self._pool_cap is None:
-            self._pool_cap = int(0.5 * self.info()["total_bytes"])
+            # freed buffers are kept for reuse up to this share of HBM (MBPLS_POOL_CAP_FRACTION; set_pool_cap):
+            # lower it when other allocators (torch, RCCL) share the device
+            frac = float(os.environ.get("MBPLS_POOL_CAP_FRACTION", "0.5"))
+            self._pool_cap = int(max(0.0, min(frac, 0.9)) * self.info()["total_bytes"])
         if nbytes >= (1 << 20) and self._pool_bytes + nbytes <= self._pool_cap:
             self._pool.setdefault(nbytes, []).append(ptr)
             self._pool_bytes += nbytes
         else:
             self.lib.mbpls_hip_free(self.handle, ptr)
+
+    def set_pool_cap(self, fraction):
+        """share of HBM the pool of freed buffers may hold (default 0.5); anything above is released now"""
+        self._pool_cap = int(max(0.0, min(float(fraction), 0.9)) * self.info()["total_bytes"])
+        if self._pool_bytes > self._pool_cap:
+            self.trim_pool()
 
     def trim_pool(self):
         for lst in self._pool.values():

