@@ -94,6 +94,7 @@ class HipEngine:
         self._istd = False          # implicit standardisation: X in HBM stays raw (see prepare)
         self._cen = False           # ... and the raw-space passes subtract the column means (offset data)
         self._kscale = False        # statistics-only preparation: X stays raw, the products standardise on the fly
+        self.host_stats = None      # (mean, scale, var) on the host when they were streamed out during the fit
         self.rs = self.r2 = None
         if not hasattr(self, "_src"):
             self._src = None
@@ -594,6 +595,7 @@ class HipEngine:
             p8, B = 8 * self.p, self.nblocks
             with self._timed("queue_passes"):
                 rq.step(0, 1, 0)
+                rq.stream_stats()
                 for k in range(K):
                     last = k == K - 1
                     self._res_sweep(k, (wslot, k))                   # second iteration (:856, :875)
@@ -621,6 +623,7 @@ class HipEngine:
             p8 = 8 * self.p
             with self._timed("queue_passes"):
                 rq.step(0, 1, 0)
+                rq.stream_stats()
                 for k in range(K):
                     last = k == K - 1
                     # w_raw = X^T u = c X^T y (:503): the column the pass left in S times the scalar the step recorded
@@ -808,14 +811,47 @@ class HipEngine:
         return np.asarray(self.G[1].get()).reshape(n, ldg).T[:n, :n]
 
 
+_COPIER = {}
+
+
+def _copier_queue():
+    """The job queue of the process-wide helper thread that copies finished columns to the host behind events.  ONE
+    thread for the life of the process: a fresh thread per fit makes the HIP runtime set up (and at some point tear
+    down, with a device-wide synchronisation) per-thread copy resources -- measured as one 23 ms stall in every sixth
+    fit."""
+    import queue
+    import threading
+    q = _COPIER.get("queue")
+    if q is None or not _COPIER["thread"].is_alive():
+        q = queue.Queue()
+
+        def work():
+            while True:
+                job = q.get()
+                if isinstance(job, threading.Event):
+                    job.set()
+                    continue
+                ctx, ev, copies, errors = job
+                try:
+                    for dst, src in copies:
+                        _capi.check(ctx.lib.mbpls_hip_memcpy_d2h_after(ctx.handle, ev, dst.ctypes.data, src, dst.nbytes))
+                except BaseException as e:      # re-raised on the thread that owns the fit
+                    errors.append(e)
+                finally:
+                    ctx.lib.mbpls_hip_event_destroy(ctx.handle, ev)
+
+        th = threading.Thread(target=work, daemon=True, name="mbpls-copier")
+        th.start()
+        _COPIER.update(queue=q, thread=th)
+    return q
+
+
 class _ResidentQueue:
     """State of one device-resident fit (csrc/resident.hip): the device buffers the step kernel works on, the helper
     thread that copies finished columns to the host behind events, and the read-back of the results.  Used as a context
     manager around the queueing of the passes; ``result`` is available afterwards."""
 
     def __init__(self, eng, Y, K, norm_kind, tol, mode):
-        import queue
-        import threading
         self.eng, self.K, self.mode = eng, K, mode
         n, B, q = eng.n, eng.nblocks, Y.shape[1]
         ctx = self.ctx = eng.ctx
@@ -836,24 +872,9 @@ class _ResidentQueue:
                                    ssq_x=b["ssqx"].ptr, iters=b["iters"].ptr, u_cur=b["u_cur"].ptr,
                                    ts_old=b["ts_old"].ptr, vpass=eng._vec_n[0].ptr, tspass=eng._vec_n[1].ptr,
                                    cu=eng._coef[0].ptr, ce=eng._coef[1].ptr, par=b["par"].ptr)
-        self.jobs, self.errors = queue.Queue(), []
-        self.thread = threading.Thread(target=self._copier, daemon=True)
+        self.errors = []
+        self.jobs = _copier_queue()
         self.result = None
-
-    # ---- helper thread: device-to-host copies ordered behind events
-    def _copier(self):
-        while True:
-            job = self.jobs.get()
-            if job is None:
-                return
-            ev, copies = job
-            try:
-                for dst, src in copies:
-                    _capi.check(self.lib.mbpls_hip_memcpy_d2h_after(self.ctx.handle, ev, dst.ctypes.data, src, dst.nbytes))
-            except BaseException as e:      # re-raised on the calling thread
-                self.errors.append(e)
-            finally:
-                self.lib.mbpls_hip_event_destroy(self.ctx.handle, ev)
 
     @staticmethod
     def col(arr, k):
@@ -864,7 +885,18 @@ class _ResidentQueue:
     def stream_out(self, copies):
         ev = _capi._vp()
         _capi.check(self.lib.mbpls_hip_event_record(self.ctx.handle, _capi.C.byref(ev)))
-        self.jobs.put((ev, copies))
+        self.jobs.put((self.ctx, ev, copies, self.errors))
+
+    def stream_stats(self):
+        """mean / scale / var of the columns are final after the first pass: they leave through the helper thread now
+        instead of three blocking copies at the end of the fit"""
+        eng = self.eng
+        if eng.mean is None or eng.scale is None:
+            return
+        arrs = [eng.mean, eng.scale] + ([eng.var] if getattr(eng, "var", None) is not None else [])
+        host = [np.empty(eng.p) for _ in arrs]
+        self.stream_out([(h, d.ptr) for h, d in zip(host, arrs)])
+        eng.host_stats = tuple(host) if len(host) == 3 else (host[0], host[1], None)
 
     # ---- launches
     def allreduce(self):
@@ -888,7 +920,6 @@ class _ResidentQueue:
 
     # ---- context manager
     def __enter__(self):
-        self.thread.start()
         _capi.check(self.lib.mbpls_hip_set_pass_params(self.ctx.handle, self.bufs["par"].ptr))
         return self
 
@@ -902,8 +933,10 @@ class _ResidentQueue:
                     par = bufs["par"].get()
         finally:
             self.lib.mbpls_hip_set_pass_params(self.ctx.handle, None)
-            self.jobs.put(None)
-            self.thread.join()
+            import threading
+            done = threading.Event()
+            self.jobs.put(done)             # every copy queued before this one has landed when it is set
+            done.wait()
         if et is not None:
             return False
         if self.errors:

@@ -309,8 +309,11 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         self.num_blocks_ = B
         self._block_offsets = list(eng.block_offsets)
         if self.standardize:
-            mean, scale = eng.mean.get(), eng.scale.get()
-            var = eng.var.get() if getattr(eng, "var", None) is not None else None
+            if getattr(eng, "host_stats", None) is not None:      # streamed out during the fit (device-resident queue)
+                mean, scale, var = eng.host_stats
+            else:
+                mean, scale = eng.mean.get(), eng.scale.get()
+                var = eng.var.get() if getattr(eng, "var", None) is not None else None
             seen = eng.count.get().astype(np.int64) if eng.sparse else None    # per-column present samples
             rm = getattr(eng, "rowmask", None)
             n_seen = eng.n if rm is None else int(np.count_nonzero(rm))        # row-subset fit: the included samples

@@ -1,5 +1,5 @@
 """Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) of
-`bench.py --steps 1 --warmup 0 --cpu-cols 0` into profiles/r01_pmc_traffic_c2.json.
+`bench.py --steps 1 --warmup 0 --cpu-cols 0 --e2e-cols 0 --no-extras` into profiles/r02_pmc_traffic_c2.json.
 
     python tools/pmc_to_json.py gpurun_out/pmc  [n] [p]
 
@@ -25,7 +25,7 @@ out = {"config": {"n": n, "p": p, "K": 10, "method": "NIPALS", "deflation": os.e
        "method": __doc__.split("Unit/correction")[1].strip(), "kernels": {}}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(os.path.join(root, c, "**", "*counter_collection.csv"), recursive=True)[0]
-    shutil.copy(f, os.path.join(here, "profiles", f"r01_pmc_{c}_bench_c2_counter_collection.csv"))
+    shutil.copy(f, os.path.join(here, "profiles", f"r02_pmc_{c}_bench_c2_counter_collection.csv"))
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"]
@@ -45,4 +45,4 @@ for nm, d in out["kernels"].items():
     d["hbm_bytes_per_launch"] = d["hbm_read_bytes"] + d["hbm_write_bytes"]
     print(f"{nm:18s} read {d['hbm_read_bytes'] / 1e9:7.2f} GB  write {d['hbm_write_bytes'] / 1e9:7.2f} GB  "
           f"= {d['hbm_bytes_per_launch'] / (8.0 * n * p):.3f} units of 8np")
-json.dump(out, open(os.path.join(here, "profiles", "r01_pmc_traffic_c2.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(here, "profiles", "r02_pmc_traffic_c2.json"), "w"), indent=1)
