@@ -172,8 +172,16 @@ class Context:
         self._pool_cap = None
 
     # ---- pooled raw allocations
-    def _raw_alloc(self, nbytes):
+    @staticmethod
+    def _bucket(nbytes):
+        """allocation size class: small buffers (vectors, K x K, parameter blocks) are pooled too -- a hipMalloc /
+        hipFree pair per buffer and fit makes the runtime release memory in batches, and that release waits for the
+        device (measured: one 20 ms stall of the running queue every sixth fit)"""
         nbytes = max(int(nbytes), 8)
+        return (nbytes + 255) // 256 * 256 if nbytes < (1 << 20) else nbytes
+
+    def _raw_alloc(self, nbytes):
+        nbytes = self._bucket(nbytes)
         lst = self._pool.get(nbytes)
         if lst:
             self._pool_bytes -= nbytes
@@ -187,13 +195,13 @@ class Context:
         return h.value
 
     def _raw_free(self, ptr, nbytes):
-        nbytes = max(int(nbytes), 8)
+        nbytes = self._bucket(nbytes)
         if self._pool_cap is None:
             # freed buffers are kept for reuse up to this share of HBM (MBPLS_POOL_CAP_FRACTION; set_pool_cap):
             # lower it when other allocators (torch, RCCL) share the device
             frac = float(os.environ.get("MBPLS_POOL_CAP_FRACTION", "0.5"))
             self._pool_cap = int(max(0.0, min(frac, 0.9)) * self.info()["total_bytes"])
-        if nbytes >= (1 << 20) and self._pool_bytes + nbytes <= self._pool_cap:
+        if self._pool_bytes + nbytes <= self._pool_cap:
             self._pool.setdefault(nbytes, []).append(ptr)
             self._pool_bytes += nbytes
         else:

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -83,6 +84,9 @@ struct mbpls_ctx {
   // StandardScaler.var_ (0 for a constant column, whose scale_ is 1)
   double* var_out = nullptr;
   void* rccl = nullptr;      // RcclState* (rccl_comm.hip) when a communicator was initialised on this context
+  // events of the ordered D2H copies are recycled (created by the queueing thread, returned by the copier thread)
+  std::mutex user_event_mutex;
+  std::vector<hipEvent_t> user_event_pool;
   // per-kernel profile (HIP events around the main kernel of every hot-path call)
   bool prof = false;
   struct Pending { hipEvent_t a, b; int kind; double bytes; };
@@ -98,6 +102,7 @@ struct mbpls_mat {
   int64_t n = 0, p = 0, ld = 0;
   int nblocks = 1;
   std::vector<int64_t> block_offsets;
+  int64_t* d_block_offsets = nullptr;   // the same on the device (nblocks + 1), uploaded once at creation
   double* data = nullptr;
   bool owns = false;
   mbpls::ChunkTable fine;    // column-pass kernels (one workgroup per chunk, full columns)

@@ -240,6 +240,7 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
     (void)hipEventDestroy(pd.b);
   }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->user_event_pool) (void)hipEventDestroy(e);
   delete ctx;
   return MBPLS_OK;
 }
@@ -412,6 +413,17 @@ int mbpls_hip_mat_create(mbpls_ctx* ctx, int64_t n, int64_t p, int nblocks, cons
     }
     m->owns = true;
   }
+  {
+    hipError_t e = hipMalloc((void**)&m->d_block_offsets, sizeof(int64_t) * (size_t)(nblocks + 1));
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(m->d_block_offsets, m->block_offsets.data(), sizeof(int64_t) * (size_t)(nblocks + 1),
+                         hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) {
+      set_error("block offsets: %s", hipGetErrorString(e));
+      mbpls_hip_mat_destroy(m);
+      return MBPLS_ERR_HIP;
+    }
+  }
   int rc = build_chunks(ctx, m->block_offsets, ctx->cus * ctx->chunks_per_cu, &m->fine);
   if (rc == MBPLS_OK) {
     // row-slab kernels: slabs of 512 rows already multiply the workgroup count
@@ -432,6 +444,7 @@ int mbpls_hip_mat_destroy(mbpls_mat* m) {
   (void)hipStreamSynchronize(m->ctx->stream);
   free_chunks(&m->fine);
   free_chunks(&m->coarse);
+  if (m->d_block_offsets) (void)hipFree(m->d_block_offsets);
   if (m->owns && m->data) (void)hipFree(m->data);
   delete m;
   return MBPLS_OK;

@@ -357,13 +357,8 @@ int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
 int mbpls_hip_block_unit_col(const mbpls_mat* m, const double* d_src, double* d_dst, const double* d_nu2) {
   MB_ARG(m && d_src && d_dst && d_nu2, "NULL argument");
   mbpls_ctx* ctx = m->ctx;
-  // block offsets on the device: the coarse chunk table does not hold them, so keep a small copy per call site --
-  // they travel through the workspace-independent small buffer of the context
   const int B = m->nblocks;
-  if (!ctx->small_m) MB_HIP(hipMalloc(&ctx->small_m, sizeof(double) * 32 * 32 * 16));
-  MB_ARG((size_t)(B + 1) * sizeof(int64_t) <= sizeof(double) * 32 * 32, "too many blocks");
-  int64_t* d_offs = (int64_t*)((double*)ctx->small_m + (size_t)(ctx->small_m_slot++ % 16) * 32 * 32);
-  MB_HIP(hipMemcpyAsync(d_offs, m->block_offsets.data(), sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, ctx->stream));
+  const int64_t* d_offs = m->d_block_offsets;      // uploaded when the matrix was created: no copy inside the queue
   hipLaunchKernelGGL(k_block_unit_col, dim3((unsigned)((m->p + 255) / 256)), dim3(256), 0, ctx->stream, m->p, d_src,
                      d_dst, (const int64_t*)d_offs, B, d_nu2, ctx->dpar);
   MB_HIP(hipGetLastError());
@@ -385,7 +380,14 @@ int mbpls_hip_event_record(mbpls_ctx* ctx, void** event) {
   MB_ARG(ctx && event, "NULL argument");
   hipEvent_t e = nullptr;
   if (!ctx->copy_stream) MB_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-  MB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  {
+    std::lock_guard<std::mutex> lock(ctx->user_event_mutex);
+    if (!ctx->user_event_pool.empty()) {
+      e = ctx->user_event_pool.back();
+      ctx->user_event_pool.pop_back();
+    }
+  }
+  if (!e) MB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   MB_HIP(hipEventRecord(e, ctx->stream));
   *event = (void*)e;
   return MBPLS_OK;
@@ -404,7 +406,10 @@ int mbpls_hip_memcpy_d2h_after(mbpls_ctx* ctx, void* event, void* h_dst, const v
 
 int mbpls_hip_event_destroy(mbpls_ctx* ctx, void* event) {
   MB_ARG(ctx, "ctx is NULL");
-  if (event) MB_HIP(hipEventDestroy((hipEvent_t)event));
+  if (event) {      // back to the pool (destroyed with the context)
+    std::lock_guard<std::mutex> lock(ctx->user_event_mutex);
+    ctx->user_event_pool.push_back((hipEvent_t)event);
+  }
   return MBPLS_OK;
 }
 

@@ -839,6 +839,9 @@ def _copier_queue():
                     errors.append(e)
                 finally:
                     ctx.lib.mbpls_hip_event_destroy(ctx.handle, ev)
+                    # drop every reference to the host arrays before blocking on the queue again: a view kept here
+                    # would pin the attribute buffers of this fit, which the next fit wants to recycle (mbpls._recyclable)
+                    job = ctx = ev = copies = errors = dst = src = None
 
         th = threading.Thread(target=work, daemon=True, name="mbpls-copier")
         th.start()
