@@ -111,13 +111,28 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         mbpls_amd.set_device(local_rank)
         ctx = mbpls_amd.get_context()
-        if shared_gpu or a.comm == "torch":
+        comm = None
+        if not shared_gpu and a.comm == "rccl":
+            # the C ABI's own communicator; every rank must agree on the outcome, so a failure anywhere (librccl not
+            # loadable, init error) sends ALL ranks to the torch.distributed all_reduce -- also RCCL, through torch
+            err = None
+            try:
+                comm = mbpls_amd.RcclComm.from_torch(ctx)
+                comm_info = dict(comm.info(), backend="rccl (C ABI, mbpls_hip_allreduce on the kernels' stream)")
+                assert comm_info["world_size"] == world, comm_info
+            except Exception as e:                      # noqa: BLE001 -- reported, then the fallback below
+                err = f"{type(e).__name__}: {e}"
+            flags = [None] * world
+            dist.all_gather_object(flags, err)
+            if any(f is not None for f in flags):
+                if comm is not None:
+                    comm.close()
+                comm = None
+                print(f"[bench] rank {rank}: C-ABI RCCL communicator unavailable ({[f for f in flags if f][0]}); "
+                      f"using torch.distributed all_reduce", file=sys.stderr, flush=True)
+        if comm is None:
             comm = mbpls_amd.TorchDistComm(device=f"cuda:{local_rank}")
             comm_info = {"backend": "torch.distributed/" + str(dist.get_backend()), "world_size": comm.world_size}
-        else:
-            comm = mbpls_amd.RcclComm.from_torch(ctx)
-            comm_info = dict(comm.info(), backend="rccl (C ABI, mbpls_hip_allreduce on the kernels' stream)")
-            assert comm_info["world_size"] == world, comm_info
         mbpls_amd.set_comm(comm)
     ctx = mbpls_amd.get_context()
 

@@ -278,6 +278,13 @@ int mbpls_hip_x_w(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int
 int mbpls_hip_nan_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode, double* d_mean,
                                     double* d_scale, double* d_count, double* d_ssq_x, const double* d_v,
                                     double* d_g, double* d_t, double* d_d, double* d_ssq_g);
+/* The same for a fit on a ROW SUBSET (cross-validation folds of data with missing values): d_rowmask has n doubles,
+ * 0 = sample excluded.  Excluded rows count in no statistic and are written as 0 into dst, where -- their entries of
+ * u and ts being 0 as well -- every later masked pass ignores them.  NULL = the plain call.                        */
+int mbpls_hip_nan_standardize_sweep_masked(const mbpls_mat* src, mbpls_mat* dst, int mode, const double* d_rowmask,
+                                           double* d_mean, double* d_scale, double* d_count, double* d_ssq_x,
+                                           const double* d_v, double* d_g, double* d_t, double* d_d,
+                                           double* d_ssq_g);
 /* One NIPALS sweep over data with missing values (one read of X).                                          */
 int mbpls_hip_nan_sweep(const mbpls_mat* m, const double* d_v, double* d_g, double* d_t, double* d_d,
                         double* d_ssq_g);

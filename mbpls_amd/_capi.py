@@ -84,6 +84,7 @@ SIGNATURES = {
     "mbpls_hip_xt_v": (_int, [_vp, _vp, _i64, _int, _dbl, _vp, _i64, _vp]),
     "mbpls_hip_x_w": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _i64]),
     "mbpls_hip_nan_standardize_sweep": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbpls_hip_nan_standardize_sweep_masked": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_nan_sweep": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_nan_deflate_sweep": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_x_w_nan": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _int, _vp, _i64]),
@@ -478,10 +479,11 @@ class DeviceMatrix:
                                          _ptr(mean), _ptr(scale), _ptr(out), int(ldo or self.n)))
 
     # ---- missing values (sparse_data=True)
-    def nan_standardize_sweep(self, dst, mode, mean, scale, count, ssq_x, v=None, g=None, t=None, d=None, ssq_g=None):
-        check(self.ctx.lib.mbpls_hip_nan_standardize_sweep(
-            self.handle, dst.handle, int(mode), _ptr(mean), _ptr(scale), _ptr(count), _ptr(ssq_x), _ptr(v), _ptr(g),
-            _ptr(t), _ptr(d), _ptr(ssq_g)))
+    def nan_standardize_sweep(self, dst, mode, mean, scale, count, ssq_x, v=None, g=None, t=None, d=None, ssq_g=None,
+                              rowmask=None):
+        check(self.ctx.lib.mbpls_hip_nan_standardize_sweep_masked(
+            self.handle, dst.handle, int(mode), _ptr(rowmask), _ptr(mean), _ptr(scale), _ptr(count), _ptr(ssq_x),
+            _ptr(v), _ptr(g), _ptr(t), _ptr(d), _ptr(ssq_g)))
 
     def nan_sweep(self, v, g, t, d, ssq_g):
         check(self.ctx.lib.mbpls_hip_nan_sweep(self.handle, _ptr(v), _ptr(g), _ptr(t), _ptr(d), _ptr(ssq_g)))

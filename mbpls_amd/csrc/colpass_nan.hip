@@ -20,6 +20,7 @@
 namespace mbpls {
 
 struct NanArgs {
+  const double* rowmask;   // standardise pass only: samples excluded from the fit (cross-validation folds)
   double* var_out;
   const double* src;
   double* dst;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   const int chunk = blockIdx.x;
   const int64_t j0 = uniform64(a.c0[chunk]), j1 = uniform64(a.c1[chunk]);
   RowMap<R> rm;
-  rm.init(n, ld, tid, T);
+  rm.init(n, ld, tid, T, STD ? a.rowmask : nullptr);   // row-subset fit: excluded samples load as 0 and count nowhere
   auto real = [&](int k) -> bool { return FULL || ((((k & 1) ? rm.in_n1 : rm.in_n0) >> (k >> 1)) & 1u); };
 
   // The n = 4096 configuration (R = 8, 512 threads) must stay at <= 128 VGPRs for two workgroups per CU (see
@@ -318,7 +319,7 @@ static int launch_nan(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, in
     T = (int)((((a.n + 3) / 4) + 63) / 64 * 64);
   }
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
-  const bool full = (a.n == (int64_t)T * cfg.R) && (a.ld == a.n) && cfg.R >= 8;
+  const bool full = (a.n == (int64_t)T * cfg.R) && (a.ld == a.n) && cfg.R >= 8 && !(STD && a.rowmask);
 #define MB_LAUNCH(R_, TM_)                                                                                       \
   do {                                                                                                           \
     if (full && (R_) >= 8 && (R_) <= 16)                                                                         \
@@ -373,6 +374,14 @@ extern "C" {
 int mbpls_hip_nan_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode, double* d_mean, double* d_scale,
                                     double* d_count, double* d_ssq_x, const double* d_v, double* d_g, double* d_t,
                                     double* d_d, double* d_ssq_g) {
+  return mbpls_hip_nan_standardize_sweep_masked(src, dst, mode, nullptr, d_mean, d_scale, d_count, d_ssq_x, d_v, d_g,
+                                                d_t, d_d, d_ssq_g);
+}
+
+int mbpls_hip_nan_standardize_sweep_masked(const mbpls_mat* src, mbpls_mat* dst, int mode, const double* d_rowmask,
+                                           double* d_mean, double* d_scale, double* d_count, double* d_ssq_x,
+                                           const double* d_v, double* d_g, double* d_t, double* d_d,
+                                           double* d_ssq_g) {
   MB_ARG(src && dst, "NULL argument");
   MB_ARG(src->n == dst->n && src->p == dst->p && src->ld == dst->ld, "src/dst shape mismatch");
   MB_ARG(mode == MBPLS_SCALE_FIT || mode == MBPLS_SCALE_APPLY || mode == MBPLS_SCALE_NONE, "bad mode %d", mode);
@@ -385,6 +394,7 @@ int mbpls_hip_nan_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mo
   a.c0 = dst->fine.d_c0; a.c1 = dst->fine.d_c1;
   a.mode = mode; a.mean = d_mean; a.scale = d_scale; a.count = d_count;
   a.var_out = ctx->var_out;
+  a.rowmask = d_rowmask;
   a.v = d_v; a.g = d_g;
   if (d_v) MB_TRY((launch_nan<true, false, true>(ctx, dst->fine, a, dst->p)));
   else MB_TRY((launch_nan<true, false, false>(ctx, dst->fine, a, dst->p)));

@@ -184,8 +184,6 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             Y = _check_array_no_scan(np.asarray(Y, dtype=np.float64).reshape(len(Y), -1))
             if np.isinf(Y).any():
                 raise ValueError("Input Y contains infinity or a value too large for dtype('float64').")
-            if row_mask is not None:
-                raise NotImplementedError("row-subset fits are not available with sparse_data=True")
             Y = np.array(Y, copy=True) if self.copy else Y
         else:
             Y = check_array(Y, dtype=np.float64, ensure_2d=False, copy=self.copy)  # :293
@@ -254,7 +252,7 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
                 if isinstance(res.get("T_"), list):
                     res["T_"] = [t[row_mask] for t in res["T_"]]
             if sparse:
-                self._sparsity_info(eng, Y)
+                self._sparsity_info(eng, Y, row_mask)
             with eng._timed("store_attributes"):
                 self._store(eng, res)
         finally:
@@ -284,10 +282,11 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         ``explained_var_xblocks_`` ...)."""
         raise NotImplementedError("MBPLS.plot is not provided by mbpls_amd; plot the fitted attributes directly")
 
-    def _sparsity_info(self, eng, Y):
+    def _sparsity_info(self, eng, Y, row_mask=None):
         """``sparse_X_info_[b]`` / ``sparse_Y_info_['Y']`` = (sparse_rows, sparse_columns, dense_rows,
         dense_columns) index arrays and the high-sparsity warnings of check_sparsity_level (mbpls.py:255-271,
-        :295-296, :313, :321), from the per-column counts of the standardise pass and one indicator pass."""
+        :295-296, :313, :321), from the per-column counts of the standardise pass and one indicator pass.  For a
+        row-subset fit the indices refer to the included samples, as if the sliced arrays had been passed."""
         def info(sparse_rows, sparse_cols):
             for flags in (sparse_cols, sparse_rows):                                  # :265-270
                 if flags.size and flags.sum() / flags.size > 0.5:
@@ -297,10 +296,13 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
                     np.where(~sparse_rows)[0], np.where(~sparse_cols)[0])
         col_present = eng.count.get()
         row_present = eng.present_per_row()
+        n_rows = eng.n
+        if row_mask is not None:            # excluded samples are zero rows of the working copy: leave them out
+            row_present, Y, n_rows = row_present[row_mask], Y[row_mask], int(np.count_nonzero(row_mask))
         sizes = _global_block_sizes(eng)
         self.sparse_X_info_ = {}
         for b, (s, e) in enumerate(zip(eng.block_offsets[:-1], eng.block_offsets[1:])):
-            self.sparse_X_info_[b] = info(row_present[:, b] < sizes[b], col_present[s:e] < eng.n)
+            self.sparse_X_info_[b] = info(row_present[:, b] < sizes[b], col_present[s:e] < n_rows)
         self.sparse_Y_info_ = {'Y': info(np.isnan(Y).any(axis=1), np.isnan(Y).any(axis=0))}
 
     def _store(self, eng, res):

@@ -194,3 +194,44 @@ def test_high_sparsity_warning(gpu_required):
         warnings.simplefilter("always")
         MBPLS(n_components=2, sparse_data=True, standardize=False).fit(X, Y)
     assert any("sparsity" in str(r.message) for r in rec)
+
+
+def test_row_subset_fit_and_cross_validation_with_missing_values(gpu_required):
+    """A fold of data with missing values: the matrix stays resident, the held-out samples become zero rows of the
+    working copy and count in no statistic (mbpls_hip_nan_standardize_sweep_masked).  Equal to the oracle fitted on
+    the sliced arrays; cross_val_predict equals a loop of oracle fits."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix, cross_val_predict
+    n, p, q, K = 420, 1500, 2, 3
+    X, Y = orc.make_latent(n, p, q, seed=12)
+    rng = np.random.RandomState(3)
+    X = X.copy(); X[rng.rand(n, p) < 0.02] = np.nan
+    Xs = [np.ascontiguousarray(X[:, :600]), np.ascontiguousarray(X[:, 600:])]
+    ctx = mbpls_amd.get_context()
+    Xd = DeviceMatrix(ctx, n, p, [0, 600, p])
+    Xd.upload(Xs[0], 0); Xd.upload(Xs[1], 600)
+    mask = np.ones(n, dtype=bool); mask[rng.choice(n, 90, replace=False)] = False
+    ref = ors.fit([b[mask] for b in Xs], Y[mask], n_components=K)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mdl = MBPLS(n_components=K, sparse_data=True)._fit(Xd, Y, mask)
+    w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="sparse row subset")
+    assert w < 1e-8, w
+    assert mdl.nipals_iterations_ == ref.nipals_iterations_
+    assert np.array_equal(np.concatenate([s.n_samples_seen_ for s in mdl.x_scalers_]), (~np.isnan(X[mask])).sum(axis=0))
+    sr, sc, dr, dc = mdl.sparse_X_info_[0]
+    ok0 = ~np.isnan(Xs[0][mask])
+    assert np.array_equal(sr, np.where(~ok0.all(axis=1))[0]) and np.array_equal(sc, np.where(~ok0.all(axis=0))[0])
+    assert util.relerr(mdl.predict(Xd)[~mask], ors.predict(ref, [b[~mask] for b in Xs])) < 1e-8
+    # cross-validation of the sparse estimator on the resident matrix
+    folds = [(np.where(np.arange(n) % 3 != f)[0], np.where(np.arange(n) % 3 == f)[0]) for f in range(3)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = cross_val_predict(MBPLS(n_components=K, sparse_data=True), Xd, Y, cv=folds)
+    want = np.empty_like(Y)
+    for tr, te in folds:
+        m = ors.fit([b[tr] for b in Xs], Y[tr], n_components=K)
+        want[te] = ors.predict(m, [b[te] for b in Xs])
+    assert util.relerr(got, want) < 1e-8
+    assert np.isnan(Xd.download(0, 600)).sum() == np.isnan(Xs[0]).sum()      # the resident matrix is untouched
+    Xd.close()
