@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 1
+#define MBPLS_HIP_ABI_VERSION 2   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise */
 
 enum {
   MBPLS_OK = 0,
