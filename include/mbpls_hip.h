@@ -323,6 +323,19 @@ int mbpls_hip_nipals_gram_step(mbpls_ctx* ctx, int64_t n, const double* d_a, con
                                const double* d_Y, int q, int norm_kind, double tol, int max_iter, double* d_ts,
                                double* d_u, double* d_v, double* d_z_next, int ntile, double* d_state);
 
+/* ---- multi-response NIPALS in the q-dimensional space of its iterates ------------------------------------------
+ * Every sweep vector of the inner loop (mbpls.py:841-913) is u = Y c, and the super score it yields is
+ * ts ~ P (sum_b X_b X_b^T) P u (P = I - Ts Ts^T: the deflation :969).  With d_G = P X (X^T (P Y)) (n x q; two
+ * many-right-hand-side products over the standardised, never-deflated X per component) an iteration is
+ * ts = G c / ||G c||, diff = ||ts_old - ts|| (:887), v = Y^T ts / ts^T ts (:899), u = Y v / v^T v normalised
+ * (:911-913) -- n x q work -- and the WHOLE loop of a component runs inside this one launch (one workgroup).
+ * d_c0: coefficients of the start vector (e_1 for Y[:, 0], :838).  Outputs: d_ts (n), d_u (n, the updated u = U_),
+ * d_v (q), d_c_used (q: the sweep vector of the last iteration is Y c_used -- the weights are taken with it),
+ * d_state = [1 converged | 2 iteration cap, iterations, last diff].  n <= 8192, q <= 16.                             */
+int mbpls_hip_nipals_subspace_loop(mbpls_ctx* ctx, int64_t n, int q, const double* d_G, const double* d_Y,
+                                   const double* d_c0, int norm_kind, double tol, int max_iter, double* d_ts,
+                                   double* d_u, double* d_v, double* d_c_used, double* d_state);
+
 /* ---- device-resident NIPALS: a whole one-response fit queued without a host round trip -----------------------
  * Between two passes over X the reference does n x (B + q) algebra on the host (mbpls.py:860-913: norms of the
  * block weights, block scores t_b, super weights sw, super score ts, the stop rule ||ts_old - ts|| <= max_tol,

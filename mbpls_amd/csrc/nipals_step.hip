@@ -179,3 +179,201 @@ extern "C" int mbpls_hip_nipals_gram_step(mbpls_ctx* ctx, int64_t n, const doubl
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The multi-response NIPALS inner loop (mbpls.py:841-913) in the q-dimensional space it actually lives in.
+//
+// Every sweep vector of the loop is u = Y c (c = e_1 for the start vector Y[:, 0], :838; afterwards u = Y v / v^T v,
+// normalised, :911-913), and the super score it produces is ts ~ T sw ~ P (sum_b X_b X_b^T) P u  (see the Gram form
+// above; P = I - Ts Ts^T carries the deflation :969).  With the n x q matrix
+//     G = P X (X^T (P Y))                       -- two many-right-hand-side products over X per COMPONENT
+// that is ts = G c / ||G c||: an iteration costs n x q work instead of two passes over X (or one product with an
+// n x n Gram), and the whole loop of a component -- 50-500 iterations with several responses -- runs inside ONE kernel
+// launch: one 1024-thread workgroup, the rows of `a`, `ts`, `u` in registers, G and Y (n x q each, L2-resident)
+// re-read per iteration, three workgroup reductions per iteration (~10 us).  Same iterates as the reference's loop up
+// to rounding; the stop rule is evaluated on the n-vector ts exactly as there.
+namespace mbpls {
+
+constexpr int SS_T = 512;      // one workgroup of 8 waves: 256 VGPRs per thread for the register-resident n-vectors
+constexpr int SS_QMAX = 16;
+
+// sum m <= M values over the workgroup: wave butterflies, then the first m threads combine the wave partials
+template <int M>
+__device__ __forceinline__ void ss_reduce(double (&v)[M], int m, double* red /* [SS_T/64][M] */, double* tot /* [M] */) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < M; ++k)
+    if (k < m) v[k] = wave_sum(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < M; ++k)
+      if (k < m) red[w * M + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < m) {
+    double s = 0.0;
+    for (int i = 0; i < SS_T / 64; ++i) s += red[i * M + threadIdx.x];
+    tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < M; ++k)
+    if (k < m) v[k] = tot[k];
+}
+
+struct SubspaceArgs {
+  int64_t n;
+  int q, norm_kind, max_iter;
+  double tol;
+  const double* G;      // n x q
+  const double* Y;      // n x q
+  const double* c0;     // q: coefficients of the start vector (u = Y c0)
+  double* ts;           // n
+  double* u;            // n: the updated, normalised u (U_ of the component)
+  double* v;            // q
+  double* c_used;       // q: coefficients of the sweep vector the LAST iteration was taken with
+  double* state;        // [0] 1 converged / 2 iteration cap, [1] iterations, [2] last diff
+};
+
+// ts and the work vector (a = G c, then u = Y v / v^T v) live in LDS for the whole loop (2 x 8n bytes: n <= 8192);
+// the q-vectors c, v are workgroup-uniform and sit in LDS as well.  Plain strided loops, nothing unrolled over rows:
+// the kernel is latency-bound (three reductions per iteration), not throughput-bound.
+__global__ __launch_bounds__(SS_T) void k_nipals_subspace_loop(SubspaceArgs s) {
+  constexpr int M = 4 + SS_QMAX;
+  extern __shared__ double s_vec[];      // [2][n]: ts, work
+  __shared__ double red[(SS_T / 64) * M];
+  __shared__ double tot[M];
+  __shared__ double s_mx[SS_T / 64], s_mn[SS_T / 64];
+  __shared__ double s_c[SS_QMAX], s_cu[SS_QMAX], s_v[SS_QMAX];
+  const int tid = threadIdx.x;
+  const int64_t n = s.n;
+  const int q = s.q;
+  double* s_ts = s_vec;
+  double* s_wk = s_vec + n;
+  if (tid < SS_QMAX) {
+    s_c[tid] = (tid < q) ? s.c0[tid] : 0.0;
+    s_cu[tid] = s_c[tid];
+    s_v[tid] = 0.0;
+  }
+  for (int64_t i = tid; i < n; i += SS_T) s_ts[i] = 0.0;
+  __syncthreads();
+  int iters = 0;
+  double diff = 0.0, flag = 0.0, un = 1.0;
+  double rv[M];
+  while (true) {
+    ++iters;
+    if (tid < SS_QMAX) s_cu[tid] = s_c[tid];
+    // ---- a = G c;  ts = a / ||a||                                                        (:856-883 in Gram form)
+#pragma unroll
+    for (int k = 0; k < M; ++k) rv[k] = 0.0;
+    for (int64_t i = tid; i < n; i += SS_T) {
+      double acc = 0.0;
+      for (int j = 0; j < q; ++j) acc = fma(s.G[(int64_t)j * n + i], s_c[j], acc);
+      s_wk[i] = acc;
+      rv[0] = fma(acc, acc, rv[0]);
+    }
+    ss_reduce<M>(rv, 1, red, tot);
+    const double nrm = sqrt(rv[0]);
+    // ---- diff = ||ts_old - ts|| (:887),  Y^T ts,  ts^T ts
+#pragma unroll
+    for (int k = 0; k < M; ++k) rv[k] = 0.0;
+    double dmax = 0.0, dmin = 1.0e300;
+    for (int64_t i = tid; i < n; i += SS_T) {
+      const double t = s_wk[i] / nrm;
+      const double d = s_ts[i] - t;
+      s_ts[i] = t;
+      rv[0] = fma(d, d, rv[0]);
+      rv[1] += fabs(d);
+      rv[2] = fma(t, t, rv[2]);
+      dmax = fmax(dmax, fabs(d));
+      dmin = fmin(dmin, fabs(d));
+#pragma unroll
+      for (int j = 0; j < SS_QMAX; ++j)
+        if (j < q) rv[4 + j] = fma(s.Y[(int64_t)j * n + i], t, rv[4 + j]);
+    }
+    ss_reduce<M>(rv, 4 + q, red, tot);
+    if (s.norm_kind == 0) diff = sqrt(rv[0]);
+    else if (s.norm_kind == 1) diff = rv[1];
+    else {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+        dmin = fmin(dmin, __shfl_xor(dmin, off, 64));
+      }
+      __syncthreads();
+      if ((tid & 63) == 0) {
+        s_mx[tid >> 6] = dmax;
+        s_mn[tid >> 6] = dmin;
+      }
+      __syncthreads();
+      for (int k = 0; k < SS_T / 64; ++k) {
+        dmax = fmax(dmax, s_mx[k]);
+        dmin = fmin(dmin, s_mn[k]);
+      }
+      diff = (s.norm_kind == 2) ? dmax : dmin;
+    }
+    // ---- v = Y^T ts / ts^T ts (:899);  u = Y v / v^T v, unit length (:911-913)  =>  c = v / (v^T v) / ||Y v / v^T v||
+    double vv = 0.0;
+#pragma unroll
+    for (int j = 0; j < SS_QMAX; ++j) {
+      const double vj = (j < q) ? rv[4 + j] / rv[2] : 0.0;
+      vv = fma(vj, vj, vv);
+      if (tid == j) s_v[j] = vj;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < M; ++k) rv[k] = 0.0;
+    for (int64_t i = tid; i < n; i += SS_T) {
+      double acc = 0.0;
+      for (int j = 0; j < q; ++j) acc = fma(s.Y[(int64_t)j * n + i], s_v[j], acc);
+      acc = acc / vv;
+      s_wk[i] = acc;
+      rv[0] = fma(acc, acc, rv[0]);
+    }
+    ss_reduce<M>(rv, 1, red, tot);
+    un = sqrt(rv[0]);
+    if (tid < SS_QMAX) s_c[tid] = s_v[tid] / vv / un;
+    __syncthreads();
+    if (iters >= 2 && diff <= s.tol) {
+      flag = 1.0;
+      break;
+    }
+    if (iters >= s.max_iter) {
+      flag = 2.0;
+      break;
+    }
+  }
+  for (int64_t i = tid; i < n; i += SS_T) {
+    s.ts[i] = s_ts[i];
+    s.u[i] = s_wk[i] / un;
+  }
+  if (tid < q) {
+    s.v[tid] = s_v[tid];
+    s.c_used[tid] = s_cu[tid];
+  }
+  if (tid == 0) {
+    s.state[0] = flag;
+    s.state[1] = (double)iters;
+    s.state[2] = diff;
+  }
+}
+
+}  // namespace mbpls
+
+extern "C" int mbpls_hip_nipals_subspace_loop(mbpls_ctx* ctx, int64_t n, int q, const double* d_G, const double* d_Y,
+                                              const double* d_c0, int norm_kind, double tol, int max_iter, double* d_ts,
+                                              double* d_u, double* d_v, double* d_c_used, double* d_state) {
+  using namespace mbpls;
+  MB_ARG(ctx && d_G && d_Y && d_c0 && d_ts && d_u && d_v && d_c_used && d_state, "NULL argument");
+  MB_ARG(n >= 1 && n <= 8192 && q >= 1 && q <= SS_QMAX, "subspace loop covers n <= 8192, q <= %d", SS_QMAX);
+  MB_ARG(norm_kind >= 0 && norm_kind <= 3 && max_iter >= 1, "bad norm kind %d / max_iter %d", norm_kind, max_iter);
+  SubspaceArgs s{n, q, norm_kind, max_iter, tol, d_G, d_Y, d_c0, d_ts, d_u, d_v, d_c_used, d_state};
+  static bool lds_attr_set = false;      // more than 64 KB of dynamic LDS needs to be allowed once per process
+  if (!lds_attr_set) {
+    MB_HIP(hipFuncSetAttribute((const void*)k_nipals_subspace_loop, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192));
+    lds_attr_set = true;
+  }
+  hipLaunchKernelGGL(k_nipals_subspace_loop, dim3(1), dim3(SS_T), (size_t)(16 * n), ctx->stream, s);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}

@@ -121,6 +121,10 @@ class HipEngine:
                 if hasattr(a, "free"):
                     a.free()
             self.Gb = None
+        if getattr(self, "_ss", None) is not None:
+            for key in ("Y", "G", "c0", "ts", "u", "v", "c", "state"):
+                self._ss[key].free()
+            self._ss = None
         if getattr(self, "_gp", None) is not None:
             for a in [self._gp[key] for key in ("Y", "a", "ts", "u", "v", "state")] + self._gp["W"]:
                 a.free()
@@ -805,6 +809,28 @@ class HipEngine:
         if dTp is not None:
             dTp.free()
         return out
+
+    def nipals_subspace_loop(self, G, Y, c0, norm_kind, tol, max_iter):
+        """The multi-response NIPALS inner loop of one component inside ONE kernel launch (csrc/nipals_step.hip,
+        k_nipals_subspace_loop): G = P X (X^T (P Y)) (n x q, host), every sweep vector is u = Y c.  Returns
+        (iterations, capped, ts, u, v, c_used) -- c_used: coefficients of the sweep vector of the last iteration.
+        None when the shape is outside the kernel's range (the caller iterates on the host then)."""
+        n, q = G.shape
+        if n > 8192 or q > 16 or norm_kind is None:
+            return None
+        ctx = self.ctx
+        st = getattr(self, "_ss", None)
+        if st is None or st["q"] != q:
+            st = self._ss = dict(q=q, Y=ctx.from_host(np.asfortranarray(Y)), G=ctx.empty((n, q)), c0=ctx.empty(q),
+                                 ts=ctx.empty(n), u=ctx.empty(n), v=ctx.empty(q), c=ctx.empty(q), state=ctx.empty(3))
+        st["G"].set(G)
+        st["c0"].set(np.ascontiguousarray(c0, dtype=np.float64).ravel())
+        _capi.check(ctx.lib.mbpls_hip_nipals_subspace_loop(ctx.handle, n, q, st["G"].ptr, st["Y"].ptr, st["c0"].ptr,
+                                                           int(norm_kind), float(tol), int(max_iter), st["ts"].ptr,
+                                                           st["u"].ptr, st["v"].ptr, st["c"].ptr, st["state"].ptr))
+        state = st["state"].get()
+        return (int(state[1]), state[0] == 2.0, st["ts"].get().reshape(-1, 1), st["u"].get().reshape(-1, 1),
+                st["v"].get().reshape(-1, 1), st["c"].get().reshape(-1, 1))
 
     def gram_apply(self, Z):
         """A @ Z for a host n x c matrix (A symmetric, so the feature-major product X W is A Z)."""

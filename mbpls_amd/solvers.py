@@ -161,6 +161,105 @@ def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_hos
 
 
 # ----------------------------------------------------------------------------------- NIPALS
+def _nipals_on_subspace(eng, q):
+    """Several responses make NIPALS iterate 50-500 times per component.  Every sweep vector of the loop is u = Y c and
+    the super score it yields is ts ~ P (sum_b X_b X_b^T) P u (P = I - Ts Ts^T carries the deflation), so with
+    G = P X (X^T (P Y)) -- two many-right-hand-side products over X per COMPONENT -- the whole loop is n x q algebra:
+    ts = G c / ||G c||.  X is standardised once and never deflated; a component costs three passes over X whatever its
+    iteration count."""
+    import os
+    return (q > 1 and q <= 16 and hasattr(eng, "x_w_slot") and not getattr(eng, "sparse", False)
+            and os.environ.get("MBPLS_NIPALS_SUBSPACE", "1") != "0")
+
+
+def _subspace_loop_host(G, Y, c0, norm, tol, max_iter):
+    """the loop of csrc/nipals_step.hip k_nipals_subspace_loop in numpy (engines without the kernel, n > 8192)"""
+    c = np.asarray(c0, dtype=np.float64).reshape(-1, 1)
+    ts_old, run, diff = None, 0, 1.0
+    while True:
+        run += 1
+        c_used = c
+        a = G.dot(c)
+        ts = a / np.linalg.norm(a)                          # (:882-883)
+        if run > 1:
+            diff = _norm(ts_old - ts, norm)                 # (:887)
+        ts_old = ts
+        v = Y.T.dot(ts) / ts.T.dot(ts)                      # (:899)
+        u = Y.dot(v) / v.T.dot(v)                           # (:911)
+        un = np.linalg.norm(u)
+        u = u / un
+        c = v / v.T.dot(v).item() / un
+        if run >= 2 and diff <= tol:
+            return run, False, ts, u, v, c_used
+        if run >= max_iter:
+            return run, True, ts, u, v, c_used
+
+
+def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter):
+    """mbpls.py:809-993 with the inner loop (:841-913) in the q-dimensional space of its iterates.  Per component:
+    G = P X (X^T (P Y)) (xt_v + x_w with q right-hand sides), the loop (one kernel launch / numpy), then ONE more pass:
+    loadings p = X^T ts (:928) together with the weights w~ = X^T (P u)/(u^T u) (:856) and the block products
+    X_b w~_b of the last sweep vector -- t_b = P X_b w~_b / ||w~_b|| (:875-877), sw_b ~ ||w~_b|| (:879)."""
+    n, B = eng.n, eng.nblocks
+    q = Y.shape[1]
+    sizes = _global_sizes(eng)
+    eng.slot("Wn", K); eng.slot("P", K); eng.slot("S", q)
+    if hasattr(eng, "use_lazy_deflation"):
+        eng.use_lazy_deflation(K, "P", prefer="explicit")   # X is never deflated here: the plain (stored) passes
+        eng._lazy_pslot = None
+    varxb, _, _ = eng.prepare(standardize)
+    varx = varxb.sum()
+    vary = (Y ** 2).sum()
+    Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
+    T = [np.empty((n, K)) for _ in range(B)]
+    nu_all = np.empty((B, K))
+    evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
+    _norm(np.zeros((2, 1)), norm)                           # raises for invalid orders exactly as the reference (:887)
+    kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
+    c0 = np.zeros((q, 1)); c0[0, 0] = 1.0                   # the start vector Y[:, 0] (:838)
+    for k in range(K):
+        Tp = Ts[:, :k]
+        PY = Y - Tp.dot(Tp.T.dot(Y))
+        eng.xt_v(PY, 1.0, "S", 0)                           # X^T (P Y)
+        G0 = eng.x_w_slot("S", 0, q)                        # X X^T P Y
+        G = G0 - Tp.dot(Tp.T.dot(G0))
+        out = eng.nipals_subspace_loop(G, Y, c0, kind, max_tol, max_iter) if hasattr(eng, "nipals_subspace_loop") else None
+        if out is None:
+            out = _subspace_loop_host(G, Y, c0, norm, max_tol, max_iter)
+        n_it, capped, ts, u, v, c_used = out
+        if capped:
+            warnings.warn(f"NIPALS component {k}: no convergence to max_tol={max_tol} after {max_iter} "
+                          f"iterations; the reference would loop forever here.")
+        iters.append(n_it)
+        u_used = Y.dot(c_used)                              # sweep vector of the last iteration
+        uu = u_used.T.dot(u_used).item()
+        z = u_used - Tp.dot(Tp.T.dot(u_used))               # P u
+        # one pass: p = X^T ts (ts is orthogonal to the earlier scores), w~ = X^T z / uu, X_b w~_b, ||w~_b||^2, ||p_b||^2
+        ssq_p, t_raw, ssq = eng.deflate_sweep(ts, 1.0, False, ("P", k), z, 1.0 / uu, ("Wn", k))
+        nu = np.sqrt(ssq)
+        Tm = (t_raw - Tp.dot(Tp.T.dot(t_raw))) / nu         # t_b = P X_b w_b (:875-877)
+        sw = nu.reshape(-1, 1) / np.linalg.norm(nu)         # sw_b ~ t_b^T u = ||w~_b|| uu (:879-880)
+        Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u; V[:, k:k + 1] = v; A[:, k:k + 1] = sw ** 2
+        nu_all[:, k] = nu
+        for b in range(B):
+            T[b][:, k] = Tm[:, b]
+        if calc_all:                                        # (:932-964)
+            tt = ts.T.dot(ts).item()
+            evx.append(tt * ssq_p.sum() / varx)
+            evy.append(tt * v.T.dot(v).item() / vary)
+            evxb[:, k] = tt * ssq_p / varxb
+            Acorr[:, k] = _bip_corrected(sw ** 2, sizes)
+    res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, nipals_iterations_=iters)
+    if calc_all:
+        res.update(explained_var_x_=evx, explained_var_y_=evy, explained_var_xblocks_=evxb, A_corrected_=Acorr)
+    else:
+        res.update(explained_var_x_=[], explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)),
+                   A_corrected_=np.empty((B, 0)))
+    _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V)
+    res.W_non_normal_ = _split(eng.fetch("Wn"), eng.block_offsets)
+    return res
+
+
 def _nipals_on_grams(eng, q):
     """Several responses make NIPALS iterate 50-500 times per component, and every iteration is a pass over X.  With
     p > n the same iterates can be had from the per-block association matrices A_b = X_b X_b^T (n x n each):
@@ -275,6 +374,8 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     max_iter = NIPALS_MAX_ITER if max_iter is None else max_iter
+    if _nipals_on_subspace(eng, q):
+        return _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     if _nipals_on_grams(eng, q):
         return _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     sizes = _global_sizes(eng)

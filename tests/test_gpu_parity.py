@@ -720,12 +720,15 @@ def test_kernel_method_never_writes_x(gpu_required, monkeypatch, offset, standar
     Xd.close()
 
 
-@pytest.mark.parametrize("gram", ["1", "0"])
-def test_multi_response_nipals_on_association_matrices(gpu_required, monkeypatch, gram):
-    """Several responses: the NIPALS inner loop runs on the per-block association matrices A_b = X_b X_b^T
-    (t_b = A_b u / sqrt(u^T A_b u)) instead of sweeping X every iteration -- same iterates, same results as the
-    X-sweeping loop (MBPLS_NIPALS_GRAM=0) and as the oracle, including row-subset fits."""
+@pytest.mark.parametrize("subspace,gram", [("1", "1"), ("0", "1"), ("0", "0")])
+def test_multi_response_nipals_on_association_matrices(gpu_required, monkeypatch, subspace, gram):
+    """Several responses: the NIPALS inner loop runs (default) in the q-dimensional space of its iterates -- u = Y c,
+    ts = G c / ||G c|| with G = P X (X^T (P Y)), the whole loop of a component in one kernel launch -- or
+    (MBPLS_NIPALS_SUBSPACE=0) on the per-block association matrices A_b = X_b X_b^T (t_b = A_b u / sqrt(u^T A_b u)),
+    instead of sweeping X every iteration: same iterates, same results as the X-sweeping loop (both switches 0) and as
+    the oracle."""
     from mbpls_amd import MBPLS
+    monkeypatch.setenv("MBPLS_NIPALS_SUBSPACE", subspace)
     monkeypatch.setenv("MBPLS_NIPALS_GRAM", gram)
     X, Y = orc.make_latent(333, 4000, 4, seed=90)
     Xs = [np.ascontiguousarray(X[:, :1500]), np.ascontiguousarray(X[:, 1500:2501]), np.ascontiguousarray(X[:, 2501:])]
@@ -741,9 +744,35 @@ def test_multi_response_nipals_on_association_matrices(gpu_required, monkeypatch
         for b, blk in enumerate(rT):
             rflat[f"T_new/{b}"] = blk
         rflat["Ts_new"], rflat["U_new"] = rTs, rU
-        w = util.compare(got, rflat, TOL, what=f"gram={gram} std={std}")
+        w = util.compare(got, rflat, TOL, what=f"subspace={subspace} gram={gram} std={std}")
         assert w < 1e-8, w
         assert all(abs(a - b) <= 2 for a, b in zip(mdl.nipals_iterations_, ref.nipals_iterations_))
+
+
+@pytest.mark.parametrize("n,q,kind,k", [(300, 2, 0, 0), (1000, 4, 1, 2), (4096, 10, 0, 5), (8192, 16, 2, 3), (777, 3, 3, 1)])
+def test_nipals_subspace_loop_kernel(ctx, n, q, kind, k):
+    """The whole multi-response NIPALS loop of a component in one launch (k_nipals_subspace_loop) against its numpy
+    statement (solvers._subspace_loop_host): iteration count, ts, u, v, the coefficients of the last sweep vector."""
+    from mbpls_amd import solvers
+    from mbpls_amd.engine import HipEngine
+    rng = np.random.RandomState(n + q)
+    Yl = rng.standard_normal((n, q)); Yl -= Yl.mean(axis=0)
+    Xl = rng.standard_normal((n, 3 * n // 2 + 7)) @ np.diag(0.97 ** np.arange(3 * n // 2 + 7))
+    Tp = np.linalg.qr(rng.standard_normal((n, k)))[0] if k else np.zeros((n, 0))
+    PY = Yl - Tp @ (Tp.T @ Yl)
+    G = Xl @ (Xl.T @ PY)
+    G = G - Tp @ (Tp.T @ G)
+    c0 = np.zeros((q, 1)); c0[0, 0] = 1.0
+    norm = {0: 2, 1: 1, 2: np.inf, 3: -np.inf}[kind]
+    want = solvers._subspace_loop_host(G, Yl, c0, norm, 1e-14, 5000)
+    eng = HipEngine(ctx=ctx)
+    eng.n = n
+    got = eng.nipals_subspace_loop(G, Yl, c0, kind, 1e-14, 5000)
+    eng._ss and [eng._ss[key].free() for key in ("Y", "G", "c0", "ts", "u", "v", "c", "state")]
+    assert got is not None
+    assert abs(got[0] - want[0]) <= max(2, want[0] // 50) and got[1] == want[1], (got[0], want[0])
+    for a, b, nm in zip(got[2:], want[2:], ("ts", "u", "v", "c_used")):
+        assert util.relerr(a, b) < 1e-9, nm
 
 
 @pytest.mark.parametrize("n,k,q,kind", [(257, 0, 1, 0), (1000, 3, 4, 0), (4096, 9, 10, 1), (5000, 16, 16, 2), (300, 2, 3, 3)])
