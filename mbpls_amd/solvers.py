@@ -525,6 +525,58 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
 
 
 # ----------------------------------------------------------------------------------- UNIPALS
+def _fit_unipals_wide_multi(eng, Y, K, standardize):
+    """UNIPALS, p > n, several responses (mbpls.py:481-572) without ever deflating X.  The deflation :535 is
+    X_k = (I - ts ts^T) X_{k-1} = P X_0 with P = I - Ts Ts^T (successive ts are orthonormal), so
+      S-factor :489   X_k X_k^T Y = P X_0 (X_0^T (P Y))         -- xt_v + x_w with q right-hand sides on X_0
+      weights  :503   X_k^T u = X_0^T (P u),  block scores :515-517  X_k,b w_b = P X_0,b w_b,
+      loadings :520   X_k^T ts / ts^T ts = X_0^T ts / ts^T ts     (ts is orthogonal to the earlier scores)
+    and the last three are ONE fused read-only pass: three passes per component instead of four plus a rewrite."""
+    n, B = eng.n, eng.nblocks
+    q = Y.shape[1]
+    sizes = _global_sizes(eng)
+    eng.slot("Wc", K); eng.slot("P", K); eng.slot("S", q)
+    if hasattr(eng, "use_lazy_deflation"):
+        eng.use_lazy_deflation(K, "P", prefer="explicit")   # plain passes on the stored X; nothing is deflated
+        eng._lazy_pslot = None
+    varxb, _, _ = eng.prepare(standardize)
+    varx = varxb.sum()
+    vary = (Y ** 2).sum()
+    F = _psd_factor(Y.T.dot(Y))
+    Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
+    T = [np.empty((n, K)) for _ in range(B)]
+    blk_nrm = np.empty((B, K)); tot_nrm = np.empty(K)
+    evx, evy, evxb, Acorr = [], [], np.empty((B, K)), np.empty((B, K))
+    for k in range(K):
+        Tp = Ts[:, :k]
+        PY = Y - Tp.dot(Tp.T.dot(Y))
+        eng.xt_v(PY, 1.0, "S", 0)
+        M = eng.x_w_slot("S", 0, q)
+        M = M - Tp.dot(Tp.T.dot(M))                         # X_k X_k^T Y (:489)
+        ts = _tlsv(M.dot(F))                                # (:489-493)
+        tt = ts.T.dot(ts).item()
+        v = Y.T.dot(ts) / tt                                # (:496)
+        u = Y.dot(v); u = u / np.linalg.norm(u)             # (:499-500)
+        z = u - Tp.dot(Tp.T.dot(u))
+        ssq_p, t_raw, ssq = eng.deflate_sweep(ts, 1.0 / tt, False, ("P", k), z, 1.0, ("Wc", k))
+        t_raw = t_raw - Tp.dot(Tp.T.dot(t_raw))             # X_k,b w_raw,b = P X_0,b w_raw,b (:515-517)
+        tot = ssq.sum()
+        blk_nrm[:, k] = np.sqrt(ssq); tot_nrm[k] = np.sqrt(tot)
+        A[:, k] = ssq / tot                                 # ||w_b||^2 of the unit-length w (:512)
+        Tm = t_raw / np.sqrt(ssq)
+        Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u; V[:, k:k + 1] = v
+        for b in range(B):
+            T[b][:, k] = Tm[:, b]
+        evx.append(tt * ssq_p.sum() / varx)                 # (:521-533)
+        evxb[:, k] = tt * ssq_p / varxb
+        evy.append(tt * v.T.dot(v).item() / vary)           # (:538-540)
+        Acorr[:, k] = _bip_corrected(A[:, k], sizes)        # (:542-553)
+    res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, explained_var_x_=evx, explained_var_y_=evy,
+                    explained_var_xblocks_=evxb, A_corrected_=Acorr)
+    _finalise_device(eng, res, "Wc", K, tot_nrm, blk_nrm, V)                            # (:569-572)
+    return res
+
+
 def fit_unipals(eng, Y, K, standardize):
     """mbpls.py:384-574 (calc_all is ignored by the reference here).
     p>n (:481-572): ts = tlsv((X (X^T Y)) F(Y^T Y));  n>=p (:388-479): w = tlsv(X^T Y)."""
@@ -532,6 +584,10 @@ def fit_unipals(eng, Y, K, standardize):
     q = Y.shape[1]
     p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
     wide = p_total > n
+    import os
+    if (wide and q > 1 and hasattr(eng, "x_w_slot") and not getattr(eng, "sparse", False)
+            and os.environ.get("MBPLS_UNIPALS_NODEFLATE", "1") != "0"):
+        return _fit_unipals_wide_multi(eng, Y, K, standardize)
     sizes = _global_sizes(eng)
     eng.slot("Wc", K)
     eng.slot("P", K)

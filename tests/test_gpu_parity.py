@@ -720,6 +720,33 @@ def test_kernel_method_never_writes_x(gpu_required, monkeypatch, offset, standar
     Xd.close()
 
 
+@pytest.mark.parametrize("nodeflate", ["1", "0"])
+def test_unipals_several_responses_never_deflates(gpu_required, monkeypatch, nodeflate):
+    """UNIPALS, p > n, q > 1: by default X is standardised once and never deflated (X_k = P X_0, P = I - Ts Ts^T applied
+    to the n-vectors around three read-only passes per component); MBPLS_UNIPALS_NODEFLATE=0 keeps the explicitly
+    deflating form.  Same numbers, equal to the oracle."""
+    from mbpls_amd import MBPLS
+    monkeypatch.setenv("MBPLS_UNIPALS_NODEFLATE", nodeflate)
+    X, Y = orc.make_latent(450, 3900, 3, seed=17)
+    Xs = [np.ascontiguousarray(X[:, :1900]), np.ascontiguousarray(X[:, 1900:])]
+    Xn, Yn = orc.make_latent(30, 3900, 3, seed=18)
+    Xns = [np.ascontiguousarray(Xn[:, :1900]), np.ascontiguousarray(Xn[:, 1900:])]
+    for std in (True, False):
+        ref = orc.fit(Xs, Y, n_components=5, method="UNIPALS", standardize=std, full_svd=True)
+        mdl = MBPLS(n_components=5, method="UNIPALS", standardize=std, full_svd=True).fit(Xs, Y)
+        got = _fit_flat(mdl, Xns, Yn, block_scores=std)
+        rflat = util.model_to_flat(ref)
+        rflat["predict"] = orc.predict(ref, Xns)
+        if std:
+            rTs, rT, rU = orc.transform(ref, Xns, Yn, return_block_scores=True)
+            for b, blk in enumerate(rT):
+                rflat[f"T_new/{b}"] = blk
+        else:
+            rTs, rU = orc.transform(ref, Xns, Yn)
+        rflat["Ts_new"], rflat["U_new"] = rTs, rU
+        assert util.compare(got, rflat, TOL, what=f"unipals nodeflate={nodeflate} std={std}") < 1e-8
+
+
 @pytest.mark.parametrize("subspace,gram", [("1", "1"), ("0", "1"), ("0", "0")])
 def test_multi_response_nipals_on_association_matrices(gpu_required, monkeypatch, subspace, gram):
     """Several responses: the NIPALS inner loop runs (default) in the q-dimensional space of its iterates -- u = Y c,
