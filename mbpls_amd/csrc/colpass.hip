@@ -429,18 +429,20 @@ __global__ __launch_bounds__(256) void k_finish_stats(int64_t p, double* __restr
 }
 
 // Second stage: fixed-order sum of the chunk partials of each block.
-//   grid (ceil(n/64), nblocks), 256 threads: wave w takes chunks cs+w, cs+w+4, ...; LDS combine in wave order.
-//   The workgroup with blockIdx.x == 0 also reduces the per-chunk scalars of its block.
-__global__ __launch_bounds__(256) void k_reduce_chunks(const double* __restrict__ part_t,
-                                                       const double* __restrict__ part_s,
-                                                       const int* __restrict__ blk_start, int64_t n,
-                                                       double* __restrict__ out_t, double* __restrict__ out_ssq_g,
-                                                       double* __restrict__ out_ssq_p, double* __restrict__ out_ssq_x,
-                                                       const double* __restrict__ part_d, int nd,
-                                                       double* __restrict__ out_d /* [nblocks][nd] */,
-                                                       double* __restrict__ out_amp /* [nblocks] max of slot 3 */,
-                                                       const double* __restrict__ dpar) {
-  __shared__ double comb[4][64];
+//   grid (ceil(n/64), nblocks), 1024 threads: wave w takes chunks cs+w, cs+w+16, ...; LDS combine in wave order.
+//   (Latency-bound: with 4 waves every lane walked 256 chunk partials one after the other, 35-50 us per pass at
+//   1024 chunks; 16 waves leave 64 each.)  The workgroup with blockIdx.x == 0 also reduces the per-chunk scalars.
+constexpr int RC_W = 16;
+__global__ __launch_bounds__(64 * RC_W) void k_reduce_chunks(const double* __restrict__ part_t,
+                                                             const double* __restrict__ part_s,
+                                                             const int* __restrict__ blk_start, int64_t n,
+                                                             double* __restrict__ out_t, double* __restrict__ out_ssq_g,
+                                                             double* __restrict__ out_ssq_p, double* __restrict__ out_ssq_x,
+                                                             const double* __restrict__ part_d, int nd,
+                                                             double* __restrict__ out_d /* [nblocks][nd] */,
+                                                             double* __restrict__ out_amp /* [nblocks] max of slot 3 */,
+                                                             const double* __restrict__ dpar) {
+  __shared__ double comb[RC_W][64];
   if (dpar && dpar[2] != 0.0) return;
   const int b = blockIdx.y;
   const int cs = blk_start[b], ce = blk_start[b + 1];
@@ -452,18 +454,23 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const double* __restrict_
       int c = cs + w;
       // 4 independent accumulators keep several loads in flight; combined in fixed order
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      for (; c + 12 < ce; c += 16) {
+      for (; c + 3 * RC_W < ce; c += 4 * RC_W) {
         s0 += part_t[(int64_t)c * n + i];
-        s1 += part_t[(int64_t)(c + 4) * n + i];
-        s2 += part_t[(int64_t)(c + 8) * n + i];
-        s3 += part_t[(int64_t)(c + 12) * n + i];
+        s1 += part_t[(int64_t)(c + RC_W) * n + i];
+        s2 += part_t[(int64_t)(c + 2 * RC_W) * n + i];
+        s3 += part_t[(int64_t)(c + 3 * RC_W) * n + i];
       }
-      for (; c < ce; c += 4) s0 += part_t[(int64_t)c * n + i];
+      for (; c < ce; c += RC_W) s0 += part_t[(int64_t)c * n + i];
       s = (s0 + s1) + (s2 + s3);
     }
     comb[w][lane] = s;
     __syncthreads();
-    if (w == 0 && i < n) out_t[(int64_t)b * n + i] = (comb[0][lane] + comb[1][lane]) + (comb[2][lane] + comb[3][lane]);
+    if (w == 0 && i < n) {
+      double tsum = 0.0;
+#pragma unroll
+      for (int k = 0; k < RC_W; ++k) tsum += comb[k][lane];
+      out_t[(int64_t)b * n + i] = tsum;
+    }
   }
   if (blockIdx.x == 0 && w < 3) {
     double* o = (w == 0) ? out_ssq_g : (w == 1 ? out_ssq_p : out_ssq_x);
@@ -481,8 +488,8 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const double* __restrict_
     for (int off = 32; off > 0; off >>= 1) s = fmax(s, __shfl_xor(s, off, 64));
     if (lane == 0) out_amp[b] = s;
   }
-  if (blockIdx.x == 0 && w == 3 && out_d) {
-    for (int i = 0; i < nd; ++i) {
+  if (blockIdx.x == 0 && w >= 4 && out_d) {   // the lazy-deflation sums: one value per wave and round (up to 39 of them)
+    for (int i = w - 4; i < nd; i += RC_W - 4) {
       double s = 0.0;
       for (int c = cs + lane; c < ce; c += 64) s += part_d[(int64_t)c * KD + i];
       s = wave_sum(s);
@@ -569,7 +576,7 @@ int reduce_chunks(mbpls_ctx* ctx, const mbpls_mat* m, const double* part_t, cons
                   double* d_t, double* d_ssq_g, double* d_ssq_p, double* d_ssq_x,
                   const double* part_d, int nd, double* d_d, double* d_amp) {
   dim3 grid(d_t ? (unsigned)((m->n + 63) / 64) : 1u, (unsigned)m->nblocks);
-  hipLaunchKernelGGL(k_reduce_chunks, grid, dim3(256), 0, ctx->stream, part_t, part_s,
+  hipLaunchKernelGGL(k_reduce_chunks, grid, dim3(64 * RC_W), 0, ctx->stream, part_t, part_s,
                      (const int*)m->fine.d_blk_start, m->n, d_t, d_ssq_g, d_ssq_p, d_ssq_x, part_d, nd, d_d, d_amp,
                      ctx->dpar);
   MB_HIP(hipGetLastError());

@@ -169,33 +169,35 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* red, int& buf
   buf ^= 1;
 }
 
-// Sum the first m of M values over a 1024-thread workgroup with two barriers per 16 values: every thread parks its
-// partials in LDS, wave g sums value g (16 strided reads + one butterfly), the totals come back through LDS.  Fixed
-// order (deterministic).  part: double[16][1024], tot: double[16].
+// Sum the first m of M <= 16 values over a 1024-thread workgroup: wave butterflies, the 16 wave partials through a
+// few hundred bytes of LDS, thread k < m adds them in wave order, everyone reads the totals back.  Fixed order
+// (deterministic), two barriers per call whatever m is.  (The first version parked every thread's partials in LDS --
+// 128 KB of traffic per 16 values -- and cost 5-7 us per call; the step kernels make seven to ten calls.)
+// part: at least 16*M doubles, tot: at least M doubles.
 constexpr int WG1024 = 1024;
 template <int M>
 __device__ __forceinline__ void reduce_many(double (&v)[M], int m, double* part, double* tot) {
-  const int tid = threadIdx.x, g = tid >> 6, lane = tid & 63;
+  static_assert(M <= 16, "tot[] of the callers holds 16 values");
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 #pragma unroll
-  for (int base = 0; base < M; base += 16) {
-    if (base < m) {   // workgroup-uniform
+  for (int k = 0; k < M; ++k)
+    if (k < m) v[k] = wave_sum(v[k]);
+  if (lane == 0) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (base + j < M && base + j < m) part[j * WG1024 + tid] = v[(base + j < M) ? base + j : 0];
-      __syncthreads();
-      if (base + g < m) {
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < WG1024 / 64; ++i) s += part[g * WG1024 + i * 64 + lane];
-        s = wave_sum(s);
-        if (lane == 0) tot[g] = s;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (base + j < M && base + j < m) v[(base + j < M) ? base + j : 0] = tot[j];
-    }
+    for (int k = 0; k < M; ++k)
+      if (k < m) part[w * M + k] = v[k];
   }
+  __syncthreads();
+  if (tid < m) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < WG1024 / 64; ++i) s += part[i * M + tid];
+    tot[tid] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < M; ++k)
+    if (k < m) v[k] = tot[k];
 }
 #endif
 

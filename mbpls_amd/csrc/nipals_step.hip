@@ -40,7 +40,7 @@ constexpr int NS_KMAX = 16;   // previous components / responses (register array
 
 __global__ __launch_bounds__(NS_T) void k_nipals_gram_step(StepArgs s) {
   static_assert(NS_T == 1024, "reduce_many maps value g to wave g of 16");
-  __shared__ double part[16 * NS_T];   // 128 KB: one workgroup owns the CU
+  __shared__ double part[16 * 16];     // wave partials of reduce_many
   __shared__ double tot[16];
   __shared__ double s_max[NS_T / 64], s_min[NS_T / 64];
   if (s.state[0] != 0.0) return;   // converged earlier in this batch: keep the state as it is

@@ -22,7 +22,7 @@ constexpr int RS_QMAX = MBPLS_STEP_MAX_RESPONSES;
 constexpr int RS_KMAX = 40;   // == KD of colpass.hip (lazily deflated components + 1)
 
 __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
-  __shared__ double part[16 * WG1024];   // 128 KB: the workgroup owns its CU
+  __shared__ double part[16 * 16];       // wave partials of reduce_many
   __shared__ double tot[16];
   __shared__ double s_mx[WG1024 / 64], s_mn[WG1024 / 64];
   double* par = s.par;
