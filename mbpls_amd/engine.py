@@ -936,7 +936,8 @@ class _ResidentQueue:
         """mean / scale / var of the columns are final after the first pass: they leave through the helper thread now
         instead of three blocking copies at the end of the fit"""
         eng = self.eng
-        if eng.mean is None or eng.scale is None:
+        import os
+        if eng.mean is None or eng.scale is None or os.environ.get("MBPLS_STREAM_STATS", "1") == "0":
             return
         arrs = [eng.mean, eng.scale] + ([eng.var] if getattr(eng, "var", None) is not None else [])
         host = [np.empty(eng.p) for _ in arrs]

@@ -543,6 +543,28 @@ def test_implicit_standardisation_of_offset_data(gpu_required, monkeypatch, offs
     Xd.close()
 
 
+@pytest.mark.parametrize("method", ["NIPALS", "UNIPALS", "KERNEL", "SIMPLS"])
+@pytest.mark.parametrize("q,blocks", [(1, [9000]), (3, [2500, 3000, 3500])])
+def test_medium_vs_faithful_oracle(gpu_required, method, q, blocks):
+    """The HIP path against the oracle's FAITHFUL mode -- the reference's own numpy op sequence (n x p outer products for
+    the explained variance :933/:946, n x n SVDs :489-493 / :712-715, D A D deflation :722-725, per-iteration sweeps),
+    not the lean restatement the GPU shares its formulas with -- at a size where that is still quick."""
+    from mbpls_amd import MBPLS
+    n, p, K = 600, sum(blocks), 4
+    X, Y = orc.make_latent(n, p, q, seed=200 + q)
+    cuts = np.cumsum(blocks)[:-1]
+    Xs = X if len(blocks) == 1 else [np.ascontiguousarray(b) for b in np.split(X, cuts, axis=1)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = orc.fit(Xs, Y, n_components=K, method=method, full_svd=True, faithful=True)
+        mdl = MBPLS(n_components=K, method=method, full_svd=True).fit(Xs, Y)
+    w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"faithful {method} q={q}")
+    assert w < 1e-8, w
+    assert util.relerr(mdl.predict(Xs), orc.predict(ref, Xs)) < 1e-8
+    if method == "NIPALS":
+        assert all(abs(a - b) <= 2 for a, b in zip(mdl.nipals_iterations_, ref.nipals_iterations_))
+
+
 @pytest.mark.parametrize("method,K,q,n,p", [("NIPALS", 40, 1, 1200, 900), ("NIPALS", 38, 1, 1200, 900),
                                             ("NIPALS", 33, 2, 1200, 900), ("UNIPALS", 40, 1, 300, 2400),
                                             ("UNIPALS", 35, 3, 300, 2400), ("KERNEL", 40, 2, 300, 2400),
