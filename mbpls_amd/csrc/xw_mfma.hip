@@ -41,11 +41,13 @@ __global__ __launch_bounds__(512) void k_xw_mfma(const double* __restrict__ X, i
                                                  const double* __restrict__ Wp,
                                                  const double2* __restrict__ ms /* (mean_j, 1/scale_j) */,
                                                  double* __restrict__ part /* [nchunks][16 NT][n] */) {
-  const int chunk = blockIdx.x;
+  // launch order: the row slabs of one column chunk are consecutive workgroups -- they run side by side and read
+  // neighbouring 2 KB pieces of the same columns (DRAM page locality), instead of 16 distant chunks at a time
+  const int chunk = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int64_t j0 = c0[chunk], j1 = c1[chunk];
-  const int64_t i0 = (int64_t)blockIdx.y * 256 + wave * 32;   // first sample of this wave's tile
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + wave * 32;   // first sample of this wave's tile
   if (i0 >= n) return;                                         // wave-uniform
   const int64_t s0 = i0 + 2 * li;                              // this lane's sample pair
   const bool in_ld = s0 < ld, ok0 = s0 < n, ok1 = s0 + 1 < n;
@@ -60,29 +62,45 @@ __global__ __launch_bounds__(512) void k_xw_mfma(const double* __restrict__ X, i
   // feature groups are aligned to absolute multiples of 4 (the packing of W); features of the first / last group
   // outside [j0, j1) belong to a neighbouring chunk and are masked out
   const int64_t g0 = j0 >> 2, g1 = (j1 + 3) >> 2;
-  for (int64_t g = g0; g < g1; ++g) {
-    const int64_t j = 4 * g + lk;
-    const bool vj = j >= j0 && j < j1;
-    double2 x = *reinterpret_cast<const double2*>(xcol + (vj ? j : j0) * ld);
-    if constexpr (SCALE) {
-      const double2 m2 = ms[vj ? j : j0];      // one 16-byte load; a division per element cost a third of the pass
-      x.x = (x.x - m2.x) * m2.y;
-      x.y = (x.y - m2.x) * m2.y;
-    }
-    if constexpr (NANM == 1) {
-      x.x = (x.x == x.x) ? x.x : 0.0;
-      x.y = (x.y == x.y) ? x.y : 0.0;
-    } else if constexpr (NANM == 2) {
-      x.x = (x.x == x.x) ? 1.0 : 0.0;
-      x.y = (x.y == x.y) ? 1.0 : 0.0;
-    }
-    const double a0 = (vj && ok0) ? x.x : 0.0, a1 = (vj && ok1) ? x.y : 0.0;
-    const double* wp = Wp + (g * NT) * 64 + lane;
+  // UG feature groups per round: all their X loads (and scaling pairs) are issued before the first MFMA -- with one
+  // group per iteration a wave had a single 1 KB load in flight and the kernel was latency-bound (5.7 ms where a
+  // plain sweep takes 4.7)
+  constexpr int UG = NT <= 2 ? 8 : 4;
+  for (int64_t g = g0; g < g1; g += UG) {
+    double2 xr[UG], mr[UG];
+    bool vr[UG];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const double b = wp[nt * 64];
-      acc[0][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][nt], 0, 0, 0);
-      acc[1][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][nt], 0, 0, 0);
+    for (int u = 0; u < UG; ++u) {
+      const int64_t j = 4 * (g + u) + lk;
+      vr[u] = (g + u < g1) && j >= j0 && j < j1;
+      const int64_t jc = vr[u] ? j : j0;
+      xr[u] = *reinterpret_cast<const double2*>(xcol + jc * ld);
+      if constexpr (SCALE) mr[u] = ms[jc];      // (mean_j, 1/scale_j): one 16-byte load
+    }
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+      if (g + u >= g1) break;                   // wave-uniform
+      double2 x = xr[u];
+      const bool vj = vr[u];
+      if constexpr (SCALE) {
+        x.x = (x.x - mr[u].x) * mr[u].y;
+        x.y = (x.y - mr[u].x) * mr[u].y;
+      }
+      if constexpr (NANM == 1) {
+        x.x = (x.x == x.x) ? x.x : 0.0;
+        x.y = (x.y == x.y) ? x.y : 0.0;
+      } else if constexpr (NANM == 2) {
+        x.x = (x.x == x.x) ? 1.0 : 0.0;
+        x.y = (x.y == x.y) ? 1.0 : 0.0;
+      }
+      const double a0 = (vj && ok0) ? x.x : 0.0, a1 = (vj && ok1) ? x.y : 0.0;
+      const double* wp = Wp + ((g + u) * NT) * 64 + lane;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const double b = wp[nt * 64];
+        acc[0][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][nt], 0, 0, 0);
+      }
     }
   }
   // D layout (f64 16x16x4): column (rhs) = lane & 15, row = (lane >> 4) + 4 * reg; row r of sub-tile s is sample
@@ -132,7 +150,7 @@ int xw_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_W, int64_t ldw, 
     hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                        d_W + (int64_t)k0 * ldw, ldw, m->p, cb, NT, total, Wp);
     MB_HIP(hipGetLastError());
-    dim3 grid((unsigned)ct.nchunks, (unsigned)((m->n + 255) / 256));
+    dim3 grid((unsigned)((m->n + 255) / 256), (unsigned)ct.nchunks);
     {
       ProfScope prof(ctx, MBPLS_K_X_W, 8.0 * (double)m->n * (double)m->p);
 #define MB_XWM(NT_, SC_, NM_)                                                                                       \

@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
