@@ -309,10 +309,42 @@ class HipEngine:
             mode = _capi.SCALE_NONE
         src = self._src if self._src is not None else self.X
         _capi.check(self.ctx.lib.mbpls_hip_set_variance_output(self.ctx.handle, _capi._ptr(self.var)))
+        self.host_stats = None
         try:
-            return self._prepare_passes(src, standardize, mode, v, alpha, g_slot, mean, defer)
+            out = self._prepare_passes(src, standardize, mode, v, alpha, g_slot, mean, defer)
         finally:
             self.ctx.lib.mbpls_hip_set_variance_output(self.ctx.handle, None)
+        if standardize and mode == _capi.SCALE_FIT:
+            self.stream_stats()
+        return out
+
+    def stream_stats(self):
+        """mean / scale / var are final once the standardise pass has run: send them to the host through the copier
+        thread now (behind an event), so the three p-length copies -- page faults of fresh arrays included -- overlap
+        with the rest of the fit instead of sitting at its end.  ``host_stats`` / ``wait_stats`` hand them over."""
+        import os
+        import threading
+        if self.mean is None or self.scale is None or os.environ.get("MBPLS_STREAM_STATS", "1") == "0":
+            return
+        arrs = [self.mean, self.scale] + ([self.var] if getattr(self, "var", None) is not None else [])
+        host = [np.empty(self.p) for _ in arrs]
+        ev = _capi._vp()
+        _capi.check(self.ctx.lib.mbpls_hip_event_record(self.ctx.handle, _capi.C.byref(ev)))
+        q = _copier_queue()
+        self._stats_errors = []
+        q.put((self.ctx, ev, [(h, d.ptr) for h, d in zip(host, arrs)], self._stats_errors))
+        self._stats_done = threading.Event()
+        q.put(self._stats_done)
+        self.host_stats = tuple(host) if len(host) == 3 else (host[0], host[1], None)
+
+    def wait_stats(self):
+        """(mean, scale, var) on the host, or None when they were not streamed"""
+        if self.host_stats is None:
+            return None
+        self._stats_done.wait()
+        if self._stats_errors:
+            raise self._stats_errors[0]
+        return self.host_stats
 
     def _prepare_passes(self, src, standardize, mode, v, alpha, g_slot, mean, defer):
         n, B = self.n, self.nblocks
@@ -399,6 +431,8 @@ class HipEngine:
         self.X, self._src = src, None              # the raw matrix, never written
         self._kscale = bool(standardize)
         self._cen = self._kscale and float(np.sqrt(np.max(self._last_d))) > self.CENTRE_FROM_OFFSET
+        if standardize:
+            self.stream_stats()
         return x
 
     # Raw-space dot products carry rounding noise of max_j |mean_j| / scale_j ulps.  Above this offset ratio the
@@ -603,7 +637,6 @@ class HipEngine:
             p8, B = 8 * self.p, self.nblocks
             with self._timed("queue_passes"):
                 rq.step(0, 1, 0)
-                rq.stream_stats()
                 for k in range(K):
                     last = k == K - 1
                     self._res_sweep(k, (wslot, k))                   # second iteration (:856, :875)
@@ -631,7 +664,6 @@ class HipEngine:
             p8 = 8 * self.p
             with self._timed("queue_passes"):
                 rq.step(0, 1, 0)
-                rq.stream_stats()
                 for k in range(K):
                     last = k == K - 1
                     # w_raw = X^T u = c X^T y (:503): the column the pass left in S times the scalar the step recorded
@@ -931,18 +963,6 @@ class _ResidentQueue:
         ev = _capi._vp()
         _capi.check(self.lib.mbpls_hip_event_record(self.ctx.handle, _capi.C.byref(ev)))
         self.jobs.put((self.ctx, ev, copies, self.errors))
-
-    def stream_stats(self):
-        """mean / scale / var of the columns are final after the first pass: they leave through the helper thread now
-        instead of three blocking copies at the end of the fit"""
-        eng = self.eng
-        import os
-        if eng.mean is None or eng.scale is None or os.environ.get("MBPLS_STREAM_STATS", "1") == "0":
-            return
-        arrs = [eng.mean, eng.scale] + ([eng.var] if getattr(eng, "var", None) is not None else [])
-        host = [np.empty(eng.p) for _ in arrs]
-        self.stream_out([(h, d.ptr) for h, d in zip(host, arrs)])
-        eng.host_stats = tuple(host) if len(host) == 3 else (host[0], host[1], None)
 
     # ---- launches
     def allreduce(self):

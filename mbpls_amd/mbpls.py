@@ -311,8 +311,9 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         self.num_blocks_ = B
         self._block_offsets = list(eng.block_offsets)
         if self.standardize:
-            if getattr(eng, "host_stats", None) is not None:      # streamed out during the fit (device-resident queue)
-                mean, scale, var = eng.host_stats
+            streamed = eng.wait_stats() if hasattr(eng, "wait_stats") else None
+            if streamed is not None:                  # left through the copier thread while the fit was running
+                mean, scale, var = streamed
             else:
                 mean, scale = eng.mean.get(), eng.scale.get()
                 var = eng.var.get() if getattr(eng, "var", None) is not None else None

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python tools/time_small.py 2>&1 | tail -8
+timeout 600 python -m pytest tests/test_gpu_sparse.py -x -q -m gpu -k "missing_responses_medium" 2>&1 | grep -E "^E |passed|failed" | head -12
