@@ -327,7 +327,8 @@ class HipEngine:
         if self.mean is None or self.scale is None or os.environ.get("MBPLS_STREAM_STATS", "1") == "0":
             return
         arrs = [self.mean, self.scale] + ([self.var] if getattr(self, "var", None) is not None else [])
-        host = [np.empty(self.p) for _ in arrs]
+        S = self.host_array((self.p, 3))           # one F-ordered p x 3 array: recycled from the previous fit's scalers
+        host = [S[:, i] for i in range(len(arrs))]
         ev = _capi._vp()
         _capi.check(self.ctx.lib.mbpls_hip_event_record(self.ctx.handle, _capi.C.byref(ev)))
         q = _copier_queue()

@@ -221,6 +221,10 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         # one stale object per column pass, right after the launch, while the host would only wait anyway.
         stale = [self.__dict__.pop(k) for k in ("P_", "W_", "W_non_normal_", "R_", "beta_", "W_concat_", "T_")
                  if k in self.__dict__]
+        old_scalers = self.__dict__.pop("x_scalers_", None)
+        if old_scalers:      # their mean_/scale_/var_ are columns of one p x 3 array (engine.stream_stats): recyclable too
+            stale.append([a for sc in old_scalers for a in (sc.mean_, sc.scale_, getattr(sc, "var_", sc.mean_))])
+            del old_scalers
         # ... unless the buffer can simply be used again: the F-ordered p x K arrays behind the old attributes that
         # nobody else holds go to the engine's host pool (their pages are mapped: copies into them run at PCIe speed)
         eng.host_pool = _recyclable(stale)
