@@ -216,7 +216,12 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
           const double eps = 2.220446049250313e-16;
           const double nme = dn * mean * eps;
           const bool constant = var <= dn * eps * var + nme * nme;
-          const double r2 = constant ? 0.0 : 1.0 / var;      // a constant column: no weight, no loading
+          // 1/var on the critical path of every column: hardware reciprocal + two Newton steps (<= 1 ulp) instead of
+          // the IEEE division sequence (twice the dependent instructions); var is a normal positive number here
+          double rv = __builtin_amdgcn_rcp(var);
+          rv = fma(fma(-var, rv, 1.0), rv, rv);
+          rv = fma(fma(-var, rv, 1.0), rv, rv);
+          const double r2 = constant ? 0.0 : rv;             // a constant column: no weight, no loading
           const double gt = a.alpha * s3[2];                 // raw-space weight g~_j
           const double cj = gt * r2;
           ssq_g = fma(gt, cj, ssq_g);

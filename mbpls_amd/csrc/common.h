@@ -138,24 +138,52 @@ struct ProfScope {
 
 // ---------------------------------------------------------------- device helpers
 #ifdef __HIPCC__
-// 64-lane butterfly: every lane ends with the same, order-fixed sum.
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// One DPP lane exchange of a double (two v_mov_b32_dpp: the data-parallel-primitive path runs on the VALU, unlike
+// __shfl_xor, which goes through the LDS crossbar as ds_bpermute_b32 pairs -- 36 LDS instructions per wave for
+// three sums, a measurable part of a column's critical path).  Lanes outside ROW_MASK receive 0.0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  constexpr bool ALL = ROW_MASK == 0xf;   // every lane has a source: no `old` value to materialise
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, ALL);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, ALL);
+  return __hiloint2double(hi, lo);
+}
+
+// 64-lane sum in a fixed order; the total is valid in lanes 48..63 (the last row) only.
+__device__ __forceinline__ double wave_sum_last_row(double v) {
+  v += dpp_move<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]: pairs
+  v += dpp_move<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]: quads
+  v += dpp_move<0x141, 0xf>(v);   // row_half_mirror: 8 lanes
+  v += dpp_move<0x140, 0xf>(v);   // row_mirror: the 16-lane row
+  v += dpp_move<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3: 32 lanes
+  v += dpp_move<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3: row 3 holds all 64
   return v;
+}
+
+// Every lane ends with the same, order-fixed sum.
+__device__ __forceinline__ double wave_sum(double v) {
+  v = wave_sum_last_row(v);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 // Sum NV values over the whole workgroup; every thread receives the same result.
 // red: LDS scratch double[2][16][4]; buf alternates so one barrier per call suffices.
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double* red, int& buf) {
-#pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
   const int nw = blockDim.x >> 6;
-  if (nw == 1) return;
+  if (nw == 1) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = wave_sum_last_row(v[k]);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   double* r = red + buf * 64;
-  if (lane == 0) {
+  if (lane == 63) {               // the wave total lives in the last DPP row
 #pragma unroll
     for (int k = 0; k < NV; ++k) r[w * 4 + k] = v[k];
   }
@@ -181,8 +209,8 @@ __device__ __forceinline__ void reduce_many(double (&v)[M], int m, double* part,
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 #pragma unroll
   for (int k = 0; k < M; ++k)
-    if (k < m) v[k] = wave_sum(v[k]);
-  if (lane == 0) {
+    if (k < m) v[k] = wave_sum_last_row(v[k]);
+  if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < M; ++k)
       if (k < m) part[w * M + k] = v[k];
