@@ -79,7 +79,6 @@ struct PassArgs {
   double* rs_out;      // standardise pass: 1 / scale_j   (optional)
   double* r2_out;      // standardise pass: 1 / scale_j^2 (optional)
 };
-constexpr int KD = 40;
 
 
 // The n=4096 workhorse (R=8, 512 threads = 8 waves) must stay at <= 128 VGPRs: 4 waves/SIMD = two
@@ -654,10 +653,8 @@ int mbpls_hip_sweep_lazy_scaled(const mbpls_mat* m, const double* d_v, double al
   MB_ARG(!d_mean || d_r2, "d_mean needs d_r2");
   MB_ARG(kprev >= 0 && kprev < KD && (kprev == 0 || (d_P && d_cu && d_d)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   mbpls_ctx* ctx = m->ctx;
-  if (long_columns(ctx, m->n)) {
-    set_error("lazy deflation needs register-resident columns (n=%lld): use the explicit passes", (long long)m->n);
-    return MBPLS_ERR_UNSUPPORTED;
-  }
+  if (long_columns(ctx, m->n))
+    return long_sweep_lazy(m, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu, d_d, d_r2, d_mean);
   PassArgs a{};
   MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s, &a.part_d));
   a.src = m->data; a.dst = nullptr; a.ld = m->ld; a.n = m->n;
@@ -687,10 +684,9 @@ int mbpls_hip_loadings_sweep_lazy_scaled(const mbpls_mat* m, const double* d_ts,
   MB_ARG(kprev >= 0 && kprev < KD - 1 && (kprev == 0 || (d_P && d_ce)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   MB_ARG(!d_v || (d_d && (kprev == 0 || d_cu)), "sweep part needs d_cu / d_d");
   mbpls_ctx* ctx = m->ctx;
-  if (long_columns(ctx, m->n)) {
-    set_error("lazy deflation needs register-resident columns (n=%lld): use the explicit passes", (long long)m->n);
-    return MBPLS_ERR_UNSUPPORTED;
-  }
+  if (long_columns(ctx, m->n))
+    return long_loadings_sweep_lazy(m, d_ts, inv_tt, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu,
+                                    d_ce, d_d, d_r2, d_mean);
   PassArgs a{};
   MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s, &a.part_d));
   a.src = m->data; a.dst = m->data; a.ld = m->ld; a.n = m->n;
@@ -752,10 +748,9 @@ int mbpls_hip_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_
   MB_ARG(mode == MBPLS_SCALE_FIT || mode == MBPLS_SCALE_NONE, "bad mode %d", mode);
   MB_ARG(mode == MBPLS_SCALE_NONE || (d_mean && d_scale), "mean/scale buffers required");
   mbpls_ctx* ctx = src->ctx;
-  if (long_columns(ctx, src->n)) {
-    set_error("the statistics-only pass needs register-resident columns (n=%lld)", (long long)src->n);
-    return MBPLS_ERR_UNSUPPORTED;
-  }
+  if (long_columns(ctx, src->n))
+    return long_standardize_stats_sweep(src, mode, d_mean, d_scale, d_rscale, d_r2, d_ssq_x, d_amp, d_v, alpha, d_g, d_t,
+                                        d_ssq_g);
   PassArgs a{};
   MB_TRY(partial_buffers(ctx, src, &a.part_t, &a.part_s));
   a.src = src->data; a.dst = nullptr; a.ld = src->ld; a.n = src->n;

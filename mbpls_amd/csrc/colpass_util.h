@@ -154,6 +154,9 @@ int reduce_chunks(mbpls_ctx* ctx, const mbpls_mat* m, const double* part_t, cons
                   const double* part_d = nullptr, int nd = 0, double* d_d = nullptr, double* d_amp = nullptr);
 
 
+// lazy deflation: at most KD - 1 previous components are corrected for inside a pass
+constexpr int KD = 40;
+
 // colpass_long.hip: the same passes for columns too long to hold in registers (n > ctx->long_columns_from)
 bool long_columns(const mbpls_ctx* ctx, int64_t n);
 int long_sweep(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g);
@@ -162,5 +165,16 @@ int long_deflate_sweep(mbpls_mat* m, const double* d_ts, double inv_tt, int defl
 int long_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode, const double* d_rowmask, double n_eff,
                            double* d_mean, double* d_scale, double* d_ssq_x, const double* d_v, double alpha,
                            double* d_g, double* d_t, double* d_ssq_g);
+// ... and their never-writes-X forms (same arguments as the mbpls_hip_*_lazy_scaled / _stats_sweep entry points)
+int long_sweep_lazy(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g,
+                    const double* d_P, int64_t ldp, int kprev, const double* d_cu, double* d_d, const double* d_r2,
+                    const double* d_mean);
+int long_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double inv_tt, double* d_p, double* d_ssq_p,
+                             const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g,
+                             const double* d_P, int64_t ldp, int kprev, const double* d_cu, const double* d_ce,
+                             double* d_d, const double* d_r2, const double* d_mean);
+int long_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_mean, double* d_scale, double* d_rscale,
+                                 double* d_r2, double* d_ssq_x, double* d_amp, const double* d_v, double alpha,
+                                 double* d_g, double* d_t, double* d_ssq_g);
 
 }  // namespace mbpls

@@ -83,6 +83,7 @@ struct mbpls_ctx {
   // optional per-column variance output of the standardise passes (mbpls_hip_set_variance_output): sklearn's
   // StandardScaler.var_ (0 for a constant column, whose scale_ is 1)
   double* var_out = nullptr;
+  void* step_ws = nullptr;   // grid barrier + per-workgroup totals of the multi-workgroup step kernel (resident.hip)
   void* rccl = nullptr;      // RcclState* (rccl_comm.hip) when a communicator was initialised on this context
   // events of the ordered D2H copies are recycled (created by the queueing thread, returned by the copier thread)
   std::mutex user_event_mutex;

@@ -232,6 +232,7 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->small_m) (void)hipFree(ctx->small_m);
+  if (ctx->step_ws) (void)hipFree(ctx->step_ws);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

@@ -13,6 +13,8 @@
 //
 // All of it is n x (B + q + k) work in one 1024-thread workgroup, L2-resident, latency-bound: ~20 us against the
 // ~170 us a blocking D2H + numpy + H2D round trip costs per pass.
+#include <algorithm>
+
 #include "common.h"
 
 namespace mbpls {
@@ -21,13 +23,67 @@ constexpr int RS_BMAX = MBPLS_STEP_MAX_BLOCKS;
 constexpr int RS_QMAX = MBPLS_STEP_MAX_RESPONSES;
 constexpr int RS_KMAX = 40;   // == KD of colpass.hip (lazily deflated components + 1)
 
-__global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
+// Long score vectors (tall data, n up to millions): the step runs on G workgroups, each owning a fixed set of rows
+// (thread t of workgroup g: rows g*1024 + t + k*G*1024 in EVERY loop, so a thread only ever re-reads rows it wrote
+// itself); the reductions become two-level -- per-workgroup totals through HBM, a grid barrier, every workgroup adds the
+// G partials in the same order and so takes the same branches.  One workgroup (n up to a few ten thousand) needs none
+// of it.  The G <= 128 workgroups of 1024 threads are co-resident on the 256 CUs (nothing else runs on the stream).
+struct StepGrid {
+  int G;                  // workgroups
+  unsigned* bar;          // grid barrier counter, zeroed before the launch
+  double* gpart;          // [2][G][16] per-workgroup totals, two alternating sets
+};
+
+__device__ __forceinline__ void grid_barrier(const StepGrid& sg, unsigned& epoch) {
+  epoch += 1;               // every thread counts: the alternating partial sets are chosen from it
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned target = epoch * (unsigned)sg.G;
+    __threadfence();
+    __hip_atomic_fetch_add(sg.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(sg.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 28)) break;   // never on a healthy queue: do not hang the device if a workgroup is missing
+    }
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+// reduce_many over the whole grid: the first m values of v summed over every thread of every workgroup, fixed order
+template <int M>
+__device__ __forceinline__ void grid_sum(double (&v)[M], int m, double* part, double* tot, const StepGrid& sg,
+                                         unsigned& epoch) {
+  reduce_many<M>(v, m, part, tot);
+  if (sg.G == 1) return;
+  const int tid = threadIdx.x;
+  double* mine = sg.gpart + ((size_t)(epoch & 1u) * sg.G + blockIdx.x) * 16;
+  const double* all = sg.gpart + (size_t)(epoch & 1u) * sg.G * 16;
+  if (tid < m) __hip_atomic_store(mine + tid, tot[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  grid_barrier(sg, epoch);
+  if (tid < m) {
+    double s = 0.0;
+    for (int g = 0; g < sg.G; ++g) s += __hip_atomic_load(all + (size_t)g * 16 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot[tid] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < M; ++k)
+    if (k < m) v[k] = tot[k];
+  __syncthreads();           // tot[] is reused by the next reduction
+}
+
+__global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, StepGrid sg) {
   __shared__ double part[16 * 16];       // wave partials of reduce_many
   __shared__ double tot[16];
   __shared__ double s_mx[WG1024 / 64], s_mn[WG1024 / 64];
   double* par = s.par;
   if (par[2] != 0.0) return;             // an earlier component needed more iterations than were queued
   const int tid = threadIdx.x;
+  const bool lead = tid == 0 && blockIdx.x == 0;       // the one thread that records scalars
+  const int64_t gtid = (int64_t)blockIdx.x * WG1024 + tid, gstride = (int64_t)sg.G * WG1024;
+  unsigned epoch = 0;
   const int64_t n = s.n;
   const int B = s.nblocks, q = s.q, kc = s.kc, nd = s.nd;
   const bool istd = s.centre != 0;
@@ -47,7 +103,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
     double worst = 0.0;
     for (int b = 0; b < B; ++b) worst = fmax(worst, dd[b]);
     if (!(worst <= s.amp2_max)) {
-      if (tid == 0) {
+      if (lead) {
         par[2] = 1.0;
         par[3] = 0.0;
         par[5] = 1.0;      // reason: offset data, queue again with the centring passes
@@ -56,7 +112,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
       return;
     }
   }
-  if (s.run == 1 && tid < B) {
+  if (s.run == 1 && tid < B && blockIdx.x == 0) {
     if (kc == 0) s.ssq_x[tid] = ssq_x[tid];
     else s.scal[(int64_t)(kc - 1) * 4 * B + 2 * B + tid] = ssq_p[tid];   // ||p_b||^2 of the component just deflated
   }
@@ -65,7 +121,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
   double sum_t[RS_BMAX], tu[RS_BMAX], mu[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int b = 0; b < RS_BMAX; ++b) sum_t[b] = tu[b] = 0.0;
-  for (int64_t i = tid; i < n; i += WG1024) {
+  for (int64_t i = gtid; i < n; i += gstride) {
     const double ui = s.u_cur[i];
     mu[0] = fma(ui, ui, mu[0]);
     mu[1] += ui;
@@ -79,9 +135,9 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
         tu[b] = fma(t, ui, tu[b]);
       }
   }
-  if (istd) reduce_many<RS_BMAX>(sum_t, B, part, tot);
-  reduce_many<RS_BMAX>(tu, B, part, tot);
-  reduce_many<4>(mu, 2, part, tot);
+  if (istd) grid_sum<RS_BMAX>(sum_t, B, part, tot, sg, epoch);
+  grid_sum<RS_BMAX>(tu, B, part, tot, sg, epoch);
+  grid_sum<4>(mu, 2, part, tot, sg, epoch);
   const double uu = mu[0], su = mu[1];
 
   // ---- t_b = t~_b / ||w~_b|| (:860, :875-877);  sw = T^T u / u^T u, unit length (:879-880)
@@ -105,7 +161,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
   // ---- ts = T sw, unit length (:882-883); scratch in vpass (the pass that read it has finished)
   //      UNIPALS: ts = sum_b X_b (X_b^T y), unit length; the block scores are scaled once c is known
   double m2[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int64_t i = tid; i < n; i += WG1024) {
+  for (int64_t i = gtid; i < n; i += gstride) {
     double acc = 0.0;
 #pragma unroll
     for (int b = 0; b < RS_BMAX; ++b)
@@ -121,7 +177,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
     s.vpass[i] = acc;
     m2[0] = fma(acc, acc, m2[0]);
   }
-  reduce_many<4>(m2, 1, part, tot);
+  grid_sum<4>(m2, 1, part, tot, sg, epoch);
   const double tsn = sqrt(m2[0]);
 
   // ---- diff = ||ts_old - ts|| (:887), Y^T ts, ts^T ts
@@ -130,7 +186,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
   double yv[RS_QMAX];
 #pragma unroll
   for (int j = 0; j < RS_QMAX; ++j) yv[j] = 0.0;
-  for (int64_t i = tid; i < n; i += WG1024) {
+  for (int64_t i = gtid; i < n; i += gstride) {
     const double t = s.vpass[i] / tsn;
     const double d = s.ts_old[i] - t;
     s.ts_old[i] = t;
@@ -144,8 +200,8 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
     for (int j = 0; j < RS_QMAX; ++j)
       if (j < q) yv[j] = fma(s.Y[(int64_t)j * n + i], t, yv[j]);
   }
-  reduce_many<4>(d4, 4, part, tot);
-  reduce_many<RS_QMAX>(yv, q, part, tot);
+  grid_sum<4>(d4, 4, part, tot, sg, epoch);
+  grid_sum<RS_QMAX>(yv, q, part, tot, sg, epoch);
   double diff;
   if (s.norm_kind == 0) diff = sqrt(d4[0]);
   else if (s.norm_kind == 1) diff = d4[1];
@@ -164,12 +220,25 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
       dmax = fmax(dmax, s_mx[w]);
       dmin = fmin(dmin, s_mn[w]);
     }
+    if (sg.G > 1) {
+      double* mine = sg.gpart + ((size_t)(epoch & 1u) * sg.G + blockIdx.x) * 16;
+      const double* all = sg.gpart + (size_t)(epoch & 1u) * sg.G * 16;
+      if (tid == 0) {
+        __hip_atomic_store(mine, dmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, dmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      grid_barrier(sg, epoch);
+      for (int g = 0; g < sg.G; ++g) {
+        dmax = fmax(dmax, __hip_atomic_load(all + (size_t)g * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        dmin = fmin(dmin, __hip_atomic_load(all + (size_t)g * 16 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+    }
     diff = (s.norm_kind == 2) ? dmax : dmin;
   }
   const bool converged = uni || (s.run > 1 && diff <= s.tol);
   if (s.run > 1 && !converged) {
     // the speculation (two iterations per component) does not hold: stop here, the host takes over at component kc
-    if (tid == 0) {
+    if (lead) {
       par[2] = 1.0;
       par[3] = (double)kc;
       par[4] = diff;
@@ -186,7 +255,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
       vv = fma(yv[j], yv[j], vv);
     }
   double un[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int64_t i = tid; i < n; i += WG1024) {
+  for (int64_t i = gtid; i < n; i += gstride) {
     double w = 0.0;
 #pragma unroll
     for (int j = 0; j < RS_QMAX; ++j)
@@ -196,7 +265,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
     un[0] = fma(w, w, un[0]);
     un[1] = fma(w, s.u_cur[i], un[1]);     // UNIPALS: u^T y (u_cur is y, the start vector)
   }
-  reduce_many<4>(un, 2, part, tot);
+  grid_sum<4>(un, 2, part, tot, sg, epoch);
   const double unrm = sqrt(un[0]);
 
   // out[j] = <Tsc_j, vec> for j < kc, 16 at a time (register budget: 1024 threads leave 128 VGPRs each)
@@ -205,33 +274,33 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
       double c[16];
 #pragma unroll
       for (int jj = 0; jj < 16; ++jj) c[jj] = 0.0;
-      for (int64_t i = tid; i < n; i += WG1024) {
+      for (int64_t i = gtid; i < n; i += gstride) {
         const double vi = vec[i];
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj)
           if (j0 + jj < kc) c[jj] = fma(s.Tsc[(int64_t)(j0 + jj) * n + i], vi, c[jj]);
       }
-      reduce_many<16>(c, min(16, kc - j0), part, tot);
+      grid_sum<16>(c, min(16, kc - j0), part, tot, sg, epoch);
 #pragma unroll
       for (int jj = 0; jj < 16; ++jj)
-        if (j0 + jj < kc && tid == 0) out[j0 + jj] = c[jj];
+        if (j0 + jj < kc && lead) out[j0 + jj] = c[jj];
     }
   };
 
   if (!converged) {
     // ---- next pass: sweep with the new u (centred copy for the raw-space passes), alpha = 1 / u^T u, cu_j = <ts_j, u>
     double a4[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int64_t i = tid; i < n; i += WG1024) {
+    for (int64_t i = gtid; i < n; i += gstride) {
       const double ui = s.tspass[i] / unrm;
       s.u_cur[i] = ui;
       a4[0] += ui;
       a4[1] = fma(ui, ui, a4[1]);
     }
-    reduce_many<4>(a4, 2, part, tot);
+    grid_sum<4>(a4, 2, part, tot, sg, epoch);
     const double mean_u = istd ? a4[0] / (double)n : 0.0;
-    for (int64_t i = tid; i < n; i += WG1024) s.vpass[i] = s.u_cur[i] - mean_u;   // each thread re-reads its own rows
+    for (int64_t i = gtid; i < n; i += gstride) s.vpass[i] = s.u_cur[i] - mean_u;   // each thread re-reads its own rows
     dots(s.vpass, s.cu);
-    if (tid == 0) {
+    if (lead) {
       par[0] = 1.0 / a4[1];
       par[4] = diff;
     }
@@ -242,7 +311,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
   //      t_b = X_b w_raw_b / ||w_raw_b|| = c t~_b / sqrt(c^2 ||g_b||^2)                         (:503-517)
   const double c_uni = uni ? (un[1] / unrm) / uu : 1.0;
   if (uni) {
-    for (int64_t i = tid; i < n; i += WG1024)
+    for (int64_t i = gtid; i < n; i += gstride)
 #pragma unroll
       for (int b = 0; b < RS_BMAX; ++b)
         if (b < B) tb[(int64_t)b * n + i] = c_uni * (tb[(int64_t)b * n + i] - mean_t[b]) / sqrt(c_uni * c_uni * ssq_g[b]);
@@ -251,7 +320,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
   // ---- converged: record component kc, then prepare loadings (+ lazy deflation) + first sweep of component kc+1
   const double* u0 = s.Y;                      // start vector of every component: Y[:, 0] (:838)
   double a4[4] = {0.0, 0.0, 0.0, 0.0};         // sum u0, u0^T u0
-  for (int64_t i = tid; i < n; i += WG1024) {
+  for (int64_t i = gtid; i < n; i += gstride) {
     const double ui = s.tspass[i] / unrm;
     s.U[(int64_t)kc * n + i] = ui;
     s.Ts[(int64_t)kc * n + i] = s.ts_old[i];
@@ -260,9 +329,9 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
     a4[0] += y0;
     a4[1] = fma(y0, y0, a4[1]);
   }
-  reduce_many<4>(a4, 2, part, tot);
+  grid_sum<4>(a4, 2, part, tot, sg, epoch);
   const double mean_ts = istd ? d4[3] / (double)n : 0.0, mean_u0 = istd ? a4[0] / (double)n : 0.0;
-  for (int64_t i = tid; i < n; i += WG1024) {
+  for (int64_t i = gtid; i < n; i += gstride) {
     const double ti = s.ts_old[i] - mean_ts, vi = u0[i] - mean_u0;
     s.tspass[i] = ti;
     s.Tsc[(int64_t)kc * n + i] = ti;
@@ -272,10 +341,10 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
   dots(s.tspass, s.ce);
 #pragma unroll
   for (int j = 0; j < RS_QMAX; ++j)
-    if (j < q && tid == 0) s.V[(int64_t)kc * q + j] = yv[j];
+    if (j < q && lead) s.V[(int64_t)kc * q + j] = yv[j];
 #pragma unroll
   for (int b = 0; b < RS_BMAX; ++b)
-    if (b < B && tid == 0) {
+    if (b < B && lead) {
       if (uni) {
         double tot_w = 0.0;
         for (int bb = 0; bb < B; ++bb) tot_w += c_uni * c_uni * ssq_g[bb];
@@ -286,7 +355,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s) {
         s.scal[(int64_t)kc * 4 * B + B + b] = sw[b] * sw[b];      // a_b (:949)
       }
     }
-  if (tid == 0) {
+  if (lead) {
     s.iters[kc] = (double)s.run;
     if (uni) {
       s.scal[(int64_t)kc * 4 * B + 3 * B] = c_uni;   // w_raw = c X^T y: the caller scales the column the pass left
@@ -349,7 +418,18 @@ int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
   MB_ARG(s->xchg && s->Y && s->Ts && s->Tsc && s->U && s->V && s->Tb && s->scal && s->ssq_x && s->iters && s->u_cur &&
              s->ts_old && s->vpass && s->tspass && s->cu && s->ce && s->par,
          "NULL pointer in mbpls_nipals_step");
-  hipLaunchKernelGGL(k_nipals_step, dim3(1), dim3(WG1024), 0, ctx->stream, *s);
+  // one workgroup up to 32768 rows (latency-bound, ~50 us); beyond that the n-vector traffic dominates (4 ms at
+  // n = 10^6 on one CU): spread the rows over up to 128 workgroups with grid-wide reductions
+  StepGrid sg{};
+  sg.G = (int)std::max<int64_t>(1, std::min<int64_t>(128, s->n / 16384));
+  if (sg.G > 1) {
+    const size_t need = 256 + sizeof(double) * 2 * 128 * 16;
+    if (!ctx->step_ws) MB_HIP(hipMalloc(&ctx->step_ws, need));
+    sg.bar = (unsigned*)ctx->step_ws;
+    sg.gpart = (double*)((char*)ctx->step_ws + 256);
+    MB_HIP(hipMemsetAsync(sg.bar, 0, 256, ctx->stream));
+  }
+  hipLaunchKernelGGL(k_nipals_step, dim3((unsigned)sg.G), dim3(WG1024), 0, ctx->stream, *s, sg);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }

@@ -236,8 +236,8 @@ class HipEngine:
         mode = os.environ.get("MBPLS_DEFLATION", prefer or self.deflation)
         if self.sparse:
             mode = "explicit"      # the implicit correction would need every row's own missing-value mask
-        if self.n > getattr(self.ctx, "long_columns_from", 8192):
-            mode = "explicit"      # streamed-column passes (csrc/colpass_long.hip) rewrite X
+        if not self._raw_space_ok():
+            mode = "explicit"      # register-resident columns above 8192 rows (spilling configurations): no lazy flavour
         self._lazy_pslot = pslot if (mode == "lazy" and K < self.KD - 1) else None
         self._lazy_ts = []
         self._lazy_K = K
@@ -442,11 +442,16 @@ class HipEngine:
     # ||ts_old - ts|| <= 1e-14 reachable for offset data.  The statistics pass itself always shifts (by the first sample).
     CENTRE_FROM_OFFSET = 8.0
 
+    def _raw_space_ok(self):
+        """The never-writes-X passes exist for register-resident columns up to 8192 rows (csrc/colpass.hip) and for the
+        two-phase long-column passes (csrc/colpass_long.hip, n > long_columns_from)."""
+        return self.n <= 8192 or self.n > getattr(self.ctx, "long_columns_from", 8192)
+
     def _implicit_ok(self, v, mean):
         import os
         return (self._lazy_pslot is not None and v is not None and mean is None and not self.sparse
                 and getattr(self, "rowmask", None) is None and hasattr(self.X, "standardize_stats_sweep")
-                and self.n <= min(8192, getattr(self.ctx, "long_columns_from", 8192))
+                and self._raw_space_ok()
                 and os.environ.get("MBPLS_IMPLICIT_STD", "1") != "0")
 
     def _prepare_implicit(self, src, standardize, mode, v, alpha, g_slot, defer=False):
@@ -1021,13 +1026,14 @@ class _ResidentQueue:
             self.result = dict(k_done=0, reason="offset", offset=float(np.sqrt(par[6])))
             return False
         k_done = K if par[2] == 0.0 else int(par[3])
-        h = eng._xchg.get()
         scal = bufs["scal"].get().reshape(K, 4, B)
         if k_done == K:
-            scal[K - 1, 2] = h[n * B + B:n * B + 2 * B]     # ||p_b||^2 of the last (loadings-only) pass
-        self.result = dict(k_done=k_done, Ts=bufs["Ts"].get(), U=bufs["U"].get(), V=bufs["V"].get(),
-                           Tb=bufs["Tb"].get().reshape(K, B, n), scal=scal, ssq_x=bufs["ssqx"].get(),
-                           iters=bufs["iters"].get(), last_diff=float(par[4]))
+            # ||p_b||^2 of the last (loadings-only) pass: B values of the exchange buffer, not all n x B of it
+            scal[K - 1, 2] = _capi.DeviceArray(self.ctx, (B,), ptr=eng._xptr(n * B + B)).get()
+        with eng._timed("d2h_scores"):
+            self.result = dict(k_done=k_done, Ts=bufs["Ts"].get(), U=bufs["U"].get(), V=bufs["V"].get(),
+                               Tb=bufs["Tb"].get().reshape(K, B, n), scal=scal, ssq_x=bufs["ssqx"].get(),
+                               iters=bufs["iters"].get(), last_diff=float(par[4]))
         if k_done < K:
             # hand the lazy-deflation state to the host-driven loop
             Tc = bufs["Tsc"].get()

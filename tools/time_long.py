@@ -29,3 +29,4 @@ for thr in ([65536, 0] if n <= 65536 else [8192]):
         print(f"n={n} p={p} long_columns_from={thr} {method}: fit {1e3 * (t1 - t0):.1f} ms  " +
               "  ".join(f"{k}: {v['avg_ms']:.2f} ms {v['GBps']:.0f} GB/s x{v['launches']}" for k, v in prof.items()),
               flush=True)
+        print("    host phases (ms):", {k: round(1e3 * v, 1) for k, v in m.fit_timings_.items()}, flush=True)
