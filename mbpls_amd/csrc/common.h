@@ -53,6 +53,8 @@ struct ChunkTable {
 
 }  // namespace mbpls
 
+constexpr int PIN_SLOTS = 4;
+
 struct mbpls_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -83,6 +85,13 @@ struct mbpls_ctx {
   // optional per-column variance output of the standardise passes (mbpls_hip_set_variance_output): sklearn's
   // StandardScaler.var_ (0 for a constant column, whose scale_ is 1)
   double* var_out = nullptr;
+  // pinned bounce buffers of the large host-to-device copies (a ring of slots, one event each): a pageable
+  // hipMemcpyAsync of a few MB sporadically takes 8-25 ms inside the runtime right after a fit
+  void* pin = nullptr;
+  size_t pin_half = 0;     // bytes per slot
+  hipEvent_t pin_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned pin_next = 0;
+  std::mutex pin_mutex;
   void* step_ws = nullptr;   // grid barrier + per-workgroup totals of the multi-workgroup step kernel (resident.hip)
   void* rccl = nullptr;      // RcclState* (rccl_comm.hip) when a communicator was initialised on this context
   // events of the ordered D2H copies are recycled (created by the queueing thread, returned by the copier thread)

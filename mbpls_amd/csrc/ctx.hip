@@ -233,6 +233,9 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->small_m) (void)hipFree(ctx->small_m);
   if (ctx->step_ws) (void)hipFree(ctx->step_ws);
+  if (ctx->pin) (void)hipHostFree(ctx->pin);
+  for (hipEvent_t e : ctx->pin_ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -332,7 +335,32 @@ int mbpls_hip_memcpy_h2d(mbpls_ctx* ctx, void* d_dst, const void* h_src, size_t 
   MB_ARG(ctx && (bytes == 0 || (d_dst && h_src)), "NULL argument");
   if (bytes == 0) return MBPLS_OK;
   // pageable source: hipMemcpyAsync stages it before returning, so the host buffer is reusable
-  MB_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (bytes < (256u << 10)) {
+    MB_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MBPLS_OK;
+  }
+  // larger copies bounce through our own ring of pinned slots (8 MB each): the host memcpy of a chunk overlaps the DMA of
+  // the ones before it
+  std::lock_guard<std::mutex> lock(ctx->pin_mutex);
+  if (!ctx->pin) {
+    ctx->pin_half = (size_t)8 << 20;
+    MB_HIP(hipHostMalloc(&ctx->pin, PIN_SLOTS * ctx->pin_half, hipHostMallocDefault));
+    for (int i = 0; i < PIN_SLOTS; ++i) {
+      MB_HIP(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+      MB_HIP(hipEventRecord(ctx->pin_ev[i], ctx->stream));
+    }
+  }
+  for (size_t off = 0; off < bytes; off += ctx->pin_half) {
+    const size_t len = std::min(ctx->pin_half, bytes - off);
+    const unsigned h = ctx->pin_next++ % PIN_SLOTS;
+    char* buf = (char*)ctx->pin + (size_t)h * ctx->pin_half;
+    // the DMA that last read this slot has finished (four copies ago: normally long done -- waiting on an event
+    // recorded in front of queued kernels was seen to take until those kernels had run)
+    MB_HIP(hipEventSynchronize(ctx->pin_ev[h]));
+    memcpy(buf, (const char*)h_src + off, len);
+    MB_HIP(hipMemcpyAsync((char*)d_dst + off, buf, len, hipMemcpyHostToDevice, ctx->stream));
+    MB_HIP(hipEventRecord(ctx->pin_ev[h], ctx->stream));
+  }
   return MBPLS_OK;
 }
 

@@ -420,13 +420,21 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
         varx = varxb.sum()
         k_start = out["k_done"]
+        whole = k_start == K
+        if whole:
+            # every component came from the device: the downloaded arrays ARE the attributes (no n x K host copies --
+            # at n = 10^6 those cost more than a pass over X)
+            Ts, U = out["Ts"], out["U"]
+            T = [out["Tb"][:, b, :].T for b in range(B)]
         for k in range(k_start):
             ts, v = out["Ts"][:, k:k + 1], out["V"][:, k:k + 1]
-            Ts[:, k:k + 1] = ts; U[:, k] = out["U"][:, k]; V[:, k:k + 1] = v
+            V[:, k:k + 1] = v
+            if not whole:
+                Ts[:, k:k + 1] = ts; U[:, k] = out["U"][:, k]
+                for b in range(B):
+                    T[b][:, k] = out["Tb"][k, b]
             A[:, k] = out["scal"][k, 1]
             nu_all[:, k] = np.sqrt(out["scal"][k, 0])
-            for b in range(B):
-                T[b][:, k] = out["Tb"][k, b]
             iters.append(int(out["iters"][k]))
             if calc_all:                                    # (:932-964), analytic (ts^T ts)(p^T p)
                 ssq_p = out["scal"][k, 2]
@@ -583,7 +591,10 @@ def fit_unipals(eng, Y, K, standardize):
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
-    wide = p_total > n
+    # One response: w = tlsv(X^T y) and ts = X w / ||X w|| of the n >= p branch (:396-417) are the X^T y / ||.|| and
+    # X (X^T y) / ||.|| of the p > n branch (:489-503) -- the same component up to the sign convention of the SVD --
+    # so tall data takes the one-pass-per-component path as well (device-resident queue, X never written).
+    wide = p_total > n or q == 1
     import os
     if (wide and q > 1 and hasattr(eng, "x_w_slot") and not getattr(eng, "sparse", False)
             and os.environ.get("MBPLS_UNIPALS_NODEFLATE", "1") != "0"):
@@ -619,14 +630,14 @@ def fit_unipals(eng, Y, K, standardize):
         if not np.all(np.isfinite(varxb)):
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
         varx = varxb.sum()
+        Ts, U = out["Ts"], out["U"]                         # the downloaded arrays are the attributes
+        T = [out["Tb"][:, b, :].T for b in range(B)]
         for k in range(K):
             ts, v = out["Ts"][:, k:k + 1], out["V"][:, k:k + 1]
-            Ts[:, k:k + 1] = ts; U[:, k] = out["U"][:, k]; V[:, k:k + 1] = v
+            V[:, k:k + 1] = v
             ssq = out["scal"][k, 0]
             A[:, k] = out["scal"][k, 1]
             blk_nrm[:, k] = np.sqrt(ssq); tot_nrm[k] = np.sqrt(ssq.sum())
-            for b in range(B):
-                T[b][:, k] = out["Tb"][k, b]
             ssq_p = out["scal"][k, 2]
             tt = ts.T.dot(ts).item()
             evx.append(tt * ssq_p.sum() / varx)             # (:521-533)
