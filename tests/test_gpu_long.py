@@ -1,4 +1,5 @@
-"""GPU parity for LONG columns (n beyond the register-resident column passes): csrc/colpass_long.hip.
+"""GPU parity for LONG columns (n beyond the register-resident column passes): csrc/colpass_long.hip -- the
+two-phase passes in their storing and their never-writes-X forms, the multi-workgroup step kernel of csrc/resident.hip.
 
 Tall data -- many samples, few features -- is what the reference's n >= p branches exist for
 (mbpls.py:388-479 UNIPALS, :580-692 KERNEL); NIPALS / SIMPLS take the same passes.  Checked (a) with the
@@ -111,7 +112,7 @@ def test_register_resident_configs_above_8192(gpu_required):
     from mbpls_amd import MBPLS
     ctx = mbpls_amd.get_context()
     X, Y = orc.make_latent(10_000, 2000, 1, seed=12)
-    a = MBPLS(n_components=3).fit(X, Y)                      # streamed columns, explicit deflation
+    a = MBPLS(n_components=3).fit(X, Y)                      # two-phase long-column passes (never write X)
     ctx.set_tunable("long_columns_from", 65536)
     try:
         b = MBPLS(n_components=3).fit(X, Y)                  # register-resident, lazy deflation
@@ -121,3 +122,49 @@ def test_register_resident_configs_above_8192(gpu_required):
     for mdl in (a, b):
         w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="n=10000")
         assert w < 1e-8, w
+
+
+@pytest.mark.parametrize("method,norm,offset", [
+    ("NIPALS", 2, 0.0),
+    ("NIPALS", np.inf, 0.0),       # the max-norm stop rule reduces over the step kernel's workgroups as well
+    ("NIPALS", 2, 300.0),          # offset data: matrix-core dots and row pass on x - mean (centring flavour)
+    ("UNIPALS", 2, 0.0),           # tall one-response UNIPALS: the one-pass-per-component queue
+    ("UNIPALS", 2, 300.0),
+])
+def test_tall_one_response_fit_is_one_queue_and_never_writes_x(gpu_required, monkeypatch, method, norm, offset):
+    """n = 70 000 (> 2 x 32768: the step kernel runs on several workgroups with grid-wide reductions), two blocks,
+    one response: statistics-only first pass, lazy deflation, everything queued on the device -- against the oracle,
+    with the caller's resident matrix bit-identical afterwards and the host-driven loop never entered."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix
+    from mbpls_amd.engine import HipEngine
+    n, p, K = 70_000, 260, 3
+    X, Y = orc.make_latent(n, p, 1, seed=5)
+    X = X + offset * (1.0 + np.arange(p) % 3)
+    blocks = [X[:, :100], X[:, 100:]]
+    ref = orc.fit(blocks, Y, n_components=K, method=method, nipals_convergence_norm=norm)
+    ctx = mbpls_amd.get_context()
+    Xd = DeviceMatrix(ctx, n, p, [0, 100, p])
+    Xd.upload(X, 0)
+    host_passes, flavours = [], []
+    real_sweep, real_close = HipEngine.sweep, HipEngine.close
+
+    def spy_sweep(self, *a, **k):
+        host_passes.append("sweep")
+        return real_sweep(self, *a, **k)
+
+    def spy_close(self):
+        flavours.append((self._istd, self._cen, self._lazy_pslot))
+        return real_close(self)
+
+    monkeypatch.setattr(HipEngine, "sweep", spy_sweep)
+    monkeypatch.setattr(HipEngine, "close", spy_close)
+    mdl = MBPLS(n_components=K, method=method, nipals_convergence_norm=norm).fit(Xd, Y)
+    assert host_passes == [], host_passes                       # no host-driven pass: the queue held
+    assert flavours == [(True, offset > 0.0, "P")], flavours    # implicit standardisation (+ centring), lazy deflation
+    assert np.array_equal(Xd.download(), X)                     # never written
+    if method == "NIPALS":
+        assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K
+    w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} norm={norm} offset={offset}")
+    assert w < (1e-8 if offset == 0.0 else 1e-6), w
+    Xd.close()
