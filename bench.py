@@ -58,11 +58,10 @@ def fill_blocks(ctx, X, dT, r, offs, rank, world, pb_global):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # (one fit among the first six of a process carries a one-time ~25 ms stall between two fits -- the HIP runtime
-    # setting something up the first time both streams are busy; it is visible in fit_wall_s_each when the warm-up is
-    # shorter than that)
+    # (the first fit of a process builds pools, pinned buffers and scratch; every later fit repeats within ~0.5 % --
+    # fit_wall_s_each lists them all)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--p", type=int, default=1_000_000, help="feature columns PER GPU")
     ap.add_argument("--K", type=int, default=10)
