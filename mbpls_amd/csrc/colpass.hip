@@ -20,65 +20,6 @@
 
 namespace mbpls {
 
-struct PassArgs {
-  const double* src;
-  double* dst;
-  int64_t ld;
-  int64_t n;
-  const int64_t* c0;
-  const int64_t* c1;
-  // sweep
-  const double* v;
-  double alpha;
-  double* g;
-  // deflate
-  const double* ts;
-  double inv_tt;
-  int deflate;
-  double* pvec;
-  // standardise
-  int mode;
-  double* mean;
-  double* scale;
-  // partial outputs
-  double* part_t;  // [nchunks][n]
-  double* part_s;  // [nchunks][4]: ssq_g, ssq_p, ssq_x, -
-  const double* rowmask;   // standardise pass only: samples excluded from the fit (cross-validation folds)
-  double n_eff;            // number of included samples (used instead of n for mean / variance)
-  // lazy (implicit) deflation: X in HBM stays X_0; X_k = X_0 - sum_{i<kprev} ts_i P[:,i]^T is applied algebraically
-  int lazy;            // 0: explicit in-place deflation, 1: implicit
-  int kprev;           // components already deflated (<= KD-1)
-  const double* Pm;    // p x K loadings of the previous components (column-major, leading dim ldp)
-  int64_t ldp;
-  const double* cu;    // [kprev]  <ts_i, v>   corrections of the sweep dot
-  const double* ce;    // [kprev]  <ts_i, ts>  corrections of the loadings dot
-  double* part_d;      // [nchunks][KD]  sum_j c_j P[j,i] (i < kprev) and sum_j c_j p_j (i = kprev)
-  // implicit standardisation (lazy passes only, template flag ISTD): X in HBM is the RAW matrix and
-  // Z = (X - mean)/scale is applied algebraically, everything computed in RAW-column space.  Every vector v / ts
-  // of a fit on standardised data sums to zero (Y is centred, scores of centred columns are centred; the caller
-  // re-centres to rounding), so the column means drop out of the dot products, <x_j - mean_j 1, v> = <x_j, v>.
-  // With raw-space weights g~_j = scale_j g_j and loadings p~_j = scale_j p_j (what the slots then hold):
-  //   scale_j z_j^(k) = x_j - mean_j 1 - sum_i ts_i P~[j,i],   g~_j = alpha (<x_j, v> - sum_i P~[j,i] cu_i),
-  //   p~_j = inv_tt (<x_j, ts> - sum_i P~[j,i] ce_i),
-  //   sum_j g_j z_j = sum_j c_j x_j - const 1 - sum_i ts_i (sum_j c_j P~[j,i]),   c_j = g~_j / scale_j^2
-  // so the kernel is the plain lazy pass plus ONE per-column scalar ir2_j = 1/scale_j^2 in the accumulations
-  // (||g_b||^2 = sum g~_j c_j, ||p_b||^2 = sum p~_j^2 ir2_j); the constant is the mean of the accumulated vector
-  // (scores are centred), removed by the caller, who also rescales finished g~ / p~ columns by 1/scale.
-  const double* ir2;
-  // ... and for OFFSET data (mu != NULL, template flag CEN) the dot products / accumulations run on x_j - mean_j 1
-  // (one subtraction per element in registers): the rounding of a raw-space dot product is amplified by
-  // |mean_j| / scale_j, enough to keep the NIPALS stop rule ||ts_old - ts|| <= 1e-14 (mbpls.py:841) out of reach
-  // once that ratio is in the hundreds.  The passes are partly issue-bound (8 % / 13 % slower with the subtraction),
-  // so it is a separate instantiation, chosen from the offset measure of the statistics pass -- which itself, not
-  // knowing the mean yet, always shifts by the column's first sample.
-  const double* mu;
-  // device-resident parameters (ctx->dpar): when given, alpha = dpar[0], inv_tt = dpar[1] and the whole pass is a
-  // no-op when dpar[2] != 0 (a speculatively queued fit that turned out to need more NIPALS iterations)
-  const double* dpar;
-  double* var_out;     // standardise passes, MBPLS_SCALE_FIT: per-column variance (optional; ctx->var_out)
-  double* rs_out;      // standardise pass: 1 / scale_j   (optional)
-  double* r2_out;      // standardise pass: 1 / scale_j^2 (optional)
-};
 
 
 // The n=4096 workhorse (R=8, 512 threads = 8 waves) must stay at <= 128 VGPRs: 4 waves/SIMD = two
@@ -519,6 +460,8 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   PassArgs an = a;
   an.dpar = ctx->dpar;
   an.var_out = ctx->var_out;
+  // few samples (n <= 256): four columns per wave, one per 16-lane DPP row (colpass_sub.hip)
+  if (a.n <= SUB_MAX_N && ctx->sub_columns) return launch_pass_sub(ctx, ct, an, STD, DEFL, SWEEP);
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
   const int D = ctx->prefetch >= 1 && ctx->prefetch <= 3 ? ctx->prefetch : 2;
   // FULL: every thread's every row pair is a real sample and columns are unpadded (n=4096, 8192, ...)

@@ -1,0 +1,419 @@
+// Column passes for FEW samples (n <= 256) -- the everyday shape of multiblock PLS: tens to hundreds of samples,
+// up to millions of features.  colpass.hip gives a column to a workgroup; with a 0.5-2 KB column its per-column
+// reduction (six DPP steps, a barrier, the scalar algebra) is all latency and the pass runs at 0.8-2.7 TB/s.
+//
+// Here a WAVE works on four columns at a time, one per 16-lane DPP row: lane s of a row owns the row pairs
+// s + 16k (k < KR, n <= 32 KR), so a load instruction still covers 256 contiguous bytes per column and a column's
+// reduction is four row-local DPP steps (quad_perm x2, row_half_mirror, row_mirror -- every lane of the row ends with
+// the total, no LDS, no barrier, no cross-row traffic).  The four waves of a workgroup are independent until the end
+// of the chunk, where the 16 row groups add their score accumulators, sums of squares and lazy-deflation sums in a
+// fixed order through LDS.  Same PassArgs, same outputs, same flavours (storing / statistics-only standardise,
+// explicit / lazy deflation, implicit standardisation, centring) as k_colpass, which documents the algebra.
+#include <algorithm>
+
+#include "colpass_util.h"
+
+namespace mbpls {
+
+// sum over the 16 lanes of a DPP row; every lane of the row receives it
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_move<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141, 0xf>(v);   // row_half_mirror
+  v += dpp_move<0x140, 0xf>(v);   // row_mirror
+  return v;
+}
+
+constexpr int SUB_LM = 3;   // lazy corrections per lane: components s, s + 16, s + 32 (KD - 1 = 39 < 48)
+
+template <int KR, int D, bool STD, bool DEFL, bool SWEEP, bool ISTD, bool CEN>
+__global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
+  constexpr int R = 2 * KR;
+  __shared__ double s_t[SUB_MAX_N];
+  __shared__ double s_s[16][4];
+  __shared__ double s_d[16][SUB_LM * 16 + 1];
+  if (a.dpar) {
+    if (a.dpar[2] != 0.0) return;
+    a.alpha = uniform_f64(a.dpar[0]);
+    a.inv_tt = uniform_f64(a.dpar[1]);
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int sub = lane & 15, grp = (tid >> 6) * 4 + (lane >> 4);   // lane inside its row; row group 0..15 of the workgroup
+  const int64_t n = a.n, ld = a.ld;
+  const int chunk = blockIdx.x;
+  const int64_t j0 = uniform64(a.c0[chunk]), j1 = uniform64(a.c1[chunk]);
+
+  // rows of this lane: pair k covers 2 (sub + 16 k), + 1
+  unsigned keep = 0u;          // bit 2k + h: a real, included sample
+  int64_t off[KR];             // element offset of the pair inside a column (clamped inside the allocation)
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const int64_t r = 2 * ((int64_t)sub + 16 * k);
+    off[k] = (r < ld) ? r : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bool m = r + h < n;
+      if (STD && m && a.rowmask) m = a.rowmask[r + h] != 0.0;
+      keep |= (m ? 1u : 0u) << (2 * k + h);
+    }
+  }
+  auto real = [&](int i) { return ((keep >> i) & 1u) != 0u; };
+  auto vec = [&](double(&o)[R], const double* p) {
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t r = 2 * ((int64_t)sub + 16 * k) + h;
+        o[2 * k + h] = (r < n) ? p[r] : 0.0;
+      }
+  };
+  double v[SWEEP ? R : 1], ts[DEFL ? R : 1], acc[SWEEP ? R : 1];
+  if constexpr (SWEEP) {
+    vec(v, a.v);
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = 0.0;
+  }
+  if constexpr (DEFL) vec(ts, a.ts);
+  double tsv = 0.0;
+  if constexpr (DEFL && SWEEP) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) tsv = fma(ts[i], v[i], tsv);
+    tsv = row16_sum(tsv);
+  }
+  const double dn = (STD && a.rowmask) ? a.n_eff : (double)n;
+  // lazy deflation: lane sub carries the corrections of the previous components sub, sub + 16, sub + 32
+  const bool lazy = !STD && a.lazy != 0;
+  double cu[SUB_LM], ce[SUB_LM], dacc[SUB_LM];
+  const double* prow[SUB_LM];
+  bool mine[SUB_LM];
+#pragma unroll
+  for (int m = 0; m < SUB_LM; ++m) {
+    const int i = sub + 16 * m;
+    mine[m] = lazy && i < a.kprev;
+    cu[m] = (mine[m] && a.cu) ? a.cu[i] : 0.0;
+    ce[m] = (mine[m] && a.ce) ? a.ce[i] : 0.0;
+    prow[m] = mine[m] ? a.Pm + (int64_t)i * a.ldp : nullptr;
+    dacc[m] = 0.0;
+  }
+  double dk = 0.0, ssq_g = 0.0, ssq_p = 0.0, ssq_x = 0.0, amp = 0.0;
+
+  // every row group walks the same number of rounds; a group past the end of the chunk re-reads the last column
+  // and contributes nothing (no divergence inside the wave, the DPP rows stay whole)
+  double x[D][R], pp[D][SUB_LM], k0v[D], muv[D];
+  auto fetch = [&](int d, int64_t jr) {
+    const int64_t j = (jr < j1) ? jr : j1 - 1;
+    const double* col = a.src + j * ld;
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const v2d_t q = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(col + off[k]));
+      x[d][2 * k] = q.x;
+      x[d][2 * k + 1] = q.y;
+    }
+#pragma unroll
+    for (int m = 0; m < SUB_LM; ++m) pp[d][m] = mine[m] ? prow[m][j] : 0.0;
+    k0v[d] = (STD && ISTD) ? col[0] : 0.0;
+    muv[d] = CEN ? a.mu[j] : 0.0;
+  };
+  const int64_t rounds = (j1 - j0 + 15) / 16;
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < rounds) fetch(d, j0 + grp + 16 * d);
+
+  for (int64_t rd = 0; rd < rounds; rd += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (rd + d >= rounds) break;
+      const int64_t jj = j0 + grp + 16 * (rd + d);
+      const bool valid = jj < j1;                 // uniform over the DPP row
+      const bool writer = valid && sub == 0;
+      double(&xc)[R] = x[d];
+      constexpr bool NOSTORE = STD && ISTD && SWEEP;
+      bool handled = false;
+      double gj = 0.0, pjk = 0.0, cj = 0.0;
+
+      if constexpr (NOSTORE) {
+        if (a.mode == MBPLS_SCALE_FIT) {
+          // statistics-only first pass: shifted one-pass sums (shift = first sample), nothing stored
+          const double K0 = k0v[d];
+          double s1 = 0.0, s2 = 0.0, sv = 0.0;
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            const double e = real(i) ? xc[i] - K0 : 0.0;
+            xc[i] = e;
+            s1 += e;
+            s2 = fma(e, e, s2);
+            sv = fma(e, v[i], sv);
+          }
+          s1 = row16_sum(s1);
+          s2 = row16_sum(s2);
+          sv = row16_sum(sv);
+          const double inv_n = 1.0 / dn;
+          const double m1 = s1 * inv_n;
+          const double mean = K0 + m1;
+          const double var = fmax((s2 - s1 * m1) * inv_n, 0.0);
+          const double eps = 2.220446049250313e-16;
+          const double nme = dn * mean * eps;
+          const bool constant = var <= dn * eps * var + nme * nme;
+          double rv = __builtin_amdgcn_rcp(var);
+          rv = fma(fma(-var, rv, 1.0), rv, rv);
+          rv = fma(fma(-var, rv, 1.0), rv, rv);
+          const double r2 = constant ? 0.0 : rv;
+          const double gt = a.alpha * sv;
+          cj = valid ? gt * r2 : 0.0;
+          ssq_g = fma(gt, cj, ssq_g);
+          if (valid) amp = fmax(amp, mean * mean * r2);
+          if (writer) {
+            ssq_x = fma(dn * var, r2, ssq_x);     // sum z^2 of the column, counted by one lane of the row
+            a.mean[jj] = mean;
+            a.scale[jj] = var;                    // k_finish_stats turns var into scale, g~ into g
+            if (a.r2_out) a.r2_out[jj] = r2;
+            if (a.g) a.g[jj] = gt;
+          }
+#pragma unroll
+          for (int i = 0; i < R; ++i) acc[i] = fma(cj, xc[i], acc[i]);
+          handled = true;
+        }
+      }
+
+      if constexpr (STD) {
+        if (!handled && a.mode != MBPLS_SCALE_NONE) {
+          double mean, scale;
+          if (a.mode == MBPLS_SCALE_FIT) {
+            // sklearn _incremental_mean_and_var: mean, then corrected two-pass variance
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) s += real(i) ? xc[i] : 0.0;
+            s = row16_sum(s);
+            mean = s / dn;
+            double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+              const double dlt = real(i) ? xc[i] - mean : 0.0;
+              xc[i] = dlt;
+              c0 += dlt;
+              c1 = fma(dlt, dlt, c1);
+            }
+            c0 = row16_sum(c0);
+            c1 = row16_sum(c1);
+            const double var = (c1 - c0 * c0 / dn) / dn;
+            const double eps = 2.220446049250313e-16;
+            const double nme = dn * mean * eps;
+            const double bound = dn * eps * var + nme * nme;
+            scale = (var <= bound) ? 1.0 : sqrt(var);
+            if (valid) amp = fmax(amp, fabs(mean) / scale);
+            if (writer) {
+              a.mean[jj] = mean;
+              a.scale[jj] = scale;
+              if (a.var_out) a.var_out[jj] = (var <= bound) ? 0.0 : var;
+            }
+          } else {
+            mean = a.mean[valid ? jj : j1 - 1];
+            scale = a.scale[valid ? jj : j1 - 1];
+#pragma unroll
+            for (int i = 0; i < R; ++i) xc[i] = real(i) ? xc[i] - mean : 0.0;
+          }
+#pragma unroll
+          for (int i = 0; i < R; ++i) xc[i] = xc[i] / scale;
+        } else if (!handled) {
+#pragma unroll
+          for (int i = 0; i < R; ++i) xc[i] = real(i) ? xc[i] : 0.0;
+        }
+        if (!handled) {
+          double s = 0.0;
+#pragma unroll
+          for (int i = 0; i < R; ++i) s = fma(xc[i], xc[i], s);
+          if (valid) ssq_x += s;                  // per-lane partial, summed over the row at the end
+        }
+        if constexpr (!NOSTORE) {
+          if (valid && a.dst) {
+            double* out = a.dst + jj * ld;
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+              const int64_t r = 2 * ((int64_t)sub + 16 * k);
+              if (r + 1 < ld) {
+                v2d_t q;
+                q.x = xc[2 * k];
+                q.y = xc[2 * k + 1];
+                __builtin_nontemporal_store(q, reinterpret_cast<v2d_t*>(out + r));
+              } else if (r < ld) {
+                out[r] = xc[2 * k];
+              }
+            }
+          }
+        }
+      } else {
+        // rows beyond n read as 0 (an explicitly deflated column stores zeros back into its padding)
+#pragma unroll
+        for (int i = 0; i < R; ++i) xc[i] = real(i) ? xc[i] : 0.0;
+      }
+
+      double r2c = 1.0;
+      if constexpr (ISTD && !STD) {
+        r2c = a.ir2[valid ? jj : j1 - 1];
+        if constexpr (CEN) {
+          const double muj = muv[d];
+#pragma unroll
+          for (int i = 0; i < R; ++i) xc[i] -= muj;
+        }
+      }
+      if constexpr (DEFL) {
+        double ab0 = 0.0, ab1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < SUB_LM; ++m) {
+          ab0 = fma(-pp[d][m], ce[m], ab0);
+          ab1 = fma(-pp[d][m], cu[m], ab1);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          ab0 = fma(xc[i], ts[i], ab0);
+          if constexpr (SWEEP) ab1 = fma(xc[i], v[i], ab1);
+        }
+        ab0 = row16_sum(ab0);
+        if constexpr (SWEEP) ab1 = row16_sum(ab1);
+        const double pj = ab0 * a.inv_tt;
+        if (valid) ssq_p = fma(pj * pj, (ISTD ? r2c : 1.0), ssq_p);
+        if (writer && a.pvec) a.pvec[jj] = pj;
+        if (a.deflate) {
+          if (!lazy) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) xc[i] = fma(-pj, ts[i], xc[i]);
+            if (valid) {
+              double* out = a.dst + jj * ld;
+#pragma unroll
+              for (int k = 0; k < KR; ++k) {
+                const int64_t r = 2 * ((int64_t)sub + 16 * k);
+                if (r + 1 < ld) {
+                  v2d_t q;
+                  q.x = xc[2 * k];
+                  q.y = xc[2 * k + 1];
+                  __builtin_nontemporal_store(q, reinterpret_cast<v2d_t*>(out + r));
+                } else if (r < ld) {
+                  out[r] = xc[2 * k];
+                }
+              }
+            }
+          }
+          if constexpr (SWEEP) gj = a.alpha * fma(-pj, tsv, ab1);
+          pjk = pj;
+        } else {
+          if constexpr (SWEEP) gj = a.alpha * ab1;
+        }
+      } else if constexpr (SWEEP) {
+        if (!handled) {
+          double b = 0.0;
+#pragma unroll
+          for (int m = 0; m < SUB_LM; ++m) b = fma(-pp[d][m], cu[m], b);
+#pragma unroll
+          for (int i = 0; i < R; ++i) b = fma(xc[i], v[i], b);
+          b = row16_sum(b);
+          gj = a.alpha * b;
+        }
+      }
+      if constexpr (SWEEP) {
+        if (!handled) {
+          cj = gj;
+          if constexpr (ISTD && !STD) cj = gj * r2c;
+          if (!valid) cj = 0.0;
+          ssq_g = fma(gj, cj, ssq_g);
+          if (writer && a.g) a.g[jj] = gj;
+#pragma unroll
+          for (int i = 0; i < R; ++i) acc[i] = fma(cj, xc[i], acc[i]);
+        }
+#pragma unroll
+        for (int m = 0; m < SUB_LM; ++m) dacc[m] = fma(cj, pp[d][m], dacc[m]);
+        if constexpr (DEFL) dk = fma(cj, pjk, dk);
+      }
+      if (rd + d + D < rounds) fetch(d, jj + 16 * D);
+    }
+  }
+
+  // ---- the 16 row groups of the workgroup combine in a fixed order
+  if constexpr (STD) ssq_x = row16_sum(ssq_x);
+  if (sub == 0) {
+    s_s[grp][0] = ssq_g;
+    s_s[grp][1] = ssq_p;
+    s_s[grp][2] = ssq_x;
+    s_s[grp][3] = amp;
+    s_d[grp][SUB_LM * 16] = dk;
+  }
+#pragma unroll
+  for (int m = 0; m < SUB_LM; ++m) s_d[grp][sub + 16 * m] = dacc[m];
+  if constexpr (SWEEP) {
+    for (int i = tid; i < SUB_MAX_N; i += 256) s_t[i] = 0.0;
+    __syncthreads();
+    for (int g = 0; g < 16; ++g) {
+      if (grp == g) {
+#pragma unroll
+        for (int k = 0; k < KR; ++k)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int r = 2 * (sub + 16 * k) + h;
+            if (r < n) s_t[r] += acc[2 * k + h];
+          }
+      }
+      __syncthreads();
+    }
+    double* out = a.part_t + (int64_t)chunk * n;
+    for (int i = tid; i < n; i += 256) out[i] = s_t[i];
+  } else {
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double sg = 0.0, sp = 0.0, sx = 0.0, am = 0.0;
+    for (int g = 0; g < 16; ++g) {
+      sg += s_s[g][0];
+      sp += s_s[g][1];
+      sx += s_s[g][2];
+      am = fmax(am, s_s[g][3]);
+    }
+    double* ps = a.part_s + (int64_t)chunk * 4;
+    ps[0] = sg;
+    ps[1] = sp;
+    ps[2] = sx;
+    ps[3] = am;
+  }
+  if (lazy && a.part_d) {
+    double* pd = a.part_d + (int64_t)chunk * KD;
+    if (tid < a.kprev) {
+      double s = 0.0;
+      for (int g = 0; g < 16; ++g) s += s_d[g][tid];
+      pd[tid] = s;
+    }
+    if (tid == 0) {
+      double s = 0.0;
+      for (int g = 0; g < 16; ++g) s += s_d[g][SUB_LM * 16];
+      pd[a.kprev] = s;
+    }
+  }
+}
+
+template <int KR, int D, bool STD, bool DEFL, bool SWEEP>
+static void launch_sub_kr(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a) {
+  dim3 grid((unsigned)ct.nchunks), block(256);
+  const bool istd = STD ? (SWEEP && a.dst == nullptr) : (a.lazy && a.ir2 != nullptr);
+  const bool cen = !STD && istd && a.mu != nullptr;
+  constexpr bool IS_ = !STD || SWEEP;
+  constexpr bool CE_ = !STD;
+  if (cen) hipLaunchKernelGGL((k_colpass_sub<KR, D, STD, DEFL, SWEEP, IS_, CE_>), grid, block, 0, ctx->stream, a);
+  else if (istd) hipLaunchKernelGGL((k_colpass_sub<KR, D, STD, DEFL, SWEEP, IS_, false>), grid, block, 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_colpass_sub<KR, D, STD, DEFL, SWEEP, false, false>), grid, block, 0, ctx->stream, a);
+}
+
+template <bool STD, bool DEFL, bool SWEEP>
+static void launch_sub(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a) {
+  if (a.n <= 64) launch_sub_kr<2, 4, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (a.n <= 128) launch_sub_kr<4, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else launch_sub_kr<8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+}
+
+int launch_pass_sub(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, bool STD, bool DEFL, bool SWEEP) {
+  if (STD && !DEFL && SWEEP) launch_sub<true, false, true>(ctx, ct, a);
+  else if (STD && !DEFL) launch_sub<true, false, false>(ctx, ct, a);
+  else if (DEFL && SWEEP) launch_sub<false, true, true>(ctx, ct, a);
+  else if (DEFL) launch_sub<false, true, false>(ctx, ct, a);
+  else launch_sub<false, false, true>(ctx, ct, a);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+}  // namespace mbpls

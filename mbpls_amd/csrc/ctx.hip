@@ -282,6 +282,7 @@ int mbpls_hip_set_tunable(mbpls_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "prefetch")) ctx->prefetch = value;
   else if (!strcmp(key, "xw_mfma_from")) ctx->xw_mfma_from = std::max(0, value);
   else if (!strcmp(key, "gram_slice_features")) ctx->gram_slice_features = std::max(0, value);
+  else if (!strcmp(key, "sub_columns")) ctx->sub_columns = value ? 1 : 0;
   else if (!strcmp(key, "long_columns_from")) ctx->long_columns_from = std::max(0, std::min(value, 65536));
   else MB_ARG(false, "unknown tunable '%s'", key);
   return MBPLS_OK;

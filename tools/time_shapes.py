@@ -1,0 +1,34 @@
+"""Pass bandwidth across sample counts at a fixed matrix size (default 8 GB): python tools/time_shapes.py [GB] [method]
+Few samples x very many features is the everyday shape of multiblock PLS (spectra, omics)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import mbpls_amd
+from mbpls_amd import MBPLS, DeviceMatrix
+from bench import planted
+
+gb = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
+method = sys.argv[2] if len(sys.argv) > 2 else "NIPALS"
+ctx = mbpls_amd.get_context()
+for n in (64, 128, 256, 500, 1024, 2048, 3000, 4096, 8192, 12000):
+    p = int(gb * 1e9 / 8 / n)
+    Ts, Y = planted(n, 1, 16, 0)
+    X = DeviceMatrix(ctx, n, p, [0, p // 3, p])
+    X.fill_latent(ctx.from_host(Ts), 16, 0.5, 1234, 0)
+    ctx.sync()
+    m = MBPLS(n_components=5, method=method)
+    for rep in range(3):
+        ctx.profile(rep == 2)
+        ctx.profile_reset()
+        t0 = time.perf_counter(); m.fit(X, Y); ctx.sync(); t1 = time.perf_counter()
+    prof = ctx.profile_get()
+    ctx.profile(False)
+    print(f"n={n:6d} p={p:9d} {method}: fit {1e3 * (t1 - t0):7.1f} ms  " +
+          "  ".join(f"{k}: {v['avg_ms']:.2f} ms {v['GBps']:.0f} GB/s x{v['launches']}" for k, v in prof.items()),
+          flush=True)
+    X.close()
+    del X
