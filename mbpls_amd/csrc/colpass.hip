@@ -103,6 +103,9 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   const double* prow = mine ? a.Pm + (int64_t)tid * a.ldp : nullptr;
   double dacc = 0.0, dk = 0.0;
 
+  // The statistics-only pass masks at the point of use (e = real ? x - K : 0): its loads stay select-free for ragged n
+  // as well, so the compiler's s_waitcnt lands one column later (n = 3000: 3.0 -> TB/s of the n = 4096 case).
+  constexpr bool LFULL = FULL || (STD && ISTD && SWEEP);
   double x[D][R];
   __shared__ double s_out[(STD && ISTD) ? 4 : 1][64];   // statistics-only pass: per-column outputs of 64 columns
   double pp[D];   // P[column, tid] of the column held in slot d (0 for threads >= kprev)
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   for (int d = 0; d < D; ++d) {
     pp[d] = 0.0;
     if (j0 + d < j1) {
-      load_col<R, FULL>(x[d], a.src + (j0 + d) * ld, rm);
+      load_col<R, LFULL>(x[d], a.src + (j0 + d) * ld, rm);
       if (mine) pp[d] = prow[j0 + d];
       if constexpr (STD && ISTD) k0v[d] = a.src[(j0 + d) * ld];
       if constexpr (CEN) muv[d] = a.mu[j0 + d];
@@ -197,6 +200,13 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
         }
       }
 
+      if constexpr (STD && LFULL && !FULL) {
+        if (!handled) {                     // (not the statistics flavour after all: mask what the load left raw)
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            xc[k] = ((((k & 1) ? rm.in_n1 : rm.in_n0) >> (k >> 1)) & 1u) ? xc[k] : 0.0;
+        }
+      }
       if constexpr (STD) {
         if (!handled && a.mode != MBPLS_SCALE_NONE) {
           double mean, scale;
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
       }
       // refill this register slot with the column D ahead (in flight while the next ones are processed)
       if (jj + D < j1) {
-        load_col<R, FULL>(xc, a.src + (jj + D) * ld, rm);
+        load_col<R, LFULL>(xc, a.src + (jj + D) * ld, rm);
         if (mine) pp[d] = prow[jj + D];
         if constexpr (STD && ISTD) k0v[d] = a.src[(jj + D) * ld];
         if constexpr (CEN) muv[d] = a.mu[jj + D];
@@ -460,7 +470,7 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   PassArgs an = a;
   an.dpar = ctx->dpar;
   an.var_out = ctx->var_out;
-  // few samples (n <= 256): four columns per wave, one per 16-lane DPP row (colpass_sub.hip)
+  // few samples (n <= 512): four (two) columns per wave, one per 16-lane DPP row (half wave) (colpass_sub.hip)
   if (a.n <= SUB_MAX_N && ctx->sub_columns) return launch_pass_sub(ctx, ct, an, STD, DEFL, SWEEP);
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
   const int D = ctx->prefetch >= 1 && ctx->prefetch <= 3 ? ctx->prefetch : 2;

@@ -1,4 +1,4 @@
-// Column passes for FEW samples (n <= 256) -- the everyday shape of multiblock PLS: tens to hundreds of samples,
+// Column passes for FEW samples (n <= 512) -- the everyday shape of multiblock PLS: tens to hundreds of samples,
 // up to millions of features.  colpass.hip gives a column to a workgroup; with a 0.5-2 KB column its per-column
 // reduction (six DPP steps, a barrier, the scalar algebra) is all latency and the pass runs at 0.8-2.7 TB/s.
 //
@@ -24,31 +24,46 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
-constexpr int SUB_LM = 3;   // lazy corrections per lane: components s, s + 16, s + 32 (KD - 1 = 39 < 48)
+// ... and over a 32-lane half wave (256 < n <= 512: two columns per wave): the row sums, then one xor-16 exchange
+// between the two rows of the half through the LDS crossbar (ds_swizzle, no memory access)
+__device__ __forceinline__ double half32_sum(double v) {
+  v = row16_sum(v);
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F);   // bit mode: and 0x1f, or 0, xor 0x10
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
+  return v + __hiloint2double(hi, lo);
+}
+template <int LG>
+__device__ __forceinline__ double group_sum(double v) {
+  if constexpr (LG == 16) return row16_sum(v);
+  else return half32_sum(v);
+}
 
-template <int KR, int D, bool STD, bool DEFL, bool SWEEP, bool ISTD, bool CEN>
+// LG lanes per column (16: four columns per wave, n <= 32 KR; 32: two columns per wave, n <= 64 KR)
+template <int LG, int KR, int D, bool STD, bool DEFL, bool SWEEP, bool ISTD, bool CEN>
 __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
   constexpr int R = 2 * KR;
+  constexpr int NG = 256 / LG;                       // column groups per workgroup
+  constexpr int SUB_LM = (KD - 1 + LG - 1) / LG;     // lazy corrections per lane: components s, s + LG, ...
   __shared__ double s_t[SUB_MAX_N];
-  __shared__ double s_s[16][4];
-  __shared__ double s_d[16][SUB_LM * 16 + 1];
+  __shared__ double s_s[NG][4];
+  __shared__ double s_d[NG][SUB_LM * LG + 1];
   if (a.dpar) {
     if (a.dpar[2] != 0.0) return;
     a.alpha = uniform_f64(a.dpar[0]);
     a.inv_tt = uniform_f64(a.dpar[1]);
   }
   const int tid = threadIdx.x, lane = tid & 63;
-  const int sub = lane & 15, grp = (tid >> 6) * 4 + (lane >> 4);   // lane inside its row; row group 0..15 of the workgroup
+  const int sub = lane & (LG - 1), grp = (tid >> 6) * (64 / LG) + lane / LG;   // lane inside its group; group of the workgroup
   const int64_t n = a.n, ld = a.ld;
   const int chunk = blockIdx.x;
   const int64_t j0 = uniform64(a.c0[chunk]), j1 = uniform64(a.c1[chunk]);
 
-  // rows of this lane: pair k covers 2 (sub + 16 k), + 1
+  // rows of this lane: pair k covers 2 (sub + LG k), + 1
   unsigned keep = 0u;          // bit 2k + h: a real, included sample
   int64_t off[KR];             // element offset of the pair inside a column (clamped inside the allocation)
 #pragma unroll
   for (int k = 0; k < KR; ++k) {
-    const int64_t r = 2 * ((int64_t)sub + 16 * k);
+    const int64_t r = 2 * ((int64_t)sub + LG * k);
     off[k] = (r < ld) ? r : 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -63,7 +78,7 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
     for (int k = 0; k < KR; ++k)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int64_t r = 2 * ((int64_t)sub + 16 * k) + h;
+        const int64_t r = 2 * ((int64_t)sub + LG * k) + h;
         o[2 * k + h] = (r < n) ? p[r] : 0.0;
       }
   };
@@ -78,7 +93,7 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
   if constexpr (DEFL && SWEEP) {
 #pragma unroll
     for (int i = 0; i < R; ++i) tsv = fma(ts[i], v[i], tsv);
-    tsv = row16_sum(tsv);
+    tsv = group_sum<LG>(tsv);
   }
   const double dn = (STD && a.rowmask) ? a.n_eff : (double)n;
   // lazy deflation: lane sub carries the corrections of the previous components sub, sub + 16, sub + 32
@@ -88,7 +103,7 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
   bool mine[SUB_LM];
 #pragma unroll
   for (int m = 0; m < SUB_LM; ++m) {
-    const int i = sub + 16 * m;
+    const int i = sub + LG * m;
     mine[m] = lazy && i < a.kprev;
     cu[m] = (mine[m] && a.cu) ? a.cu[i] : 0.0;
     ce[m] = (mine[m] && a.ce) ? a.ce[i] : 0.0;
@@ -114,17 +129,17 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
     k0v[d] = (STD && ISTD) ? col[0] : 0.0;
     muv[d] = CEN ? a.mu[j] : 0.0;
   };
-  const int64_t rounds = (j1 - j0 + 15) / 16;
+  const int64_t rounds = (j1 - j0 + NG - 1) / NG;
 #pragma unroll
   for (int d = 0; d < D; ++d)
-    if (d < rounds) fetch(d, j0 + grp + 16 * d);
+    if (d < rounds) fetch(d, j0 + grp + NG * d);
 
   for (int64_t rd = 0; rd < rounds; rd += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       if (rd + d >= rounds) break;
-      const int64_t jj = j0 + grp + 16 * (rd + d);
-      const bool valid = jj < j1;                 // uniform over the DPP row
+      const int64_t jj = j0 + grp + NG * (rd + d);
+      const bool valid = jj < j1;                 // uniform over the group
       const bool writer = valid && sub == 0;
       double(&xc)[R] = x[d];
       constexpr bool NOSTORE = STD && ISTD && SWEEP;
@@ -144,9 +159,9 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
             s2 = fma(e, e, s2);
             sv = fma(e, v[i], sv);
           }
-          s1 = row16_sum(s1);
-          s2 = row16_sum(s2);
-          sv = row16_sum(sv);
+          s1 = group_sum<LG>(s1);
+          s2 = group_sum<LG>(s2);
+          sv = group_sum<LG>(sv);
           const double inv_n = 1.0 / dn;
           const double m1 = s1 * inv_n;
           const double mean = K0 + m1;
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
             double s = 0.0;
 #pragma unroll
             for (int i = 0; i < R; ++i) s += real(i) ? xc[i] : 0.0;
-            s = row16_sum(s);
+            s = group_sum<LG>(s);
             mean = s / dn;
             double c0 = 0.0, c1 = 0.0;
 #pragma unroll
@@ -193,8 +208,8 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
               c0 += dlt;
               c1 = fma(dlt, dlt, c1);
             }
-            c0 = row16_sum(c0);
-            c1 = row16_sum(c1);
+            c0 = group_sum<LG>(c0);
+            c1 = group_sum<LG>(c1);
             const double var = (c1 - c0 * c0 / dn) / dn;
             const double eps = 2.220446049250313e-16;
             const double nme = dn * mean * eps;
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
             double* out = a.dst + jj * ld;
 #pragma unroll
             for (int k = 0; k < KR; ++k) {
-              const int64_t r = 2 * ((int64_t)sub + 16 * k);
+              const int64_t r = 2 * ((int64_t)sub + LG * k);
               if (r + 1 < ld) {
                 v2d_t q;
                 q.x = xc[2 * k];
@@ -268,8 +283,8 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
           ab0 = fma(xc[i], ts[i], ab0);
           if constexpr (SWEEP) ab1 = fma(xc[i], v[i], ab1);
         }
-        ab0 = row16_sum(ab0);
-        if constexpr (SWEEP) ab1 = row16_sum(ab1);
+        ab0 = group_sum<LG>(ab0);
+        if constexpr (SWEEP) ab1 = group_sum<LG>(ab1);
         const double pj = ab0 * a.inv_tt;
         if (valid) ssq_p = fma(pj * pj, (ISTD ? r2c : 1.0), ssq_p);
         if (writer && a.pvec) a.pvec[jj] = pj;
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
               double* out = a.dst + jj * ld;
 #pragma unroll
               for (int k = 0; k < KR; ++k) {
-                const int64_t r = 2 * ((int64_t)sub + 16 * k);
+                const int64_t r = 2 * ((int64_t)sub + LG * k);
                 if (r + 1 < ld) {
                   v2d_t q;
                   q.x = xc[2 * k];
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
           for (int m = 0; m < SUB_LM; ++m) b = fma(-pp[d][m], cu[m], b);
 #pragma unroll
           for (int i = 0; i < R; ++i) b = fma(xc[i], v[i], b);
-          b = row16_sum(b);
+          b = group_sum<LG>(b);
           gj = a.alpha * b;
         }
       }
@@ -323,31 +338,31 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
         for (int m = 0; m < SUB_LM; ++m) dacc[m] = fma(cj, pp[d][m], dacc[m]);
         if constexpr (DEFL) dk = fma(cj, pjk, dk);
       }
-      if (rd + d + D < rounds) fetch(d, jj + 16 * D);
+      if (rd + d + D < rounds) fetch(d, jj + NG * D);
     }
   }
 
   // ---- the 16 row groups of the workgroup combine in a fixed order
-  if constexpr (STD) ssq_x = row16_sum(ssq_x);
+  if constexpr (STD) ssq_x = group_sum<LG>(ssq_x);
   if (sub == 0) {
     s_s[grp][0] = ssq_g;
     s_s[grp][1] = ssq_p;
     s_s[grp][2] = ssq_x;
     s_s[grp][3] = amp;
-    s_d[grp][SUB_LM * 16] = dk;
+    s_d[grp][SUB_LM * LG] = dk;
   }
 #pragma unroll
-  for (int m = 0; m < SUB_LM; ++m) s_d[grp][sub + 16 * m] = dacc[m];
+  for (int m = 0; m < SUB_LM; ++m) s_d[grp][sub + LG * m] = dacc[m];
   if constexpr (SWEEP) {
     for (int i = tid; i < SUB_MAX_N; i += 256) s_t[i] = 0.0;
     __syncthreads();
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < NG; ++g) {
       if (grp == g) {
 #pragma unroll
         for (int k = 0; k < KR; ++k)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const int r = 2 * (sub + 16 * k) + h;
+            const int r = 2 * (sub + LG * k) + h;
             if (r < n) s_t[r] += acc[2 * k + h];
           }
       }
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
   }
   if (tid == 0) {
     double sg = 0.0, sp = 0.0, sx = 0.0, am = 0.0;
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < NG; ++g) {
       sg += s_s[g][0];
       sp += s_s[g][1];
       sx += s_s[g][2];
@@ -376,34 +391,35 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
     double* pd = a.part_d + (int64_t)chunk * KD;
     if (tid < a.kprev) {
       double s = 0.0;
-      for (int g = 0; g < 16; ++g) s += s_d[g][tid];
+      for (int g = 0; g < NG; ++g) s += s_d[g][tid];
       pd[tid] = s;
     }
     if (tid == 0) {
       double s = 0.0;
-      for (int g = 0; g < 16; ++g) s += s_d[g][SUB_LM * 16];
+      for (int g = 0; g < NG; ++g) s += s_d[g][SUB_LM * LG];
       pd[a.kprev] = s;
     }
   }
 }
 
-template <int KR, int D, bool STD, bool DEFL, bool SWEEP>
+template <int LG, int KR, int D, bool STD, bool DEFL, bool SWEEP>
 static void launch_sub_kr(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a) {
   dim3 grid((unsigned)ct.nchunks), block(256);
   const bool istd = STD ? (SWEEP && a.dst == nullptr) : (a.lazy && a.ir2 != nullptr);
   const bool cen = !STD && istd && a.mu != nullptr;
   constexpr bool IS_ = !STD || SWEEP;
   constexpr bool CE_ = !STD;
-  if (cen) hipLaunchKernelGGL((k_colpass_sub<KR, D, STD, DEFL, SWEEP, IS_, CE_>), grid, block, 0, ctx->stream, a);
-  else if (istd) hipLaunchKernelGGL((k_colpass_sub<KR, D, STD, DEFL, SWEEP, IS_, false>), grid, block, 0, ctx->stream, a);
-  else hipLaunchKernelGGL((k_colpass_sub<KR, D, STD, DEFL, SWEEP, false, false>), grid, block, 0, ctx->stream, a);
+  if (cen) hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, IS_, CE_>), grid, block, 0, ctx->stream, a);
+  else if (istd) hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, IS_, false>), grid, block, 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, false, false>), grid, block, 0, ctx->stream, a);
 }
 
 template <bool STD, bool DEFL, bool SWEEP>
 static void launch_sub(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a) {
-  if (a.n <= 64) launch_sub_kr<2, 4, STD, DEFL, SWEEP>(ctx, ct, a);
-  else if (a.n <= 128) launch_sub_kr<4, 2, STD, DEFL, SWEEP>(ctx, ct, a);
-  else launch_sub_kr<8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  if (a.n <= 64) launch_sub_kr<16, 2, 4, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (a.n <= 128) launch_sub_kr<16, 4, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (a.n <= 256) launch_sub_kr<16, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else launch_sub_kr<32, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
 }
 
 int launch_pass_sub(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, bool STD, bool DEFL, bool SWEEP) {

@@ -215,8 +215,8 @@ struct PassArgs {
   double* r2_out;      // standardise pass: 1 / scale_j^2 (optional)
 };
 
-// colpass_sub.hip: the same passes for n <= SUB_MAX_N samples, several columns per wave
-constexpr int SUB_MAX_N = 256;
+// colpass_sub.hip: the same passes for n <= SUB_MAX_N samples, several columns per wave (KD is used there: keep it above)
+constexpr int SUB_MAX_N = 512;
 int launch_pass_sub(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, bool STD, bool DEFL, bool SWEEP);
 
 // lazy deflation: at most KD - 1 previous components are corrected for inside a pass

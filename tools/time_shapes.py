@@ -14,7 +14,7 @@ from bench import planted
 gb = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
 method = sys.argv[2] if len(sys.argv) > 2 else "NIPALS"
 ctx = mbpls_amd.get_context()
-for n in (64, 128, 256, 500, 1024, 2048, 3000, 4096, 8192, 12000):
+for n in (40, 64, 100, 128, 200, 256, 300, 500, 1000, 1024, 2048, 3000, 4096, 5000, 8192, 12000):
     p = int(gb * 1e9 / 8 / n)
     Ts, Y = planted(n, 1, 16, 0)
     X = DeviceMatrix(ctx, n, p, [0, p // 3, p])
