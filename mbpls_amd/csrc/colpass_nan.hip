@@ -19,27 +19,6 @@
 
 namespace mbpls {
 
-struct NanArgs {
-  const double* rowmask;   // standardise pass only: samples excluded from the fit (cross-validation folds)
-  double* var_out;
-  const double* src;
-  double* dst;
-  int64_t ld, n;
-  const int64_t* c0;
-  const int64_t* c1;
-  const double* v;    // sweep vector (u)
-  double* g;          // [p] un-normalised weights
-  const double* ts;   // superscore
-  int deflate;
-  double* pvec;       // [p] loadings
-  int mode;
-  double* mean;
-  double* scale;
-  double* count;      // [p] present samples per column (standardise pass, optional)
-  double* part_t;     // [nchunks][n]  A
-  double* part_d;     // [nchunks][n]  D
-  double* part_s;     // [nchunks][4]  ssq_g, ssq_p, ssq_x, -
-};
 
 // Workgroup sum of NV <= 8 values (LDS scratch double[2][16][8]; one barrier per call).
 template <int NV>
@@ -306,6 +285,8 @@ static int launch_nan(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, in
   const bool writes = STD || (DEFL && a.deflate);
   const int kind = STD ? MBPLS_K_STANDARDIZE : (DEFL ? (SWEEP ? MBPLS_K_DEFLATE_SWEEP : MBPLS_K_DEFLATE) : MBPLS_K_SWEEP);
   ProfScope prof(ctx, kind, 8.0 * (double)a.n * (double)p * (writes ? 2.0 : 1.0));
+  // few samples: several columns per wave (colpass_sub.hip)
+  if (a.n <= SUB_MAX_N && ctx->sub_columns) return launch_nan_sub(ctx, ct, a, STD, DEFL, SWEEP);
   Cfg cfg;
   int T = 0;
   if (!pick_cfg(ctx, a.n, &cfg, &T, false)) {

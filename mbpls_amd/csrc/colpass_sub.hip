@@ -432,4 +432,290 @@ int launch_pass_sub(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, boo
   return MBPLS_OK;
 }
 
+// ------------------------------------------------------------------------------------------- missing values
+// k_colpass_nan with the same column groups: a NaN marks a missing entry, stays NaN in HBM, and every sum skips it.
+template <int LG, int KR, int D, bool STD, bool DEFL, bool SWEEP>
+__global__ __launch_bounds__(256) void k_colpass_nan_sub(NanArgs a) {
+  constexpr int R = 2 * KR;
+  constexpr int NG = 256 / LG;
+  __shared__ double s_t[SWEEP ? SUB_MAX_N : 1], s_dd[SWEEP ? SUB_MAX_N : 1];
+  __shared__ double s_s[NG][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int sub = lane & (LG - 1), grp = (tid >> 6) * (64 / LG) + lane / LG;
+  const int64_t n = a.n, ld = a.ld;
+  const int chunk = blockIdx.x;
+  const int64_t j0 = uniform64(a.c0[chunk]), j1 = uniform64(a.c1[chunk]);
+  unsigned keep = 0u;
+  int64_t off[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const int64_t r = 2 * ((int64_t)sub + LG * k);
+    off[k] = (r < ld) ? r : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bool m = r + h < n;
+      if (STD && m && a.rowmask) m = a.rowmask[r + h] != 0.0;   // row-subset fit: excluded samples read as 0
+      keep |= (m ? 1u : 0u) << (2 * k + h);
+    }
+  }
+  auto real = [&](int i) { return ((keep >> i) & 1u) != 0u; };
+  auto vec = [&](double(&o)[R], const double* p) {
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t r = 2 * ((int64_t)sub + LG * k) + h;
+        o[2 * k + h] = (r < n) ? p[r] : 0.0;
+      }
+  };
+  double v[SWEEP ? R : 1], ts[DEFL ? R : 1], acc[SWEEP ? R : 1], dac[SWEEP ? R : 1];
+  if constexpr (SWEEP) {
+    vec(v, a.v);
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = dac[i] = 0.0;
+  }
+  if constexpr (DEFL) vec(ts, a.ts);
+  double ssq_g = 0.0, ssq_p = 0.0, ssq_x = 0.0;
+
+  double x[D][R];
+  auto fetch = [&](int d, int64_t jr) {
+    const double* col = a.src + ((jr < j1) ? jr : j1 - 1) * ld;
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const v2d_t q = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(col + off[k]));
+      x[d][2 * k] = q.x;
+      x[d][2 * k + 1] = q.y;
+    }
+  };
+  auto store = [&](const double(&xc)[R], int64_t jj) {
+    double* out = a.dst + jj * ld;
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int64_t r = 2 * ((int64_t)sub + LG * k);
+      if (r + 1 < ld) {
+        v2d_t q;
+        q.x = xc[2 * k];
+        q.y = xc[2 * k + 1];
+        __builtin_nontemporal_store(q, reinterpret_cast<v2d_t*>(out + r));
+      } else if (r < ld) {
+        out[r] = xc[2 * k];
+      }
+    }
+  };
+  const int64_t rounds = (j1 - j0 + NG - 1) / NG;
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < rounds) fetch(d, j0 + grp + NG * d);
+
+  for (int64_t rd = 0; rd < rounds; rd += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (rd + d >= rounds) break;
+      const int64_t jj = j0 + grp + NG * (rd + d);
+      const bool valid = jj < j1;
+      const bool writer = valid && sub == 0;
+      const int64_t jc = valid ? jj : j1 - 1;
+      double(&xc)[R] = x[d];
+      // rows beyond n (and excluded samples) read as 0: present, and without weight in any sum
+      unsigned pm = 0u;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        xc[i] = real(i) ? xc[i] : 0.0;
+        pm |= ((xc[i] == xc[i]) ? 1u : 0u) << i;
+      }
+      auto present = [&](int i) -> bool { return (pm >> i) & 1u; };
+
+      if constexpr (STD) {
+        if (a.mode != MBPLS_SCALE_FIT && a.count) {
+          double c = 0.0;
+#pragma unroll
+          for (int i = 0; i < R; ++i) c += (present(i) && real(i)) ? 1.0 : 0.0;
+          c = group_sum<LG>(c);
+          if (writer) a.count[jj] = c;
+        }
+        if (a.mode != MBPLS_SCALE_NONE) {
+          double mean, scale;
+          if (a.mode == MBPLS_SCALE_FIT) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+              const bool use = present(i) && real(i);
+              s0 += use ? xc[i] : 0.0;
+              s1 += use ? 1.0 : 0.0;
+            }
+            s0 = group_sum<LG>(s0);
+            s1 = group_sum<LG>(s1);
+            const double cnt = s1;
+            mean = s0 / cnt;
+            double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+              const bool use = present(i) && real(i);
+              const double dlt = use ? xc[i] - mean : 0.0;
+              if (real(i)) xc[i] = xc[i] - mean;    // NaN stays NaN
+              c0 += dlt;
+              c1 = fma(dlt, dlt, c1);
+            }
+            c0 = group_sum<LG>(c0);
+            c1 = group_sum<LG>(c1);
+            const double var = (c1 - c0 * c0 / cnt) / cnt;
+            const double eps = 2.220446049250313e-16;
+            const double nme = cnt * mean * eps;
+            const double bound = cnt * eps * var + nme * nme;
+            scale = (var <= bound) ? 1.0 : sqrt(var);
+            if (writer) {
+              a.mean[jj] = mean;
+              a.scale[jj] = scale;
+              if (a.count) a.count[jj] = cnt;
+              if (a.var_out) a.var_out[jj] = (var <= bound) ? 0.0 : var;
+            }
+          } else {
+            mean = a.mean[jc];
+            scale = a.scale[jc];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+              if (real(i)) xc[i] = xc[i] - mean;
+          }
+#pragma unroll
+          for (int i = 0; i < R; ++i) xc[i] = xc[i] / scale;
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const double z = present(i) ? xc[i] : 0.0;
+          s = fma(z, z, s);                          // nansum(X^2), mbpls.py:826
+        }
+        if (valid) {
+          ssq_x += s;
+          store(xc, jj);
+        }
+      }
+
+      double gj = 0.0;
+      if constexpr (DEFL) {
+        double r5[SWEEP ? 5 : 2];
+#pragma unroll
+        for (int q = 0; q < (SWEEP ? 5 : 2); ++q) r5[q] = 0.0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const bool pr = present(i);
+          const double xz = pr ? xc[i] : 0.0;
+          const double tz = pr ? ts[i] : 0.0;
+          r5[0] = fma(xz, ts[i], r5[0]);
+          r5[1] = fma(tz, ts[i], r5[1]);
+          if constexpr (SWEEP) {
+            const double vz = pr ? v[i] : 0.0;
+            r5[2] = fma(xz, v[i], r5[2]);
+            r5[3] = fma(vz, v[i], r5[3]);
+            r5[4] = fma(tz, v[i], r5[4]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < (SWEEP ? 5 : 2); ++q) r5[q] = group_sum<LG>(r5[q]);
+        const double pj = (r5[1] != 0.0) ? r5[0] / r5[1] : 0.0;
+        if (valid) ssq_p = fma(pj, pj, ssq_p);
+        if (writer && a.pvec) a.pvec[jj] = pj;
+        if (a.deflate) {
+#pragma unroll
+          for (int i = 0; i < R; ++i) xc[i] = fma(-pj, ts[i], xc[i]);     // NaN stays NaN (:969)
+          if (valid) store(xc, jj);
+          if constexpr (SWEEP) gj = (r5[3] != 0.0) ? fma(-pj, r5[4], r5[2]) / r5[3] : 0.0;
+        } else {
+          if constexpr (SWEEP) gj = (r5[3] != 0.0) ? r5[2] / r5[3] : 0.0;
+        }
+      } else if constexpr (SWEEP) {
+        double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const bool pr = present(i);
+          r0 = fma(pr ? xc[i] : 0.0, v[i], r0);
+          r1 = fma(pr ? v[i] : 0.0, v[i], r1);
+        }
+        r0 = group_sum<LG>(r0);
+        r1 = group_sum<LG>(r1);
+        gj = (r1 != 0.0) ? r0 / r1 : 0.0;
+      }
+      if constexpr (SWEEP) {
+        if (!valid) gj = 0.0;
+        ssq_g = fma(gj, gj, ssq_g);
+        if (writer && a.g) a.g[jj] = gj;
+        const double g2 = gj * gj;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const bool pr = present(i);
+          acc[i] = fma(gj, pr ? xc[i] : 0.0, acc[i]);
+          dac[i] += pr ? g2 : 0.0;
+        }
+      }
+      if (rd + d + D < rounds) fetch(d, jj + NG * D);
+    }
+  }
+
+  if constexpr (STD) ssq_x = group_sum<LG>(ssq_x);
+  if (sub == 0) {
+    s_s[grp][0] = ssq_g;
+    s_s[grp][1] = ssq_p;
+    s_s[grp][2] = ssq_x;
+  }
+  if constexpr (SWEEP) {
+    for (int i = tid; i < SUB_MAX_N; i += 256) s_t[i] = s_dd[i] = 0.0;
+    __syncthreads();
+    for (int g = 0; g < NG; ++g) {
+      if (grp == g) {
+#pragma unroll
+        for (int k = 0; k < KR; ++k)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int r = 2 * (sub + LG * k) + h;
+            if (r < n) {
+              s_t[r] += acc[2 * k + h];
+              s_dd[r] += dac[2 * k + h];
+            }
+          }
+      }
+      __syncthreads();
+    }
+    double* out = a.part_t + (int64_t)chunk * n;
+    double* outd = a.part_d + (int64_t)chunk * n;
+    for (int i = tid; i < n; i += 256) {
+      out[i] = s_t[i];
+      outd[i] = s_dd[i];
+    }
+  } else {
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double sg = 0.0, sp = 0.0, sx = 0.0;
+    for (int g = 0; g < NG; ++g) {
+      sg += s_s[g][0];
+      sp += s_s[g][1];
+      sx += s_s[g][2];
+    }
+    double* ps = a.part_s + (int64_t)chunk * 4;
+    ps[0] = sg;
+    ps[1] = sp;
+    ps[2] = sx;
+    ps[3] = 0.0;
+  }
+}
+
+template <bool STD, bool DEFL, bool SWEEP>
+static void launch_nan_sub_t(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a) {
+  dim3 grid((unsigned)ct.nchunks), block(256);
+  if (a.n <= 64) hipLaunchKernelGGL((k_colpass_nan_sub<16, 2, 4, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
+  else if (a.n <= 128) hipLaunchKernelGGL((k_colpass_nan_sub<16, 4, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
+  else if (a.n <= 256) hipLaunchKernelGGL((k_colpass_nan_sub<16, 8, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_colpass_nan_sub<32, 8, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
+}
+
+int launch_nan_sub(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, bool STD, bool DEFL, bool SWEEP) {
+  if (STD && SWEEP) launch_nan_sub_t<true, false, true>(ctx, ct, a);
+  else if (STD) launch_nan_sub_t<true, false, false>(ctx, ct, a);
+  else if (DEFL && SWEEP) launch_nan_sub_t<false, true, true>(ctx, ct, a);
+  else if (DEFL) launch_nan_sub_t<false, true, false>(ctx, ct, a);
+  else launch_nan_sub_t<false, false, true>(ctx, ct, a);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
 }  // namespace mbpls

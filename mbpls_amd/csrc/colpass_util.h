@@ -219,6 +219,30 @@ struct PassArgs {
 constexpr int SUB_MAX_N = 512;
 int launch_pass_sub(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, bool STD, bool DEFL, bool SWEEP);
 
+// Arguments of a missing-value column pass (colpass_nan.hip; colpass_sub.hip for few samples).
+struct NanArgs {
+  const double* rowmask;   // standardise pass only: samples excluded from the fit (cross-validation folds)
+  double* var_out;
+  const double* src;
+  double* dst;
+  int64_t ld, n;
+  const int64_t* c0;
+  const int64_t* c1;
+  const double* v;    // sweep vector (u)
+  double* g;          // [p] un-normalised weights
+  const double* ts;   // superscore
+  int deflate;
+  double* pvec;       // [p] loadings
+  int mode;
+  double* mean;
+  double* scale;
+  double* count;      // [p] present samples per column (standardise pass, optional)
+  double* part_t;     // [nchunks][n]  A
+  double* part_d;     // [nchunks][n]  D
+  double* part_s;     // [nchunks][4]  ssq_g, ssq_p, ssq_x, -
+};
+int launch_nan_sub(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, bool STD, bool DEFL, bool SWEEP);
+
 // lazy deflation: at most KD - 1 previous components are corrected for inside a pass
 constexpr int KD = 40;
 

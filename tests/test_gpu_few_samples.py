@@ -102,3 +102,42 @@ def test_offset_data_and_row_subsets(gpu_required, n):
     for mdl in _both(ctx, lambda: MBPLS(n_components=3)._fit(dX, Y, mask)):
         assert util.compare(util.model_to_flat(mdl), util.model_to_flat(refm), TOL, what="fold") < 1e-9
     dX.close()
+
+
+@pytest.mark.parametrize("n,q", [(30, 1), (64, 2), (100, 1), (250, 2), (400, 1), (512, 1)])
+def test_missing_values(gpu_required, n, q):
+    """sparse_data=True: the masked passes (standardise + sweep, sweep, loadings + deflation + sweep) in their
+    column-group form, against the NaN-aware oracle and the one-column-per-workgroup kernels; a fold of such data too"""
+    import warnings
+
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix
+    from oracle import mbpls_oracle_sparse as ors
+    ctx = mbpls_amd.get_context()
+    p, K = 1100, 3
+    X, Y = orc.make_latent(n, p, q, seed=7 * n)
+    rng = np.random.RandomState(n)
+    X = X.copy()
+    X[rng.rand(n, p) < 0.04] = np.nan
+    blocks = [X[:, :500], X[:, 500:]]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = ors.fit(blocks, Y, n_components=K)
+        a, b = _both(ctx, lambda: MBPLS(n_components=K, sparse_data=True).fit(blocks, Y))
+    for mdl in (a, b):
+        w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"sparse n={n}")
+        assert w < 1e-8, w
+        assert mdl.nipals_iterations_ == ref.nipals_iterations_
+    assert util.compare(util.model_to_flat(a), util.model_to_flat(b), 1e-9, what="sub vs generic") < 1e-9
+    if q == 1:
+        mask = np.ones(n, dtype=bool)
+        mask[1::4] = False
+        dX = DeviceMatrix(ctx, n, p, [0, 500, p])
+        dX.upload(X, 0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            refm = ors.fit([X[mask][:, :500], X[mask][:, 500:]], Y[mask], n_components=2)
+            folds = _both(ctx, lambda: MBPLS(n_components=2, sparse_data=True)._fit(dX, Y, mask))
+        for mdl in folds:
+            assert util.compare(util.model_to_flat(mdl), util.model_to_flat(refm), TOL, what="sparse fold") < 1e-8
+        dX.close()
