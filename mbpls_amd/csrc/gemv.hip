@@ -140,6 +140,67 @@ __global__ __launch_bounds__(256) void k_xw(const double* __restrict__ X, int64_
   }
 }
 
+// The same product for FEW samples (n <= 256): a 512-row slab would leave most of the workgroup idle (n = 64: 32 of
+// 256 threads).  Here N2 = pow2 >= n/2 threads cover the row pairs and the other 256 / N2 "column lanes" take every
+// (256/N2)-th column of the chunk; the lanes' accumulators are added through LDS in lane order.
+template <int CB, bool SCALE, int NANM = 0>
+__global__ __launch_bounds__(256) void k_xw_small(const double* __restrict__ X, int64_t ld, int64_t n, int log2_n2,
+                                                  const int64_t* __restrict__ c0, const int64_t* __restrict__ c1,
+                                                  const double* __restrict__ W, int64_t ldw, int cb,
+                                                  const double* __restrict__ mean, const double* __restrict__ scale,
+                                                  double* __restrict__ part /* [nchunks][CB][n] */) {
+  __shared__ double s_acc[256 * CB * 2];
+  const int chunk = blockIdx.x, tid = threadIdx.x;
+  const int n2 = 1 << log2_n2, CL = 256 >> log2_n2;
+  const int rp = tid & (n2 - 1), cl = tid >> log2_n2;
+  const int64_t r0 = 2 * (int64_t)rp;
+  const int64_t j0 = c0[chunk], j1 = c1[chunk];
+  const bool in0 = r0 < n, in1 = r0 + 1 < n, inld = r0 < ld;
+  double acc[CB][2];
+#pragma unroll
+  for (int q = 0; q < CB; ++q) acc[q][0] = acc[q][1] = 0.0;
+#pragma unroll 4
+  for (int64_t j = j0 + cl; j < j1; j += CL) {
+    double2 t = make_double2(0.0, 0.0);
+    if (inld) t = *reinterpret_cast<const double2*>(X + j * ld + r0);
+    double x0 = in0 ? t.x : 0.0, x1 = in1 ? t.y : 0.0;
+    if constexpr (SCALE) {
+      const double mu = mean[j], rsc = scale[j];     // reciprocals (k_recip)
+      x0 = in0 ? (x0 - mu) * rsc : 0.0;
+      x1 = in1 ? (x1 - mu) * rsc : 0.0;
+    }
+    if constexpr (NANM == 1) {
+      x0 = (x0 == x0) ? x0 : 0.0;
+      x1 = (x1 == x1) ? x1 : 0.0;
+    } else if constexpr (NANM == 2) {
+      x0 = (in0 && x0 == x0) ? 1.0 : 0.0;
+      x1 = (in1 && x1 == x1) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {
+      const double w = (q < cb) ? W[q * ldw + j] : 0.0;
+      acc[q][0] = fma(w, x0, acc[q][0]);
+      acc[q][1] = fma(w, x1, acc[q][1]);
+    }
+  }
+  // s_acc[cl][q][row]: 256 * CB * 2 doubles whatever n2 is
+#pragma unroll
+  for (int q = 0; q < CB; ++q) {
+    s_acc[((cl * CB + q) << (log2_n2 + 1)) + 2 * rp] = acc[q][0];
+    s_acc[((cl * CB + q) << (log2_n2 + 1)) + 2 * rp + 1] = acc[q][1];
+  }
+  __syncthreads();
+  double* out = part + (int64_t)chunk * CB * n;
+  for (int e = tid; e < CB * 2 * n2; e += 256) {
+    const int q = e >> (log2_n2 + 1), row = e & (2 * n2 - 1);
+    if (row < n) {
+      double sum = 0.0;
+      for (int l = 0; l < CL; ++l) sum += s_acc[((l * CB + q) << (log2_n2 + 1)) + row];
+      out[(int64_t)q * n + row] = sum;
+    }
+  }
+}
+
 // out[(b or 0)][q][i] = sum over chunks (of block b, or all) of part[chunk][q][i], fixed order.
 //   grid (ceil(n/64), cb, blocks), 256 threads: lane = row, wave w takes chunks cs+w, cs+w+4, ... with four independent
 //   accumulators (16 loads in flight per row -- the sum is latency-bound), LDS combine in wave order.
@@ -307,11 +368,22 @@ static int x_w_impl(const mbpls_mat* m, const double* d_W, int64_t ldw, int c, i
     const int cb = std::min(CB, c - k0);
     const double* W = d_W + (int64_t)k0 * ldw;
     dim3 grid((unsigned)ct.nchunks, slabs);
+    const bool small = m->n <= 256 && ctx->sub_columns;
+    int log2_n2 = 4;                                      // row-pair threads: 16 .. 128
+    while ((2 << log2_n2) < m->n) ++log2_n2;
     {
     ProfScope prof(ctx, MBPLS_K_X_W, 8.0 * (double)m->n * (double)m->p);
 #define MB_XW(SC_, NM_)                                                                                            \
-  hipLaunchKernelGGL((k_xw<CB, SC_, NM_>), grid, dim3(256), 0, ctx->stream, (const double*)m->data, m->ld, m->n,   \
-                     (const int64_t*)ct.d_c0, (const int64_t*)ct.d_c1, W, ldw, cb, d_mean, d_scale, part)
+  do {                                                                                                             \
+    if (small)                                                                                                     \
+      hipLaunchKernelGGL((k_xw_small<CB, SC_, NM_>), dim3((unsigned)ct.nchunks), dim3(256), 0, ctx->stream,        \
+                         (const double*)m->data, m->ld, m->n, log2_n2, (const int64_t*)ct.d_c0,                    \
+                         (const int64_t*)ct.d_c1, W, ldw, cb, d_mean, d_scale, part);                              \
+    else                                                                                                           \
+      hipLaunchKernelGGL((k_xw<CB, SC_, NM_>), grid, dim3(256), 0, ctx->stream, (const double*)m->data, m->ld,     \
+                         m->n, (const int64_t*)ct.d_c0, (const int64_t*)ct.d_c1, W, ldw, cb, d_mean, d_scale,      \
+                         part);                                                                                    \
+  } while (0)
     if (nanm == 2) MB_XW(false, 2);                       // the indicator needs no scaling
     else if (nanm == 1 && d_mean) MB_XW(true, 1);
     else if (nanm == 1) MB_XW(false, 1);

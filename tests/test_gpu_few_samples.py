@@ -141,3 +141,26 @@ def test_missing_values(gpu_required, n, q):
         for mdl in folds:
             assert util.compare(util.model_to_flat(mdl), util.model_to_flat(refm), TOL, what="sparse fold") < 1e-8
         dX.close()
+
+
+@pytest.mark.parametrize("n", [20, 64, 100, 256])
+def test_predict_and_transform_products(gpu_required, n):
+    """X W products (predict, transform, block scores) with the row pairs x column lanes mapping of k_xw_small"""
+    import mbpls_amd
+    from mbpls_amd import MBPLS
+    from tests.test_gpu_parity import _fit_flat
+    ctx = mbpls_amd.get_context()
+    X, Y = orc.make_latent(n, 1300, 3, seed=n + 1)
+    blocks = [X[:, :500], X[:, 500:]]
+    Xn, Yn = orc.make_latent(n, 1300, 3, seed=n + 2)        # new data with as few samples
+    bn = [Xn[:, :500], Xn[:, 500:]]
+    for method in ("NIPALS", "KERNEL"):
+        ref = orc.fit(blocks, Y, n_components=3, method=method)
+        flat = util.model_to_flat(ref)
+        flat["predict"] = orc.predict(ref, bn)
+        Ts, T, U = orc.transform(ref, bn, Yn, return_block_scores=True)
+        flat["Ts_new"], flat["U_new"] = Ts, U
+        for b, blk in enumerate(T):
+            flat[f"T_new/{b}"] = blk
+        for mdl_flat in _both(ctx, lambda: _fit_flat(MBPLS(n_components=3, method=method).fit(blocks, Y), bn, Yn)):
+            assert util.compare(mdl_flat, flat, TOL, what=f"{method} n={n}") < 1e-8
