@@ -1,4 +1,4 @@
-// Column passes for FEW samples (n <= 512) -- the everyday shape of multiblock PLS: tens to hundreds of samples,
+// Column passes for FEW samples (n <= 1024) -- the everyday shape of multiblock PLS: tens to hundreds of samples,
 // up to millions of features.  colpass.hip gives a column to a workgroup; with a 0.5-2 KB column its per-column
 // reduction (six DPP steps, a barrier, the scalar algebra) is all latency and the pass runs at 0.8-2.7 TB/s.
 //
@@ -35,10 +35,11 @@ __device__ __forceinline__ double half32_sum(double v) {
 template <int LG>
 __device__ __forceinline__ double group_sum(double v) {
   if constexpr (LG == 16) return row16_sum(v);
-  else return half32_sum(v);
+  else if constexpr (LG == 32) return half32_sum(v);
+  else return wave_sum(v);      // one column per wave (512 < n <= 1024): still no barrier, no LDS per column
 }
 
-// LG lanes per column (16: four columns per wave, n <= 32 KR; 32: two columns per wave, n <= 64 KR)
+// LG lanes per column (16: four columns per wave, n <= 32 KR; 32: two per wave, n <= 64 KR; 64: one, n <= 128 KR)
 template <int LG, int KR, int D, bool STD, bool DEFL, bool SWEEP, bool ISTD, bool CEN>
 __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
   constexpr int R = 2 * KR;
@@ -419,7 +420,8 @@ static void launch_sub(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a) 
   if (a.n <= 64) launch_sub_kr<16, 2, 4, STD, DEFL, SWEEP>(ctx, ct, a);
   else if (a.n <= 128) launch_sub_kr<16, 4, 2, STD, DEFL, SWEEP>(ctx, ct, a);
   else if (a.n <= 256) launch_sub_kr<16, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
-  else launch_sub_kr<32, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (a.n <= 512) launch_sub_kr<32, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else launch_sub_kr<64, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
 }
 
 int launch_pass_sub(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, bool STD, bool DEFL, bool SWEEP) {
@@ -705,7 +707,8 @@ static void launch_nan_sub_t(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs
   if (a.n <= 64) hipLaunchKernelGGL((k_colpass_nan_sub<16, 2, 4, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
   else if (a.n <= 128) hipLaunchKernelGGL((k_colpass_nan_sub<16, 4, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
   else if (a.n <= 256) hipLaunchKernelGGL((k_colpass_nan_sub<16, 8, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
-  else hipLaunchKernelGGL((k_colpass_nan_sub<32, 8, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
+  else if (a.n <= 512) hipLaunchKernelGGL((k_colpass_nan_sub<32, 8, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_colpass_nan_sub<64, 8, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
 }
 
 int launch_nan_sub(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, bool STD, bool DEFL, bool SWEEP) {

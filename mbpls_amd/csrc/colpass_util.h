@@ -216,7 +216,7 @@ struct PassArgs {
 };
 
 // colpass_sub.hip: the same passes for n <= SUB_MAX_N samples, several columns per wave (KD is used there: keep it above)
-constexpr int SUB_MAX_N = 512;
+constexpr int SUB_MAX_N = 1024;
 int launch_pass_sub(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, bool STD, bool DEFL, bool SWEEP);
 
 // Arguments of a missing-value column pass (colpass_nan.hip; colpass_sub.hip for few samples).
