@@ -1,5 +1,5 @@
-"""GPU parity for FEW samples (n <= 512): csrc/colpass_sub.hip -- four columns per wave on 16-lane DPP rows (n <= 256),
-two on half waves (n <= 512).  Every flavour of the column pass has a counterpart there; each is checked against the
+"""GPU parity for FEW samples (n <= 1024): csrc/colpass_sub.hip -- four columns per wave on 16-lane DPP rows (n <= 256),
+two on half waves (n <= 512), one per wave without any barrier (n <= 1024).  Every flavour of the column pass has a counterpart there; each is checked against the
 oracle and against the one-column-per-workgroup kernels (tunable sub_columns = 0) on the same data.
 Tolerance 1e-6 relative, sign-aligned."""
 import numpy as np
@@ -24,7 +24,7 @@ def _both(ctx, make):
     return out
 
 
-@pytest.mark.parametrize("n", [17, 64, 65, 128, 129, 200, 256, 257, 300, 511, 512])
+@pytest.mark.parametrize("n", [17, 64, 65, 128, 129, 200, 256, 257, 300, 511, 512, 513, 700, 1024])
 @pytest.mark.parametrize("method", ["NIPALS", "UNIPALS"])
 def test_one_response_never_writes_x(gpu_required, method, n):
     """the device-resident queue: statistics-only first pass, lazy sweep, lazy loadings + sweep, loadings only"""
@@ -42,7 +42,7 @@ def test_one_response_never_writes_x(gpu_required, method, n):
     assert util.compare(util.model_to_flat(a), util.model_to_flat(b), 1e-9, what="sub vs generic") < 1e-10
 
 
-@pytest.mark.parametrize("n,K", [(100, 20), (300, 38)])
+@pytest.mark.parametrize("n,K", [(100, 20), (300, 38), (600, 38)])
 def test_many_lazy_corrections(gpu_required, n, K):
     """kprev beyond the lanes of a column group: a lane carries components s, s + 16, s + 32 (s, s + 32 on half waves)"""
     import mbpls_amd
@@ -59,7 +59,7 @@ def test_many_lazy_corrections(gpu_required, n, K):
     assert util.compare(util.model_to_flat(a), util.model_to_flat(b), TOL, what="sub vs generic") < TOL
 
 
-@pytest.mark.parametrize("n", [40, 150, 400])
+@pytest.mark.parametrize("n", [40, 150, 400, 900])
 @pytest.mark.parametrize("env", [{"MBPLS_DEFLATION": "explicit", "MBPLS_IMPLICIT_STD": "0"},
                                  {"MBPLS_IMPLICIT_STD": "0"}, {"MBPLS_RESIDENT": "0"}])
 def test_storing_and_host_driven_flavours(gpu_required, monkeypatch, n, env):
@@ -104,7 +104,7 @@ def test_offset_data_and_row_subsets(gpu_required, n):
     dX.close()
 
 
-@pytest.mark.parametrize("n,q", [(30, 1), (64, 2), (100, 1), (250, 2), (400, 1), (512, 1)])
+@pytest.mark.parametrize("n,q", [(30, 1), (64, 2), (100, 1), (250, 2), (400, 1), (512, 1), (800, 1)])
 def test_missing_values(gpu_required, n, q):
     """sparse_data=True: the masked passes (standardise + sweep, sweep, loadings + deflation + sweep) in their
     column-group form, against the NaN-aware oracle and the one-column-per-workgroup kernels; a fold of such data too"""
