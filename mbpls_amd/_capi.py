@@ -243,7 +243,7 @@ class Context:
         check(self.lib.mbpls_hip_device_info(self.handle, name, 256, C.byref(cus), C.byref(tot), C.byref(free)))
         return dict(name=name.value.decode(), compute_units=cus.value, total_bytes=tot.value, free_bytes=free.value)
 
-    long_columns_from = 8192     # mirrors the C default; n above it -> streamed-column passes
+    long_columns_from = 8192     # mirrors the C default; n above it -> two-phase long-column passes
 
     def set_tunable(self, key, value):
         check(self.lib.mbpls_hip_set_tunable(self.handle, key.encode(), int(value)))
