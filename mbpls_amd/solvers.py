@@ -195,6 +195,36 @@ def _subspace_loop_host(G, Y, c0, norm, tol, max_iter):
             return run, True, ts, u, v, c_used
 
 
+def _subspace_loop_qspace(G, Y, c0, tol, max_iter):
+    """The same loop for LONG score vectors (n > 8192, where the kernel's LDS-resident form does not apply) and the
+    2-norm stop rule, entirely in q x q algebra: with M1 = G^T G, M2 = Y^T G, M3 = Y^T Y every quantity of an iteration
+    is a function of c -- ||G c||^2 = c^T M1 c, v = M2 c~ (c~ = c/||G c||, ts^T ts = 1), ||Y v||^2 = v^T M3 v -- and
+    the stop rule ||ts_old - ts|| = ||G (c~_old - c~)|| = sqrt(d^T M1 d) is taken on the DIFFERENCE of the
+    coefficient vectors (formed in q dimensions, so it resolves 1e-14 where 2 - 2 cos would stop at 1e-8).
+    An iteration costs O(q^2) instead of five passes over n x q arrays (n = 10^6: 10 ms each, hundreds per component)."""
+    M1, M2, M3 = G.T.dot(G), Y.T.dot(G), Y.T.dot(Y)
+    c = np.asarray(c0, dtype=np.float64).reshape(-1, 1)
+    ct_old, run, diff = None, 0, 1.0
+    while True:
+        run += 1
+        c_used = c
+        ct = c / np.sqrt(c.T.dot(M1).dot(c).item())         # ts = G c~, unit length (:882-883)
+        if run > 1:
+            d = ct_old - ct
+            diff = np.sqrt(max(d.T.dot(M1).dot(d).item(), 0.0))                 # (:887)
+        ct_old = ct
+        v = M2.dot(ct)                                      # (:899)
+        vv = v.T.dot(v).item()
+        un = np.sqrt(v.T.dot(M3).dot(v).item()) / vv        # ||Y v / v^T v|| (:911-913)
+        c = v / vv / un
+        if (run >= 2 and diff <= tol) or run >= max_iter:
+            ts = G.dot(ct)
+            ts = ts / np.linalg.norm(ts)
+            u = Y.dot(v) / vv
+            u = u / np.linalg.norm(u)
+            return run, not (run >= 2 and diff <= tol), ts, u, Y.T.dot(ts) / ts.T.dot(ts), c_used
+
+
 def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter):
     """mbpls.py:809-993 with the inner loop (:841-913) in the q-dimensional space of its iterates.  Per component:
     G = P X (X^T (P Y)) (xt_v + x_w with q right-hand sides), the loop (one kernel launch / numpy), then ONE more pass:
@@ -224,6 +254,8 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
         G0 = eng.x_w_slot("S", 0, q)                        # X X^T P Y
         G = G0 - Tp.dot(Tp.T.dot(G0))
         out = eng.nipals_subspace_loop(G, Y, c0, kind, max_tol, max_iter) if hasattr(eng, "nipals_subspace_loop") else None
+        if out is None and kind == 0 and n > 8192:
+            out = _subspace_loop_qspace(G, Y, c0, max_tol, max_iter)
         if out is None:
             out = _subspace_loop_host(G, Y, c0, norm, max_tol, max_iter)
         n_it, capped, ts, u, v, c_used = out

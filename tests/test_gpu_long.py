@@ -65,6 +65,7 @@ def test_fixture_matrix_with_streamed_columns(forced_long, fixture):
     ("NIPALS", 1001, 3000, 2, 3, [1000, 2000]),
     ("UNIPALS", 777, 2500, 1, 3, [2500]),
     ("NIPALS", 100_000, 300, 1, 3, [100, 200]),       # genuinely long columns (n > 65536), n >= p
+    ("NIPALS", 30_000, 260, 3, 2, [100, 160]),         # several responses: the inner loop in q x q algebra
     ("UNIPALS", 100_000, 240, 2, 3, [240]),
     ("KERNEL", 70_001, 200, 1, 3, [80, 120]),
     ("SIMPLS", 90_000, 150, 2, 3, [150]),
