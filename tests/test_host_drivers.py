@@ -97,3 +97,23 @@ def test_recyclable_host_buffers_refcount_rule():
     assert sorted(a.ctypes.data for a in pool) == sorted([p_addr, b_addr])
     assert w_addr not in [a.ctypes.data for a in pool] and held_view.base is not None and held_whole is not None
     assert len(stale) == 1 and isinstance(stale[0], list) and stale[0][0].shape == (5, 2)   # small arrays stay
+
+
+@pytest.mark.parametrize("n,q,seed", [(9000, 2, 0), (20000, 3, 1), (12000, 5, 2)])
+def test_subspace_loop_in_q_space_matches_the_n_vector_loop(n, q, seed):
+    """solvers._subspace_loop_qspace (tall data, several responses: the NIPALS inner loop on q x q matrices, stop rule on
+    the difference of the coefficient vectors) against the n-vector form of the same loop: iteration counts and iterates."""
+    rng = np.random.default_rng(seed)
+    T = rng.standard_normal((n, q + 1))
+    Y = T[:, :q] @ rng.standard_normal((q, q)) + 0.05 * rng.standard_normal((n, q))
+    Y = (Y - Y.mean(0)) / Y.std(0)
+    X = T @ rng.standard_normal((q + 1, 40)) + 0.3 * rng.standard_normal((n, 40))
+    X -= X.mean(0)
+    G = X @ (X.T @ Y)
+    c0 = np.zeros((q, 1)); c0[0] = 1.0
+    a = solvers._subspace_loop_host(G, Y, c0, 2, 1e-14, 10000)
+    b = solvers._subspace_loop_qspace(G, Y, c0, 1e-14, 10000)
+    assert not a[1] and not b[1]
+    assert abs(a[0] - b[0]) <= 2, (a[0], b[0])               # the stop test sits at the rounding floor of both forms
+    for i in (2, 3, 4, 5):
+        assert np.abs(a[i] - b[i]).max() <= 1e-11 * np.abs(a[i]).max()
