@@ -32,14 +32,24 @@ __device__ __forceinline__ double half32_sum(double v) {
   const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
   return v + __hiloint2double(hi, lo);
 }
+// sum over 8 lanes (half a DPP row: n <= 64, eight columns per wave -- the per-column scalar algebra costs the same
+// whatever the column length, so the shortest columns are VALU-issue bound and want the most columns per instruction)
+__device__ __forceinline__ double oct8_sum(double v) {
+  v += dpp_move<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141, 0xf>(v);   // row_half_mirror
+  return v;
+}
 template <int LG>
 __device__ __forceinline__ double group_sum(double v) {
-  if constexpr (LG == 16) return row16_sum(v);
+  if constexpr (LG == 8) return oct8_sum(v);
+  else if constexpr (LG == 16) return row16_sum(v);
   else if constexpr (LG == 32) return half32_sum(v);
   else return wave_sum(v);      // one column per wave (512 < n <= 1024): still no barrier, no LDS per column
 }
 
-// LG lanes per column (16: four columns per wave, n <= 32 KR; 32: two per wave, n <= 64 KR; 64: one, n <= 128 KR)
+// LG lanes per column (8: eight columns per wave, n <= 16 KR; 16: four, n <= 32 KR; 32: two, n <= 64 KR; 64: one,
+// n <= 128 KR)
 template <int LG, int KR, int D, bool STD, bool DEFL, bool SWEEP, bool ISTD, bool CEN>
 __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
   constexpr int R = 2 * KR;
@@ -417,7 +427,8 @@ static void launch_sub_kr(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& 
 
 template <bool STD, bool DEFL, bool SWEEP>
 static void launch_sub(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a) {
-  if (a.n <= 64) launch_sub_kr<16, 2, 4, STD, DEFL, SWEEP>(ctx, ct, a);
+  if (a.n <= 32) launch_sub_kr<8, 2, 4, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (a.n <= 64) launch_sub_kr<8, 4, 2, STD, DEFL, SWEEP>(ctx, ct, a);
   else if (a.n <= 128) launch_sub_kr<16, 4, 2, STD, DEFL, SWEEP>(ctx, ct, a);
   else if (a.n <= 256) launch_sub_kr<16, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
   else if (a.n <= 512) launch_sub_kr<32, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
@@ -704,7 +715,8 @@ __global__ __launch_bounds__(256) void k_colpass_nan_sub(NanArgs a) {
 template <bool STD, bool DEFL, bool SWEEP>
 static void launch_nan_sub_t(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a) {
   dim3 grid((unsigned)ct.nchunks), block(256);
-  if (a.n <= 64) hipLaunchKernelGGL((k_colpass_nan_sub<16, 2, 4, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
+  if (a.n <= 32) hipLaunchKernelGGL((k_colpass_nan_sub<8, 2, 4, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
+  else if (a.n <= 64) hipLaunchKernelGGL((k_colpass_nan_sub<8, 4, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
   else if (a.n <= 128) hipLaunchKernelGGL((k_colpass_nan_sub<16, 4, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
   else if (a.n <= 256) hipLaunchKernelGGL((k_colpass_nan_sub<16, 8, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
   else if (a.n <= 512) hipLaunchKernelGGL((k_colpass_nan_sub<32, 8, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
