@@ -425,13 +425,25 @@ static void launch_sub_kr(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& 
   else hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, false, false>), grid, block, 0, ctx->stream, a);
 }
 
+// (lanes per column, row pairs per lane) by n: the tightest cover of the column -- lanes past the end of a column
+// still issue their (clamped, cached) loads and their share of every reduction.  64 < n <= 128: the statistics and
+// sweep-only flavours gain 5-19 % from 8-lane groups, the fused loadings + sweep (ts and v in registers) loses 10-15 %.
 template <bool STD, bool DEFL, bool SWEEP>
 static void launch_sub(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a) {
-  if (a.n <= 32) launch_sub_kr<8, 2, 4, STD, DEFL, SWEEP>(ctx, ct, a);
-  else if (a.n <= 64) launch_sub_kr<8, 4, 2, STD, DEFL, SWEEP>(ctx, ct, a);
-  else if (a.n <= 128) launch_sub_kr<16, 4, 2, STD, DEFL, SWEEP>(ctx, ct, a);
-  else if (a.n <= 256) launch_sub_kr<16, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
-  else if (a.n <= 512) launch_sub_kr<32, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  const int64_t n = a.n;
+  constexpr bool NARROW = !DEFL;
+  if (n <= 32) launch_sub_kr<8, 2, 4, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (n <= 48) launch_sub_kr<8, 3, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (n <= 64) launch_sub_kr<8, 4, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (n <= 96 && NARROW) launch_sub_kr<8, 6, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (n <= 96) launch_sub_kr<16, 3, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (n <= 128 && NARROW) launch_sub_kr<8, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (n <= 128) launch_sub_kr<16, 4, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (n <= 192) launch_sub_kr<16, 6, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (n <= 256) launch_sub_kr<16, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (n <= 384) launch_sub_kr<32, 6, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (n <= 512) launch_sub_kr<32, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
+  else if (n <= 768) launch_sub_kr<64, 6, 2, STD, DEFL, SWEEP>(ctx, ct, a);
   else launch_sub_kr<64, 8, 2, STD, DEFL, SWEEP>(ctx, ct, a);
 }
 
@@ -715,12 +727,21 @@ __global__ __launch_bounds__(256) void k_colpass_nan_sub(NanArgs a) {
 template <bool STD, bool DEFL, bool SWEEP>
 static void launch_nan_sub_t(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a) {
   dim3 grid((unsigned)ct.nchunks), block(256);
-  if (a.n <= 32) hipLaunchKernelGGL((k_colpass_nan_sub<8, 2, 4, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
-  else if (a.n <= 64) hipLaunchKernelGGL((k_colpass_nan_sub<8, 4, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
-  else if (a.n <= 128) hipLaunchKernelGGL((k_colpass_nan_sub<16, 4, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
-  else if (a.n <= 256) hipLaunchKernelGGL((k_colpass_nan_sub<16, 8, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
-  else if (a.n <= 512) hipLaunchKernelGGL((k_colpass_nan_sub<32, 8, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
-  else hipLaunchKernelGGL((k_colpass_nan_sub<64, 8, 2, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a);
+  const int64_t n = a.n;
+#define MB_NS(LG_, KR_, D_) \
+  hipLaunchKernelGGL((k_colpass_nan_sub<LG_, KR_, D_, STD, DEFL, SWEEP>), grid, block, 0, ctx->stream, a)
+  if (n <= 32) MB_NS(8, 2, 4);
+  else if (n <= 48) MB_NS(8, 3, 2);
+  else if (n <= 64) MB_NS(8, 4, 2);
+  else if (n <= 96) MB_NS(16, 3, 2);
+  else if (n <= 128) MB_NS(16, 4, 2);
+  else if (n <= 192) MB_NS(16, 6, 2);
+  else if (n <= 256) MB_NS(16, 8, 2);
+  else if (n <= 384) MB_NS(32, 6, 2);
+  else if (n <= 512) MB_NS(32, 8, 2);
+  else if (n <= 768) MB_NS(64, 6, 2);
+  else MB_NS(64, 8, 2);
+#undef MB_NS
 }
 
 int launch_nan_sub(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, bool STD, bool DEFL, bool SWEEP) {

@@ -24,7 +24,7 @@ def _both(ctx, make):
     return out
 
 
-@pytest.mark.parametrize("n", [17, 64, 65, 128, 129, 200, 256, 257, 300, 511, 512, 513, 700, 1024])
+@pytest.mark.parametrize("n", [17, 40, 64, 65, 90, 128, 129, 150, 192, 200, 256, 257, 300, 384, 511, 512, 513, 700, 768, 1024])
 @pytest.mark.parametrize("method", ["NIPALS", "UNIPALS"])
 def test_one_response_never_writes_x(gpu_required, method, n):
     """the device-resident queue: statistics-only first pass, lazy sweep, lazy loadings + sweep, loadings only"""
@@ -59,7 +59,7 @@ def test_many_lazy_corrections(gpu_required, n, K):
     assert util.compare(util.model_to_flat(a), util.model_to_flat(b), TOL, what="sub vs generic") < TOL
 
 
-@pytest.mark.parametrize("n", [40, 150, 400, 900])
+@pytest.mark.parametrize("n", [40, 90, 150, 400, 700, 900])
 @pytest.mark.parametrize("env", [{"MBPLS_DEFLATION": "explicit", "MBPLS_IMPLICIT_STD": "0"},
                                  {"MBPLS_IMPLICIT_STD": "0"}, {"MBPLS_RESIDENT": "0"}])
 def test_storing_and_host_driven_flavours(gpu_required, monkeypatch, n, env):
@@ -104,7 +104,8 @@ def test_offset_data_and_row_subsets(gpu_required, n):
     dX.close()
 
 
-@pytest.mark.parametrize("n,q", [(30, 1), (64, 2), (100, 1), (250, 2), (400, 1), (512, 1), (800, 1)])
+@pytest.mark.parametrize("n,q", [(30, 1), (45, 1), (64, 2), (90, 1), (100, 1), (150, 1), (250, 2), (350, 1), (400, 1), (512, 1),
+                                 (700, 1), (800, 1)])
 def test_missing_values(gpu_required, n, q):
     """sparse_data=True: the masked passes (standardise + sweep, sweep, loadings + deflation + sweep) in their
     column-group form, against the NaN-aware oracle and the one-column-per-workgroup kernels; a fold of such data too"""
