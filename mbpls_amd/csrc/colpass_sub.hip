@@ -93,17 +93,35 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
         o[2 * k + h] = (r < n) ? p[r] : 0.0;
       }
   };
-  double v[SWEEP ? R : 1], ts[DEFL ? R : 1], acc[SWEEP ? R : 1];
+  // The fused loadings + sweep flavour with many row pairs per lane would hold x[2], ts, v and acc in registers
+  // (290 VGPRs at KR = 8: one wave per SIMD); its two n-vectors live in LDS instead, as (ts_r, v_r) pairs -- every
+  // lane re-reads its own rows each round (the groups of a wave read the same addresses: broadcast).
+  constexpr bool VEC_LDS = DEFL && SWEEP && KR >= 6;
+  __shared__ double2 s_tv[VEC_LDS ? SUB_MAX_N : 1];
+  double v[(SWEEP && !VEC_LDS) ? R : 1], ts[(DEFL && !VEC_LDS) ? R : 1], acc[SWEEP ? R : 1];
+  if constexpr (VEC_LDS) {
+    for (int r = tid; r < SUB_MAX_N; r += 256) s_tv[r] = (r < n) ? make_double2(a.ts[r], a.v[r]) : make_double2(0.0, 0.0);
+    __syncthreads();
+  } else {
+    if constexpr (SWEEP) vec(v, a.v);
+    if constexpr (DEFL) vec(ts, a.ts);
+  }
   if constexpr (SWEEP) {
-    vec(v, a.v);
 #pragma unroll
     for (int i = 0; i < R; ++i) acc[i] = 0.0;
   }
-  if constexpr (DEFL) vec(ts, a.ts);
+  // (ts, v) of this lane's i-th row
+  auto tv = [&](int i) -> double2 {
+    if constexpr (VEC_LDS) return s_tv[2 * (sub + LG * (i >> 1)) + (i & 1)];
+    else return make_double2(DEFL ? ts[DEFL ? i : 0] : 0.0, SWEEP ? v[SWEEP ? i : 0] : 0.0);
+  };
   double tsv = 0.0;
   if constexpr (DEFL && SWEEP) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) tsv = fma(ts[i], v[i], tsv);
+    for (int i = 0; i < R; ++i) {
+      const double2 q = tv(i);
+      tsv = fma(q.x, q.y, tsv);
+    }
     tsv = group_sum<LG>(tsv);
   }
   const double dn = (STD && a.rowmask) ? a.n_eff : (double)n;
@@ -291,8 +309,13 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          ab0 = fma(xc[i], ts[i], ab0);
-          if constexpr (SWEEP) ab1 = fma(xc[i], v[i], ab1);
+          // LDS form: fetch the vectors four rows at a time, just before use (a compiler barrier keeps it from
+          // hoisting all 2R values into registers again, which is what the LDS copy is there to avoid)
+          if constexpr (VEC_LDS)
+            if ((i & 3) == 0) asm volatile("" ::: "memory");
+          const double2 q = tv(i);
+          ab0 = fma(xc[i], q.x, ab0);
+          if constexpr (SWEEP) ab1 = fma(xc[i], q.y, ab1);
         }
         ab0 = group_sum<LG>(ab0);
         if constexpr (SWEEP) ab1 = group_sum<LG>(ab1);
@@ -302,7 +325,11 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
         if (a.deflate) {
           if (!lazy) {
 #pragma unroll
-            for (int i = 0; i < R; ++i) xc[i] = fma(-pj, ts[i], xc[i]);
+            for (int i = 0; i < R; ++i) {
+              if constexpr (VEC_LDS)
+                if ((i & 3) == 0) asm volatile("" ::: "memory");
+              xc[i] = fma(-pj, tv(i).x, xc[i]);
+            }
             if (valid) {
               double* out = a.dst + jj * ld;
 #pragma unroll

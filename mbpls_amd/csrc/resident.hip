@@ -32,6 +32,7 @@ struct StepGrid {
   int G;                  // workgroups
   unsigned* bar;          // grid barrier counter, zeroed before the launch
   double* gpart;          // [2][G][16] per-workgroup totals, two alternating sets
+  double* par;            // par[7] = 1: a barrier timed out (the host raises)
 };
 
 __device__ __forceinline__ void grid_barrier(const StepGrid& sg, unsigned& epoch) {
@@ -44,7 +45,11 @@ __device__ __forceinline__ void grid_barrier(const StepGrid& sg, unsigned& epoch
     unsigned spins = 0;
     while (__hip_atomic_load(sg.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 28)) break;   // never on a healthy queue: do not hang the device if a workgroup is missing
+      if (++spins > (1u << 28)) {        // never on a healthy queue: do not hang the device if a workgroup is missing
+        sg.par[7] = 1.0;
+        sg.par[2] = 1.0;                 // everything queued behind becomes a no-op
+        break;
+      }
     }
     __threadfence();
   }
@@ -427,6 +432,7 @@ int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
     if (!ctx->step_ws) MB_HIP(hipMalloc(&ctx->step_ws, need));
     sg.bar = (unsigned*)ctx->step_ws;
     sg.gpart = (double*)((char*)ctx->step_ws + 256);
+    sg.par = s->par;
     MB_HIP(hipMemsetAsync(sg.bar, 0, 256, ctx->stream));
   }
   hipLaunchKernelGGL(k_nipals_step, dim3((unsigned)sg.G), dim3(WG1024), 0, ctx->stream, *s, sg);

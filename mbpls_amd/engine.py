@@ -1019,6 +1019,10 @@ class _ResidentQueue:
                 if key != "Tsc" or eng._istd:
                     b.free()
 
+        if par[7] != 0.0:
+            free_all()
+            raise _capi.HipError("device-resident fit: a grid barrier of the step kernel timed out (the workgroups of "
+                                 "one launch were not co-resident -- is another stream occupying the GPU?)")
         if par[2] != 0.0 and par[5] == 1.0:
             # offset data (max |mean|/scale = sqrt(par[6])): the caller queues again, now with centring passes
             eng._cen = True
