@@ -520,13 +520,31 @@ __global__ __launch_bounds__(256) void k_colpass_nan_sub(NanArgs a) {
         o[2 * k + h] = (r < n) ? p[r] : 0.0;
       }
   };
-  double v[SWEEP ? R : 1], ts[DEFL ? R : 1], acc[SWEEP ? R : 1], dac[SWEEP ? R : 1];
+  // many row pairs per lane: the n-vectors live in LDS as (ts_r, v_r) pairs and are fetched just before use (see
+  // k_colpass_sub): x[2], acc, dac and both vectors in registers cost 280-306 VGPRs, one wave per SIMD
+  constexpr bool VEC_LDS = KR >= 6 && (SWEEP || DEFL);
+  __shared__ double2 s_tv[VEC_LDS ? SUB_MAX_N : 1];
+  double v[(SWEEP && !VEC_LDS) ? R : 1], ts[(DEFL && !VEC_LDS) ? R : 1], acc[SWEEP ? R : 1], dac[SWEEP ? R : 1];
+  if constexpr (VEC_LDS) {
+    for (int r = tid; r < SUB_MAX_N; r += 256)
+      s_tv[r] = (r < n) ? make_double2(DEFL ? a.ts[r] : 0.0, SWEEP ? a.v[r] : 0.0) : make_double2(0.0, 0.0);
+    __syncthreads();
+  } else {
+    if constexpr (SWEEP) vec(v, a.v);
+    if constexpr (DEFL) vec(ts, a.ts);
+  }
   if constexpr (SWEEP) {
-    vec(v, a.v);
 #pragma unroll
     for (int i = 0; i < R; ++i) acc[i] = dac[i] = 0.0;
   }
-  if constexpr (DEFL) vec(ts, a.ts);
+  auto tv = [&](int i) -> double2 {
+    if constexpr (VEC_LDS) {
+      if ((i & 3) == 0) asm volatile("" ::: "memory");      // keeps the compiler from hoisting all 2R values again
+      return s_tv[2 * (sub + LG * (i >> 1)) + (i & 1)];
+    } else {
+      return make_double2(DEFL ? ts[DEFL ? i : 0] : 0.0, SWEEP ? v[SWEEP ? i : 0] : 0.0);
+    }
+  };
   double ssq_g = 0.0, ssq_p = 0.0, ssq_x = 0.0;
 
   double x[D][R];
@@ -651,15 +669,16 @@ __global__ __launch_bounds__(256) void k_colpass_nan_sub(NanArgs a) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
           const bool pr = present(i);
+          const double2 q2 = tv(i);
           const double xz = pr ? xc[i] : 0.0;
-          const double tz = pr ? ts[i] : 0.0;
-          r5[0] = fma(xz, ts[i], r5[0]);
-          r5[1] = fma(tz, ts[i], r5[1]);
+          const double tz = pr ? q2.x : 0.0;
+          r5[0] = fma(xz, q2.x, r5[0]);
+          r5[1] = fma(tz, q2.x, r5[1]);
           if constexpr (SWEEP) {
-            const double vz = pr ? v[i] : 0.0;
-            r5[2] = fma(xz, v[i], r5[2]);
-            r5[3] = fma(vz, v[i], r5[3]);
-            r5[4] = fma(tz, v[i], r5[4]);
+            const double vz = pr ? q2.y : 0.0;
+            r5[2] = fma(xz, q2.y, r5[2]);
+            r5[3] = fma(vz, q2.y, r5[3]);
+            r5[4] = fma(tz, q2.y, r5[4]);
           }
         }
 #pragma unroll
@@ -669,7 +688,7 @@ __global__ __launch_bounds__(256) void k_colpass_nan_sub(NanArgs a) {
         if (writer && a.pvec) a.pvec[jj] = pj;
         if (a.deflate) {
 #pragma unroll
-          for (int i = 0; i < R; ++i) xc[i] = fma(-pj, ts[i], xc[i]);     // NaN stays NaN (:969)
+          for (int i = 0; i < R; ++i) xc[i] = fma(-pj, tv(i).x, xc[i]);   // NaN stays NaN (:969)
           if (valid) store(xc, jj);
           if constexpr (SWEEP) gj = (r5[3] != 0.0) ? fma(-pj, r5[4], r5[2]) / r5[3] : 0.0;
         } else {
@@ -680,8 +699,9 @@ __global__ __launch_bounds__(256) void k_colpass_nan_sub(NanArgs a) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
           const bool pr = present(i);
-          r0 = fma(pr ? xc[i] : 0.0, v[i], r0);
-          r1 = fma(pr ? v[i] : 0.0, v[i], r1);
+          const double vi = tv(i).y;
+          r0 = fma(pr ? xc[i] : 0.0, vi, r0);
+          r1 = fma(pr ? vi : 0.0, vi, r1);
         }
         r0 = group_sum<LG>(r0);
         r1 = group_sum<LG>(r1);
