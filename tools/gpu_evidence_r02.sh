@@ -1,5 +1,5 @@
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02p
+O=$R/gpurun_out/r02q
 mkdir -p $O
 cd $R
 python bench.py > $O/bench_full.log 2>&1; echo bench rc=$?; tail -1 $O/bench_full.log > $O/r02_bench_c2_line.json

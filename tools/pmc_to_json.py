@@ -14,7 +14,7 @@ import os
 import shutil
 import sys
 
-root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02p/pmc"
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02q/pmc"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 p = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

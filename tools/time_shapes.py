@@ -15,7 +15,7 @@ gb = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
 method = sys.argv[2] if len(sys.argv) > 2 else "NIPALS"
 q = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 ctx = mbpls_amd.get_context()
-for n in (40, 64, 100, 128, 200, 256, 300, 500, 1000, 1024, 2048, 3000, 4096, 5000, 8192, 12000):
+for n in (40, 64, 100, 128, 200, 256, 300, 500, 1000, 1024, 1200, 1500, 1800, 2048, 2500, 3000, 3500, 4096, 5000, 6000, 8192, 12000):
     p = int(gb * 1e9 / 8 / n)
     Ts, Y = planted(n, q, 16, 0)
     X = DeviceMatrix(ctx, n, p, [0, p // 3, p])
