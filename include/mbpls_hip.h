@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 2   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise */
+#define MBPLS_HIP_ABI_VERSION 3   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw */
 
 enum {
   MBPLS_OK = 0,
@@ -240,6 +240,12 @@ int mbpls_hip_loadings_sweep_lazy_scaled(const mbpls_mat* m, const double* d_ts,
                                          double* d_t, double* d_ssq_g, const double* d_P, int64_t ldp, int kprev,
                                          const double* d_cu, const double* d_ce, double* d_d,
                                          const double* d_r2, const double* d_mean);
+/* The same pass WITHOUT deflating: p~ = inv_tt X^T ts and, from the same read, the sweep g~ = alpha X^T v,
+ * t_b = sum_j c_j x_j of the UNDEFLATED raw matrix (several responses: X is standardised implicitly and never
+ * deflated, mbpls_amd/solvers.py _fit_nipals_subspace).  Arguments as above with kprev = 0.                      */
+int mbpls_hip_loadings_sweep_raw(const mbpls_mat* m, const double* d_ts, double inv_tt, double* d_p, double* d_ssq_p,
+                                 const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g,
+                                 const double* d_r2, const double* d_mean);
 /* d_C[j, k] = d_A[j, k] * d_r[j] for a p x c column-major array (row scaling; raw-space -> true loadings).      */
 int mbpls_hip_scale_rows(mbpls_ctx* ctx, int64_t p, int c, const double* d_A, int64_t lda, const double* d_r,
                          double* d_C, int64_t ldc);

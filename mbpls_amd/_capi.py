@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmbpls_hip.so")
 ROW_MAJOR, COL_MAJOR = 0, 1
 COMM_ID_BYTES = 128
 SCALE_FIT, SCALE_APPLY, SCALE_NONE = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i64, _dbl, _int, _sz = C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
@@ -80,6 +80,7 @@ SIGNATURES = {
     "mbpls_hip_sweep_lazy_scaled": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "mbpls_hip_loadings_sweep_lazy_scaled": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int,
                                                     _vp, _vp, _vp, _vp, _vp]),
+    "mbpls_hip_loadings_sweep_raw": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_loadings_sweep_lazy": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int,
                                              _vp, _vp, _vp]),
     "mbpls_hip_xt_v": (_int, [_vp, _vp, _i64, _int, _dbl, _vp, _i64, _vp]),
@@ -466,6 +467,11 @@ class DeviceMatrix:
         check(self.ctx.lib.mbpls_hip_loadings_sweep_lazy(self.handle, _ptr(ts), float(inv_tt), _ptr(p), _ptr(ssq_p),
                                                          _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g),
                                                          _ptr(P), int(ldp), int(kprev), _ptr(cu), _ptr(ce), _ptr(d)))
+
+    def loadings_sweep_raw(self, ts, inv_tt, p, ssq_p, v, alpha, g, t, ssq_g, r2, mean=None):
+        check(self.ctx.lib.mbpls_hip_loadings_sweep_raw(self.handle, _ptr(ts), float(inv_tt), _ptr(p), _ptr(ssq_p),
+                                                        _ptr(v), float(alpha), _ptr(g), _ptr(t), _ptr(ssq_g),
+                                                        _ptr(r2), _ptr(mean)))
 
     def xt_v(self, V, c, alpha, G, ssq=None, ldv=None, ldg=None, mean=None, rscale=None):
         if mean is not None:      # raw matrix, standardised on the fly

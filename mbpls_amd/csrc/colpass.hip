@@ -657,6 +657,25 @@ int mbpls_hip_loadings_sweep_lazy_scaled(const mbpls_mat* m, const double* d_ts,
   return MBPLS_OK;
 }
 
+int mbpls_hip_loadings_sweep_raw(const mbpls_mat* m, const double* d_ts, double inv_tt, double* d_p, double* d_ssq_p,
+                                 const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g,
+                                 const double* d_r2, const double* d_mean) {
+  MB_ARG(m && d_ts && d_v && d_t && d_r2, "NULL argument");
+  mbpls_ctx* ctx = m->ctx;
+  if (long_columns(ctx, m->n)) return long_loadings_sweep_raw(m, d_ts, inv_tt, d_p, d_ssq_p, d_v, alpha, d_g, d_t,
+                                                              d_ssq_g, d_r2, d_mean);
+  PassArgs a{};
+  MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s, &a.part_d));
+  a.src = m->data; a.dst = m->data; a.ld = m->ld; a.n = m->n;
+  a.c0 = m->fine.d_c0; a.c1 = m->fine.d_c1;
+  a.ts = d_ts; a.inv_tt = inv_tt; a.deflate = 0; a.pvec = d_p;     // the sweep sees the matrix as it is
+  a.v = d_v; a.alpha = alpha; a.g = d_g;
+  a.lazy = 1; a.kprev = 0;                                         // lazy = nothing is ever stored
+  a.ir2 = d_r2; a.mu = d_mean;
+  MB_TRY((launch_pass<false, true, true>(ctx, m->fine, a, m->p)));
+  return reduce_chunks(ctx, m, a.part_t, a.part_s, d_t, d_ssq_g, d_ssq_p, nullptr);
+}
+
 int mbpls_hip_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode, double* d_mean, double* d_scale,
                                 double* d_ssq_x, const double* d_v, double alpha, double* d_g, double* d_t,
                                 double* d_ssq_g) {

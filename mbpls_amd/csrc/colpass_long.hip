@@ -648,6 +648,13 @@ int long_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double inv_
                              d_ssq_g, d_P, ldp, kprev, d_cu, d_ce, d_v ? d_d : nullptr, d_r2, d_mean);
 }
 
+int long_loadings_sweep_raw(const mbpls_mat* m, const double* d_ts, double inv_tt, double* d_p, double* d_ssq_p,
+                            const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g,
+                            const double* d_r2, const double* d_mean) {
+  return long_loadings_sweep(const_cast<mbpls_mat*>(m), d_ts, inv_tt, 0, 0, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g,
+                             nullptr, 0, 0, nullptr, nullptr, nullptr, d_r2, d_mean);
+}
+
 int long_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode, const double* d_rowmask, double n_eff,
                            double* d_mean, double* d_scale, double* d_ssq_x, const double* d_v, double alpha,
                            double* d_g, double* d_t, double* d_ssq_g) {

@@ -262,6 +262,9 @@ int long_loadings_sweep_lazy(const mbpls_mat* m, const double* d_ts, double inv_
                              const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g,
                              const double* d_P, int64_t ldp, int kprev, const double* d_cu, const double* d_ce,
                              double* d_d, const double* d_r2, const double* d_mean);
+int long_loadings_sweep_raw(const mbpls_mat* m, const double* d_ts, double inv_tt, double* d_p, double* d_ssq_p,
+                            const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g,
+                            const double* d_r2, const double* d_mean);
 int long_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_mean, double* d_scale, double* d_rscale,
                                  double* d_r2, double* d_ssq_x, double* d_amp, const double* d_v, double alpha,
                                  double* d_g, double* d_t, double* d_ssq_g);

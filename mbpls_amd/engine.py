@@ -547,6 +547,22 @@ class HipEngine:
                 self.run_deferred()
             t, g, p, _ = self._finish_pass(v is not None, v is not None, True, False)
             return p, t, g
+        if self._kscale and not self._lazy_pslot:
+            # statistics-only preparation (prepare_stats): X is the caller's RAW matrix and is never deflated either
+            # (several responses, solvers._fit_nipals_subspace) -- loadings and sweep in raw-column space, one read
+            assert not deflate and v is not None and p_slot is not None and g_slot is not None
+            dts, dv = self._put_vec(1, self._centre(ts)), self._put_vec(0, self._centre(v))
+            self.X.loadings_sweep_raw(dts, inv_tt, self._slot_col(p_slot), self._xptr(n * B + B), dv, alpha,
+                                      self._slot_col(g_slot), self._xptr(0), self._xptr(n * B), self.r2,
+                                      mean=self.mean if self._cen else None)
+            self._scale_col(p_slot, p_slot)              # p~ -> p, g~ -> g
+            self._scale_col(g_slot, g_slot)
+            if overlap is not None:
+                overlap()
+            else:
+                self.run_deferred()
+            t, g, p, _ = self._finish_pass(True, True, True, False)
+            return p, t - t.mean(axis=0), g
         if self._lazy_pslot:
             assert p_slot is not None and p_slot[0] == self._lazy_pslot and p_slot[1] == len(self._lazy_ts)
             k = len(self._lazy_ts)

@@ -237,7 +237,12 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     if hasattr(eng, "use_lazy_deflation"):
         eng.use_lazy_deflation(K, "P", prefer="explicit")   # X is never deflated here: the plain (stored) passes
         eng._lazy_pslot = None
-    varxb, _, _ = eng.prepare(standardize)
+    if hasattr(eng, "prepare_stats") and eng.stats_only_ok():
+        # no room for a standardised working copy (or forced): statistics only, the three passes of a component
+        # standardise their operand in registers and the caller's matrix is never written
+        varxb = eng.prepare_stats(standardize)
+    else:
+        varxb, _, _ = eng.prepare(standardize)
     varx = varxb.sum()
     vary = (Y ** 2).sum()
     Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))

@@ -742,6 +742,49 @@ def test_kernel_method_never_writes_x(gpu_required, monkeypatch, offset, standar
     Xd.close()
 
 
+@pytest.mark.parametrize("offset,standardize,n", [(0.0, True, 640), (300.0, True, 200), (0.0, False, 640), (0.0, True, 9000)])
+def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, offset, standardize, n):
+    """NIPALS with several responses when a standardised working copy does not fit (forced here): statistics-only
+    preparation, then per component X^T (P Y), X (X^T P Y) with the operand standardised in registers and ONE raw-space
+    pass for the loadings, the weights of the last sweep vector and their block scores (mbpls_hip_loadings_sweep_raw:
+    no deflation) -- against the oracle and the stored path, with the caller's matrix bit-identical afterwards.
+    n = 9000: the two-phase long-column form of the same pass."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix
+    from mbpls_amd.engine import HipEngine
+    p = 3001 if n < 8192 else 400
+    X, Y = orc.make_latent(n, p, 3, seed=5)
+    X = X + offset * (1.0 + np.arange(p) % 4)
+    offs = [0, p // 3, p]
+    Xs = [np.ascontiguousarray(X[:, a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    ref = orc.fit(Xs, Y, n_components=3, standardize=standardize)
+    used = []
+    real = HipEngine.prepare_stats
+
+    def spy(self, *a, **k):
+        used.append(True)
+        return real(self, *a, **k)
+
+    monkeypatch.setattr(HipEngine, "prepare_stats", spy)
+    monkeypatch.setenv("MBPLS_KERNEL_IMPLICIT", "1")
+    ctx = mbpls_amd.get_context()
+    Xd = DeviceMatrix(ctx, n, p, offs)
+    Xd.upload(X)
+    mdl = MBPLS(n_components=3, standardize=standardize).fit(Xd, Y)
+    if n <= 8192:                                            # (the statistics-only policy covers register-resident n)
+        assert used == [True]
+    assert np.array_equal(Xd.download(), X)
+    tol = max(1e-8, 1e4 * offset * np.finfo(float).eps)
+    assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="q=3 never-writes-X") < tol
+    assert [abs(a - b) <= 2 for a, b in zip(mdl.nipals_iterations_, ref.nipals_iterations_)] == [True] * 3
+    monkeypatch.setenv("MBPLS_KERNEL_IMPLICIT", "0")
+    used.clear()
+    m2 = MBPLS(n_components=3, standardize=standardize).fit(Xd, Y)
+    assert used == []
+    assert util.compare(util.model_to_flat(m2), util.model_to_flat(mdl), TOL, what="stored vs never-writes-X") < tol
+    Xd.close()
+
+
 @pytest.mark.parametrize("nodeflate", ["1", "0"])
 def test_unipals_several_responses_never_deflates(gpu_required, monkeypatch, nodeflate):
     """UNIPALS, p > n, q > 1: by default X is standardised once and never deflated (X_k = P X_0, P = I - Ts Ts^T applied
