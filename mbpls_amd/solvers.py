@@ -161,6 +161,16 @@ def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_hos
 
 
 # ----------------------------------------------------------------------------------- NIPALS
+def _prepare_products(eng, standardize):
+    """a1 for the solvers whose X-sized work is products on a matrix that is never deflated (several-response NIPALS /
+    UNIPALS, SIMPLS): a standardised working copy when it fits -- else (or when forced, MBPLS_KERNEL_IMPLICIT)
+    statistics only: the products standardise their operand in registers and the caller's matrix is never written.
+    Returns the per-block sums of squares of the standardised matrix."""
+    if hasattr(eng, "prepare_stats") and eng.stats_only_ok():
+        return eng.prepare_stats(standardize)
+    return eng.prepare(standardize)[0]
+
+
 def _nipals_on_subspace(eng, q):
     """Several responses make NIPALS iterate 50-500 times per component.  Every sweep vector of the loop is u = Y c and
     the super score it yields is ts ~ P (sum_b X_b X_b^T) P u (P = I - Ts Ts^T carries the deflation), so with
@@ -237,12 +247,7 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     if hasattr(eng, "use_lazy_deflation"):
         eng.use_lazy_deflation(K, "P", prefer="explicit")   # X is never deflated here: the plain (stored) passes
         eng._lazy_pslot = None
-    if hasattr(eng, "prepare_stats") and eng.stats_only_ok():
-        # no room for a standardised working copy (or forced): statistics only, the three passes of a component
-        # standardise their operand in registers and the caller's matrix is never written
-        varxb = eng.prepare_stats(standardize)
-    else:
-        varxb, _, _ = eng.prepare(standardize)
+    varxb = _prepare_products(eng, standardize)
     varx = varxb.sum()
     vary = (Y ** 2).sum()
     Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
@@ -584,7 +589,7 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
     if hasattr(eng, "use_lazy_deflation"):
         eng.use_lazy_deflation(K, "P", prefer="explicit")   # plain passes on the stored X; nothing is deflated
         eng._lazy_pslot = None
-    varxb, _, _ = eng.prepare(standardize)
+    varxb = _prepare_products(eng, standardize)
     varx = varxb.sum()
     vary = (Y ** 2).sum()
     F = _psd_factor(Y.T.dot(Y))
@@ -967,7 +972,7 @@ def fit_simpls(eng, Y, K, standardize):
     q = Y.shape[1]
     if K + 1 + q > 32 or not hasattr(eng, "right_mul"):
         return _fit_simpls_hostvec(eng, Y, K, standardize)
-    eng.prepare(standardize)
+    _prepare_products(eng, standardize)
     nz = K + 1 + q
     cS = K + 1                                              # first S column inside Z
     eng.slot("Z", nz); eng.slot("R", K); eng.slot("W", K); eng.slot("P", K)
@@ -1018,7 +1023,7 @@ def _fit_simpls_hostvec(eng, Y, K, standardize):
     device helpers)."""
     n = eng.n
     q = Y.shape[1]
-    eng.prepare(standardize)
+    _prepare_products(eng, standardize)
     eng.slot("S", q); eng.slot("r", 1); eng.slot("p", 1)
     eng.xt_v(Y, 1.0, "S", 0)
     S = eng.fetch("S")                                      # (:998)

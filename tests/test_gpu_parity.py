@@ -742,9 +742,12 @@ def test_kernel_method_never_writes_x(gpu_required, monkeypatch, offset, standar
     Xd.close()
 
 
-@pytest.mark.parametrize("offset,standardize,n", [(0.0, True, 640), (300.0, True, 200), (0.0, False, 640), (0.0, True, 9000)])
-def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, offset, standardize, n):
-    """NIPALS with several responses when a standardised working copy does not fit (forced here): statistics-only
+@pytest.mark.parametrize("method,offset,standardize,n", [
+    ("NIPALS", 0.0, True, 640), ("NIPALS", 300.0, True, 200), ("NIPALS", 0.0, False, 640), ("NIPALS", 0.0, True, 9000),
+    ("UNIPALS", 0.0, True, 640), ("UNIPALS", 300.0, True, 200), ("SIMPLS", 0.0, True, 640), ("SIMPLS", 300.0, True, 200),
+    ("SIMPLS", 0.0, False, 640)])
+def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, method, offset, standardize, n):
+    """Several responses (NIPALS, UNIPALS) and SIMPLS when a standardised working copy does not fit (forced here): statistics-only
     preparation, then per component X^T (P Y), X (X^T P Y) with the operand standardised in registers and ONE raw-space
     pass for the loadings, the weights of the last sweep vector and their block scores (mbpls_hip_loadings_sweep_raw:
     no deflation) -- against the oracle and the stored path, with the caller's matrix bit-identical afterwards.
@@ -757,7 +760,7 @@ def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, offs
     X = X + offset * (1.0 + np.arange(p) % 4)
     offs = [0, p // 3, p]
     Xs = [np.ascontiguousarray(X[:, a:b]) for a, b in zip(offs[:-1], offs[1:])]
-    ref = orc.fit(Xs, Y, n_components=3, standardize=standardize)
+    ref = orc.fit(Xs, Y, n_components=3, method=method, standardize=standardize, full_svd=True)
     used = []
     real = HipEngine.prepare_stats
 
@@ -770,16 +773,17 @@ def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, offs
     ctx = mbpls_amd.get_context()
     Xd = DeviceMatrix(ctx, n, p, offs)
     Xd.upload(X)
-    mdl = MBPLS(n_components=3, standardize=standardize).fit(Xd, Y)
+    mdl = MBPLS(n_components=3, method=method, standardize=standardize, full_svd=True).fit(Xd, Y)
     if n <= 8192:                                            # (the statistics-only policy covers register-resident n)
         assert used == [True]
     assert np.array_equal(Xd.download(), X)
     tol = max(1e-8, 1e4 * offset * np.finfo(float).eps)
-    assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="q=3 never-writes-X") < tol
-    assert [abs(a - b) <= 2 for a, b in zip(mdl.nipals_iterations_, ref.nipals_iterations_)] == [True] * 3
+    assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} q=3 never-writes-X") < tol
+    if method == "NIPALS":
+        assert [abs(a - b) <= 2 for a, b in zip(mdl.nipals_iterations_, ref.nipals_iterations_)] == [True] * 3
     monkeypatch.setenv("MBPLS_KERNEL_IMPLICIT", "0")
     used.clear()
-    m2 = MBPLS(n_components=3, standardize=standardize).fit(Xd, Y)
+    m2 = MBPLS(n_components=3, method=method, standardize=standardize, full_svd=True).fit(Xd, Y)
     assert used == []
     assert util.compare(util.model_to_flat(m2), util.model_to_flat(mdl), TOL, what="stored vs never-writes-X") < tol
     Xd.close()
