@@ -1,4 +1,4 @@
-"""Pass bandwidth across sample counts at a fixed matrix size (default 8 GB): python tools/time_shapes.py [GB] [method] [responses]
+"""Pass bandwidth across sample counts at a fixed matrix size (default 8 GB): python tools/time_shapes.py [GB] [method] [responses] [n,n,...]
 Few samples x very many features is the everyday shape of multiblock PLS (spectra, omics)."""
 import os
 import sys
@@ -15,7 +15,10 @@ gb = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
 method = sys.argv[2] if len(sys.argv) > 2 else "NIPALS"
 q = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 ctx = mbpls_amd.get_context()
-for n in (40, 64, 100, 128, 200, 256, 300, 500, 1000, 1024, 1200, 1500, 1800, 2048, 2500, 3000, 3500, 4096, 5000, 6000, 8192, 12000):
+sizes = (40, 64, 100, 128, 200, 256, 300, 500, 1000, 1024, 1200, 1500, 1800, 2048, 2500, 3000, 3500, 4096, 5000, 6000, 8192, 12000)
+if len(sys.argv) > 4:
+    sizes = tuple(int(x) for x in sys.argv[4].split(","))
+for n in sizes:
     p = int(gb * 1e9 / 8 / n)
     Ts, Y = planted(n, q, 16, 0)
     X = DeviceMatrix(ctx, n, p, [0, p // 3, p])
