@@ -28,6 +28,12 @@ constexpr int RS_KMAX = 40;   // == KD of colpass.hip (lazily deflated component
 // itself); the reductions become two-level -- per-workgroup totals through HBM, a grid barrier, every workgroup adds the
 // G partials in the same order and so takes the same branches.  One workgroup (n up to a few ten thousand) needs none
 // of it.  The G <= 128 workgroups of 1024 threads are co-resident on the 256 CUs (nothing else runs on the stream).
+// workgroups of a step: one per STEP_ROWS_PER_WG rows, co-resident (at most one per CU).  Measured at n = 10^6:
+// 355 us per step with 61 or 128 workgroups, 790 us with 244 -- the ~10 grid barriers of a step (each a release /
+// acquire pair at agent scope: L2 write-back and invalidate on every XCD) are what a step costs, not its row loops.
+constexpr int STEP_MAX_WG = 128;
+constexpr int STEP_ROWS_PER_WG = 16384;
+
 struct StepGrid {
   int G;                  // workgroups
   unsigned* bar;          // grid barrier counter, zeroed before the launch
@@ -426,9 +432,9 @@ int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
   // one workgroup up to 32768 rows (latency-bound, ~50 us); beyond that the n-vector traffic dominates (4 ms at
   // n = 10^6 on one CU): spread the rows over up to 128 workgroups with grid-wide reductions
   StepGrid sg{};
-  sg.G = (int)std::max<int64_t>(1, std::min<int64_t>(128, s->n / 16384));
+  sg.G = (int)std::max<int64_t>(1, std::min<int64_t>(STEP_MAX_WG, s->n / STEP_ROWS_PER_WG));
   if (sg.G > 1) {
-    const size_t need = 256 + sizeof(double) * 2 * 128 * 16;
+    const size_t need = 256 + sizeof(double) * 2 * STEP_MAX_WG * 16;
     if (!ctx->step_ws) MB_HIP(hipMalloc(&ctx->step_ws, need));
     sg.bar = (unsigned*)ctx->step_ws;
     sg.gpart = (double*)((char*)ctx->step_ws + 256);
