@@ -29,8 +29,8 @@ constexpr int RS_KMAX = 40;   // == KD of colpass.hip (lazily deflated component
 // G partials in the same order and so takes the same branches.  One workgroup (n up to a few ten thousand) needs none
 // of it.  The G <= 128 workgroups of 1024 threads are co-resident on the 256 CUs (nothing else runs on the stream).
 // workgroups of a step: one per STEP_ROWS_PER_WG rows, co-resident (at most one per CU).  Measured at n = 10^6:
-// 355 us per step with 61 or 128 workgroups, 790 us with 244 -- the ~10 grid barriers of a step (each a release /
-// acquire pair at agent scope: L2 write-back and invalidate on every XCD) are what a step costs, not its row loops.
+// 355 us per step with 61 or 128 workgroups, 790 us with 244 (barrier contention); 334 us once the barrier stopped
+// fencing the L2 -- what remains is the latency of ~ten dependent row loops (16 rows per thread) plus ten barriers.
 constexpr int STEP_MAX_WG = 128;
 constexpr int STEP_ROWS_PER_WG = 16384;
 
@@ -42,14 +42,18 @@ struct StepGrid {
 };
 
 __device__ __forceinline__ void grid_barrier(const StepGrid& sg, unsigned& epoch) {
+  // The only data that crosses workgroups are the per-workgroup totals and this counter.  They live in FINE-GRAINED
+  // device memory (uncached: hipDeviceMallocFinegrained) and are accessed with relaxed agent-scope atomics, so no
+  // release / acquire fence is needed -- at agent scope those write back and invalidate the whole L2 of every XCD,
+  // with the n-vectors of the step dirty in it (355 -> 334 us per step at n = 10^6, ten barriers).
+  // __syncthreads() orders the workgroup's total stores (completed: s_waitcnt) before thread 0 signals.
   epoch += 1;               // every thread counts: the alternating partial sets are chosen from it
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned target = epoch * (unsigned)sg.G;
-    __threadfence();
-    __hip_atomic_fetch_add(sg.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(sg.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0;
-    while (__hip_atomic_load(sg.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (__hip_atomic_load(sg.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
       if (++spins > (1u << 28)) {        // never on a healthy queue: do not hang the device if a workgroup is missing
         sg.par[7] = 1.0;
@@ -57,7 +61,6 @@ __device__ __forceinline__ void grid_barrier(const StepGrid& sg, unsigned& epoch
         break;
       }
     }
-    __threadfence();
   }
   __syncthreads();
 }
@@ -435,7 +438,7 @@ int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
   sg.G = (int)std::max<int64_t>(1, std::min<int64_t>(STEP_MAX_WG, s->n / STEP_ROWS_PER_WG));
   if (sg.G > 1) {
     const size_t need = 256 + sizeof(double) * 2 * STEP_MAX_WG * 16;
-    if (!ctx->step_ws) MB_HIP(hipMalloc(&ctx->step_ws, need));
+    if (!ctx->step_ws) MB_HIP(hipExtMallocWithFlags(&ctx->step_ws, need, hipDeviceMallocFinegrained));
     sg.bar = (unsigned*)ctx->step_ws;
     sg.gpart = (double*)((char*)ctx->step_ws + 256);
     sg.par = s->par;
