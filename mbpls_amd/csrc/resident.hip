@@ -88,6 +88,9 @@ __device__ __forceinline__ void grid_sum(double (&v)[M], int m, double* part, do
   __syncthreads();           // tot[] is reused by the next reduction
 }
 
+// BM / QM: compile-time bounds of the per-block / per-response register arrays (the common few-blocks, one-response
+// case must not carry 6 x 16 doubles per thread: at 1024 threads that is the whole register file)
+template <int BM, int QM>
 __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, StepGrid sg) {
   __shared__ double part[16 * 16];       // wave partials of reduce_many
   __shared__ double tot[16];
@@ -132,15 +135,15 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   }
 
   // ---- t~_b = A_b - Ts d_b (lazy deflation), its mean (implicit standardisation), t~_b^T u, u^T u
-  double sum_t[RS_BMAX], tu[RS_BMAX], mu[4] = {0.0, 0.0, 0.0, 0.0};
+  double sum_t[BM], tu[BM], mu[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int b = 0; b < RS_BMAX; ++b) sum_t[b] = tu[b] = 0.0;
+  for (int b = 0; b < BM; ++b) sum_t[b] = tu[b] = 0.0;
   for (int64_t i = gtid; i < n; i += gstride) {
     const double ui = s.u_cur[i];
     mu[0] = fma(ui, ui, mu[0]);
     mu[1] += ui;
 #pragma unroll
-    for (int b = 0; b < RS_BMAX; ++b)
+    for (int b = 0; b < BM; ++b)
       if (b < B) {
         double t = tr[(int64_t)b * n + i];
         for (int j = 0; j < nd; ++j) t = fma(-s.Tsc[(int64_t)j * n + i], dd[b * nd + j], t);
@@ -149,16 +152,16 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
         tu[b] = fma(t, ui, tu[b]);
       }
   }
-  if (istd) grid_sum<RS_BMAX>(sum_t, B, part, tot, sg, epoch);
-  grid_sum<RS_BMAX>(tu, B, part, tot, sg, epoch);
+  if (istd) grid_sum<BM>(sum_t, B, part, tot, sg, epoch);
+  grid_sum<BM>(tu, B, part, tot, sg, epoch);
   grid_sum<4>(mu, 2, part, tot, sg, epoch);
   const double uu = mu[0], su = mu[1];
 
   // ---- t_b = t~_b / ||w~_b|| (:860, :875-877);  sw = T^T u / u^T u, unit length (:879-880)
-  double sw[RS_BMAX], mean_t[RS_BMAX], nu[RS_BMAX];
+  double sw[BM], mean_t[BM], nu[BM];
   double sw2 = 0.0;
 #pragma unroll
-  for (int b = 0; b < RS_BMAX; ++b) {
+  for (int b = 0; b < BM; ++b) {
     sw[b] = mean_t[b] = 0.0;
     nu[b] = 1.0;
     if (b < B) {
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   }
   const double swn = sqrt(sw2);
 #pragma unroll
-  for (int b = 0; b < RS_BMAX; ++b) sw[b] = sw[b] / swn;
+  for (int b = 0; b < BM; ++b) sw[b] = sw[b] / swn;
 
   // ---- ts = T sw, unit length (:882-883); scratch in vpass (the pass that read it has finished)
   //      UNIPALS: ts = sum_b X_b (X_b^T y), unit length; the block scores are scaled once c is known
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   for (int64_t i = gtid; i < n; i += gstride) {
     double acc = 0.0;
 #pragma unroll
-    for (int b = 0; b < RS_BMAX; ++b)
+    for (int b = 0; b < BM; ++b)
       if (b < B) {
         if (uni) {
           acc += tb[(int64_t)b * n + i] - mean_t[b];
@@ -197,9 +200,9 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   // ---- diff = ||ts_old - ts|| (:887), Y^T ts, ts^T ts
   double d4[4] = {0.0, 0.0, 0.0, 0.0};
   double dmax = 0.0, dmin = 1.0e300;
-  double yv[RS_QMAX];
+  double yv[QM];
 #pragma unroll
-  for (int j = 0; j < RS_QMAX; ++j) yv[j] = 0.0;
+  for (int j = 0; j < QM; ++j) yv[j] = 0.0;
   for (int64_t i = gtid; i < n; i += gstride) {
     const double t = s.vpass[i] / tsn;
     const double d = s.ts_old[i] - t;
@@ -211,11 +214,11 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
     dmax = fmax(dmax, fabs(d));
     dmin = fmin(dmin, fabs(d));
 #pragma unroll
-    for (int j = 0; j < RS_QMAX; ++j)
+    for (int j = 0; j < QM; ++j)
       if (j < q) yv[j] = fma(s.Y[(int64_t)j * n + i], t, yv[j]);
   }
   grid_sum<4>(d4, 4, part, tot, sg, epoch);
-  grid_sum<RS_QMAX>(yv, q, part, tot, sg, epoch);
+  grid_sum<QM>(yv, q, part, tot, sg, epoch);
   double diff;
   if (s.norm_kind == 0) diff = sqrt(d4[0]);
   else if (s.norm_kind == 1) diff = d4[1];
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   // ---- v = Y^T ts / ts^T ts (:899);  u = Y v / v^T v, unit length (:911-913); scratch in tspass
   double vv = 0.0;
 #pragma unroll
-  for (int j = 0; j < RS_QMAX; ++j)
+  for (int j = 0; j < QM; ++j)
     if (j < q) {
       yv[j] = yv[j] / d4[2];
       vv = fma(yv[j], yv[j], vv);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   for (int64_t i = gtid; i < n; i += gstride) {
     double w = 0.0;
 #pragma unroll
-    for (int j = 0; j < RS_QMAX; ++j)
+    for (int j = 0; j < QM; ++j)
       if (j < q) w = fma(s.Y[(int64_t)j * n + i], yv[j], w);
     w = w / vv;
     s.tspass[i] = w;
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   if (uni) {
     for (int64_t i = gtid; i < n; i += gstride)
 #pragma unroll
-      for (int b = 0; b < RS_BMAX; ++b)
+      for (int b = 0; b < BM; ++b)
         if (b < B) tb[(int64_t)b * n + i] = c_uni * (tb[(int64_t)b * n + i] - mean_t[b]) / sqrt(c_uni * c_uni * ssq_g[b]);
   }
 
@@ -354,10 +357,10 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   dots(s.vpass, s.cu);     // j < kc only: the component being deflated is handled inside the pass (its <ts, v>)
   dots(s.tspass, s.ce);
 #pragma unroll
-  for (int j = 0; j < RS_QMAX; ++j)
+  for (int j = 0; j < QM; ++j)
     if (j < q && lead) s.V[(int64_t)kc * q + j] = yv[j];
 #pragma unroll
-  for (int b = 0; b < RS_BMAX; ++b)
+  for (int b = 0; b < BM; ++b)
     if (b < B && lead) {
       if (uni) {
         double tot_w = 0.0;
@@ -444,7 +447,10 @@ int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
     sg.par = s->par;
     MB_HIP(hipMemsetAsync(sg.bar, 0, 256, ctx->stream));
   }
-  hipLaunchKernelGGL(k_nipals_step, dim3((unsigned)sg.G), dim3(WG1024), 0, ctx->stream, *s, sg);
+  if (s->nblocks <= 4 && s->q == 1)
+    hipLaunchKernelGGL((k_nipals_step<4, 1>), dim3((unsigned)sg.G), dim3(WG1024), 0, ctx->stream, *s, sg);
+  else
+    hipLaunchKernelGGL((k_nipals_step<RS_BMAX, RS_QMAX>), dim3((unsigned)sg.G), dim3(WG1024), 0, ctx->stream, *s, sg);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }
