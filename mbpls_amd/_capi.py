@@ -295,12 +295,16 @@ class DeviceArray:
     the p x K / n x c conventions of the C ABI."""
 
     def __init__(self, ctx, shape, zero=False, ptr=None):
+        # (dozens of views per fit are built through here: no numpy calls)
         if isinstance(shape, int):
             shape = (shape,)
         self.ctx = ctx
-        self.shape = tuple(int(s) for s in shape)
-        self.size = int(np.prod(self.shape)) if self.shape else 1
-        self.nbytes = 8 * self.size
+        self.shape = shape = tuple(int(s) for s in shape)
+        size = 1
+        for v in shape:
+            size *= v
+        self.size = size
+        self.nbytes = 8 * size
         self._own = ptr is None
         if ptr is None:
             self.ptr = ctx._raw_alloc(self.nbytes)
