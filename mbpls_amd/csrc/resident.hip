@@ -152,9 +152,29 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
         tu[b] = fma(t, ui, tu[b]);
       }
   }
-  if (istd) grid_sum<BM>(sum_t, B, part, tot, sg, epoch);
-  grid_sum<BM>(tu, B, part, tot, sg, epoch);
-  grid_sum<4>(mu, 2, part, tot, sg, epoch);
+  if constexpr (2 * BM + 2 <= 16) {
+    // few blocks: the three reductions as one (a grid-wide reduction is a barrier on every workgroup)
+    double c3[2 * BM + 2];
+#pragma unroll
+    for (int b = 0; b < BM; ++b) {
+      c3[b] = sum_t[b];
+      c3[BM + b] = tu[b];
+    }
+    c3[2 * BM] = mu[0];
+    c3[2 * BM + 1] = mu[1];
+    grid_sum<2 * BM + 2>(c3, 2 * BM + 2, part, tot, sg, epoch);
+#pragma unroll
+    for (int b = 0; b < BM; ++b) {
+      sum_t[b] = c3[b];
+      tu[b] = c3[BM + b];
+    }
+    mu[0] = c3[2 * BM];
+    mu[1] = c3[2 * BM + 1];
+  } else {
+    if (istd) grid_sum<BM>(sum_t, B, part, tot, sg, epoch);
+    grid_sum<BM>(tu, B, part, tot, sg, epoch);
+    grid_sum<4>(mu, 2, part, tot, sg, epoch);
+  }
   const double uu = mu[0], su = mu[1];
 
   // ---- t_b = t~_b / ||w~_b|| (:860, :875-877);  sw = T^T u / u^T u, unit length (:879-880)
@@ -217,8 +237,21 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
     for (int j = 0; j < QM; ++j)
       if (j < q) yv[j] = fma(s.Y[(int64_t)j * n + i], t, yv[j]);
   }
-  grid_sum<4>(d4, 4, part, tot, sg, epoch);
-  grid_sum<QM>(yv, q, part, tot, sg, epoch);
+  if constexpr (QM + 4 <= 16) {
+    double c2[QM + 4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c2[j] = d4[j];
+#pragma unroll
+    for (int j = 0; j < QM; ++j) c2[4 + j] = yv[j];
+    grid_sum<QM + 4>(c2, QM + 4, part, tot, sg, epoch);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d4[j] = c2[j];
+#pragma unroll
+    for (int j = 0; j < QM; ++j) yv[j] = c2[4 + j];
+  } else {
+    grid_sum<4>(d4, 4, part, tot, sg, epoch);
+    grid_sum<QM>(yv, q, part, tot, sg, epoch);
+  }
   double diff;
   if (s.norm_kind == 0) diff = sqrt(d4[0]);
   else if (s.norm_kind == 1) diff = d4[1];
