@@ -314,8 +314,9 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
     s.tspass[i] = w;
     un[0] = fma(w, w, un[0]);
     un[1] = fma(w, s.u_cur[i], un[1]);     // UNIPALS: u^T y (u_cur is y, the start vector)
+    un[2] += w;                            // sum of the new u (its mean, for the centred copy of the next sweep)
   }
-  grid_sum<4>(un, 2, part, tot, sg, epoch);
+  grid_sum<4>(un, 3, part, tot, sg, epoch);
   const double unrm = sqrt(un[0]);
 
   // out[j] = <Tsc_j, vec> for j < kc, 16 at a time (register budget: 1024 threads leave 128 VGPRs each)
@@ -339,19 +340,16 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
 
   if (!converged) {
     // ---- next pass: sweep with the new u (centred copy for the raw-space passes), alpha = 1 / u^T u, cu_j = <ts_j, u>
-    double a4[4] = {0.0, 0.0, 0.0, 0.0};
+    // (sum u and u^T u follow from the reduction just taken: one loop and one grid-wide reduction less)
+    const double mean_u = istd ? (un[2] / unrm) / (double)n : 0.0;
     for (int64_t i = gtid; i < n; i += gstride) {
       const double ui = s.tspass[i] / unrm;
       s.u_cur[i] = ui;
-      a4[0] += ui;
-      a4[1] = fma(ui, ui, a4[1]);
+      s.vpass[i] = ui - mean_u;
     }
-    grid_sum<4>(a4, 2, part, tot, sg, epoch);
-    const double mean_u = istd ? a4[0] / (double)n : 0.0;
-    for (int64_t i = gtid; i < n; i += gstride) s.vpass[i] = s.u_cur[i] - mean_u;   // each thread re-reads its own rows
     dots(s.vpass, s.cu);
     if (lead) {
-      par[0] = 1.0 / a4[1];
+      par[0] = (unrm * unrm) / un[0];      // 1 / u^T u of the unit-length u
       par[4] = diff;
     }
     return;
