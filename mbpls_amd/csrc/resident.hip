@@ -14,6 +14,7 @@
 // All of it is n x (B + q + k) work in one 1024-thread workgroup, L2-resident, latency-bound: ~20 us against the
 // ~170 us a blocking D2H + numpy + H2D round trip costs per pass.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -112,7 +113,20 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   const double* ssq_p = ssq_g + B;
   const double* ssq_x = ssq_g + 2 * B;
   const double* dd = ssq_g + 3 * B;      // [B][nd] lazy-deflation sums
-  double* tb = s.Tb + (int64_t)kc * B * n;   // block scores of this component: scratch now, final at convergence
+  // The n-vectors of a step are distinct buffers: the few-blocks instantiation says so (__restrict__) and unrolls its
+  // row loops four times, so several rows' loads are in flight (238 -> 221 us per step at n = 10^6); the general one
+  // has no registers to spare (restrict alone took its spills from 28 to 70).
+  constexpr int UNR = (BM <= 4 && QM == 1) ? 4 : 1;
+  using cptr = std::conditional_t<(UNR > 1), const double* __restrict__, const double*>;
+  using mptr = std::conditional_t<(UNR > 1), double* __restrict__, double*>;
+  mptr tb = s.Tb + (int64_t)kc * B * n;   // block scores of this component: scratch now, final at convergence
+  cptr r_tr = tr;
+  cptr r_Tsc = s.Tsc;
+  cptr r_Y = s.Y;
+  mptr r_u = s.u_cur;
+  mptr r_vp = s.vpass;
+  mptr r_to = s.ts_old;
+  mptr r_tp = s.tspass;
 
   if (s.run == 1 && kc == 0 && s.amp2_max > 0.0) {
     // the statistics pass left max_j (mean_j/scale_j)^2 per block where the lazy sums of later passes go: raw-space
@@ -138,15 +152,16 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   double sum_t[BM], tu[BM], mu[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int b = 0; b < BM; ++b) sum_t[b] = tu[b] = 0.0;
+#pragma unroll UNR
   for (int64_t i = gtid; i < n; i += gstride) {
-    const double ui = s.u_cur[i];
+    const double ui = r_u[i];
     mu[0] = fma(ui, ui, mu[0]);
     mu[1] += ui;
 #pragma unroll
     for (int b = 0; b < BM; ++b)
       if (b < B) {
-        double t = tr[(int64_t)b * n + i];
-        for (int j = 0; j < nd; ++j) t = fma(-s.Tsc[(int64_t)j * n + i], dd[b * nd + j], t);
+        double t = r_tr[(int64_t)b * n + i];
+        for (int j = 0; j < nd; ++j) t = fma(-r_Tsc[(int64_t)j * n + i], dd[b * nd + j], t);
         tb[(int64_t)b * n + i] = t;
         sum_t[b] += t;
         tu[b] = fma(t, ui, tu[b]);
@@ -198,6 +213,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   // ---- ts = T sw, unit length (:882-883); scratch in vpass (the pass that read it has finished)
   //      UNIPALS: ts = sum_b X_b (X_b^T y), unit length; the block scores are scaled once c is known
   double m2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll UNR
   for (int64_t i = gtid; i < n; i += gstride) {
     double acc = 0.0;
 #pragma unroll
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
           acc = fma(tm, sw[b], acc);
         }
       }
-    s.vpass[i] = acc;
+    r_vp[i] = acc;
     m2[0] = fma(acc, acc, m2[0]);
   }
   grid_sum<4>(m2, 1, part, tot, sg, epoch);
@@ -223,10 +239,11 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   double yv[QM];
 #pragma unroll
   for (int j = 0; j < QM; ++j) yv[j] = 0.0;
+#pragma unroll UNR
   for (int64_t i = gtid; i < n; i += gstride) {
-    const double t = s.vpass[i] / tsn;
-    const double d = s.ts_old[i] - t;
-    s.ts_old[i] = t;
+    const double t = r_vp[i] / tsn;
+    const double d = r_to[i] - t;
+    r_to[i] = t;
     d4[0] = fma(d, d, d4[0]);
     d4[1] += fabs(d);
     d4[2] = fma(t, t, d4[2]);
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
     dmin = fmin(dmin, fabs(d));
 #pragma unroll
     for (int j = 0; j < QM; ++j)
-      if (j < q) yv[j] = fma(s.Y[(int64_t)j * n + i], t, yv[j]);
+      if (j < q) yv[j] = fma(r_Y[(int64_t)j * n + i], t, yv[j]);
   }
   if constexpr (QM + 4 <= 16) {
     double c2[QM + 4];
@@ -305,15 +322,16 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
       vv = fma(yv[j], yv[j], vv);
     }
   double un[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll UNR
   for (int64_t i = gtid; i < n; i += gstride) {
     double w = 0.0;
 #pragma unroll
     for (int j = 0; j < QM; ++j)
-      if (j < q) w = fma(s.Y[(int64_t)j * n + i], yv[j], w);
+      if (j < q) w = fma(r_Y[(int64_t)j * n + i], yv[j], w);
     w = w / vv;
-    s.tspass[i] = w;
+    r_tp[i] = w;
     un[0] = fma(w, w, un[0]);
-    un[1] = fma(w, s.u_cur[i], un[1]);     // UNIPALS: u^T y (u_cur is y, the start vector)
+    un[1] = fma(w, r_u[i], un[1]);     // UNIPALS: u^T y (u_cur is y, the start vector)
     un[2] += w;                            // sum of the new u (its mean, for the centred copy of the next sweep)
   }
   grid_sum<4>(un, 3, part, tot, sg, epoch);
