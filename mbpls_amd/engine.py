@@ -392,7 +392,7 @@ class HipEngine:
         of X on a 288 GB device).  MBPLS_KERNEL_IMPLICIT=1/0 forces either."""
         import os
         if (self.sparse or getattr(self, "rowmask", None) is not None or not hasattr(self.X, "standardize_stats_sweep")
-                or self.n > min(8192, getattr(self.ctx, "long_columns_from", 8192))
+                or not self._raw_space_ok()
                 or os.environ.get("MBPLS_IMPLICIT_STD", "1") == "0"):
             return False
         force = os.environ.get("MBPLS_KERNEL_IMPLICIT")

@@ -745,7 +745,7 @@ def test_kernel_method_never_writes_x(gpu_required, monkeypatch, offset, standar
 @pytest.mark.parametrize("method,offset,standardize,n", [
     ("NIPALS", 0.0, True, 640), ("NIPALS", 300.0, True, 200), ("NIPALS", 0.0, False, 640), ("NIPALS", 0.0, True, 9000),
     ("UNIPALS", 0.0, True, 640), ("UNIPALS", 300.0, True, 200), ("SIMPLS", 0.0, True, 640), ("SIMPLS", 300.0, True, 200),
-    ("SIMPLS", 0.0, False, 640)])
+    ("SIMPLS", 0.0, False, 640), ("UNIPALS", 0.0, True, 9000), ("SIMPLS", 0.0, True, 9000), ("KERNEL", 0.0, True, 9000)])
 def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, method, offset, standardize, n):
     """Several responses (NIPALS, UNIPALS) and SIMPLS when a standardised working copy does not fit (forced here): statistics-only
     preparation, then per component X^T (P Y), X (X^T P Y) with the operand standardised in registers and ONE raw-space
@@ -755,7 +755,7 @@ def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, meth
     import mbpls_amd
     from mbpls_amd import MBPLS, DeviceMatrix
     from mbpls_amd.engine import HipEngine
-    p = 3001 if n < 8192 else 400
+    p = 3001 if n < 8192 else (400 if method in ("NIPALS", "SIMPLS") else 9500)   # (UNIPALS / KERNEL: the p > n branches)
     X, Y = orc.make_latent(n, p, 3, seed=5)
     X = X + offset * (1.0 + np.arange(p) % 4)
     offs = [0, p // 3, p]
@@ -774,8 +774,7 @@ def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, meth
     Xd = DeviceMatrix(ctx, n, p, offs)
     Xd.upload(X)
     mdl = MBPLS(n_components=3, method=method, standardize=standardize, full_svd=True).fit(Xd, Y)
-    if n <= 8192:                                            # (the statistics-only policy covers register-resident n)
-        assert used == [True]
+    assert used == [True]
     assert np.array_equal(Xd.download(), X)
     tol = max(1e-8, 1e4 * offset * np.finfo(float).eps)
     assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} q=3 never-writes-X") < tol
