@@ -952,3 +952,23 @@ def test_no_device_memory_growth(gpu_required):
     for _ in range(3):
         one_round()
     assert before - free_bytes() < (8 << 20)
+
+
+@pytest.mark.parametrize("mbytes", [0.2, 1, 9, 40, 100])
+def test_large_host_to_device_copies_round_trip(gpu_required, mbytes):
+    """Uploads above 256 KB bounce through the context's ring of four pinned 8 MB slots (ctx.hip): single chunk, several
+    chunks, and more chunks than slots (the ring wraps and waits for the DMA that last read a slot) -- also back to back
+    with the source overwritten right after the call returns, which the bounce makes legal."""
+    import mbpls_amd
+    ctx = mbpls_amd.get_context()
+    n = int(mbytes * (1 << 20) / 8)
+    rng = np.random.default_rng(int(mbytes * 10))
+    a = rng.standard_normal(n)
+    d1, d2 = ctx.empty(n), ctx.empty(n)
+    d1.set(a)
+    b = a.copy()
+    d2.set(b)
+    b[:] = -1.0                                   # the call has returned: the source may be reused
+    assert np.array_equal(d1.get(), a)
+    assert np.array_equal(d2.get(), a)
+    d1.free(); d2.free()
