@@ -169,3 +169,16 @@ def test_tall_one_response_fit_is_one_queue_and_never_writes_x(gpu_required, mon
     w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} norm={norm} offset={offset}")
     assert w < (1e-8 if offset == 0.0 else 1e-6), w
     Xd.close()
+
+
+def test_many_lazy_corrections_through_the_finishing_kernel(forced_long):
+    """kprev up to 29 in k_fin_lazy (the corrections sum_i P[j,i] cu_i / ce_i and the d sums of the two-phase passes)"""
+    from mbpls_amd import MBPLS
+    rng = np.random.default_rng(4)
+    n, p, K = 500, 900, 30
+    X = rng.standard_normal((n, p))
+    Y = X[:, :6].sum(axis=1, keepdims=True) + 0.1 * rng.standard_normal((n, 1))
+    # (UNIPALS: no iteration -- NIPALS on deep components of noise never meets its stop rule, here or in the reference)
+    ref = orc.fit(X, Y, n_components=K, method="UNIPALS")
+    mdl = MBPLS(n_components=K, method="UNIPALS").fit(X, Y)
+    assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"UNIPALS K={K}") < 1e-6
