@@ -78,11 +78,15 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the explicit-deflation / fixed-point extras")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process only starts the N ranks (fresh processes,
+        # before anything here has touched the GPU), relays rank 0's JSON line and exits with their status
+        sys.exit(launch_ranks(a.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if a.gpus != world:
+        sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     import mbpls_amd
     from mbpls_amd import MBPLS, DeviceMatrix
 
@@ -118,7 +122,8 @@ def main():
             try:
                 comm = mbpls_amd.RcclComm.from_torch(ctx)
                 comm_info = dict(comm.info(), backend="rccl (C ABI, mbpls_hip_allreduce on the kernels' stream)")
-                assert comm_info["world_size"] == world, comm_info
+                # what RCCL itself reports (ncclCommCount / ncclCommUserRank), not what was passed in
+                assert comm_info["rccl_ranks"] == world and comm_info["rccl_user_rank"] == rank, comm_info
             except Exception as e:                      # noqa: BLE001 -- reported, then the fallback below
                 err = f"{type(e).__name__}: {e}"
             flags = [None] * world
@@ -277,6 +282,108 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------------ N > 1 helpers
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(world, argv, timeout=None, python=None):
+    """Start `world` child processes `python argv...`, one rank each (RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment -- what torch.distributed.run would export), wait for them,
+    print the LAST line of rank 0's stdout that parses as JSON as the last line of this process's stdout, and return
+    the exit status: 0 only when every rank returned 0.  Everything else the ranks print goes to stderr, prefixed.
+    The first rank that fails takes the others down (they would otherwise wait in a collective); the caller itself
+    never touches the GPU, so the children are ordinary fresh processes (no exec from a GPU-initialised process).
+    When the node shows fewer GPUs than ranks and MBPLS_BENCH_SHARED_GPU is not set, nothing is started."""
+    import subprocess
+    import threading
+    python = python or sys.executable
+    if os.environ.get("MBPLS_BENCH_SHARED_GPU") != "1" and os.environ.get("MBPLS_BENCH_SKIP_GPU_COUNT") != "1":
+        try:
+            import torch
+            have = torch.cuda.device_count()           # counting devices does not initialise the GPU runtime
+        except Exception:
+            have = None
+        if have is not None and have < world:
+            print(f"[bench] --gpus {world} but only {have} GPU(s) visible (MBPLS_BENCH_SHARED_GPU=1 runs the ranks on "
+                  f"one GPU over gloo as a dry run)", file=sys.stderr, flush=True)
+            return 2
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(env.get("MASTER_PORT") or free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    procs, lines0, pumps = [], [], []
+
+    def pump(stream, rank, keep):
+        for raw in iter(stream.readline, b""):
+            text = raw.decode(errors="replace").rstrip("\n")
+            if keep is not None:
+                keep.append(text)
+            else:
+                print(f"[rank {rank}] {text}", file=sys.stderr, flush=True)
+
+    for r in range(world):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        pr = subprocess.Popen([python] + list(argv), env=e, stdout=subprocess.PIPE, stderr=None,
+                              start_new_session=True)
+        th = threading.Thread(target=pump, args=(pr.stdout, r, lines0 if r == 0 else None), daemon=True)
+        th.start()
+        procs.append(pr)
+        pumps.append(th)
+    t0 = time.time()
+    rcs = [None] * world
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, pr in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = pr.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None or (timeout is not None and time.time() - t0 > timeout):
+            for r, pr in enumerate(procs):           # exactly the processes started here (their own sessions)
+                if rcs[r] is None:
+                    try:
+                        os.killpg(pr.pid, 15)
+                    except ProcessLookupError:
+                        pass
+            deadline = time.time() + 10
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = pr.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        os.killpg(pr.pid, 9)
+                        rcs[r] = pr.wait()
+            break
+        time.sleep(0.05)
+    for th in pumps:
+        th.join(timeout=5)
+    line = None
+    for text in lines0:
+        try:
+            if text.lstrip().startswith("{") and isinstance(json.loads(text), dict):
+                line = text
+                continue
+        except ValueError:
+            pass
+        print(f"[rank 0] {text}", file=sys.stderr, flush=True)
+    ok = all(rc == 0 for rc in rcs)
+    if not ok:
+        why = f"rank {failed} exited with {rcs[failed]}" if failed is not None else f"timeout after {timeout} s"
+        print(f"[bench] {why}; exit codes {rcs}", file=sys.stderr, flush=True)
+    if line is not None and ok:
+        print(line, flush=True)
+    elif ok:
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        return 1
+    if ok:
+        return 0
+    bad = rcs[failed] if failed is not None else next(rc for rc in rcs if rc)
+    return bad if 0 < bad < 256 else 1
+
+
 def sharded_self_check(ctx, mbpls_amd, dT, Y, r, rank, world):
     """A small 3-block problem fitted (a) column-sharded over all ranks through the communicator and (b) unsharded on
     this rank's own GPU: every rank compares its shard of (a) with (b).  Both are the product path -- this checks the
@@ -284,7 +391,7 @@ def sharded_self_check(ctx, mbpls_amd, dT, Y, r, rank, world):
     from mbpls_amd import MBPLS, DeviceMatrix, LocalComm
     from mbpls_amd.comm import shard_columns
     n = Y.shape[0]
-    sizes = [3000 * world, 2000 * world + 3, 4000 * world + 1]       # ragged: the shards differ in width
+    sizes = [1000 * world, 700 * world + 3, 1300 * world + 1]        # ragged: the shards differ in width
     goffs = np.concatenate(([0], np.cumsum(sizes)))
     full = DeviceMatrix(ctx, n, int(goffs[-1]), [int(o) for o in goffs])
     full.fill_latent(dT, r, 0.5, 99, 0)
@@ -296,10 +403,26 @@ def sharded_self_check(ctx, mbpls_amd, dT, Y, r, rank, world):
         view.fill_latent(dT, r, 0.5, 99, int(goffs[b]) + lo)
         view.close()
     ctx.sync()
-    worst = 0.0
+    worst, worst_oracle = 0.0, None
     comm = mbpls_amd.get_comm()
+    Xh = full.download() if rank == 0 else None      # rank 0 also checks its shard against the CPU oracle
     for method in ("NIPALS", "UNIPALS"):
         sharded = MBPLS(n_components=4, method=method).fit(local, Y)
+        if rank == 0:
+            from oracle import mbpls_oracle as orc     # checker only, nothing timed here
+            blocks = [Xh[:, int(goffs[b]):int(goffs[b + 1])] for b in range(len(sizes))]
+            o = orc.fit(blocks, Y, n_components=4, method=method, faithful=True)
+            so = np.sign(np.sum(o.Ts_ * sharded.Ts_, axis=0))
+            eo = [np.max(np.abs(sharded.Ts_ * so - o.Ts_)) / np.max(np.abs(o.Ts_)),
+                  np.max(np.abs(sharded.U_ * so - o.U_)) / np.max(np.abs(o.U_))]
+            for b, (lo, hi) in enumerate(ranges):
+                eo.append(np.max(np.abs(sharded.P_[b] * so - o.P_[b][lo:hi])) / np.max(np.abs(o.P_[b])))
+                eo.append(np.max(np.abs(sharded.W_[b] * so - o.W_[b][lo:hi])) / np.max(np.abs(o.W_[b])))
+            gl = np.concatenate([np.arange(int(goffs[b]) + lo, int(goffs[b]) + hi) for b, (lo, hi) in enumerate(ranges)])
+            eo.append(np.max(np.abs(sharded.beta_ - o.beta_[gl])) / np.max(np.abs(o.beta_)))
+            if method == "NIPALS" and list(sharded.nipals_iterations_) != list(o.nipals_iterations_):
+                eo.append(1.0)
+            worst_oracle = max(worst_oracle or 0.0, float(max(eo)))
         mbpls_amd.set_comm(LocalComm())
         try:
             ref = MBPLS(n_components=4, method=method).fit(full, Y)
@@ -316,11 +439,15 @@ def sharded_self_check(ctx, mbpls_amd, dT, Y, r, rank, world):
         worst = max(worst, float(max(errs)))
     full.close(); local.close()
     ok = np.isfinite(worst) and worst < 1e-8
-    print(f"[bench] rank {rank}/{world}: sharded fit vs unsharded fit, worst rel. error {worst:.2e} "
-          f"({'ok' if ok else 'MISMATCH'})", file=sys.stderr, flush=True)
+    if worst_oracle is not None:
+        ok = ok and np.isfinite(worst_oracle) and worst_oracle < 1e-6     # north_star: 1e-6 relative, sign-aligned
+    print(f"[bench] rank {rank}/{world}: sharded fit vs unsharded fit, worst rel. error {worst:.2e}"
+          + (f"; vs the CPU oracle {worst_oracle:.2e}" if worst_oracle is not None else "")
+          + f" ({'ok' if ok else 'MISMATCH'})", file=sys.stderr, flush=True)
     if not ok:
         os._exit(3)
-    return {"worst_rel_err": worst, "methods": ["NIPALS", "UNIPALS"], "blocks": sizes}
+    return {"worst_rel_err": worst, "worst_rel_err_vs_oracle_rank0": worst_oracle, "methods": ["NIPALS", "UNIPALS"],
+            "blocks": sizes, "checked": "Ts_, U_, P_, W_, beta_ shard slices, nipals_iterations_"}
 
 
 def time_allreduce(ctx, comm, count, reps=200):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 3   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw */
+#define MBPLS_HIP_ABI_VERSION 4   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query */
 
 enum {
   MBPLS_OK = 0,
@@ -422,6 +422,9 @@ int mbpls_hip_event_destroy(mbpls_ctx* ctx, void* event);
 int mbpls_hip_comm_unique_id(void* id_out);
 int mbpls_hip_comm_init_rank(mbpls_ctx* ctx, int world_size, int rank, const void* id_in);
 int mbpls_hip_comm_info(mbpls_ctx* ctx, int* world_size, int* rank, int* rccl_version);
+/* What the communicator ITSELF reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) -- mbpls_hip_comm_info
+ * returns the world size / rank the caller passed in; a launcher proves that RCCL really spans N ranks with this.   */
+int mbpls_hip_comm_query(mbpls_ctx* ctx, int* rccl_ranks, int* rccl_user_rank, int* rccl_device);
 int mbpls_hip_comm_destroy(mbpls_ctx* ctx);
 int mbpls_hip_allreduce(mbpls_ctx* ctx, double* d_buf, size_t count);   /* sum, in place, asynchronous */
 

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmbpls_hip.so")
 ROW_MAJOR, COL_MAJOR = 0, 1
 COMM_ID_BYTES = 128
 SCALE_FIT, SCALE_APPLY, SCALE_NONE = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp, _i64, _dbl, _int, _sz = C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
@@ -96,6 +96,7 @@ SIGNATURES = {
     "mbpls_hip_comm_unique_id": (_int, [_vp]),
     "mbpls_hip_comm_init_rank": (_int, [_vp, _int, _int, _vp]),
     "mbpls_hip_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
+    "mbpls_hip_comm_query": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
     "mbpls_hip_comm_destroy": (_int, [_vp]),
     "mbpls_hip_allreduce": (_int, [_vp, _vp, _sz]),
     "mbpls_hip_nipals_step": (_int, [_vp, C.POINTER(NipalsStep)]),

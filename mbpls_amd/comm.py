@@ -123,14 +123,24 @@ class RcclComm:
         _capi.check(ctx.lib.mbpls_hip_comm_init_rank(ctx.handle, self.world_size, self.rank, idbuf))
         self._small = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     @classmethod
     def from_torch(cls, ctx, group=None):
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
 
+        # (broadcast_object_list takes a GLOBAL rank: the group's first member, not necessarily global rank 0)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+
         def bootstrap(payload):
             box = [payload]
-            dist.broadcast_object_list(box, src=0, group=group)
+            dist.broadcast_object_list(box, src=src, group=group)
             return box[0]
 
         return cls(ctx, rank, world, bootstrap)
@@ -140,7 +150,11 @@ class RcclComm:
         w, r, v = C.c_int(0), C.c_int(0), C.c_int(0)
         from . import _capi
         _capi.check(self.ctx.lib.mbpls_hip_comm_info(self.ctx.handle, C.byref(w), C.byref(r), C.byref(v)))
-        return dict(world_size=w.value, rank=r.value, rccl_version=v.value)
+        # ... and what the communicator itself says (ncclCommCount / ncclCommUserRank / ncclCommCuDevice)
+        cn, cr, cd = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        _capi.check(self.ctx.lib.mbpls_hip_comm_query(self.ctx.handle, C.byref(cn), C.byref(cr), C.byref(cd)))
+        return dict(world_size=w.value, rank=r.value, rccl_version=v.value, rccl_ranks=cn.value,
+                    rccl_user_rank=cr.value, rccl_device=cd.value)
 
     def close(self):
         if self.ctx is not None and self.ctx.handle:

@@ -19,6 +19,9 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*GetVersion)(int*) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
 };
 
 struct RcclState {
@@ -55,6 +58,9 @@ static int load_rccl() {
   MB_SYM(AllReduce, "ncclAllReduce");
   MB_SYM(GetErrorString, "ncclGetErrorString");
   MB_SYM(GetVersion, "ncclGetVersion");
+  MB_SYM(CommCount, "ncclCommCount");
+  MB_SYM(CommUserRank, "ncclCommUserRank");
+  MB_SYM(CommCuDevice, "ncclCommCuDevice");
 #undef MB_SYM
   g_rccl.handle = h;
   return MBPLS_OK;
@@ -114,6 +120,27 @@ int mbpls_hip_comm_info(mbpls_ctx* ctx, int* world, int* rank, int* rccl_version
   if (rccl_version) {
     *rccl_version = 0;
     if (g_rccl.handle) (void)g_rccl.GetVersion(rccl_version);
+  }
+  return MBPLS_OK;
+}
+
+int mbpls_hip_comm_query(mbpls_ctx* ctx, int* rccl_ranks, int* rccl_user_rank, int* rccl_device) {
+  MB_ARG(ctx, "ctx is NULL");
+  RcclState* st = (RcclState*)ctx->rccl;
+  MB_ARG(st != nullptr, "no communicator on this context (mbpls_hip_comm_init_rank)");
+  // what the communicator itself reports -- not what the caller passed to mbpls_hip_comm_init_rank
+  int v = 0;
+  if (rccl_ranks) {
+    MB_NCCL(g_rccl.CommCount(st->comm, &v));
+    *rccl_ranks = v;
+  }
+  if (rccl_user_rank) {
+    MB_NCCL(g_rccl.CommUserRank(st->comm, &v));
+    *rccl_user_rank = v;
+  }
+  if (rccl_device) {
+    MB_NCCL(g_rccl.CommCuDevice(st->comm, &v));
+    *rccl_device = v;
   }
   return MBPLS_OK;
 }
