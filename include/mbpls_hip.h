@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 4   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query */
+#define MBPLS_HIP_ABI_VERSION 4   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host */
 
 enum {
   MBPLS_OK = 0,
@@ -392,6 +392,9 @@ typedef struct mbpls_nipals_step {
   double* ce;              /* >= kc: <ts_i, tspass>                                                                */
   double* par;             /* >= 8: [alpha, inv_tt, skip flag, failed component, last diff, reason (1 = offset data),
                               offset measure, -]                                                                    */
+  double* nu2_host;        /* optional (NULL: unused): K x nblocks doubles in HOST-MAPPED memory (mbpls_hip_host_alloc):
+                              the step that records component kc also stores scal[kc][0][:] there, so a host thread
+                              waiting on an event behind the step can read the block norms without a copy            */
 } mbpls_nipals_step;
 int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s);
 /* d_par != NULL: every column pass on this context reads alpha = d_par[0], inv_tt = d_par[1] from the device and
@@ -400,12 +403,24 @@ int mbpls_hip_set_pass_params(mbpls_ctx* ctx, const double* d_par);
 /* d_dst[j] = d_src[j] / sqrt(d_nu2[block of j]): block weights w_b = w~_b / ||w~_b|| (mbpls.py:860) with the norms
  * still on the device (d_nu2: nblocks squared norms).                                                              */
 int mbpls_hip_block_unit_col(const mbpls_mat* m, const double* d_src, double* d_dst, const double* d_nu2);
+/* True-space outputs of the raw-space passes (those given d_r2 = 1/scale_j^2: mbpls_hip_sweep_lazy_scaled,
+ * mbpls_hip_loadings_sweep_lazy_scaled, mbpls_hip_loadings_sweep_raw).  With d_rscale (1/scale_j, p doubles) set, the
+ * weights they store into d_g are the TRUE-space g_j = g~_j / scale_j (mbpls.py:856 on the standardised matrix), and
+ * d_p_true (optional, p doubles) receives the true-space loadings p_j = p~_j / scale_j (:928) beside the raw-space
+ * ones in d_p (which the lazy corrections of later passes keep using) -- no p-sized rescaling kernel behind the pass.
+ * Stays in force until changed; NULL restores raw-space outputs.                                                    */
+int mbpls_hip_set_true_space_outputs(mbpls_ctx* ctx, const double* d_rscale, double* d_p_true);
 /* d_dst[j] = d_src[j] * d_scalar[0] for a p-length column (UNIPALS: w = X^T u = c X^T y, mbpls.py:503).              */
 int mbpls_hip_scale_col_by(mbpls_ctx* ctx, int64_t p, const double* d_src, double* d_dst, const double* d_scalar);
 /* Ordered device-to-host copies for finished columns: record an event behind the kernels queued so far; a HELPER
  * thread then waits for that event only (not for the stream) and copies on the copy stream, so the queueing thread
  * never blocks.                                                                                                   */
 int mbpls_hip_event_record(mbpls_ctx* ctx, void** event);
+/* Pinned host memory the device can write directly (zero copy): *h_ptr for the host, *d_ptr for kernels.  For a few
+ * scalars a kernel hands to a waiting host thread -- a blocking copy of 8 bytes into pageable memory is a blit kernel
+ * that queues up behind (and slows) whatever is running.                                                           */
+int mbpls_hip_host_alloc(mbpls_ctx* ctx, size_t bytes, void** h_ptr, void** d_ptr);
+int mbpls_hip_host_free(mbpls_ctx* ctx, void* h_ptr);
 int mbpls_hip_memcpy_d2h_after(mbpls_ctx* ctx, void* event, void* h_dst, const void* d_src, size_t bytes);
 int mbpls_hip_event_destroy(mbpls_ctx* ctx, void* event);
 
@@ -433,6 +448,11 @@ int mbpls_hip_allreduce(mbpls_ctx* ctx, double* d_buf, size_t count);   /* sum, 
  * :569, :737).  Deterministic two-stage reduction; synchronous (the result is on the host on return). */
 int mbpls_hip_cross_product(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1,
                             const double* d_B, int64_t ldb, int c2, double* h_out);
+/* The same with the result left on the DEVICE (d_out: c1 x c2 row-major, c1, c2 <= 32) and no synchronisation: the
+ * product can sit in a queue of launches, e.g. behind the last pass of a device-resident fit, and come back to the host
+ * together with its other results.                                                                                  */
+int mbpls_hip_cross_product_dev(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1,
+                                const double* d_B, int64_t ldb, int c2, double* d_out);
 /* d_C (p x c2, ldc) = d_A (p x c1, lda) @ h_M (c1 x c2 row-major HOST matrix):
  * R_ = W (P^T W)^+ and beta_ = R_ V^T (mbpls.py:988-989), column scalings W_b = W~_b diag(1/||w~_b||)
  * (:860) with a diagonal M on the row range of block b. */

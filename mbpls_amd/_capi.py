@@ -30,7 +30,7 @@ class NipalsStep(C.Structure):
                 ("centre", _int), ("norm_kind", _int), ("mode", _int), ("tol", _dbl), ("amp2_max", _dbl),
                 ("xchg", _vp), ("Y", _vp), ("Ts", _vp), ("Tsc", _vp), ("U", _vp), ("V", _vp), ("Tb", _vp),
                 ("scal", _vp), ("ssq_x", _vp), ("iters", _vp), ("u_cur", _vp), ("ts_old", _vp), ("vpass", _vp),
-                ("tspass", _vp), ("cu", _vp), ("ce", _vp), ("par", _vp)]
+                ("tspass", _vp), ("cu", _vp), ("ce", _vp), ("par", _vp), ("nu2_host", _vp)]
 
 
 STEP_MAX_BLOCKS = 16
@@ -103,11 +103,15 @@ SIGNATURES = {
     "mbpls_hip_set_pass_params": (_int, [_vp, _vp]),
     "mbpls_hip_set_variance_output": (_int, [_vp, _vp]),
     "mbpls_hip_block_unit_col": (_int, [_vp, _vp, _vp, _vp]),
+    "mbpls_hip_set_true_space_outputs": (_int, [_vp, _vp, _vp]),
     "mbpls_hip_scale_col_by": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "mbpls_hip_event_record": (_int, [_vp, _pp]),
+    "mbpls_hip_host_alloc": (_int, [_vp, _sz, _pp, _pp]),
+    "mbpls_hip_host_free": (_int, [_vp, _vp]),
     "mbpls_hip_memcpy_d2h_after": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "mbpls_hip_event_destroy": (_int, [_vp, _vp]),
     "mbpls_hip_cross_product": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp]),
+    "mbpls_hip_cross_product_dev": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp]),
     "mbpls_hip_right_multiply": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _int, _vp, _i64]),
 }
 
@@ -226,6 +230,9 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            if getattr(self, "_mapped", None) is not None:
+                self.lib.mbpls_hip_host_free(self.handle, self._mapped[2])
+                self._mapped = None
             self.trim_pool()
             self.lib.mbpls_hip_destroy(self.handle)
             self.handle = None
@@ -238,6 +245,20 @@ class Context:
 
     def sync(self):
         check(self.lib.mbpls_hip_sync(self.handle))
+
+    def mapped_scalars(self, count):
+        """(numpy view, device pointer) of a small block of pinned host memory the device writes directly; one per
+        context, kept for its life (grown on demand)"""
+        cur = getattr(self, "_mapped", None)
+        if cur is None or cur[0].size < count:
+            if cur is not None:
+                self.lib.mbpls_hip_host_free(self.handle, cur[2])
+            h, d = _vp(), _vp()
+            size = max(int(count), 4096)
+            check(self.lib.mbpls_hip_host_alloc(self.handle, 8 * size, C.byref(h), C.byref(d)))
+            arr = np.ctypeslib.as_array((C.c_double * size).from_address(h.value))
+            cur = self._mapped = (arr, d.value, h.value)
+        return cur[0], cur[1]
 
     def info(self):
         name = C.create_string_buffer(256)

@@ -17,6 +17,7 @@ class LocalComm:
     rank = 0
     world_size = 1
     is_distributed = False
+    device_views_ok = True       # allreduce_device accepts any DeviceArray (views of larger buffers included)
 
     def exchange_buffer(self, ctx, count):
         from ._capi import DeviceArray
@@ -57,6 +58,7 @@ class TorchDistComm:
     (RCCL refuses duplicate devices), used to exercise the real engine's sharded path with world_size 2 on
     a single-GPU box."""
     is_distributed = True
+    device_views_ok = False      # reduces torch tensors it allocated itself (exchange_buffer)
 
     def __init__(self, group=None, device=None):
         import torch
@@ -109,6 +111,7 @@ class RcclComm:
     over torch.distributed's store, MPI, or a file.  ``RcclComm.from_torch`` builds one from an initialised
     torch.distributed process group (any backend; only the 128-byte id goes through it)."""
     is_distributed = True
+    device_views_ok = True
 
     def __init__(self, ctx, rank, world_size, bootstrap):
         import ctypes as C

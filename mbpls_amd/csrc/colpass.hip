@@ -98,6 +98,27 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   // lazy deflation: thread i < kprev carries the correction of previous component i
   const bool lazy = !STD && a.lazy != 0;
   const bool mine = lazy && tid < a.kprev;
+  // Per-column outputs (g_j, p_j): lane 0 parks them in LDS, wave 0 writes 64 columns at a time as coalesced 512-byte
+  // rows -- the scattered 8-byte stores sat on the critical path of every column (the other waves meet wave 0 at the
+  // next reduction).  True-space outputs of the raw-space passes (a.rs = 1/scale_j given): g~_j rs_j and p~_j rs_j are
+  // what the attributes hold; scaled at write-out, once per 64 columns with one coalesced load of rs -- no p-sized
+  // kernel behind the pass (scaling inside the per-column path -- a prefetched rs_j in one lane, or sqrt(1/scale_j^2) --
+  // cost the loadings pass 3-10 %).  Only wave 0 touches s_go, in program order: no barrier.
+  const bool outs = ISTD && !STD && a.rs != nullptr;
+  int oslot = 0;                // (workgroup-uniform) slot of the current column in the output batch
+  auto flush_outputs = [&](int64_t jj, int slot, double (*s_go)[64]) {
+    if (slot == 63 || jj == j1 - 1) {
+      const int64_t jb = jj - slot;
+      if (tid <= slot) {
+        const double r = outs ? a.rs[jb + tid] : 1.0;
+        if (SWEEP && a.g) a.g[jb + tid] = s_go[0][tid] * r;
+        if (DEFL && a.pvec) {
+          a.pvec[jb + tid] = s_go[1][tid];                   // raw-space loading (what later lazy corrections use)
+          if (outs && a.pvec_true) a.pvec_true[jb + tid] = s_go[1][tid] * r;
+        }
+      }
+    }
+  };
   const double cu_i = (mine && a.cu) ? a.cu[tid] : 0.0;
   const double ce_i = (mine && a.ce) ? a.ce[tid] : 0.0;
   const double* prow = mine ? a.Pm + (int64_t)tid * a.ldp : nullptr;
@@ -108,6 +129,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   constexpr bool LFULL = FULL || (STD && ISTD && SWEEP);
   double x[D][R];
   __shared__ double s_out[(STD && ISTD) ? 4 : 1][64];   // statistics-only pass: per-column outputs of 64 columns
+  __shared__ double s_go[2][64];                          // g_j / p_j of up to 64 columns (see flush_outputs)
   double pp[D];   // P[column, tid] of the column held in slot d (0 for threads >= kprev)
   double k0v[(STD && ISTD) ? D : 1];   // statistics-only pass: first sample of the column in slot d (the shift)
   double muv[CEN ? D : 1];  // raw-space passes on offset data: mean of the column in slot d, requested with the column
@@ -292,7 +314,11 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
         const double pj = ab[0] * a.inv_tt;        // ISTD: the raw-space loading p~_j
         if constexpr (ISTD) ssq_p = fma(pj * pj, r2c, ssq_p);
         else ssq_p = fma(pj, pj, ssq_p);
-        if (tid == 0 && a.pvec) a.pvec[jj] = pj;
+        if (tid == 0) s_go[1][oslot] = pj;
+        if constexpr (!SWEEP) {
+          if (tid < 64) flush_outputs(jj, oslot, s_go);
+          oslot = (oslot + 1) & 63;
+        }
         if (a.deflate) {
           if (!lazy) {
 #pragma unroll
@@ -322,7 +348,11 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
           double cj = gj;                    // ISTD: gj is g~_j, cj the weight of the RAW column in the scores
           if constexpr (ISTD && !STD) cj = gj * r2c;
           ssq_g = fma(gj, cj, ssq_g);
-          if (tid == 0 && a.g) a.g[jj] = gj;
+          if (tid < 64) {
+            if (tid == 0) s_go[0][oslot] = gj;
+            flush_outputs(jj, oslot, s_go);
+          }
+          oslot = (oslot + 1) & 63;
 #pragma unroll
           for (int k = 0; k < R; ++k) acc[k] = fma(cj, xc[k], acc[k]);
           dacc = fma(cj, pp[d], dacc);
@@ -455,6 +485,29 @@ __global__ __launch_bounds__(64 * RC_W) void k_reduce_chunks(const double* __res
 
 // ------------------------------------------------------------------------------- dispatch
 
+// mbpls_hip_set_true_space_outputs for the kernel families that do not scale in the kernel (few samples, long columns):
+// the same result with p-sized kernels behind the pass.
+__global__ __launch_bounds__(256) void k_true_space(int64_t p, const double* __restrict__ rs, double* __restrict__ g,
+                                                    const double* __restrict__ p_raw, double* __restrict__ p_true,
+                                                    const double* __restrict__ dpar) {
+  if (dpar && dpar[2] != 0.0) return;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  const double r = rs[j];
+  if (g) g[j] *= r;
+  if (p_true) p_true[j] = p_raw[j] * r;
+}
+
+int true_space_cols(mbpls_ctx* ctx, int64_t p, double* g, const double* p_raw) {
+  if (!ctx->ts_rscale) return MBPLS_OK;
+  double* pt = (p_raw && ctx->ts_p_true) ? ctx->ts_p_true : nullptr;
+  if (!g && !pt) return MBPLS_OK;
+  hipLaunchKernelGGL(k_true_space, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, p,
+                     (const double*)ctx->ts_rscale, g, p_raw, pt, ctx->dpar);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
 template <bool STD, bool DEFL, bool SWEEP>
 static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, int64_t p) {
   // algorithmic bytes: read 8np, plus 8np write when the pass stores X
@@ -471,7 +524,14 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   an.dpar = ctx->dpar;
   an.var_out = ctx->var_out;
   // few samples (n <= 512): four (two) columns per wave, one per 16-lane DPP row (half wave) (colpass_sub.hip)
-  if (a.n <= SUB_MAX_N && ctx->sub_columns) return launch_pass_sub(ctx, ct, an, STD, DEFL, SWEEP);
+  if (a.n <= SUB_MAX_N && ctx->sub_columns) {
+    MB_TRY(launch_pass_sub(ctx, ct, an, STD, DEFL, SWEEP));
+    return (!STD && a.ir2) ? true_space_cols(ctx, p, a.g, DEFL ? a.pvec : nullptr) : MBPLS_OK;
+  }
+  if (!STD && a.ir2 && ctx->ts_rscale) {       // raw-space pass: true-space g / p written by the kernel itself
+    an.rs = ctx->ts_rscale;
+    an.pvec_true = DEFL ? ctx->ts_p_true : nullptr;
+  }
   dim3 grid((unsigned)ct.nchunks), block((unsigned)T);
   const int D = ctx->prefetch >= 1 && ctx->prefetch <= 3 ? ctx->prefetch : 2;
   // FULL: every thread's every row pair is a real sample and columns are unpadded (n=4096, 8192, ...)
@@ -606,8 +666,10 @@ int mbpls_hip_sweep_lazy_scaled(const mbpls_mat* m, const double* d_v, double al
   MB_ARG(!d_mean || d_r2, "d_mean needs d_r2");
   MB_ARG(kprev >= 0 && kprev < KD && (kprev == 0 || (d_P && d_cu && d_d)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   mbpls_ctx* ctx = m->ctx;
-  if (long_columns(ctx, m->n))
-    return long_sweep_lazy(m, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu, d_d, d_r2, d_mean);
+  if (long_columns(ctx, m->n)) {
+    MB_TRY(long_sweep_lazy(m, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu, d_d, d_r2, d_mean));
+    return d_r2 ? true_space_cols(ctx, m->p, d_g, nullptr) : MBPLS_OK;
+  }
   PassArgs a{};
   MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s, &a.part_d));
   a.src = m->data; a.dst = nullptr; a.ld = m->ld; a.n = m->n;
@@ -637,9 +699,11 @@ int mbpls_hip_loadings_sweep_lazy_scaled(const mbpls_mat* m, const double* d_ts,
   MB_ARG(kprev >= 0 && kprev < KD - 1 && (kprev == 0 || (d_P && d_ce)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   MB_ARG(!d_v || (d_d && (kprev == 0 || d_cu)), "sweep part needs d_cu / d_d");
   mbpls_ctx* ctx = m->ctx;
-  if (long_columns(ctx, m->n))
-    return long_loadings_sweep_lazy(m, d_ts, inv_tt, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu,
-                                    d_ce, d_d, d_r2, d_mean);
+  if (long_columns(ctx, m->n)) {
+    MB_TRY(long_loadings_sweep_lazy(m, d_ts, inv_tt, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu,
+                                    d_ce, d_d, d_r2, d_mean));
+    return d_r2 ? true_space_cols(ctx, m->p, d_v ? d_g : nullptr, d_p) : MBPLS_OK;
+  }
   PassArgs a{};
   MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s, &a.part_d));
   a.src = m->data; a.dst = m->data; a.ld = m->ld; a.n = m->n;
@@ -662,8 +726,10 @@ int mbpls_hip_loadings_sweep_raw(const mbpls_mat* m, const double* d_ts, double 
                                  const double* d_r2, const double* d_mean) {
   MB_ARG(m && d_ts && d_v && d_t && d_r2, "NULL argument");
   mbpls_ctx* ctx = m->ctx;
-  if (long_columns(ctx, m->n)) return long_loadings_sweep_raw(m, d_ts, inv_tt, d_p, d_ssq_p, d_v, alpha, d_g, d_t,
-                                                              d_ssq_g, d_r2, d_mean);
+  if (long_columns(ctx, m->n)) {
+    MB_TRY(long_loadings_sweep_raw(m, d_ts, inv_tt, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g, d_r2, d_mean));
+    return true_space_cols(ctx, m->p, d_g, d_p);
+  }
   PassArgs a{};
   MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s, &a.part_d));
   a.src = m->data; a.dst = m->data; a.ld = m->ld; a.n = m->n;

@@ -213,7 +213,14 @@ struct PassArgs {
   double* var_out;     // standardise passes, MBPLS_SCALE_FIT: per-column variance (optional; ctx->var_out)
   double* rs_out;      // standardise pass: 1 / scale_j   (optional)
   double* r2_out;      // standardise pass: 1 / scale_j^2 (optional)
+  // raw-space passes (ir2 given), mbpls_hip_set_true_space_outputs: rs = 1/scale_j -> g holds the TRUE-space weights
+  // g~_j rs_j, and pvec_true (optional) the true-space loadings p~_j rs_j beside the raw-space ones in pvec
+  const double* rs;
+  double* pvec_true;
 };
+
+// kernels that do not scale their outputs themselves: the same with a p-sized kernel behind the pass (colpass.hip)
+int true_space_cols(mbpls_ctx* ctx, int64_t p, double* g, const double* p_raw);
 
 // colpass_sub.hip: the same passes for n <= SUB_MAX_N samples, several columns per wave (KD is used there: keep it above)
 constexpr int SUB_MAX_N = 1024;

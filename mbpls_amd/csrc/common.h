@@ -86,6 +86,11 @@ struct mbpls_ctx {
   // optional per-column variance output of the standardise passes (mbpls_hip_set_variance_output): sklearn's
   // StandardScaler.var_ (0 for a constant column, whose scale_ is 1)
   double* var_out = nullptr;
+  // true-space outputs of the raw-space passes (mbpls_hip_set_true_space_outputs): 1/scale_j and the destination of
+  // the true-space loadings of the next loadings pass
+  const double* ts_rscale = nullptr;
+  double* ts_p_true = nullptr;
+  void* pin_d2h = nullptr;             // pinned bounce buffer of the small blocking device-to-host copies
   // pinned bounce buffers of the large host-to-device copies (a ring of slots, one event each): a pageable
   // hipMemcpyAsync of a few MB sporadically takes 8-25 ms inside the runtime right after a fit
   void* pin = nullptr;
@@ -93,6 +98,8 @@ struct mbpls_ctx {
   hipEvent_t pin_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned pin_next = 0;
   std::mutex pin_mutex;
+  int step_reg = 1;          // device-resident step: the register-resident kernel where it applies (step_reg.hip); 0 = general kernel
+  unsigned step_spin_limit = 1u << 28;   // polls before a grid barrier of the multi-workgroup step gives up (tests lower it)
   void* step_ws = nullptr;   // grid barrier + per-workgroup totals of the multi-workgroup step kernel (resident.hip)
   void* rccl = nullptr;      // RcclState* (rccl_comm.hip) when a communicator was initialised on this context
   // events of the ordered D2H copies are recycled (created by the queueing thread, returned by the copier thread)
@@ -136,6 +143,10 @@ int xw_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_W, int64_t ldw, 
 // axpy_cols.hip: OUT = X g for one right-hand side as a full-column streaming pass (MBPLS_ERR_UNSUPPORTED when the
 // shape is not handled there and the caller should use the row-slab kernel)
 int axpy_cols(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_g, int per_block, double* d_out);
+
+// step_reg.hip: the device-resident step with a thread's rows in registers (one response, <= 4 blocks, n <= 4096);
+// MBPLS_ERR_UNSUPPORTED for other shapes (resident.hip has the general kernel)
+int launch_step_reg(mbpls_ctx* ctx, const mbpls_nipals_step* s);
 
 // RAII bracket: records an event pair around a kernel launch when profiling is on.
 struct ProfScope {

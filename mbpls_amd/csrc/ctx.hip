@@ -237,6 +237,7 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
   for (hipEvent_t e : ctx->pin_ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->pin_d2h) (void)hipHostFree(ctx->pin_d2h);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (auto& pd : ctx->pending) {
@@ -283,6 +284,8 @@ int mbpls_hip_set_tunable(mbpls_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "xw_mfma_from")) ctx->xw_mfma_from = std::max(0, value);
   else if (!strcmp(key, "gram_slice_features")) ctx->gram_slice_features = std::max(0, value);
   else if (!strcmp(key, "sub_columns")) ctx->sub_columns = value ? 1 : 0;
+  else if (!strcmp(key, "step_reg")) ctx->step_reg = value ? 1 : 0;
+  else if (!strcmp(key, "step_spin_limit")) ctx->step_spin_limit = (unsigned)std::max(1, value);
   else if (!strcmp(key, "long_columns_from")) ctx->long_columns_from = std::max(0, std::min(value, 65536));
   else MB_ARG(false, "unknown tunable '%s'", key);
   return MBPLS_OK;
@@ -332,6 +335,24 @@ int mbpls_hip_free(mbpls_ctx* ctx, void* d_ptr) {
   return MBPLS_OK;
 }
 
+int mbpls_hip_host_alloc(mbpls_ctx* ctx, size_t bytes, void** h_ptr, void** d_ptr) {
+  MB_ARG(ctx && h_ptr && d_ptr && bytes > 0, "bad argument");
+  MB_HIP(hipSetDevice(ctx->device));
+  *h_ptr = *d_ptr = nullptr;
+  MB_HIP(hipHostMalloc(h_ptr, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+  memset(*h_ptr, 0, bytes);
+  MB_HIP(hipHostGetDevicePointer(d_ptr, *h_ptr, 0));
+  return MBPLS_OK;
+}
+
+int mbpls_hip_host_free(mbpls_ctx* ctx, void* h_ptr) {
+  MB_ARG(ctx, "ctx is NULL");
+  if (!h_ptr) return MBPLS_OK;
+  MB_HIP(hipStreamSynchronize(ctx->stream));
+  MB_HIP(hipHostFree(h_ptr));
+  return MBPLS_OK;
+}
+
 int mbpls_hip_memcpy_h2d(mbpls_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   MB_ARG(ctx && (bytes == 0 || (d_dst && h_src)), "NULL argument");
   if (bytes == 0) return MBPLS_OK;
@@ -368,6 +389,17 @@ int mbpls_hip_memcpy_h2d(mbpls_ctx* ctx, void* d_dst, const void* h_src, size_t 
 int mbpls_hip_memcpy_d2h(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   MB_ARG(ctx && (bytes == 0 || (h_dst && d_src)), "NULL argument");
   if (bytes == 0) return MBPLS_OK;
+  constexpr size_t BOUNCE = (size_t)4 << 20;
+  if (bytes <= BOUNCE) {
+    // small results (scores, K x K matrices, parameter blocks): DMA into a pinned buffer of the context, then a host
+    // memcpy -- a blocking copy straight into pageable memory took 30-250 us of runtime bookkeeping per call
+    std::lock_guard<std::mutex> lock(ctx->pin_mutex);
+    if (!ctx->pin_d2h) MB_HIP(hipHostMalloc(&ctx->pin_d2h, BOUNCE, hipHostMallocDefault));
+    MB_HIP(hipMemcpyAsync(ctx->pin_d2h, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MB_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(h_dst, ctx->pin_d2h, bytes);
+    return MBPLS_OK;
+  }
   MB_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   MB_HIP(hipStreamSynchronize(ctx->stream));
   return MBPLS_OK;

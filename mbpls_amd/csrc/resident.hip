@@ -39,29 +39,38 @@ struct StepGrid {
   int G;                  // workgroups
   unsigned* bar;          // grid barrier counter, zeroed before the launch
   double* gpart;          // [2][G][16] per-workgroup totals, two alternating sets
-  double* par;            // par[7] = 1: a barrier timed out (the host raises)
+  double* par;            // par[7] = 1: a barrier timed out (the host finishes the fit with its own loop)
+  unsigned spin_limit;    // polls of the counter before a barrier gives up
+  unsigned* dead;         // LDS word of the workgroup (set by the kernel): a barrier of this launch gave up
 };
 
 __device__ __forceinline__ void grid_barrier(const StepGrid& sg, unsigned& epoch) {
   // The only data that crosses workgroups are the per-workgroup totals and this counter.  They live in FINE-GRAINED
-  // device memory (uncached: hipDeviceMallocFinegrained) and are accessed with relaxed agent-scope atomics, so no
-  // release / acquire fence is needed -- at agent scope those write back and invalidate the whole L2 of every XCD,
-  // with the n-vectors of the step dirty in it (355 -> 334 us per step at n = 10^6, ten barriers).
-  // __syncthreads() orders the workgroup's total stores (completed: s_waitcnt) before thread 0 signals.
+  // device memory (uncached: hipDeviceMallocFinegrained).  The totals are stored by threads tid < m, then
+  // __syncthreads(), then thread 0 signals with a RELEASE increment; a waiter spins on relaxed loads and finishes with
+  // one ACQUIRE load before anybody reads the totals -- the formally required ordering across XCDs (a stale partial
+  // would silently change ts and the stop decision, possibly differently on different ranks).  Costs the L2
+  // write-back / invalidate of agent-scope release / acquire per barrier (334 -> 355 us per step at n = 10^6, ten
+  // barriers, against 5 ms passes).
+  // The launch is cooperative (all workgroups co-resident by construction); the poll limit only keeps a broken queue
+  // from hanging the device: once a barrier gave up, the later ones of the launch return at once (epoch bit 31).
+  const bool dead = *sg.dead != 0u;     // (written before the previous barrier's second __syncthreads: uniform)
   epoch += 1;               // every thread counts: the alternating partial sets are chosen from it
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && !dead) {
     const unsigned target = epoch * (unsigned)sg.G;
-    __hip_atomic_fetch_add(sg.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(sg.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0;
     while (__hip_atomic_load(sg.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 28)) {        // never on a healthy queue: do not hang the device if a workgroup is missing
+      if (++spins > sg.spin_limit) {
         sg.par[7] = 1.0;
         sg.par[2] = 1.0;                 // everything queued behind becomes a no-op
+        *sg.dead = 1u;
         break;
       }
     }
+    (void)__hip_atomic_load(sg.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
 }
@@ -96,9 +105,13 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   __shared__ double part[16 * 16];       // wave partials of reduce_many
   __shared__ double tot[16];
   __shared__ double s_mx[WG1024 / 64], s_mn[WG1024 / 64];
+  __shared__ unsigned s_dead;
   double* par = s.par;
   if (par[2] != 0.0) return;             // an earlier component needed more iterations than were queued
   const int tid = threadIdx.x;
+  if (tid == 0) s_dead = 0u;
+  sg.dead = &s_dead;
+  __syncthreads();
   const bool lead = tid == 0 && blockIdx.x == 0;       // the one thread that records scalars
   const int64_t gtid = (int64_t)blockIdx.x * WG1024 + tid, gstride = (int64_t)sg.G * WG1024;
   unsigned epoch = 0;
@@ -356,6 +369,32 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
     }
   };
 
+  // Re-orthogonalised sweep vector (see step_reg.hip): vpass <- vpass - sum_{j < kk} <Tsc_j, vpass> Tsc_j.  X_k^T v is
+  // the same for both (X_k = (I - Ts Ts^T) X_0), but the lazy pass takes it as X_0^T v - sum_j P[:,j] <ts_j, v>: with the
+  // projected vector the two terms are no longer large against their difference.  The scores are unit length and
+  // mutually orthogonal to rounding; the pass still gets the exact coefficients of what it reads (dots afterwards).
+  auto project = [&](int kk) {
+    for (int j0 = 0; j0 < kk; j0 += 16) {
+      double c[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) c[jj] = 0.0;
+      for (int64_t i = gtid; i < n; i += gstride) {
+        const double vi = s.vpass[i];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj)
+          if (j0 + jj < kk) c[jj] = fma(s.Tsc[(int64_t)(j0 + jj) * n + i], vi, c[jj]);
+      }
+      grid_sum<16>(c, min(16, kk - j0), part, tot, sg, epoch);
+      for (int64_t i = gtid; i < n; i += gstride) {
+        double vi = s.vpass[i];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj)
+          if (j0 + jj < kk) vi = fma(-c[jj], s.Tsc[(int64_t)(j0 + jj) * n + i], vi);
+        s.vpass[i] = vi;
+      }
+    }
+  };
+
   if (!converged) {
     // ---- next pass: sweep with the new u (centred copy for the raw-space passes), alpha = 1 / u^T u, cu_j = <ts_j, u>
     // (sum u and u^T u follow from the reduction just taken: one loop and one grid-wide reduction less)
@@ -365,6 +404,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
       s.u_cur[i] = ui;
       s.vpass[i] = ui - mean_u;
     }
+    project(kc);
     dots(s.vpass, s.cu);
     if (lead) {
       par[0] = (unrm * unrm) / un[0];      // 1 / u^T u of the unit-length u
@@ -403,6 +443,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
     s.Tsc[(int64_t)kc * n + i] = ti;
     s.vpass[i] = vi;
   }
+  project(kc + 1);         // ... against the score being deflated as well (Tsc[:, kc], just written by this thread)
   dots(s.vpass, s.cu);     // j < kc only: the component being deflated is handled inside the pass (its <ts, v>)
   dots(s.tspass, s.ce);
 #pragma unroll
@@ -420,6 +461,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
         s.scal[(int64_t)kc * 4 * B + b] = ssq_g[b];               // ||w~_b||^2 of the last iteration
         s.scal[(int64_t)kc * 4 * B + B + b] = sw[b] * sw[b];      // a_b (:949)
       }
+      if (s.nu2_host) s.nu2_host[(int64_t)kc * B + b] = s.scal[(int64_t)kc * 4 * B + b];
     }
   if (lead) {
     s.iters[kc] = (double)s.run;
@@ -468,6 +510,14 @@ int mbpls_hip_set_pass_params(mbpls_ctx* ctx, const double* d_par) {
   return MBPLS_OK;
 }
 
+int mbpls_hip_set_true_space_outputs(mbpls_ctx* ctx, const double* d_rscale, double* d_p_true) {
+  MB_ARG(ctx, "ctx is NULL");
+  MB_ARG(d_rscale || !d_p_true, "d_p_true needs d_rscale");
+  ctx->ts_rscale = d_rscale;
+  ctx->ts_p_true = d_p_true;
+  return MBPLS_OK;
+}
+
 int mbpls_hip_set_variance_output(mbpls_ctx* ctx, double* d_var) {
   MB_ARG(ctx, "ctx is NULL");
   ctx->var_out = d_var;
@@ -484,22 +534,41 @@ int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
   MB_ARG(s->xchg && s->Y && s->Ts && s->Tsc && s->U && s->V && s->Tb && s->scal && s->ssq_x && s->iters && s->u_cur &&
              s->ts_old && s->vpass && s->tspass && s->cu && s->ce && s->par,
          "NULL pointer in mbpls_nipals_step");
-  // one workgroup up to 32768 rows (latency-bound, ~50 us); beyond that the n-vector traffic dominates (4 ms at
-  // n = 10^6 on one CU): spread the rows over up to 128 workgroups with grid-wide reductions
+  // one workgroup up to 32768 rows (latency-bound); beyond that the n-vector traffic dominates (4 ms at n = 10^6 on one
+  // CU): spread the rows over up to 128 workgroups with grid-wide reductions
   StepGrid sg{};
   sg.G = (int)std::max<int64_t>(1, std::min<int64_t>(STEP_MAX_WG, s->n / STEP_ROWS_PER_WG));
+  if (sg.G == 1 && ctx->step_reg) {
+    // the everyday shape (one response, <= 4 blocks, n <= 4096): rows in registers (step_reg.hip)
+    const int rc = launch_step_reg(ctx, s);
+    if (rc != MBPLS_ERR_UNSUPPORTED) return rc;
+  }
+  const bool few = s->nblocks <= 4 && s->q == 1;
+  const void* fn = few ? (const void*)k_nipals_step<4, 1> : (const void*)k_nipals_step<RS_BMAX, RS_QMAX>;
+  if (sg.G > 1) {
+    // the grid barrier needs every workgroup resident at once: never more than the device can hold (a partitioned or
+    // smaller part), and launched cooperatively so the runtime guarantees it whatever else the GPU is doing
+    int per_cu = 0;
+    MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WG1024, 0));
+    sg.G = std::max(1, std::min(sg.G, per_cu * ctx->cus));
+  }
   if (sg.G > 1) {
     const size_t need = 256 + sizeof(double) * 2 * STEP_MAX_WG * 16;
     if (!ctx->step_ws) MB_HIP(hipExtMallocWithFlags(&ctx->step_ws, need, hipDeviceMallocFinegrained));
     sg.bar = (unsigned*)ctx->step_ws;
     sg.gpart = (double*)((char*)ctx->step_ws + 256);
     sg.par = s->par;
+    sg.spin_limit = ctx->step_spin_limit;
     MB_HIP(hipMemsetAsync(sg.bar, 0, 256, ctx->stream));
+    mbpls_nipals_step sv = *s;
+    void* args[] = {(void*)&sv, (void*)&sg};
+    MB_HIP(hipLaunchCooperativeKernel(fn, dim3((unsigned)sg.G), dim3(WG1024), args, 0, ctx->stream));
+    return MBPLS_OK;
   }
-  if (s->nblocks <= 4 && s->q == 1)
-    hipLaunchKernelGGL((k_nipals_step<4, 1>), dim3((unsigned)sg.G), dim3(WG1024), 0, ctx->stream, *s, sg);
+  if (few)
+    hipLaunchKernelGGL((k_nipals_step<4, 1>), dim3(1), dim3(WG1024), 0, ctx->stream, *s, sg);
   else
-    hipLaunchKernelGGL((k_nipals_step<RS_BMAX, RS_QMAX>), dim3((unsigned)sg.G), dim3(WG1024), 0, ctx->stream, *s, sg);
+    hipLaunchKernelGGL((k_nipals_step<RS_BMAX, RS_QMAX>), dim3(1), dim3(WG1024), 0, ctx->stream, *s, sg);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }

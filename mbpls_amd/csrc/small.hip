@@ -91,6 +91,22 @@ using namespace mbpls;
 
 extern "C" {
 
+int mbpls_hip_cross_product_dev(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1, const double* d_B,
+                                int64_t ldb, int c2, double* d_out) {
+  MB_ARG(ctx && d_A && d_B && d_out, "NULL argument");
+  MB_ARG(p >= 1 && c1 >= 1 && c2 >= 1 && c1 <= CMAX && c2 <= CMAX, "need 1 <= c1, c2 <= %d", CMAX);
+  MB_ARG(lda >= p && ldb >= p, "leading dimension < p");
+  const int nwg = (int)std::min<int64_t>((p + 255) / 256, (int64_t)ctx->cus * 4);
+  const int cc = c1 * c2;
+  MB_TRY(ensure_ws(ctx, sizeof(double) * ((size_t)nwg * cc)));
+  double* partial = (double*)ctx->ws;
+  hipLaunchKernelGGL(k_cross_partial, dim3(nwg), dim3(256), 0, ctx->stream, p, d_A, lda, c1, d_B, ldb, c2, partial);
+  MB_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_cross_final, dim3(cc), dim3(64), 0, ctx->stream, (const double*)partial, nwg, cc, d_out);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
 int mbpls_hip_cross_product(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1, const double* d_B,
                             int64_t ldb, int c2, double* h_out) {
   MB_ARG(ctx && d_A && d_B && h_out, "NULL argument");

@@ -100,6 +100,8 @@ class HipEngine:
             self._src = None
 
     def close(self):
+        if self.ctx.handle:
+            self.ctx.lib.mbpls_hip_set_true_space_outputs(self.ctx.handle, None, None)
         for s in self.slots.values():
             s.free()
         self.slots = {}
@@ -173,6 +175,27 @@ class HipEngine:
             return out
         _capi.check(self.ctx.lib.mbpls_hip_memcpy_d2h_overlap(self.ctx.handle, out.ctypes.data, S.ptr, out.nbytes))
         return out
+
+    def fetch_async(self, name):
+        """D2H of a whole slot by the helper thread, behind everything queued on the compute stream so far; returns
+        (host array, wait) -- wait() blocks until the array is complete (and re-raises a copy error)."""
+        import threading
+        S = self.slots[name]
+        out = self.host_array(S.shape)
+        ev = _capi._vp()
+        _capi.check(self.ctx.lib.mbpls_hip_event_record(self.ctx.handle, _capi.C.byref(ev)))
+        errors, done = [], threading.Event()
+        q = _copier_queue()
+        q.put((self.ctx, ev, [(out, S.ptr)], errors))
+        q.put(done)
+
+        def wait():
+            done.wait()
+            if errors:
+                raise errors[0]
+            return out
+
+        return out, wait
 
     def put(self, name, arr):
         arr = np.asarray(arr, dtype=np.float64)
@@ -251,6 +274,20 @@ class HipEngine:
         buf = np.zeros(self.KD)
         buf[:c.size] = c
         return self._coef[idx].set(buf)
+
+    def _lazy_project(self, v, extra_ts=None):
+        """Sweep vector of a lazy pass minus its components along the scores deflated so far (and ``extra_ts``, the score
+        the pass itself deflates).  X_k^T v is the same for both (X_k = (I - Ts Ts^T) X_0), but the pass takes it as
+        X_0^T v - sum_i P[:, i] <ts_i, v>: with the projected vector the two terms are no longer large against their
+        difference -- without it the rounding of deep components (y long since explained: <ts_i, y> big, <x_j^k, y>
+        tiny) was amplified until ||ts_old - ts|| <= 1e-14 (mbpls.py:841) went out of reach beyond ~25 components.
+        Same re-orthogonalisation as the device-resident step (csrc/step_reg.hip)."""
+        cols = list(self._lazy_ts) + ([np.asarray(extra_ts, dtype=np.float64).ravel()] if extra_ts is not None else [])
+        if not cols or v is None:
+            return v
+        T = np.column_stack(cols)
+        v = np.array(v, dtype=np.float64).reshape(-1, 1)
+        return v - T.dot(T.T.dot(v) / (T * T).sum(axis=0)[:, None])
 
     def _lazy_fix(self, t, d, extra_ts=None):
         """t~_b = A_b - Ts d_b  (A_b: raw accumulation over the undeflated columns)"""
@@ -471,6 +508,7 @@ class HipEngine:
             self._istd = bool(standardize)
             if self._istd:
                 self.slot("P~raw", self._lazy_K)
+                self._true_space()
             return "queued"
         self.run_deferred(2)
         t, g, _, x = self._finish_pass(True, True, False, True, nd=1)
@@ -481,6 +519,7 @@ class HipEngine:
         self._cen = self._istd and float(np.sqrt(np.max(self._last_d))) > self.CENTRE_FROM_OFFSET
         if self._istd:
             self.slot("P~raw", self._lazy_K)
+            self._true_space()
             t = t - t.mean(axis=0)           # raw-space accumulation: remove the column means' share
         return x, t, g
 
@@ -489,11 +528,12 @@ class HipEngine:
         v = np.asarray(v, dtype=np.float64)
         return v - v.mean(axis=0)
 
-    def _scale_col(self, src_spec, dst_spec):
-        """dst[:, k] = src[:, k] / scale: a finished raw-space column (g~, p~) becomes the true g, p"""
-        s, d = self._slot_col(src_spec), self._slot_col(dst_spec)
-        _capi.check(self.ctx.lib.mbpls_hip_scale_rows(self.ctx.handle, self.p, 1, s.ptr, self.p, self.rs.ptr, d.ptr,
-                                                      self.p))
+    def _true_space(self, p_true=None):
+        """Raw-space passes store TRUE-space weights (g~_j / scale_j) and, into ``p_true`` (a device column), true-space
+        loadings beside the raw-space ones -- inside the pass, no p-sized rescaling kernel behind it
+        (mbpls_hip_set_true_space_outputs).  In force until the next call; close() clears it."""
+        _capi.check(self.ctx.lib.mbpls_hip_set_true_space_outputs(self.ctx.handle, _capi._ptr(self.rs),
+                                                                  _capi._ptr(p_true)))
 
     def sweep(self, v, alpha, g_slot, overlap=None):
         """a2+a3: g = alpha X^T v (into the slot column), t~_b = X_b g_b, ||g_b||^2.  One read of X.
@@ -501,16 +541,17 @@ class HipEngine:
         n, B = self.n, self.nblocks
         if self._istd:
             v = self._centre(v)
+        if self._lazy_pslot:
+            v = self._lazy_project(v)
         dv = self._put_vec(0, v)
         k = len(self._lazy_ts) if self._lazy_pslot else 0
         if self.sparse:      # alpha is implied: every column divides by its own masked <u, u>
             self.X.nan_sweep(dv, self._slot_col(g_slot), self._xptr(0), self._xptr(self._d_off), self._xptr(n * B))
         elif self._istd:
+            self._true_space()
             self.X.sweep_lazy(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B),
                               self.slots["P~raw"], self.p, k, self._lazy_coef(0, v), self._xptr(n * B + 3 * B),
                               r2=self.r2, mean=self.mean if self._cen else None)
-            if g_slot is not None:
-                self._scale_col(g_slot, g_slot)
         elif k:
             P = self.slots[self._lazy_pslot]
             self.X.sweep_lazy(dv, alpha, self._slot_col(g_slot), self._xptr(0), self._xptr(n * B), P, self.p, k,
@@ -534,6 +575,8 @@ class HipEngine:
         if self._istd:       # raw-space pass: zero-sum vectors
             ts = self._centre(ts)
             v = self._centre(v) if v is not None else None
+        if self._lazy_pslot and v is not None:
+            v = self._lazy_project(v, extra_ts=ts if deflate else None)
         dts = self._put_vec(1, ts)
         dv = self._put_vec(0, v) if v is not None else None
         if self.sparse:      # inv_tt is implied: every column divides by its own masked <ts, ts>
@@ -552,11 +595,10 @@ class HipEngine:
             # (several responses, solvers._fit_nipals_subspace) -- loadings and sweep in raw-column space, one read
             assert not deflate and v is not None and p_slot is not None and g_slot is not None
             dts, dv = self._put_vec(1, self._centre(ts)), self._put_vec(0, self._centre(v))
+            self._true_space(self._slot_col(p_slot))     # p~ -> p in place (the raw-space loading is not needed), g~ -> g
             self.X.loadings_sweep_raw(dts, inv_tt, self._slot_col(p_slot), self._xptr(n * B + B), dv, alpha,
                                       self._slot_col(g_slot), self._xptr(0), self._xptr(n * B), self.r2,
                                       mean=self.mean if self._cen else None)
-            self._scale_col(p_slot, p_slot)              # p~ -> p, g~ -> g
-            self._scale_col(g_slot, g_slot)
             if overlap is not None:
                 overlap()
             else:
@@ -569,9 +611,10 @@ class HipEngine:
             P = self.slots[self._lazy_pslot]
             p_out = self._slot_col(p_slot)
             if self._istd:
-                # raw-space pass: raw-space loadings in their own slot, true columns afterwards
+                # raw-space pass: raw-space loadings in their own slot, the true column beside it
                 P = self.slots["P~raw"]
                 p_out = P.col(k)
+                self._true_space(self._slot_col(p_slot))
             self.X.loadings_sweep_lazy(dts, inv_tt, p_out, self._xptr(n * B + B), dv, alpha,
                                        self._slot_col(g_slot), self._xptr(0) if v is not None else None,
                                        self._xptr(n * B) if v is not None else None, P, self.p, k,
@@ -579,10 +622,6 @@ class HipEngine:
                                        self._xptr(n * B + 3 * B) if v is not None else None,
                                        r2=self.r2 if self._istd else None,
                                        mean=self.mean if self._cen else None)
-            if self._istd:
-                self._scale_col(("P~raw", k), p_slot)
-                if v is not None and g_slot is not None:
-                    self._scale_col(g_slot, g_slot)
             if overlap is not None:
                 overlap()
             else:
@@ -606,6 +645,14 @@ class HipEngine:
         return p, t, g
 
     # ------------------------------------------------------------------ device-resident NIPALS (one response)
+    def deferred_first_pass(self, standardize, v, alpha, g_slot):
+        """The first pass of a device-resident fit (statistics + first sweep, only queued) as a callable for
+        nipals_resident / unipals_resident: they launch it FIRST and build the queue's device state while it runs
+        (queued again when the first step reports offset data)."""
+        def first_pass():
+            self.prepare(standardize, v=v, alpha=alpha, g_slot=g_slot, defer=True)
+        return first_pass
+
     def resident_supported(self, q, K, norm_kind):
         """The whole fit can be queued without a host round trip: lazy deflation (X is never written, so a wrong
         speculation costs nothing but the skipped launches), one response, shapes the step kernel covers."""
@@ -622,7 +669,6 @@ class HipEngine:
             self.X.sweep_lazy(dv, 1.0, g, self._xptr(0), self._xptr(n * B), self.slots["P~raw"], self.p, k,
                               self._coef[0], self._xptr(n * B + 3 * B), r2=self.r2,
                               mean=self.mean if self._cen else None)
-            self._scale_col(g_slot, g_slot)
         elif k:
             self.X.sweep_lazy(dv, 1.0, g, self._xptr(0), self._xptr(n * B), self.slots[self._lazy_pslot], self.p, k,
                               self._coef[0], self._xptr(n * B + 3 * B))
@@ -636,17 +682,15 @@ class HipEngine:
         pslot = self._lazy_pslot
         P = self.slots["P~raw"] if self._istd else self.slots[pslot]
         dv = None if last else self._vec_n[0]
+        if self._istd:
+            self._true_space(self.slots[pslot].col(k))
         self.X.loadings_sweep_lazy(self._vec_n[1], 1.0, P.col(k), self._xptr(n * B + B), dv, 1.0,
                                    None if last else self._slot_col(g_slot), None if last else self._xptr(0),
                                    None if last else self._xptr(n * B), P, self.p, k, self._coef[0], self._coef[1],
                                    self._xptr(n * B + 3 * B), r2=self.r2 if self._istd else None,
                                    mean=self.mean if self._cen else None)
-        if self._istd:
-            self._scale_col(("P~raw", k), (pslot, k))
-            if not last:
-                self._scale_col(g_slot, g_slot)
 
-    def nipals_resident(self, Y, K, norm_kind, tol, wslot, Wn_h, W_h, P_h):
+    def nipals_resident(self, Y, K, norm_kind, tol, wslot, Wn_h, W_h, P_h, first_pass):
         """Queue a complete one-response NIPALS fit (mbpls.py:836-969 for every component) on the device: the first
         pass must already be queued (prepare(..., defer=True)).  Per component: step, sweep, step, loadings (+ lazy
         deflation + next first sweep); the step kernel (csrc/resident.hip) does the n x B algebra and the stop test
@@ -654,8 +698,9 @@ class HipEngine:
         Finished columns of W~, W and P are copied to the host by a helper thread behind events.  The queue is
         speculative (two iterations per component, which is what one response takes); returns the results of the
         components that converged that way (``k_done`` of them -- the caller resumes from there when k_done < K)."""
+        first_pass()          # statistics + first sweep: running while the queue's device state is built and uploaded
         with _ResidentQueue(self, Y, K, norm_kind, tol, mode=0) as rq:
-            Wn, Wb, Pm = self.slots[wslot], self.slot("Wblk", K), self.slots[self._lazy_pslot]
+            Wn, Pm = self.slots[wslot], self.slots[self._lazy_pslot]
             p8, B = 8 * self.p, self.nblocks
             with self._timed("queue_passes"):
                 rq.step(0, 1, 0)
@@ -663,26 +708,30 @@ class HipEngine:
                     last = k == K - 1
                     self._res_sweep(k, (wslot, k))                   # second iteration (:856, :875)
                     rq.step(k, 2, k)
-                    # w_b = w~_b / ||w~_b|| (:860) with the norms the step just recorded
-                    rq.block_unit_col(Wn.ptr + p8 * k, Wb.ptr + p8 * k, k)
-                    rq.stream_out([(rq.col(Wn_h, k), Wn.ptr + p8 * k), (rq.col(W_h, k), Wb.ptr + p8 * k)]
-                                  + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []))
+                    # w~ column k is final; w_b = w~_b / ||w~_b|| (:860) is formed on the host from it and the norms the
+                    # step just recorded
+                    nu_copy, unit = rq.unit_blocks_on_host(Wn_h, W_h, k)
+                    rq.stream_out([(rq.col(Wn_h, k), Wn.ptr + p8 * k)] + nu_copy
+                                  + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []), post=unit)
                     self._res_loadings(k, last, None if last else (wslot, k + 1))   # (:928, :969) + next first sweep
                     if not last:
                         rq.step(k + 1, 1, k + 1)
                     else:
                         rq.allreduce()
+                rq.last_loadings_norms()
                 rq.stream_out([(rq.col(P_h, K - 1), Pm.ptr + p8 * (K - 1))])
+                rq.cross(self._lazy_pslot, wslot)
         return rq.result
 
-    def unipals_resident(self, Y, K, wslot, gslot, W_h, P_h):
+    def unipals_resident(self, Y, K, wslot, gslot, W_h, P_h, first_pass):
         """The p > n branch of UNIPALS with one response (mbpls.py:481-572) as one device queue: a component costs ONE
         pass (loadings + lazy deflation + the products X^T y, X_b (X^T y)_b of the next component, see
         solvers.fit_unipals); the step kernel forms ts = X (X^T y) / ||.||, v, u, the scalar c with w = c X^T y, the block
         norms and scores between the passes.  No iteration, so nothing is speculative; the offset check of the first
         step is the same as for NIPALS."""
+        first_pass()
         with _ResidentQueue(self, Y, K, 0, 0.0, mode=1) as rq:
-            S, Wc, Wb, Pm = self.slots[gslot], self.slots[wslot], self.slot("Wblk", K), self.slots[self._lazy_pslot]
+            S, Wc, Pm = self.slots[gslot], self.slots[wslot], self.slots[self._lazy_pslot]
             p8 = 8 * self.p
             with self._timed("queue_passes"):
                 rq.step(0, 1, 0)
@@ -690,15 +739,17 @@ class HipEngine:
                     last = k == K - 1
                     # w_raw = X^T u = c X^T y (:503): the column the pass left in S times the scalar the step recorded
                     rq.scale_col(S.ptr, Wc.ptr + p8 * k, k)
-                    rq.block_unit_col(Wc.ptr + p8 * k, Wb.ptr + p8 * k, k)           # w_b / ||w_b|| (:510-512)
-                    rq.stream_out([(rq.col(W_h, k), Wb.ptr + p8 * k)]
-                                  + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []))
+                    nu_copy, unit = rq.unit_blocks_on_host(W_h, W_h, k)              # w_b / ||w_b|| (:510-512)
+                    rq.stream_out([(rq.col(W_h, k), Wc.ptr + p8 * k)] + nu_copy
+                                  + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []), post=unit)
                     self._res_loadings(k, last, None if last else (gslot, 0))        # p (:520), deflation (:535)
                     if not last:
                         rq.step(k + 1, 1, k + 1)
                     else:
                         rq.allreduce()
+                rq.last_loadings_norms()
                 rq.stream_out([(rq.col(P_h, K - 1), Pm.ptr + p8 * (K - 1))])
+                rq.cross(self._lazy_pslot, wslot)
         return rq.result
 
     def xt_v(self, V, alpha, slot, k0=0, want_ssq=False):
@@ -927,17 +978,20 @@ def _copier_queue():
                 if isinstance(job, threading.Event):
                     job.set()
                     continue
-                ctx, ev, copies, errors = job
+                ctx, ev, copies, errors = job[:4]
+                post = job[4] if len(job) > 4 else None
                 try:
                     for dst, src in copies:
                         _capi.check(ctx.lib.mbpls_hip_memcpy_d2h_after(ctx.handle, ev, dst.ctypes.data, src, dst.nbytes))
+                    if post is not None:
+                        post()                  # host arithmetic on what just arrived (numpy releases the GIL)
                 except BaseException as e:      # re-raised on the thread that owns the fit
                     errors.append(e)
                 finally:
                     ctx.lib.mbpls_hip_event_destroy(ctx.handle, ev)
                     # drop every reference to the host arrays before blocking on the queue again: a view kept here
                     # would pin the attribute buffers of this fit, which the next fit wants to recycle (mbpls._recyclable)
-                    job = ctx = ev = copies = errors = dst = src = None
+                    job = ctx = ev = copies = errors = dst = src = post = None
 
         th = threading.Thread(target=work, daemon=True, name="mbpls-copier")
         th.start()
@@ -951,26 +1005,45 @@ class _ResidentQueue:
     manager around the queueing of the passes; ``result`` is available afterwards."""
 
     def __init__(self, eng, Y, K, norm_kind, tol, mode):
-        self.eng, self.K, self.mode = eng, K, mode
+        self.eng, self.K, self.mode, self.istd = eng, K, mode, bool(eng._istd)
         n, B, q = eng.n, eng.nblocks, Y.shape[1]
         ctx = self.ctx = eng.ctx
         self.lib = ctx.lib
-        Ts = ctx.empty((n, K))
-        self.bufs = dict(Y=ctx.from_host(np.asfortranarray(Y)), Ts=Ts, Tsc=ctx.empty((n, K)) if eng._istd else Ts,
-                         U=ctx.empty((n, K)), V=ctx.empty((q, K)), Tb=ctx.empty(n * B * K),
-                         scal=ctx.empty(K * 4 * B, zero=True), ssqx=ctx.empty(B), iters=ctx.empty(K, zero=True),
-                         u_cur=ctx.from_host(np.ascontiguousarray(Y[:, 0])), ts_old=ctx.empty(n, zero=True),
-                         par=ctx.from_host(np.zeros(8)))
-        b = self.bufs
+        # ONE device allocation, ONE upload, ONE download: [u_cur | Y | ts_old | par | scal | iters | ssq_x | C | V | Ts |
+        # U | Tb | Tsc].  Everything up to V is uploaded (zeros where the step expects them); par .. Tb come back in one
+        # copy.
+        sizes = [("u_cur", n), ("Y", n * q), ("ts_old", n), ("par", 8), ("scal", K * 4 * B), ("iters", K), ("ssqx", B),
+                 ("C", K * K), ("V", q * K), ("Ts", n * K), ("U", n * K), ("Tb", n * B * K)] \
+            + ([("Tsc", n * K)] if self.istd else [])
+        self.crossed = False
+        self.off, o = {}, 0
+        for key, sz in sizes:
+            self.off[key] = (o, sz)
+            o += sz
+        self.state = ctx.empty(o)
+        up = np.zeros(self.off["V"][0])
+        up[:n] = Y[:, 0]
+        up[n:n + n * q] = np.asfortranarray(Y).ravel(order="F")
+        _capi.check(self.lib.mbpls_hip_memcpy_h2d(ctx.handle, self.state.ptr, up.ctypes.data, up.nbytes))
+        self._up = up                               # (the copy is stream-ordered: keep the source alive)
+        ptr = {key: self.state.ptr + 8 * o for key, (o, _) in self.off.items()}
+        if not self.istd:
+            ptr["Tsc"] = ptr["Ts"]
+        self.ptr = ptr
         # raw-space passes without centring are only good for modestly offset data: the first step checks the measure
         # the statistics pass left behind and stops the queue when the centring flavour is needed
-        amp2 = eng.CENTRE_FROM_OFFSET ** 2 if (eng._istd and not eng._cen) else 0.0
-        self.st = _capi.NipalsStep(n=n, nblocks=B, q=q, centre=int(eng._istd), norm_kind=int(norm_kind), tol=float(tol),
-                                   amp2_max=amp2, mode=int(mode), xchg=eng._xchg.ptr, Y=b["Y"].ptr, Ts=Ts.ptr,
-                                   Tsc=b["Tsc"].ptr, U=b["U"].ptr, V=b["V"].ptr, Tb=b["Tb"].ptr, scal=b["scal"].ptr,
-                                   ssq_x=b["ssqx"].ptr, iters=b["iters"].ptr, u_cur=b["u_cur"].ptr,
-                                   ts_old=b["ts_old"].ptr, vpass=eng._vec_n[0].ptr, tspass=eng._vec_n[1].ptr,
-                                   cu=eng._coef[0].ptr, ce=eng._coef[1].ptr, par=b["par"].ptr)
+        amp2 = eng.CENTRE_FROM_OFFSET ** 2 if (self.istd and not eng._cen) else 0.0
+        self.st = _capi.NipalsStep(n=n, nblocks=B, q=q, centre=int(self.istd), norm_kind=int(norm_kind), tol=float(tol),
+                                   amp2_max=amp2, mode=int(mode), xchg=eng._xchg.ptr, Y=ptr["Y"], Ts=ptr["Ts"],
+                                   Tsc=ptr["Tsc"], U=ptr["U"], V=ptr["V"], Tb=ptr["Tb"], scal=ptr["scal"],
+                                   ssq_x=ptr["ssqx"], iters=ptr["iters"], u_cur=ptr["u_cur"],
+                                   ts_old=ptr["ts_old"], vpass=eng._vec_n[0].ptr, tspass=eng._vec_n[1].ptr,
+                                   cu=eng._coef[0].ptr, ce=eng._coef[1].ptr, par=ptr["par"])
+        # block norms of every recorded component, written by the step straight into pinned host memory: the helper
+        # thread that forms w_b = w~_b / ||w~_b|| reads them there (a copy of B doubles into pageable memory is a blit
+        # kernel that waits behind -- and slows -- the running pass: 180 us each)
+        self.nu2_h, nu2_d = ctx.mapped_scalars(K * B)
+        self.st.nu2_host = nu2_d
         self.errors = []
         self.jobs = _copier_queue()
         self.result = None
@@ -981,10 +1054,30 @@ class _ResidentQueue:
         assert c.flags.c_contiguous
         return c
 
-    def stream_out(self, copies):
+    def stream_out(self, copies, post=None):
+        """copy finished device columns to the host (helper thread) behind everything queued on the compute stream so
+        far; ``post``: host arithmetic the helper thread does on them afterwards"""
         ev = _capi._vp()
         _capi.check(self.lib.mbpls_hip_event_record(self.ctx.handle, _capi.C.byref(ev)))
-        self.jobs.put((self.ctx, ev, copies, self.errors))
+        self.jobs.put((self.ctx, ev, copies, self.errors, post))
+
+    def unit_blocks_on_host(self, src_h, dst_h, k):
+        """(copies, post) for stream_out: w_b = w~_b / ||w~_b|| (mbpls.py:860 / :510-512) for column k, formed by the
+        helper thread from the column it has just copied (``src_h[:, k]``, may be ``dst_h`` itself) and the block norms
+        the step of component k left on the device -- a p-sized kernel between two passes costs the queue more than
+        the division costs a thread that is waiting anyway (on a side stream it ran 60x slower and slowed the pass:
+        the fat pass workgroups leave no registers for a second kernel's waves)."""
+        B = self.eng.nblocks
+        offs = self.eng.block_offsets
+        nu2 = self.nu2_h
+
+        def post():
+            with np.errstate(divide="ignore", invalid="ignore"):       # (a block without weight: as on the device)
+                for b in range(B):
+                    r0, r1 = offs[b], offs[b + 1]
+                    np.divide(src_h[r0:r1, k], np.sqrt(nu2[k * B + b]), out=dst_h[r0:r1, k])
+
+        return [], post
 
     # ---- launches
     def allreduce(self):
@@ -996,67 +1089,98 @@ class _ResidentQueue:
         self.st.kc, self.st.run, self.st.nd = kc, run, nd
         _capi.check(self.lib.mbpls_hip_nipals_step(self.ctx.handle, self.st))
 
-    def block_unit_col(self, src, dst, k):
-        B = self.eng.nblocks
-        _capi.check(self.lib.mbpls_hip_block_unit_col(self.eng.X.handle, src, dst, self.bufs["scal"].ptr + 8 * 4 * B * k))
+    def last_loadings_norms(self):
+        """||p_b||^2 of the last (loadings-only) pass: B values of the exchange buffer, moved into the results block on
+        the device (the step of the next component records them otherwise)"""
+        eng, B = self.eng, self.eng.nblocks
+        _capi.check(self.lib.mbpls_hip_memcpy_d2d(self.ctx.handle, self.ptr["scal"] + 8 * (4 * B * (self.K - 1) + 2 * B),
+                                                  eng._xptr(eng.n * B + B), 8 * B))
+
+    def cross(self, pslot, wslot):
+        """C = P^T W~ (K x K, mbpls.py:988) queued behind the last pass, summed over the column shards on the device:
+        it comes back with the other results instead of costing a host round trip of its own after the queue"""
+        eng, K = self.eng, self.K
+        if K > 32 or not getattr(eng.comm, "device_views_ok", False):
+            return
+        A, Bm = eng.slots[pslot], eng.slots[wslot]
+        dC = _capi.DeviceArray(self.ctx, (K * K,), ptr=self.ptr["C"])
+        _capi.check(self.lib.mbpls_hip_cross_product_dev(self.ctx.handle, eng.p, A.ptr, eng.p, K, Bm.ptr, eng.p, K, dC.ptr))
+        if eng.comm.is_distributed:
+            eng.comm.allreduce_device(dC)
+        self.crossed = True
 
     def scale_col(self, src, dst, k):
         """dst = src * c_k with the scalar the step of component k left at scal[k][3][0]"""
         B = self.eng.nblocks
         _capi.check(self.lib.mbpls_hip_scale_col_by(self.ctx.handle, self.eng.p, src, dst,
-                                                    self.bufs["scal"].ptr + 8 * (4 * B * k + 3 * B)))
+                                                    self.ptr["scal"] + 8 * (4 * B * k + 3 * B)))
 
     # ---- context manager
     def __enter__(self):
-        _capi.check(self.lib.mbpls_hip_set_pass_params(self.ctx.handle, self.bufs["par"].ptr))
+        _capi.check(self.lib.mbpls_hip_set_pass_params(self.ctx.handle, self.ptr["par"]))
         return self
 
+    def _view(self, h, key, shape=None):
+        o, sz = self.off[key]
+        o -= self.off["par"][0]
+        a = h[o:o + sz]
+        return a if shape is None else a.reshape(shape, order="F")
+
     def __exit__(self, et, ev, tb):
-        eng, bufs, K = self.eng, self.bufs, self.K
-        n, B = eng.n, eng.nblocks
+        eng, K = self.eng, self.K
+        n, B, q = eng.n, eng.nblocks, self.st.q
+        h = None
         try:
             if et is None:
                 eng.run_deferred(all_of_it=True)          # host chores while the GPU works through the queue
                 with eng._timed("wait_kernel+d2h_small"):
-                    par = bufs["par"].get()
+                    # par .. Tb in ONE copy (waits for the queue)
+                    o0, o1 = self.off["par"][0], self.off["Tb"][0] + self.off["Tb"][1]
+                    h = np.empty(o1 - o0)
+                    _capi.check(self.lib.mbpls_hip_memcpy_d2h(self.ctx.handle, h.ctypes.data, self.state.ptr + 8 * o0,
+                                                              h.nbytes))
         finally:
             self.lib.mbpls_hip_set_pass_params(self.ctx.handle, None)
             import threading
             done = threading.Event()
             self.jobs.put(done)             # every copy queued before this one has landed when it is set
+            errors = self.errors
+
+            def wait_copies():
+                done.wait()
+                if errors:
+                    raise errors[0]
+
+        if et is not None or h is None:
             done.wait()
-        if et is not None:
+            self.state.free()
             return False
-        if self.errors:
-            raise self.errors[0]
-
-        def free_all():
-            for key, b in bufs.items():
-                if key != "Tsc" or eng._istd:
-                    b.free()
-
+        par = self._view(h, "par")
         if par[7] != 0.0:
-            free_all()
-            raise _capi.HipError("device-resident fit: a grid barrier of the step kernel timed out (the workgroups of "
-                                 "one launch were not co-resident -- is another stream occupying the GPU?)")
+            # a grid barrier of the multi-workgroup step gave up (cooperative launch: should never happen) -- nothing
+            # was written to X, so the caller simply runs the fit with its host-driven loop
+            wait_copies()
+            self.state.free()
+            self.result = dict(k_done=0, reason="barrier")
+            return False
         if par[2] != 0.0 and par[5] == 1.0:
             # offset data (max |mean|/scale = sqrt(par[6])): the caller queues again, now with centring passes
             eng._cen = True
-            free_all()
+            wait_copies()
+            self.state.free()
             self.result = dict(k_done=0, reason="offset", offset=float(np.sqrt(par[6])))
             return False
         k_done = K if par[2] == 0.0 else int(par[3])
-        scal = bufs["scal"].get().reshape(K, 4, B)
-        if k_done == K:
-            # ||p_b||^2 of the last (loadings-only) pass: B values of the exchange buffer, not all n x B of it
-            scal[K - 1, 2] = _capi.DeviceArray(self.ctx, (B,), ptr=eng._xptr(n * B + B)).get()
-        with eng._timed("d2h_scores"):
-            self.result = dict(k_done=k_done, Ts=bufs["Ts"].get(), U=bufs["U"].get(), V=bufs["V"].get(),
-                               Tb=bufs["Tb"].get().reshape(K, B, n), scal=scal, ssq_x=bufs["ssqx"].get(),
-                               iters=bufs["iters"].get(), last_diff=float(par[4]))
+        scal = self._view(h, "scal").reshape(K, 4, B)
+        # the attribute columns the helper thread is still copying / scaling must have landed before they are used:
+        # the caller waits right before it hands them out (wait_copies), not here
+        self.result = dict(k_done=k_done, wait_copies=wait_copies, Ts=self._view(h, "Ts", (n, K)), U=self._view(h, "U", (n, K)),
+                           V=self._view(h, "V", (q, K)), Tb=self._view(h, "Tb").reshape(K, B, n), scal=scal,
+                           ssq_x=self._view(h, "ssqx").copy(), iters=self._view(h, "iters"), last_diff=float(par[4]),
+                           PtW=self._view(h, "C").reshape(K, K).copy() if (self.crossed and k_done == K) else None)
         if k_done < K:
             # hand the lazy-deflation state to the host-driven loop
-            Tc = bufs["Tsc"].get()
+            Tc = _capi.DeviceArray(self.ctx, (n, K), ptr=self.ptr["Tsc"]).get()
             eng._lazy_ts = [np.ascontiguousarray(Tc[:, i]) for i in range(k_done)]
-        free_all()
+        self.state.free()
         return False

@@ -11,7 +11,10 @@ Deliberate deviations from the reference (documented in DESIGN.md):
   host (n x q) for EVERY row, where the reference only patches the sparse rows of the last X block and fails on any
   other (mbpls.py:903): same numbers wherever the reference produces any.
 * NIPALS has an iteration cap (``solvers.NIPALS_MAX_ITER``) with a warning; the reference loops
-  forever on data without latent structure (mbpls.py:841).
+  forever on data without latent structure (mbpls.py:841).  With ONE complete response the loop also gives up after
+  ``solvers.NIPALS_Q1_NOISE_FLOOR_ITER`` iterations -- always with a warning, ``nipals_converged_[k] = False`` -- when
+  ``||ts_old - ts||`` is still above ``max_tol``: the iteration is at its fixed point after the first pass, what is
+  left is rounding noise of a response that is exhausted, and the reference does not terminate there either.
 * SIMPLS with one response and ``full_svd=False`` works (the reference raises inside scipy ``svds``).
 * X may also be a ``DeviceMatrix`` already resident in HBM (feature-major); ``copy`` then decides
   whether it is deflated in place.
@@ -423,7 +426,8 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             out.append(T)
         if Y is not None:
             if self.sparse_data is True:                                            # :1120, NaN allowed
-                Y = np.array(Y, dtype=np.float64, copy=copy)
+                # (numpy >= 2: copy=False raises when a conversion is needed; check_array(copy=False) copies only then)
+                Y = np.array(Y, dtype=np.float64) if copy else np.asarray(Y, dtype=np.float64)
                 if np.isinf(Y).any():
                     raise ValueError("Input Y contains infinity or a value too large for dtype('float64').")
             else:

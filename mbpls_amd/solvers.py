@@ -19,6 +19,15 @@ import numpy as np
 # Guard against the reference's unbounded ``while diff_t > max_tol`` (mbpls.py:841): on data
 # without latent structure it never terminates.  Far above any converging case (q=10: ~100).
 NIPALS_MAX_ITER = 5000
+# One complete response: u = Y v / ||Y v|| = +-y/||y|| whatever ts was (v is 1 x 1), so the NIPALS iteration sits at its
+# fixed point after the FIRST pass and every later pass recomputes the same ts; successive ts then differ by rounding
+# only.  Where y is (nearly) exhausted -- beyond ~29 components at n = 4096 on the bench's planted data: explained Y
+# > 0.9999 -- that rounding is amplified by ||y|| / ||y residual|| and ||ts_old - ts|| <= 1e-14 (mbpls.py:841) is out of
+# reach for the reference too: its loop does not end (the CPU oracle, explicit deflation, shows 2 iterations for
+# components 0..28 and then 6, cap, cap, 4, cap, ... on the same data -- tools/deep_iterations_cpu.py).  More passes
+# only re-roll the rounding, so the one-response loop gives up after this many iterations, ALWAYS with a warning, and
+# the component is flagged in ``nipals_converged_``.  Listed among the deliberate deviations.
+NIPALS_Q1_NOISE_FLOOR_ITER = 4
 
 
 def _norm(x, order):
@@ -126,7 +135,7 @@ def _finalise(eng, res, Wcols, P, V):
     res.P_ = _split(P, eng.block_offsets)
 
 
-def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_host=None, P_host=None, fetch=True):
+def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_host=None, P_host=None, fetch=True, C=None):
     """End-of-fit algebra on the device (mbpls.py:986-991, :569-572, :733-738).
 
     wslot holds raw weight columns; the unit-length weights are W = wslot diag(1/col_norm) and the
@@ -135,7 +144,8 @@ def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_hos
         R_ = W (P^T W)^+ = wslot [D (C D)^+],   beta_ = R_ V^T = wslot [D (C D)^+ V^T]
     so only K x K matrices touch the host; p x K arrays are fetched once each, as attributes."""
     D = 1.0 / np.asarray(col_norm, dtype=np.float64)
-    C = eng.cross((pslot, 0, K), (wslot, 0, K))
+    if C is None:                       # (a device-resident fit brings it along with its other results)
+        C = eng.cross((pslot, 0, K), (wslot, 0, K))
     M = D[:, None] * np.linalg.pinv(C * D[None, :])
     q = V.shape[0]
     eng.slot("R", K)
@@ -155,9 +165,20 @@ def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_hos
         res.W_ = _split(W_host if W_host is not None else eng.fetch("Wblk", **kw), offs)
         res.P_ = _split(P_host if P_host is not None else eng.fetch(pslot, **kw), offs)
 
+    if fetch == "async" and hasattr(eng, "fetch_async") and W_host is not None and P_host is not None:
+        # R_ and beta_ leave through the helper thread while the caller does its host-side bookkeeping
+        (_, wait_r), (_, wait_b) = eng.fetch_async("R"), eng.fetch_async("beta")
+
+        def finish():
+            res.R_, res.beta_ = wait_r(), wait_b()
+            res.W_, res.P_ = _split(W_host, offs), _split(P_host, offs)
+
+        return finish
     if not fetch:
         return fetch_all
     fetch_all()
+    if fetch == "async":
+        return lambda: None
 
 
 # ----------------------------------------------------------------------------------- NIPALS
@@ -439,6 +460,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     T = [np.empty((n, K)) for _ in range(B)]
     nu_all = np.empty((B, K))
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
+    converged = []          # per component: the stop rule of mbpls.py:841 was met (not a cap / noise-floor stop)
     # host copies of the p x K attributes, filled column by column while later passes run on the GPU
     Wn_h, W_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
     vary = resp.ssq
@@ -450,24 +472,37 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
             and eng.resident_supported(q, K, kind)):
         # One response: the whole fit is queued on the device (two iterations per component -- what one response takes),
         # the host reads the results once.  Components the speculation did not hold for are resumed below.
-        eng.prepare(standardize, v=u0, alpha=alpha0, g_slot=("Wn", 0), defer=True)
-        out = eng.nipals_resident(Y, K, kind, max_tol, "Wn", Wn_h, W_h, P_h)
+        first = eng.deferred_first_pass(standardize, u0, alpha0, ("Wn", 0))
+        out = eng.nipals_resident(Y, K, kind, max_tol, "Wn", Wn_h, W_h, P_h, first)
         if out.get("reason") == "offset":
             # badly offset columns: the same queue again with the passes that centre in registers (the first pass is
             # repeated because a sharded run has already summed its exchange buffer once more)
-            eng.prepare(standardize, v=u0, alpha=alpha0, g_slot=("Wn", 0), defer=True)
-            out = eng.nipals_resident(Y, K, kind, max_tol, "Wn", Wn_h, W_h, P_h)
+            out = eng.nipals_resident(Y, K, kind, max_tol, "Wn", Wn_h, W_h, P_h, first)
+        resident = out.get("reason") != "barrier"
+    else:
+        resident = False
+    if resident:
         varxb = out["ssq_x"]                                # summed over the column shards on the device already
         if not np.all(np.isfinite(varxb)):
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
         varx = varxb.sum()
         k_start = out["k_done"]
         whole = k_start == K
+        finish = None
+        res = FitResult()
         if whole:
             # every component came from the device: the downloaded arrays ARE the attributes (no n x K host copies --
             # at n = 10^6 those cost more than a pass over X)
             Ts, U = out["Ts"], out["U"]
             T = [out["Tb"][:, b, :].T for b in range(B)]
+            # end-of-fit algebra first (K x K pinv here, R_ / beta_ on the device, their copies in the helper thread);
+            # the per-component bookkeeping below runs while they travel
+            nu_all[:] = np.sqrt(out["scal"][:, 0, :].T)
+            V[:] = out["V"]
+            finish = _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V, W_host=W_h,
+                                      P_host=P_h, fetch="async", C=out.get("PtW"))
+        if not whole:
+            out["wait_copies"]()                            # the host loop below writes the same host columns
         for k in range(k_start):
             ts, v = out["Ts"][:, k:k + 1], out["V"][:, k:k + 1]
             V[:, k:k + 1] = v
@@ -478,6 +513,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
             A[:, k] = out["scal"][k, 1]
             nu_all[:, k] = np.sqrt(out["scal"][k, 0])
             iters.append(int(out["iters"][k]))
+            converged.append(True)                          # (the device step records a component only when it converged)
             if calc_all:                                    # (:932-964), analytic (ts^T ts)(p^T p)
                 ssq_p = out["scal"][k, 2]
                 tt = ts.T.dot(ts).item()
@@ -524,16 +560,14 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
                 warnings.warn(f"NIPALS component {k}: no convergence to max_tol={max_tol} after {max_iter} "
                               f"iterations (last diff {diff:.3e}); the reference would loop forever here.")
                 break
-            if q == 1 and not resp.sparse and run - 1 >= 4 and diff > max_tol:
-                # One complete response: u = Y v / ||Y v|| = +-y/||y|| whatever ts was, so the iteration sits at its
-                # fixed point after the first pass and successive ts differ by rounding only.  A difference that is
-                # still above max_tol now is the noise floor of this component (deep components of a nearly exhausted
-                # X), not a lack of iterations: more passes would only re-roll the rounding.
-                if diff > 1e4 * max_tol:
-                    warnings.warn(f"NIPALS component {k}: ||ts_old - ts|| = {diff:.3e} stays above max_tol={max_tol} "
-                                  f"(rounding noise of a nearly exhausted X); stopped after {run - 1} iterations.")
+            if q == 1 and not resp.sparse and run - 1 >= NIPALS_Q1_NOISE_FLOOR_ITER and diff > max_tol:
+                warnings.warn(f"NIPALS component {k}: ||ts_old - ts|| = {diff:.3e} stays above max_tol={max_tol} after "
+                              f"{run - 1} iterations -- with one response the iteration has been at its fixed point "
+                              f"since the first pass, the difference is rounding noise (y is nearly exhausted); "
+                              f"stopped here, the reference would keep iterating (nipals_converged_[{k}] = False).")
                 break
         iters.append(run - 1)
+        converged.append(bool(diff <= max_tol))
         last = (k == K - 1)
 
         def stream_out(k=k, nu=nu):
@@ -561,15 +595,21 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
             evxb[:, k] = tt * ssq_p / varxb
             Acorr[:, k] = _bip_corrected(sw ** 2, sizes)
         t_raw, ssq = t_next, ssq_next
-    res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, nipals_iterations_=iters)
+    if not resident:
+        res, finish = FitResult(), None
+    res.update(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, nipals_iterations_=iters, nipals_converged_=converged)
     if calc_all:
         res.update(explained_var_x_=evx, explained_var_y_=evy, explained_var_xblocks_=evxb, A_corrected_=Acorr)
     else:
         res.update(explained_var_x_=[], explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)),
                    A_corrected_=np.empty((B, 0)))
-    # ||W~[:, k]||^2 = sum_b ||w~_b||^2 of the last iteration (already summed over shards)  (:986-987)
-    eng.fetch_col("P", K - 1, P_h)
-    _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V, W_host=W_h, P_host=P_h)
+    if callable(finish):
+        finish()
+        out["wait_copies"]()                                # streamed columns of W~, W, P complete
+    else:
+        # ||W~[:, k]||^2 = sum_b ||w~_b||^2 of the last iteration (already summed over shards)  (:986-987)
+        eng.fetch_col("P", K - 1, P_h)
+        _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V, W_host=W_h, P_host=P_h)
     res.W_non_normal_ = _split(Wn_h, eng.block_offsets)
     return res
 
@@ -663,11 +703,15 @@ def fit_unipals(eng, Y, K, standardize):
     if fuse and hasattr(eng, "unipals_resident") and eng.resident_supported(q, K, 0):
         # one response: a component is ONE pass and everything between two passes is n x B algebra -- the whole fit
         # is queued on the device (engine.unipals_resident), the host reads the results once
+        first = eng.deferred_first_pass(standardize, y0, 1.0, ("S", 0))
         for attempt in range(2):
-            eng.prepare(standardize, v=y0, alpha=1.0, g_slot=("S", 0), defer=True)
-            out = eng.unipals_resident(Y, K, "Wc", "S", W_h, P_h)
+            out = eng.unipals_resident(Y, K, "Wc", "S", W_h, P_h, first)
             if out.get("reason") != "offset":
                 break                                       # (offset data: queued again with centring passes)
+        resident = out.get("reason") != "barrier"
+    else:
+        resident = False
+    if resident:
         varxb = out["ssq_x"]
         if not np.all(np.isfinite(varxb)):
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
@@ -688,7 +732,8 @@ def fit_unipals(eng, Y, K, standardize):
             Acorr[:, k] = _bip_corrected(A[:, k], sizes)    # (:542-553)
         res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, explained_var_x_=evx, explained_var_y_=evy,
                         explained_var_xblocks_=evxb, A_corrected_=Acorr)
-        _finalise_device(eng, res, "Wc", K, tot_nrm, blk_nrm, V, W_host=W_h, P_host=P_h)   # (:569-572)
+        _finalise_device(eng, res, "Wc", K, tot_nrm, blk_nrm, V, W_host=W_h, P_host=P_h, C=out.get("PtW"))   # (:569-572)
+        out["wait_copies"]()                                # streamed columns of W, P complete
         return res
     varxb, m_raw, g_ssq = eng.prepare(standardize, v=y0 if fuse else None, alpha=1.0, g_slot=("S", 0) if fuse else None)
     yy = y0.T.dot(y0).item()

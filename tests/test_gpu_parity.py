@@ -366,14 +366,9 @@ def test_medium_vs_oracle(gpu_required, method, n, p, q, K, blocks):
     assert w < 1e-8, w
     if method == "NIPALS" and q == 1:
         assert ref.nipals_iterations_ == [2] * K
-        # Lazy deflation (K < 39) applies X_k = X_0 - sum ts_i p_i^T algebraically: its rounding is relative to X_0, not
-        # to the (much smaller) deflated X_k, so deep components can miss ||ts_old - ts|| <= 1e-14 by a hair on the
-        # second iteration and take a third or fourth (where the one-response loop stops: the iteration has been at its
-        # fixed point since the first pass) -- same numbers (asserted above), a pass or two more.
-        assert mdl.nipals_iterations_[:10] == [2] * min(K, 10)
-        assert all(i in (2, 3, 4) for i in mdl.nipals_iterations_), mdl.nipals_iterations_
-        if K >= 39:
-            assert mdl.nipals_iterations_ == [2] * K
+        # lazy deflation (K < 39) with re-orthogonalised sweep vectors reaches the stop rule ||ts_old - ts|| <= 1e-14
+        # (mbpls.py:841) on the second iteration of EVERY component, as the explicitly deflated reference does
+        assert list(mdl.nipals_iterations_) == list(ref.nipals_iterations_), mdl.nipals_iterations_
 
 
 @pytest.mark.parametrize("p,c1,c2", [(70, 2, 2), (1001, 3, 1), (50000, 10, 10), (300001, 20, 7), (4097, 32, 32)])
@@ -586,14 +581,40 @@ def test_many_components(gpu_required, method, K, q, n, p):
     assert w < 1e-8, w
     if method == "NIPALS" and q == 1:
         assert ref.nipals_iterations_ == [2] * K
-        # Lazy deflation (K < 39) applies X_k = X_0 - sum ts_i p_i^T algebraically: its rounding is relative to X_0, not
-        # to the (much smaller) deflated X_k, so deep components can miss ||ts_old - ts|| <= 1e-14 by a hair on the
-        # second iteration and take a third or fourth (where the one-response loop stops: the iteration has been at its
-        # fixed point since the first pass) -- same numbers (asserted above), a pass or two more.
-        assert mdl.nipals_iterations_[:10] == [2] * min(K, 10)
-        assert all(i in (2, 3, 4) for i in mdl.nipals_iterations_), mdl.nipals_iterations_
-        if K >= 39:
-            assert mdl.nipals_iterations_ == [2] * K
+        # lazy deflation (K < 39) with re-orthogonalised sweep vectors reaches the stop rule ||ts_old - ts|| <= 1e-14
+        # (mbpls.py:841) on the second iteration of EVERY component, as the explicitly deflated reference does
+        assert list(mdl.nipals_iterations_) == list(ref.nipals_iterations_), mdl.nipals_iterations_
+
+
+@pytest.mark.parametrize("n,p,K", [(512, 8192, 30), (1024, 16384, 34)])
+def test_exhausted_response_iterations_follow_the_oracle(gpu_required, n, p, K):
+    """Deep components of a response that p >> n columns fit exactly: the REFERENCE algorithm (oracle, explicit
+    deflation) meets ||ts_old - ts|| <= 1e-14 on the second iteration for the first 24 / 27 components and then no
+    longer terminates (iteration cap).  The lazily deflated fit -- sweep vectors re-orthogonalised against the earlier
+    scores -- takes exactly the oracle's iterations for every component of that converging stretch (device-resident
+    queue and resumed host loop), gives up on the others after NIPALS_Q1_NOISE_FLOOR_ITER passes with a warning, and
+    says which in nipals_converged_."""
+    from mbpls_amd import MBPLS, solvers
+    X, Y = orc.make_latent(n, p, 1, seed=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = orc.fit(X, Y, n_components=K, method="NIPALS", faithful=False, max_iter=12)
+    good = next(i for i, it in enumerate(ref.nipals_iterations_) if it != 2)
+    assert 20 <= good < K, ref.nipals_iterations_
+    good -= 2       # (the last components before the oracle gives up sit at the noise floor themselves: either may take a pass more)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        mdl = MBPLS(n_components=K).fit(X, Y)
+    assert list(mdl.nipals_iterations_[:good]) == [2] * good, (mdl.nipals_iterations_, ref.nipals_iterations_)
+    assert all(mdl.nipals_converged_[:good])
+    assert all(it <= solvers.NIPALS_Q1_NOISE_FLOOR_ITER for it in mdl.nipals_iterations_)
+    stopped = [k for k, c in enumerate(mdl.nipals_converged_) if not c]
+    assert all(k >= good for k in stopped)
+    assert len([w for w in rec if "stays above max_tol" in str(w.message)]) == len(stopped)
+    # the converging stretch agrees with the oracle to the usual tolerance
+    s = np.sign(np.sum(ref.Ts_[:, :good] * mdl.Ts_[:, :good], axis=0))
+    assert util.relerr(mdl.Ts_[:, :good] * s, ref.Ts_[:, :good]) < 1e-8
+    assert util.relerr(mdl.P_[0][:, :good] * s, ref.P_[0][:, :good]) < 1e-8
 
 
 @pytest.mark.parametrize("blocks,standardize,norm,implicit", [(1, True, 2, "1"), (3, True, 2, "1"), (3, False, 1, "1"),
