@@ -2,8 +2,9 @@
 // everyday shape: one response, up to four blocks, n <= 4096 samples.  Same inputs, same outputs, same decisions
 // (mbpls.py:860-913 between two passes over X; :489-517 for UNIPALS with one response) -- but a thread keeps ITS rows of
 // every n-vector in registers from the first load to the last store: the general kernel walks ten dependent row loops
-// through L2 (25-55 us, growing with the component index), this one issues all its loads up front and is bounded by
-// its six workgroup reductions (one barrier each, partials double-buffered in LDS).
+// through L2 (25-55 us, growing with the component index), this one issues all its loads up front -- the first eight
+// earlier scores included -- and is bounded by its six to eight workgroup reductions (one barrier each, partials
+// double-buffered in LDS).  256 threads, one wave per SIMD: up to 512 registers per thread.
 //
 // Re-orthogonalised sweep vectors (lazy deflation).  The passes that follow take X_k^T v as X_0^T v - sum_i P[:,i] <ts_i, v>.
 // For a deep component <x_j^0, v> and the correction are both large against their difference (y is explained by the
@@ -17,49 +18,63 @@
 
 namespace mbpls {
 
-constexpr int SR_T = 512;          // threads (8 waves)
-constexpr int SR_W = SR_T / 64;
+// Launch shapes: n <= 2048: 256 threads (one wave per SIMD, up to 512 registers each), the first 8 earlier scores in
+// registers; n <= 4096: 512 threads (256 registers each), the first 4.
 
-// Sum M <= 16 values over the workgroup; every thread gets the totals.  One barrier (alternating partial sets); the
-// eight wave partials of value k are read by the eight lanes 8(k mod 8) .. 8(k mod 8) + 7, summed with three DPP steps
-// and handed to every lane with v_readlane -- two LDS loads per thread whatever M is (reading all 8 M partials per
+// Sum M <= 16 values over a workgroup of W = 4 or 8 waves; every thread gets the totals.  One barrier (alternating
+// partial sets); the W wave partials of value k are read by W neighbouring lanes, summed with two / three DPP steps and
+// handed to every lane with v_readlane -- one or two LDS loads per thread whatever M is (reading all W M partials per
 // thread cost 256 registers at M = 16).  Fixed order.
-template <int M>
+template <int M, int W>
 __device__ __forceinline__ void sr_sum(double (&v)[M], double* part, int& buf) {
-  static_assert(M <= 16 && SR_W == 8, "8 wave partials of up to 16 values");
+  static_assert(M <= 16 && (W == 4 || W == 8), "4 or 8 wave partials of up to 16 values");
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < M; ++k) v[k] = wave_sum_last_row(v[k]);
-  double* r = part + buf * (SR_W * 16);
+  double* r = part + buf * (8 * 16);
   if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < M; ++k) r[w * 16 + k] = v[k];
   }
   __syncthreads();
-  double a = r[(lane & 7) * 16 + (lane >> 3)];
-  double b = (M > 8) ? r[(lane & 7) * 16 + 8 + (lane >> 3)] : 0.0;
-  a += dpp_move<0xB1, 0xf>(a);    // quad_perm [1,0,3,2]
-  a += dpp_move<0x4E, 0xf>(a);    // quad_perm [2,3,0,1]
-  a += dpp_move<0x141, 0xf>(a);   // row_half_mirror: all 8 lanes of the group hold the total
-  if constexpr (M > 8) {
-    b += dpp_move<0xB1, 0xf>(b);
-    b += dpp_move<0x4E, 0xf>(b);
-    b += dpp_move<0x141, 0xf>(b);
-  }
+  if constexpr (W == 4) {
+    double a = r[(lane & 3) * 16 + (lane >> 2)];
+    a += dpp_move<0xB1, 0xf>(a);    // quad_perm [1,0,3,2]
+    a += dpp_move<0x4E, 0xf>(a);    // quad_perm [2,3,0,1]: the 4 lanes of a quad hold the total of value lane / 4
 #pragma unroll
-  for (int k = 0; k < M; ++k) {
-    const double src = (k < 8) ? a : b;
-    const int lo = __builtin_amdgcn_readlane(__double2loint(src), 8 * (k & 7));
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(src), 8 * (k & 7));
-    v[k] = __hiloint2double(hi, lo);
+    for (int k = 0; k < M; ++k) {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(a), 4 * k);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(a), 4 * k);
+      v[k] = __hiloint2double(hi, lo);
+    }
+  } else {
+    double a = r[(lane & 7) * 16 + (lane >> 3)];
+    double b = (M > 8) ? r[(lane & 7) * 16 + 8 + (lane >> 3)] : 0.0;
+    a += dpp_move<0xB1, 0xf>(a);
+    a += dpp_move<0x4E, 0xf>(a);
+    a += dpp_move<0x141, 0xf>(a);   // row_half_mirror: the 8 lanes of a group hold the total
+    if constexpr (M > 8) {
+      b += dpp_move<0xB1, 0xf>(b);
+      b += dpp_move<0x4E, 0xf>(b);
+      b += dpp_move<0x141, 0xf>(b);
+    }
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      const double src = (k < 8) ? a : b;
+      const int lo = __builtin_amdgcn_readlane(__double2loint(src), 8 * (k & 7));
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(src), 8 * (k & 7));
+      v[k] = __hiloint2double(hi, lo);
+    }
   }
   buf ^= 1;
 }
 
-template <int RPT, int BM, bool FULL>
+template <int SR_T, int RPT, int SR_JC, int BM, bool FULL>
 __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
-  __shared__ double part[2 * SR_W * 16];
-  __shared__ double s_mx[2][SR_W], s_mn[2][SR_W];
+  constexpr int SR_W = SR_T / 64;
+  constexpr int NJ = SR_JC < 7 ? SR_JC : 7;       // scores per re-orthogonalisation round
+  __shared__ double part[2 * 8 * 16];
+  __shared__ double s_mx[SR_W], s_mn[SR_W];
   int buf = 0;
   double* par = s.par;
   if (par[2] != 0.0) return;             // an earlier component needed more iterations than were queued
@@ -95,10 +110,11 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
     else s.scal[(int64_t)(kc - 1) * 4 * B + 2 * B + tid] = ssq_p[tid];   // ||p_b||^2 of the component just deflated
   }
 
-  // ---- this thread's rows: tid + 512 i (a wave instruction covers 512 contiguous bytes: one workgroup = one CU's
-  // 64 B/clk of L1 is what bounds the sweeps over the earlier scores; rows contiguous per thread ran 3x slower).
-  // Every access is a wave-uniform base + a 32-bit lane offset shared by all arrays -- 64-bit addresses per row and
-  // array overflowed the register file.  FULL: n = 512 RPT, no masks.  Everything that needs no reduction is requested now.
+  // ---- this thread's rows: tid + 256 i (a wave instruction covers 512 contiguous bytes).  Every access is a
+  // wave-uniform base + a 32-bit lane offset shared by all arrays (64-bit addresses per row and array overflowed the
+  // register file).  FULL: n = 256 RPT, no masks.  EVERYTHING the step reads is requested now, the first SR_JC earlier
+  // scores included: they serve the lazy-deflation fix, the re-orthogonalisation and the coefficients of the next pass
+  // from registers (walking them through L2 once per phase cost ~3 us each, four times per step).
   unsigned ro[RPT];
   bool ok[RPT];
 #pragma unroll
@@ -110,7 +126,7 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
     if constexpr (FULL) return base[ro[i]];
     else return ok[i] ? base[ro[i]] : 0.0;
   };
-  double u[RPT], y[RPT], to[RPT], t[BM][RPT];
+  double u[RPT], y[RPT], to[RPT], t[BM][RPT], tc[SR_JC][RPT];
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     u[i] = ld(s.u_cur, i);
@@ -123,8 +139,25 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
 #pragma unroll
     for (int i = 0; i < RPT; ++i) t[b][i] = (b < B) ? ld(trb, i) : 0.0;
   }
-  // t~_b = A_b - Ts d_b (lazy deflation)
-  for (int j = 0; j < nd; ++j) {
+#pragma unroll
+  for (int j = 0; j < SR_JC; ++j) {
+    const double* tcj = s.Tsc + (int64_t)(j < kc ? j : 0) * n;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) tc[j][i] = (j < kc) ? ld(tcj, i) : 0.0;
+  }
+  // t~_b = A_b - Ts d_b (lazy deflation): nd is 0 or kc
+#pragma unroll
+  for (int j = 0; j < SR_JC; ++j)
+    if (j < nd) {
+#pragma unroll
+      for (int b = 0; b < BM; ++b)
+        if (b < B) {
+          const double dbj = dd[b * nd + j];
+#pragma unroll
+          for (int i = 0; i < RPT; ++i) t[b][i] = fma(-tc[j][i], dbj, t[b][i]);
+        }
+    }
+  for (int j = SR_JC; j < nd; ++j) {
     double tj[RPT];
     const double* tcj = s.Tsc + (int64_t)j * n;
 #pragma unroll
@@ -154,7 +187,7 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
     c1[2 * BM + 2] += y[i];
     c1[2 * BM + 3] = fma(y[i], y[i], c1[2 * BM + 3]);
   }
-  sr_sum<2 * BM + 4>(c1, part, buf);
+  sr_sum<2 * BM + 4, SR_W>(c1, part, buf);
   const double uu = c1[2 * BM], su = c1[2 * BM + 1], sy = c1[2 * BM + 2], yy = c1[2 * BM + 3];
 
   // ---- t_b = t~_b / ||w~_b|| (:860, :875-877);  sw = T^T u / u^T u, unit length (:879-880)
@@ -196,7 +229,7 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
     ts[i] = acc;
     m2[0] = fma(acc, acc, m2[0]);
   }
-  sr_sum<1>(m2, part, buf);
+  sr_sum<1, SR_W>(m2, part, buf);
   const double tsn = sqrt(m2[0]);
 
   // ---- diff = ||ts_old - ts|| (:887), Y^T ts, ts^T ts, sum ts
@@ -218,7 +251,7 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
     c2[3] += tt;
     c2[4] = fma(y[i], tt, c2[4]);
   }
-  sr_sum<5>(c2, part, buf);
+  sr_sum<5, SR_W>(c2, part, buf);
   double diff;
   if (s.norm_kind == 0) diff = sqrt(c2[0]);
   else if (s.norm_kind == 1) diff = c2[1];
@@ -229,13 +262,13 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
       dmin = fmin(dmin, __shfl_xor(dmin, off, 64));
     }
     if ((tid & 63) == 0) {
-      s_mx[0][tid >> 6] = dmax;
-      s_mn[0][tid >> 6] = dmin;
+      s_mx[tid >> 6] = dmax;
+      s_mn[tid >> 6] = dmin;
     }
     __syncthreads();
     for (int w = 0; w < SR_W; ++w) {
-      dmax = fmax(dmax, s_mx[0][w]);
-      dmin = fmin(dmin, s_mn[0][w]);
+      dmax = fmax(dmax, s_mx[w]);
+      dmin = fmin(dmin, s_mn[w]);
     }
     diff = (s.norm_kind == 2) ? dmax : dmin;
   }
@@ -264,10 +297,10 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
     c3[1] = fma(w, u[i], c3[1]);         // UNIPALS: u^T y (u_cur is y, the start vector)
     c3[2] += w;
   }
-  sr_sum<3>(c3, part, buf);
+  sr_sum<3, SR_W>(c3, part, buf);
   const double unrm = sqrt(c3[0]);
 
-  // ---- converged: record component kc now (its registers are free for the re-orthogonalisation below)
+  // ---- converged: record component kc now (its registers are free for what follows)
   // UNIPALS: w_raw = X^T u = c X^T y with c = u^T y / y^T y, so ||w_raw_b||^2 = c^2 ||X_b^T y||^2 and
   //          t_b = X_b w_raw_b / ||w_raw_b|| = c t~_b / sqrt(c^2 ||g_b||^2)                         (:503-517)
   const double c_uni = uni ? (c3[1] / unrm) / uu : 1.0;
@@ -276,9 +309,10 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
     for (int b = 0; b < BM; ++b)
       if (b < B) {
         const double f = uni ? c_uni / sqrt(c_uni * c_uni * ssq_g[b]) : 1.0;
+        double* tbo = s.Tb + ((int64_t)kc * B + b) * n;
 #pragma unroll
         for (int i = 0; i < RPT; ++i)
-          if (ok[i]) (s.Tb + ((int64_t)kc * B + b) * n)[ro[i]] = uni ? f * t[b][i] : t[b][i];
+          if (ok[i]) tbo[ro[i]] = uni ? f * t[b][i] : t[b][i];
       }
     if (lead) {
       s.V[kc] = yv;
@@ -325,25 +359,26 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
     }
   } else {
     const double mean_ts = istd ? c2[3] / dn : 0.0, mean_y = istd ? sy / dn : 0.0;
+    double* uo = s.U + (int64_t)kc * n;
+    double* tso = s.Ts + (int64_t)kc * n;
+    double* tco = s.Tsc + (int64_t)kc * n;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       tsp[i] = ok[i] ? ts[i] - mean_ts : 0.0;
       vp[i] = ok[i] ? y[i] - mean_y : 0.0;
       if (ok[i]) {
-        (s.U + (int64_t)kc * n)[ro[i]] = w_[i] / unrm;
-        (s.Ts + (int64_t)kc * n)[ro[i]] = ts[i];
-        s.u_cur[ro[i]] = y[i];                              // start vector of every component: Y[:, 0] (:838)
+        uo[ro[i]] = w_[i] / unrm;
+        tso[ro[i]] = ts[i];
+        s.u_cur[ro[i]] = y[i];                               // start vector of every component: Y[:, 0] (:838)
         s.tspass[ro[i]] = tsp[i];
-        (s.Tsc + (int64_t)kc * n)[ro[i]] = tsp[i];
+        tco[ro[i]] = tsp[i];
       }
     }
   }
 
-  // Dot products with the earlier (re-centred) scores, IB rows of NJ scores requested at a time: the loads of one
-  // block are all in flight together, the scheduling barrier keeps the next block's from piling onto the registers.
-  constexpr int IB = RPT < 4 ? RPT : 4;
-  // a_j = <Tsc_j, vp>, e_j = <Tsc_j, tsp> (j < kc), seven components per reduction; the component being deflated
-  // (converged: j = kc, tsp itself) joins the re-orthogonalisation with <tsp, vp> / <tsp, tsp>
+  // ---- re-orthogonalisation: a_j = <Tsc_j, vp>, e_j = <Tsc_j, tsp> (= ce_j), seven scores per reduction; the
+  // component being deflated (converged: tsp itself) joins with <tsp, vp> / <tsp, tsp>.  The scores are unit length and
+  // mutually orthogonal to rounding: one Gram-Schmidt sweep with the coefficients of the ORIGINAL vector.
   double cur[2] = {0.0, 0.0};
   if (converged) {
 #pragma unroll
@@ -355,58 +390,46 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
   double vq[RPT];                                    // vp minus its components along the scores
 #pragma unroll
   for (int i = 0; i < RPT; ++i) vq[i] = vp[i];
-  for (int j0 = 0; j0 < kc || (j0 == 0 && converged); j0 += 7) {
+  for (int j0 = 0; j0 < kc || (j0 == 0 && converged); j0 += NJ) {
     double c[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) c[k] = 0.0;
-    const int m = min(7, kc - j0);
+    const int m = min(NJ, kc - j0);
+    double tj[NJ][RPT];
 #pragma unroll
-    for (int i0 = 0; i0 < RPT; i0 += IB) {
-      double tj[7][IB];
+    for (int jj = 0; jj < NJ; ++jj) {
+      const bool cached = j0 == 0;                   // (j0 + jj < SR_JC whenever j0 == 0)
+      const double* tcj = s.Tsc + (int64_t)(jj < m ? j0 + jj : 0) * n;
 #pragma unroll
-      for (int jj = 0; jj < 7; ++jj)
-#pragma unroll
-        for (int ii = 0; ii < IB; ++ii)
-          tj[jj][ii] = (jj < m) ? ld(s.Tsc + (int64_t)(j0 + jj) * n, i0 + ii) : 0.0;
-#pragma unroll
-      for (int jj = 0; jj < 7; ++jj)
-#pragma unroll
-        for (int ii = 0; ii < IB; ++ii) {
-          c[2 * jj] = fma(tj[jj][ii], vp[i0 + ii], c[2 * jj]);
-          c[2 * jj + 1] = fma(tj[jj][ii], tsp[i0 + ii], c[2 * jj + 1]);
-        }
-      __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < RPT; ++i) tj[jj][i] = cached ? tc[jj][i] : ((jj < m) ? ld(tcj, i) : 0.0);
     }
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        c[2 * jj] = fma(tj[jj][i], vp[i], c[2 * jj]);
+        c[2 * jj + 1] = fma(tj[jj][i], tsp[i], c[2 * jj + 1]);
+      }
     c[14] = cur[0];
     c[15] = cur[1];
-    sr_sum<16>(c, part, buf);
+    sr_sum<16, SR_W>(c, part, buf);
     if (j0 == 0 && converged) {
       const double f = c[14] / c[15];
 #pragma unroll
       for (int i = 0; i < RPT; ++i) vq[i] = fma(-f, tsp[i], vq[i]);
     }
-    // (the scores are unit length and mutually orthogonal to rounding: one Gram-Schmidt sweep with <ts_j, v>)
 #pragma unroll
-    for (int i0 = 0; i0 < RPT; i0 += IB) {
-      double tj[7][IB];
+    for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-      for (int jj = 0; jj < 7; ++jj)
-#pragma unroll
-        for (int ii = 0; ii < IB; ++ii)
-          tj[jj][ii] = (jj < m) ? ld(s.Tsc + (int64_t)(j0 + jj) * n, i0 + ii) : 0.0;
-#pragma unroll
-      for (int jj = 0; jj < 7; ++jj)
-#pragma unroll
-        for (int ii = 0; ii < IB; ++ii) vq[i0 + ii] = fma(-c[2 * jj], tj[jj][ii], vq[i0 + ii]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+      for (int i = 0; i < RPT; ++i) vq[i] = fma(-c[2 * jj], tj[jj][i], vq[i]);   // (c = 0 beyond m)
     if (lead && converged) {
 #pragma unroll
-      for (int jj = 0; jj < 7; ++jj)
+      for (int jj = 0; jj < NJ; ++jj)
         if (jj < m) s.ce[j0 + jj] = c[2 * jj + 1];
     }
   }
-  // the pass reads vq; its exact coefficients cu_j = <Tsc_j, vq> (rounding level now), sixteen per reduction
+  // ---- the pass reads vq; its exact coefficients cu_j = <Tsc_j, vq> (rounding level now): the first SR_JC from the
+  // registers, sixteen per reduction
 #pragma unroll
   for (int i = 0; i < RPT; ++i)
     if (ok[i]) s.vpass[ro[i]] = vq[i];
@@ -416,20 +439,17 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
     for (int k = 0; k < 16; ++k) c[k] = 0.0;
     const int m = min(16, kc - j0);
 #pragma unroll
-    for (int i0 = 0; i0 < RPT; i0 += IB) {
-      double tj[16][IB];
+    for (int jj = 0; jj < 16; ++jj) {
+      if (j0 == 0 && jj < SR_JC) {
 #pragma unroll
-      for (int jj = 0; jj < 16; ++jj)
+        for (int i = 0; i < RPT; ++i) c[jj] = fma(tc[jj][i], vq[i], c[jj]);      // (tc = 0 beyond kc)
+      } else if (jj < m) {
+        const double* tcj = s.Tsc + (int64_t)(j0 + jj) * n;
 #pragma unroll
-        for (int ii = 0; ii < IB; ++ii)
-          tj[jj][ii] = (jj < m) ? ld(s.Tsc + (int64_t)(j0 + jj) * n, i0 + ii) : 0.0;
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj)
-#pragma unroll
-        for (int ii = 0; ii < IB; ++ii) c[jj] = fma(tj[jj][ii], vq[i0 + ii], c[jj]);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < RPT; ++i) c[jj] = fma(ld(tcj, i), vq[i], c[jj]);
+      }
     }
-    sr_sum<16>(c, part, buf);
+    sr_sum<16, SR_W>(c, part, buf);
     if (lead) {
 #pragma unroll
       for (int jj = 0; jj < 16; ++jj)
@@ -440,20 +460,21 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
 
 // MBPLS_ERR_UNSUPPORTED: shape outside this kernel (the caller uses the general one)
 int launch_step_reg(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
-  if (s->q != 1 || s->nblocks > 4 || s->n > 8 * SR_T) return MBPLS_ERR_UNSUPPORTED;   // (16 rows per thread spill)
-  const int rpt = (int)((s->n + SR_T - 1) / SR_T);
-#define MB_STEP(R_)                                                                                        \
-  do {                                                                                                     \
-    const bool full = s->n == (int64_t)(R_) * SR_T;                                                        \
-    if (s->nblocks == 1 && full) hipLaunchKernelGGL((k_step_reg<R_, 1, true>), dim3(1), dim3(SR_T), 0, ctx->stream, *s);       \
-    else if (s->nblocks == 1) hipLaunchKernelGGL((k_step_reg<R_, 1, false>), dim3(1), dim3(SR_T), 0, ctx->stream, *s);         \
-    else if (full) hipLaunchKernelGGL((k_step_reg<R_, 4, true>), dim3(1), dim3(SR_T), 0, ctx->stream, *s); \
-    else hipLaunchKernelGGL((k_step_reg<R_, 4, false>), dim3(1), dim3(SR_T), 0, ctx->stream, *s);          \
+  if (s->q != 1 || s->nblocks > 4 || s->n > 4096) return MBPLS_ERR_UNSUPPORTED;
+#define MB_STEP(T_, R_, J_)                                                                                  \
+  do {                                                                                                       \
+    const bool full = s->n == (int64_t)(R_) * (T_);                                                          \
+    if (s->nblocks == 1 && full) hipLaunchKernelGGL((k_step_reg<T_, R_, J_, 1, true>), dim3(1), dim3(T_), 0, ctx->stream, *s);   \
+    else if (s->nblocks == 1) hipLaunchKernelGGL((k_step_reg<T_, R_, J_, 1, false>), dim3(1), dim3(T_), 0, ctx->stream, *s);     \
+    else if (full) hipLaunchKernelGGL((k_step_reg<T_, R_, J_, 4, true>), dim3(1), dim3(T_), 0, ctx->stream, *s);                 \
+    else hipLaunchKernelGGL((k_step_reg<T_, R_, J_, 4, false>), dim3(1), dim3(T_), 0, ctx->stream, *s);      \
   } while (0)
-  if (rpt <= 1) MB_STEP(1);
-  else if (rpt <= 2) MB_STEP(2);
-  else if (rpt <= 4) MB_STEP(4);
-  else MB_STEP(8);
+  const int64_t n = s->n;
+  if (n <= 256) MB_STEP(256, 1, 8);
+  else if (n <= 512) MB_STEP(256, 2, 8);
+  else if (n <= 1024) MB_STEP(256, 4, 8);
+  else if (n <= 2048) MB_STEP(256, 8, 8);
+  else MB_STEP(512, 8, 4);
 #undef MB_STEP
   MB_HIP(hipGetLastError());
   return MBPLS_OK;

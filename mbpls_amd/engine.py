@@ -16,6 +16,7 @@ import numpy as np
 
 from . import _capi
 from .comm import LocalComm
+from .plan import FitOptions
 
 
 class HipEngine:
@@ -39,6 +40,8 @@ class HipEngine:
         self.timings = {}
         # missing values (sparse_data=True): NaN-aware column passes (csrc/colpass_nan.hip); set before load_*
         self.sparse = False
+        self.opts = FitOptions.from_env()     # route switches, read once per engine (= per fit)
+        self.plan = {}                        # the route this fit took (MBPLS.fit_plan_)
 
     @contextlib.contextmanager
     def _timed(self, name):
@@ -152,23 +155,33 @@ class HipEngine:
             _capi.check(self.ctx.lib.mbpls_hip_memcpy_d2h_overlap(self.ctx.handle, col.ctypes.data,
                                                                   S.ptr + 8 * self.p * k, 8 * self.p))
 
-    def host_array(self, shape):
-        """F-ordered host array for a p x K attribute.  A refit hands over the previous fit's attribute buffers when
-        nobody else references them (``host_pool``, filled by the estimator): their pages are already mapped, so the
-        device-to-host copy runs at PCIe speed (55 GB/s) instead of page-fault speed (23 GB/s measured into a fresh
-        numpy array) and nothing has to be unmapped."""
-        pool = getattr(self, "host_pool", None)
-        if pool:
-            for i, a in enumerate(pool):
-                if a.shape == tuple(shape):
-                    return pool.pop(i)
-        return np.empty(shape, order="F")
+    def host_array(self, shape, reserve=None, prefault=True):
+        """F-ordered host array for a p x K attribute.  A device-to-host copy into a fresh numpy array runs at
+        page-fault speed (23 GB/s measured; 55 GB/s once the pages are mapped), so large arrays are handed to a helper
+        thread that maps their pages (madvise(MADV_POPULATE_WRITE): contents untouched, safe beside a copy that is
+        already writing) while the GPU works -- every fit, also the first of a fresh estimator, then receives its
+        attributes at PCIe speed.  (Round 2 recycled the previous fit's buffers behind a reference-count heuristic
+        instead; that only helped refits of the same estimator.)  ``reserve``: keep the array for the later fetch of
+        the slot of that name."""
+        ready = getattr(self, "_host_ready", None)
+        if ready is None:
+            ready = self._host_ready = {}
+        out = np.empty(shape, order="F")
+        if prefault:
+            _prefault(out)
+        if reserve is not None:
+            ready[reserve] = out
+        return out
+
+    def _host_for_slot(self, name, shape):
+        a = getattr(self, "_host_ready", {}).pop(name, None)
+        return a if a is not None and a.shape == tuple(shape) else self.host_array(shape)
 
     def fetch(self, name, overlapped=False):
         """D2H of a whole slot.  overlapped=True: on the copy stream, not ordered behind the kernels queued on
         the compute stream (the slot must be final); safe to call from a helper thread."""
         S = self.slots[name]
-        out = self.host_array(S.shape)
+        out = self._host_for_slot(name, S.shape)
         if not overlapped:
             with self._timed("d2h_slots"):
                 _capi.check(self.ctx.lib.mbpls_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data, S.ptr, out.nbytes))
@@ -181,7 +194,7 @@ class HipEngine:
         (host array, wait) -- wait() blocks until the array is complete (and re-raises a copy error)."""
         import threading
         S = self.slots[name]
-        out = self.host_array(S.shape)
+        out = self._host_for_slot(name, S.shape)
         ev = _capi._vp()
         _capi.check(self.ctx.lib.mbpls_hip_event_record(self.ctx.handle, _capi.C.byref(ev)))
         errors, done = [], threading.Event()
@@ -255,8 +268,7 @@ class HipEngine:
         """Called by a solver whose passes all go through sweep/deflate_sweep: enable lazy deflation
         when the component count fits the kernel's correction registers.  ``prefer`` is the solver's own
         choice ("lazy"/"explicit"); the MBPLS_DEFLATION environment variable overrides both."""
-        import os
-        mode = os.environ.get("MBPLS_DEFLATION", prefer or self.deflation)
+        mode = self.opts.deflation or prefer or self.deflation
         if self.sparse:
             mode = "explicit"      # the implicit correction would need every row's own missing-value mask
         if not self._raw_space_ok():
@@ -264,6 +276,7 @@ class HipEngine:
         self._lazy_pslot = pslot if (mode == "lazy" and K < self.KD - 1) else None
         self._lazy_ts = []
         self._lazy_K = K
+        self.plan["deflation"] = "lazy" if self._lazy_pslot is not None else "explicit"
         return self._lazy_pslot is not None
 
     def _lazy_coef(self, idx, vec):
@@ -359,12 +372,11 @@ class HipEngine:
         """mean / scale / var are final once the standardise pass has run: send them to the host through the copier
         thread now (behind an event), so the three p-length copies -- page faults of fresh arrays included -- overlap
         with the rest of the fit instead of sitting at its end.  ``host_stats`` / ``wait_stats`` hand them over."""
-        import os
         import threading
-        if self.mean is None or self.scale is None or os.environ.get("MBPLS_STREAM_STATS", "1") == "0":
+        if self.mean is None or self.scale is None or not self.opts.stream_stats:
             return
         arrs = [self.mean, self.scale] + ([self.var] if getattr(self, "var", None) is not None else [])
-        S = self.host_array((self.p, 3))           # one F-ordered p x 3 array: recycled from the previous fit's scalers
+        S = self.host_array((self.p, 3), prefault=False)   # one F-ordered p x 3 array (copied right after the first pass)
         host = [S[:, i] for i in range(len(arrs))]
         ev = _capi._vp()
         _capi.check(self.ctx.lib.mbpls_hip_event_record(self.ctx.handle, _capi.C.byref(ev)))
@@ -387,8 +399,11 @@ class HipEngine:
     def _prepare_passes(self, src, standardize, mode, v, alpha, g_slot, mean, defer):
         n, B = self.n, self.nblocks
         if self._implicit_ok(v, mean):
+            self.plan["standardisation"] = "implicit (X never written)" if standardize else "none (X never written)"
             out = self._prepare_implicit(src, standardize, mode, v, alpha, g_slot, defer)
             return None if defer else out
+        self.plan["standardisation"] = ("stored working copy" if self._src is not None else "stored in place") \
+            if standardize else "none"
         self._working_copy()
         dv = self._put_vec(0, v) if v is not None else None
         # row subset (cross-validation fold): excluded samples become zero rows of the working copy and the
@@ -427,14 +442,11 @@ class HipEngine:
         is kept whenever a standardised working copy comfortably fits beside the caller's matrix (or copy=False lets
         the matrix itself be overwritten) and the never-writes-X path takes over when it does not (config[3]: 131 GB
         of X on a 288 GB device).  MBPLS_KERNEL_IMPLICIT=1/0 forces either."""
-        import os
         if (self.sparse or getattr(self, "rowmask", None) is not None or not hasattr(self.X, "standardize_stats_sweep")
-                or not self._raw_space_ok()
-                or os.environ.get("MBPLS_IMPLICIT_STD", "1") == "0"):
+                or not self._raw_space_ok() or not self.opts.implicit_std):
             return False
-        force = os.environ.get("MBPLS_KERNEL_IMPLICIT")
-        if force in ("0", "1"):
-            return force == "1"
+        if self.opts.kernel_implicit is not None:
+            return self.opts.kernel_implicit == "1"
         if self._src is None:
             return False                              # the matrix is ours to overwrite: standardise in place
         need = self.X.nbytes + 8 * self.n * self.n * 3 + (17 << 30)     # working copy + Gram + its split-K slices
@@ -467,6 +479,7 @@ class HipEngine:
         if not np.all(np.isfinite(x)):
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
         self.X, self._src = src, None              # the raw matrix, never written
+        self.plan["standardisation"] = "statistics only (products standardise in registers)" if standardize else "none"
         self._kscale = bool(standardize)
         self._cen = self._kscale and float(np.sqrt(np.max(self._last_d))) > self.CENTRE_FROM_OFFSET
         if standardize:
@@ -485,11 +498,9 @@ class HipEngine:
         return self.n <= 8192 or self.n > getattr(self.ctx, "long_columns_from", 8192)
 
     def _implicit_ok(self, v, mean):
-        import os
         return (self._lazy_pslot is not None and v is not None and mean is None and not self.sparse
                 and getattr(self, "rowmask", None) is None and hasattr(self.X, "standardize_stats_sweep")
-                and self._raw_space_ok()
-                and os.environ.get("MBPLS_IMPLICIT_STD", "1") != "0")
+                and self._raw_space_ok() and self.opts.implicit_std)
 
     def _prepare_implicit(self, src, standardize, mode, v, alpha, g_slot, defer=False):
         """First pass of a fit that never writes X (lazy deflation + implicit standardisation): statistics and the
@@ -656,10 +667,8 @@ class HipEngine:
     def resident_supported(self, q, K, norm_kind):
         """The whole fit can be queued without a host round trip: lazy deflation (X is never written, so a wrong
         speculation costs nothing but the skipped launches), one response, shapes the step kernel covers."""
-        import os
         return (self._lazy_pslot is not None and not self.sparse and norm_kind is not None and q == 1
-                and self.nblocks <= _capi.STEP_MAX_BLOCKS and K < self.KD - 1
-                and os.environ.get("MBPLS_RESIDENT", "1") != "0")
+                and self.nblocks <= _capi.STEP_MAX_BLOCKS and K < self.KD - 1 and self.opts.resident)
 
     def _res_sweep(self, k, g_slot):
         """sweep with the device-resident vector / coefficients (written by the step kernel); alpha comes from par"""
@@ -709,11 +718,17 @@ class HipEngine:
                     self._res_sweep(k, (wslot, k))                   # second iteration (:856, :875)
                     rq.step(k, 2, k)
                     # w~ column k is final; w_b = w~_b / ||w~_b|| (:860) is formed on the host from it and the norms the
-                    # step just recorded
+                    # step just recorded.  The event the copies wait for is recorded BEHIND the loadings pass (an event
+                    # between the step and the pass cost the queue 6 us of idle each) -- except for the last component,
+                    # whose columns would otherwise leave after the fit's last kernel
                     nu_copy, unit = rq.unit_blocks_on_host(Wn_h, W_h, k)
-                    rq.stream_out([(rq.col(Wn_h, k), Wn.ptr + p8 * k)] + nu_copy
-                                  + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []), post=unit)
+                    cols = ([(rq.col(Wn_h, k), Wn.ptr + p8 * k)] + nu_copy
+                            + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []))
+                    if last:
+                        rq.stream_out(cols, post=unit)
                     self._res_loadings(k, last, None if last else (wslot, k + 1))   # (:928, :969) + next first sweep
+                    if not last:
+                        rq.stream_out(cols, post=unit)
                     if not last:
                         rq.step(k + 1, 1, k + 1)
                     else:
@@ -959,6 +974,53 @@ class HipEngine:
 
 
 _COPIER = {}
+_PREFAULT = {}
+
+
+def _prefault(arr, min_bytes=1 << 20):
+    """Map the pages of a freshly allocated host array in a helper thread (see HipEngine.host_array).  Linux
+    madvise(MADV_POPULATE_WRITE) populates writable pages WITHOUT touching their contents, so it may run beside the
+    copy that fills the array; the call releases the GIL.  Where it is not available nothing happens (the copy then
+    faults the pages in itself)."""
+    if arr.nbytes < min_bytes or _PREFAULT.get("off"):
+        return
+    import ctypes
+    import queue
+    import threading
+    q = _PREFAULT.get("queue")
+    if q is None or not _PREFAULT["thread"].is_alive():
+        try:
+            libc = ctypes.CDLL(None, use_errno=True)
+            madvise = libc.madvise
+            madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+            madvise.restype = ctypes.c_int
+        except Exception:
+            _PREFAULT["off"] = True
+            return
+        q = queue.Queue()
+
+        def work():
+            page = 4096
+            while True:
+                addr, nbytes = q.get()
+                lo = (addr + page - 1) // page * page
+                hi = (addr + nbytes) // page * page
+                # in small pieces: the call holds the process's mmap lock while it populates, and every allocation /
+                # release of a large array on another thread (np.empty -> mmap) waits for it -- 8 MB pieces made a
+                # 3 MB np.empty on the fitting thread take 0.35 ms
+                step = 512 << 10
+                while lo < hi:
+                    n = min(step, hi - lo)
+                    if madvise(lo, n, 23) != 0:     # MADV_POPULATE_WRITE (Linux >= 5.14)
+                        if ctypes.get_errno() == 22:    # EINVAL: not supported here
+                            _PREFAULT["off"] = True
+                        break
+                    lo += n
+
+        th = threading.Thread(target=work, daemon=True, name="mbpls-prefault")
+        th.start()
+        _PREFAULT.update(queue=q, thread=th)
+    q.put((arr.ctypes.data, arr.nbytes))
 
 
 def _copier_queue():
@@ -989,8 +1051,7 @@ def _copier_queue():
                     errors.append(e)
                 finally:
                     ctx.lib.mbpls_hip_event_destroy(ctx.handle, ev)
-                    # drop every reference to the host arrays before blocking on the queue again: a view kept here
-                    # would pin the attribute buffers of this fit, which the next fit wants to recycle (mbpls._recyclable)
+                    # drop every reference to the host arrays before blocking on the queue again
                     job = ctx = ev = copies = errors = dst = src = post = None
 
         th = threading.Thread(target=work, daemon=True, name="mbpls-copier")

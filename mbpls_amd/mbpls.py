@@ -88,46 +88,6 @@ def _global_block_sizes(eng):
     return eng.comm.allreduce_host(np.asarray(eng.block_sizes, dtype=np.float64))
 
 
-def _unreferenced_count():
-    """what sys.getrefcount reports, inside the comprehension of _recyclable, for an array nothing else references
-    (3 on CPython <= 3.11 -- list slot, loop variable, the call's argument -- fewer on interpreters that borrow)"""
-    import sys
-    probe = [np.empty(1)]
-    return [sys.getrefcount(r) for r in probe][0]
-
-
-_UNREFERENCED = _unreferenced_count()
-
-
-def _recyclable(stale):
-    """Empties ``stale`` (attributes of the previous fit) and returns the large F-ordered 2-D base arrays behind them
-    that are referenced from nowhere else -- safe to overwrite.  Everything else stays in ``stale``."""
-    import sys
-    roots, keep = {}, []
-    while stale:
-        obj = stale.pop()
-        parts = obj if isinstance(obj, list) else [obj]
-        mine = True
-        for a in parts:
-            r = a
-            while isinstance(r, np.ndarray) and isinstance(r.base, np.ndarray):
-                r = r.base
-            if (isinstance(r, np.ndarray) and r.base is None and r.ndim == 2 and r.flags.f_contiguous
-                    and r.flags.writeable and r.nbytes >= (1 << 20)):
-                roots[id(r)] = r
-            else:
-                mine = False
-        if not mine:
-            keep.append(obj)
-        del obj, parts, a, r
-    stale.extend(keep)
-    del keep
-    roots = list(roots.values())
-    # references to a root now: the list `roots`, the loop variable, getrefcount's argument (+ views someone kept);
-    # the expected count is calibrated at import (_UNREFERENCED) rather than assumed
-    return [r for r in roots if sys.getrefcount(r) == _UNREFERENCED]
-
-
 def _is_block_list(X):
     return isinstance(X, list) and not isinstance(X[0], list)       # mbpls.py:301
 
@@ -188,6 +148,11 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             if np.isinf(Y).any():
                 raise ValueError("Input Y contains infinity or a value too large for dtype('float64').")
             Y = np.array(Y, copy=True) if self.copy else Y
+        elif (type(Y) is np.ndarray and Y.dtype == np.float64 and Y.ndim in (1, 2) and Y.size
+              and np.isfinite(Y).all()):
+            # (the common case without sklearn's 0.1 ms of validation machinery -- anything else goes through it,
+            # with its errors)
+            Y = Y.copy() if self.copy else Y
         else:
             Y = check_array(Y, dtype=np.float64, ensure_2d=False, copy=self.copy)  # :293
         if Y.ndim == 1:
@@ -228,9 +193,6 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         if old_scalers:      # their mean_/scale_/var_ are columns of one p x 3 array (engine.stream_stats): recyclable too
             stale.append([a for sc in old_scalers for a in (sc.mean_, sc.scale_, getattr(sc, "var_", sc.mean_))])
             del old_scalers
-        # ... unless the buffer can simply be used again: the F-ordered p x K arrays behind the old attributes that
-        # nobody else holds go to the engine's host pool (their pages are mapped: copies into them run at PCIe speed)
-        eng.host_pool = _recyclable(stale)
         eng.deferred_host_work = [stale.pop for _ in stale]
         import time as _time
         t_fit0 = _time.perf_counter()
@@ -269,6 +231,14 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
                 eng.close()
             eng.timings["total"] = _time.perf_counter() - t_fit0
             self.fit_timings_ = dict(eng.timings)   # seconds per host-side phase (not in the reference)
+            # the route this fit took (not in the reference): solver form, deflation, standardisation, kernel family,
+            # centring of offset data, column shards -- decided in engine / solvers from plan.FitOptions, recorded here
+            n_ = getattr(eng, "n", 0)
+            fam = ("few samples (column groups per wave)" if n_ <= 1024 else
+                   "register-resident columns" if n_ <= getattr(eng.ctx, "long_columns_from", 8192) else
+                   "long columns (two streaming phases)")
+            self.fit_plan_ = dict(method=self.method, **eng.plan, kernels=fam, centred_in_registers=bool(getattr(eng, "_cen", False)),
+                                  column_shards=int(getattr(eng.comm, "world_size", 1)), sparse=bool(sparse))
         return self
 
     def check_sparsity_level(self, data):

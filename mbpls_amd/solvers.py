@@ -108,6 +108,22 @@ class _Responses:
         return u / np.linalg.norm(u)
 
 
+def _opts(eng):
+    """route switches of this fit (plan.FitOptions; engines without them -- the test-only numpy engine -- get defaults)"""
+    o = getattr(eng, "opts", None)
+    if o is None:
+        from .plan import FitOptions
+        o = FitOptions.from_env()
+    return o
+
+
+def _plan(eng, **kw):
+    """record the route the fit takes (MBPLS.fit_plan_)"""
+    p = getattr(eng, "plan", None)
+    if p is not None:
+        p.update(kw)
+
+
 class FitResult(dict):
     __getattr__ = dict.__getitem__
 
@@ -116,8 +132,9 @@ class FitResult(dict):
 
 
 def _host_array(eng, shape):
-    """F-ordered host array for a p x K attribute (recycled from the previous fit when the engine can)"""
-    return eng.host_array(shape) if hasattr(eng, "host_array") else np.empty(shape, order="F")
+    """F-ordered host array for a p x K attribute that is filled column by column DURING the fit (the copies' own page
+    faults hide behind the passes: no helper-thread mapping for these)"""
+    return eng.host_array(shape, prefault=False) if hasattr(eng, "host_array") else np.empty(shape, order="F")
 
 
 def _global_sizes(eng):
@@ -198,9 +215,8 @@ def _nipals_on_subspace(eng, q):
     G = P X (X^T (P Y)) -- two many-right-hand-side products over X per COMPONENT -- the whole loop is n x q algebra:
     ts = G c / ||G c||.  X is standardised once and never deflated; a component costs three passes over X whatever its
     iteration count."""
-    import os
     return (q > 1 and q <= 16 and hasattr(eng, "x_w_slot") and not getattr(eng, "sparse", False)
-            and os.environ.get("MBPLS_NIPALS_SUBSPACE", "1") != "0")
+            and _opts(eng).nipals_subspace)
 
 
 def _subspace_loop_host(G, Y, c0, norm, tol, max_iter):
@@ -328,9 +344,7 @@ def _nipals_on_grams(eng, q):
     p > n the same iterates can be had from the per-block association matrices A_b = X_b X_b^T (n x n each):
     t_b = X_b w_b = A_b u / sqrt(u^T A_b u), so an iteration touches B n^2 doubles instead of n p.  Worth it once the
     fit needs more than about n/75 passes (the Gram costs n(n+1)p flop) -- always the case for q > 1 in practice."""
-    import os
-    if (q == 1 or not hasattr(eng, "gram_blocks") or getattr(eng, "sparse", False)
-            or os.environ.get("MBPLS_NIPALS_GRAM", "1") == "0"):
+    if (q == 1 or not hasattr(eng, "gram_blocks") or getattr(eng, "sparse", False) or not _opts(eng).nipals_gram):
         return False
     p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
     return p_total > eng.n and eng.n <= 16384 and 8.0 * eng.nblocks * eng.n ** 2 <= 16 * 2 ** 30
@@ -438,8 +452,10 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     q = Y.shape[1]
     max_iter = NIPALS_MAX_ITER if max_iter is None else max_iter
     if _nipals_on_subspace(eng, q):
+        _plan(eng, solver="nipals: inner loop in the q-space of its iterates, three passes per component")
         return _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     if _nipals_on_grams(eng, q):
+        _plan(eng, solver="nipals: inner loop on per-block association matrices")
         return _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     sizes = _global_sizes(eng)
     resp = _Responses(Y)
@@ -453,14 +469,18 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
         # responses iterate 50-500 times per component (paper protocol, q = 10): every sweep then pays the lazy
         # correction (~6 %), far more than one rewrite of X per component (measured 7.05 s -> 6.72 s).
         eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
-    import os
-    q1_fixed_point = (q == 1 and os.environ.get("MBPLS_NIPALS_Q1_FIXED_POINT", "0") == "1" and not getattr(eng, "sparse", False)
+    q1_fixed_point = (q == 1 and _opts(eng).q1_fixed_point and not getattr(eng, "sparse", False)
                       and hasattr(eng, "right_mul"))
     Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
     T = [np.empty((n, K)) for _ in range(B)]
     nu_all = np.empty((B, K))
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
     converged = []          # per component: the stop rule of mbpls.py:841 was met (not a cap / noise-floor stop)
+    if hasattr(eng, "host_array"):
+        # host buffers of the attributes that only exist at the very end of the fit (nothing hides THEIR page faults):
+        # allocated now, their pages mapped by the helper thread while the GPU has 2K + 1 passes to do
+        eng.host_array((eng.p, K), reserve="R")
+        eng.host_array((eng.p, q), reserve="beta")
     # host copies of the p x K attributes, filled column by column while later passes run on the GPU
     Wn_h, W_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
     vary = resp.ssq
@@ -481,7 +501,9 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
         resident = out.get("reason") != "barrier"
     else:
         resident = False
+    _plan(eng, solver="nipals: device-resident queue" if resident else "nipals: host-driven loop")
     if resident:
+        _plan(eng, resumed_on_host_at=None if out["k_done"] == K else int(out["k_done"]))
         varxb = out["ssq_x"]                                # summed over the column shards on the device already
         if not np.all(np.isfinite(varxb)):
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
@@ -604,8 +626,10 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
         res.update(explained_var_x_=[], explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)),
                    A_corrected_=np.empty((B, 0)))
     if callable(finish):
-        finish()
-        out["wait_copies"]()                                # streamed columns of W~, W, P complete
+        with eng._timed("wait_R_beta"):
+            finish()
+        with eng._timed("wait_streamed_columns"):
+            out["wait_copies"]()                            # streamed columns of W~, W, P complete
     else:
         # ||W~[:, k]||^2 = sum_b ||w~_b||^2 of the last iteration (already summed over shards)  (:986-987)
         eng.fetch_col("P", K - 1, P_h)
@@ -677,9 +701,9 @@ def fit_unipals(eng, Y, K, standardize):
     # X (X^T y) / ||.|| of the p > n branch (:489-503) -- the same component up to the sign convention of the SVD --
     # so tall data takes the one-pass-per-component path as well (device-resident queue, X never written).
     wide = p_total > n or q == 1
-    import os
     if (wide and q > 1 and hasattr(eng, "x_w_slot") and not getattr(eng, "sparse", False)
-            and os.environ.get("MBPLS_UNIPALS_NODEFLATE", "1") != "0"):
+            and _opts(eng).unipals_nodeflate):
+        _plan(eng, solver="unipals: never-deflated products (several responses)")
         return _fit_unipals_wide_multi(eng, Y, K, standardize)
     sizes = _global_sizes(eng)
     eng.slot("Wc", K)
@@ -704,6 +728,8 @@ def fit_unipals(eng, Y, K, standardize):
         # one response: a component is ONE pass and everything between two passes is n x B algebra -- the whole fit
         # is queued on the device (engine.unipals_resident), the host reads the results once
         first = eng.deferred_first_pass(standardize, y0, 1.0, ("S", 0))
+        eng.host_array((eng.p, K), reserve="R")
+        eng.host_array((eng.p, q), reserve="beta")
         for attempt in range(2):
             out = eng.unipals_resident(Y, K, "Wc", "S", W_h, P_h, first)
             if out.get("reason") != "offset":
@@ -711,6 +737,8 @@ def fit_unipals(eng, Y, K, standardize):
         resident = out.get("reason") != "barrier"
     else:
         resident = False
+    _plan(eng, solver=("unipals: device-resident queue, one pass per component" if resident else
+                       "unipals: host-driven loop" + (", one pass per component" if fuse else "")))
     if resident:
         varxb = out["ssq_x"]
         if not np.all(np.isfinite(varxb)):

@@ -79,24 +79,28 @@ def test_q1_fixed_point_option(monkeypatch):
     util.compare(util.model_to_flat(res), util.sub(g, "ref/q1/multi/NIPALS/std1/ca1"), TOL, skip=FIT_ONLY_SKIP)
 
 
-def test_recyclable_host_buffers_refcount_rule():
-    """mbpls._recyclable: a refit may overwrite the buffer behind an old attribute only if nothing else references
-    it -- directly or through a view -- and only large F-ordered 2-D arrays qualify."""
-    from mbpls_amd.mbpls import _recyclable
-    P = np.empty((200_000, 10), order="F")
-    R = np.empty((200_000, 10), order="F")
-    W = np.empty((200_000, 10), order="F")
-    beta = np.empty((200_000, 1), order="F")
-    T = [np.zeros((5, 2))]
-    p_addr, b_addr, w_addr = P.ctypes.data, beta.ctypes.data, W.ctypes.data
-    held_whole = R                          # the caller kept R_ itself
-    held_view = W[:100]                     # ... and a view into W_'s buffer
-    stale = [[P[:100_000], P[100_000:]], R, [W[:150_000], W[150_000:]], beta, T]
-    del P, R, W, beta, T
-    pool = _recyclable(stale)
-    assert sorted(a.ctypes.data for a in pool) == sorted([p_addr, b_addr])
-    assert w_addr not in [a.ctypes.data for a in pool] and held_view.base is not None and held_whole is not None
-    assert len(stale) == 1 and isinstance(stale[0], list) and stale[0][0].shape == (5, 2)   # small arrays stay
+def test_prefault_leaves_contents_alone():
+    """engine._prefault maps the pages of a fresh attribute buffer in a helper thread while a copy may already be writing
+    into it: whatever is in the array stays (madvise(MADV_POPULATE_WRITE), or nothing at all where unsupported)."""
+    import time
+    from mbpls_amd import engine
+    a = np.empty((300_000, 10), order="F")
+    a[:] = np.arange(10.0)
+    a[::4096, 0] = -1.0
+    engine._prefault(a)
+    b = np.empty((1 << 16,))                # below the size limit: left alone
+    engine._prefault(b)
+    for _ in range(3):                      # keep writing while the helper runs
+        a[::1000, 3] = 7.0
+        time.sleep(0.01)
+    q = engine._PREFAULT.get("queue")
+    if q is not None:
+        t0 = time.time()
+        while not q.empty() and time.time() - t0 < 10:
+            time.sleep(0.01)
+        time.sleep(0.05)
+    assert np.all(a[::4096, 0] == -1.0) and np.all(a[1::1000, 3] == 3.0) and np.all(a[::1000, 3] == 7.0)
+    assert np.all(a[:, 9] == 9.0)
 
 
 @pytest.mark.parametrize("n,q,seed", [(9000, 2, 0), (20000, 3, 1), (12000, 5, 2)])

@@ -42,7 +42,6 @@ for nm in ("__init__", "__exit__", "step", "stream_out"):
     wrap(engine._ResidentQueue, nm, "rq." + nm)
 wrap(solvers, "_finalise_device")
 wrap(solvers, "_global_sizes")
-wrap(mb, "_recyclable")
 wrap(mb, "check_array")
 wrap(mb.MBPLS, "_store")
 wrap(mb.MBPLS, "_engine")
