@@ -1,7 +1,7 @@
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03i
+O=$R/gpurun_out/r03j
 mkdir -p $O
 cd $R
-timeout 300 python tools/host_timeline.py 1000000 > $O/host_timeline_c2.txt 2>&1; grep -v "_res_\|rq.step\|rq.stream_out" $O/host_timeline_c2.txt | tail -22
-timeout 600 python3 bench.py --cpu-cols 0 --e2e-cols 0 > $O/bench_c2.log 2>&1; echo bench rc=$?; tail -1 $O/bench_c2.log | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(d['fit_wall_s'], d['fit_wall_s_same_estimator_refit'], d['value'], d['roofline']['frac'], {k:v['avg_ms'] for k,v in d['kernels'].items()}); print(d['shard_proxy']); print(d['host_phases_ms_last_fit'])"
+timeout 900 python tools/paper_protocol.py a --cpu > $O/paper_a.jsonl 2> $O/paper_a.err; echo a rc=$?; cut -c1-900 $O/paper_a.jsonl; tail -3 $O/paper_a.err
+timeout 1200 python tools/paper_protocol.py b --cpu > $O/paper_b.jsonl 2> $O/paper_b.err; echo b rc=$?; cut -c1-900 $O/paper_b.jsonl; tail -3 $O/paper_b.err
+for v in 0 1; do for c in simpls nipals_q10 unipals_q10; do echo -n "IMPLICIT=$v "; MBPLS_KERNEL_IMPLICIT=$v timeout 300 python tools/bench_configs.py $c 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['config'], d['fit_s'], {k:(v['launches'],v['avg_ms']) for k,v in d['kernels'].items()})"; done; done
