@@ -414,10 +414,14 @@ __global__ __launch_bounds__(256) void k_finish_stats(int64_t p, double* __restr
 }
 
 // Second stage: fixed-order sum of the chunk partials of each block.
-//   grid (ceil(n/64), nblocks), 1024 threads: wave w takes chunks cs+w, cs+w+16, ...; LDS combine in wave order.
-//   (Latency-bound: with 4 waves every lane walked 256 chunk partials one after the other, 35-50 us per pass at
-//   1024 chunks; 16 waves leave 64 each.)  The workgroup with blockIdx.x == 0 also reduces the per-chunk scalars.
+//   grid (ceil(n/16), nblocks), 1024 threads.  A workgroup owns 16 rows: lane l of wave w reads row (l & 15) of the chunks
+//   cs + 4w + (l >> 4) + 64 k -- a wave instruction covers four chunks x 128 bytes -- so 256 workgroups (n = 4096) share
+//   the 33 MB of partials and a lane walks 16 of the 1024 chunks (latency-bound: 64 rows per workgroup = 64 workgroups,
+//   64 dependent loads per lane: 16 us per pass; this form: half of that).  Combined in a fixed order: four accumulators
+//   per lane, the four quarter-waves, then the 16 waves through LDS.  The workgroup with blockIdx.x == 0 also reduces the
+//   per-chunk scalars.
 constexpr int RC_W = 16;
+constexpr int RC_ROWS = 16;
 __global__ __launch_bounds__(64 * RC_W) void k_reduce_chunks(const double* __restrict__ part_t,
                                                              const double* __restrict__ part_s,
                                                              const int* __restrict__ blk_start, int64_t n,
@@ -427,30 +431,36 @@ __global__ __launch_bounds__(64 * RC_W) void k_reduce_chunks(const double* __res
                                                              double* __restrict__ out_d /* [nblocks][nd] */,
                                                              double* __restrict__ out_amp /* [nblocks] max of slot 3 */,
                                                              const double* __restrict__ dpar) {
-  __shared__ double comb[RC_W][64];
+  __shared__ double comb[RC_W][RC_ROWS];
   if (dpar && dpar[2] != 0.0) return;
   const int b = blockIdx.y;
   const int cs = blk_start[b], ce = blk_start[b + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (out_t) {
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const int row = lane & (RC_ROWS - 1), sub = lane >> 4;
+    const int64_t i = (int64_t)blockIdx.x * RC_ROWS + row;
     double s = 0.0;
-    if (i < n) {
-      int c = cs + w;
+    {
+      constexpr int ST = 4 * RC_W;                   // chunks covered by one round of the workgroup
+      int c = cs + 4 * w + sub;
+      const int64_t ic = i < n ? i : 0;
       // 4 independent accumulators keep several loads in flight; combined in fixed order
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      for (; c + 3 * RC_W < ce; c += 4 * RC_W) {
-        s0 += part_t[(int64_t)c * n + i];
-        s1 += part_t[(int64_t)(c + RC_W) * n + i];
-        s2 += part_t[(int64_t)(c + 2 * RC_W) * n + i];
-        s3 += part_t[(int64_t)(c + 3 * RC_W) * n + i];
+      for (; c + 3 * ST < ce; c += 4 * ST) {
+        s0 += part_t[(int64_t)c * n + ic];
+        s1 += part_t[(int64_t)(c + ST) * n + ic];
+        s2 += part_t[(int64_t)(c + 2 * ST) * n + ic];
+        s3 += part_t[(int64_t)(c + 3 * ST) * n + ic];
       }
-      for (; c < ce; c += RC_W) s0 += part_t[(int64_t)c * n + i];
+      for (; c < ce; c += ST) s0 += part_t[(int64_t)c * n + ic];
       s = (s0 + s1) + (s2 + s3);
     }
-    comb[w][lane] = s;
+    // the four quarter-waves (chunks 4w .. 4w + 3 of every round): lanes l, l + 16, l + 32, l + 48
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < RC_ROWS) comb[w][lane] = s;
     __syncthreads();
-    if (w == 0 && i < n) {
+    if (w == 0 && lane < RC_ROWS && i < n) {
       double tsum = 0.0;
 #pragma unroll
       for (int k = 0; k < RC_W; ++k) tsum += comb[k][lane];
@@ -592,7 +602,7 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
 int reduce_chunks(mbpls_ctx* ctx, const mbpls_mat* m, const double* part_t, const double* part_s,
                   double* d_t, double* d_ssq_g, double* d_ssq_p, double* d_ssq_x,
                   const double* part_d, int nd, double* d_d, double* d_amp) {
-  dim3 grid(d_t ? (unsigned)((m->n + 63) / 64) : 1u, (unsigned)m->nblocks);
+  dim3 grid(d_t ? (unsigned)((m->n + RC_ROWS - 1) / RC_ROWS) : 1u, (unsigned)m->nblocks);
   hipLaunchKernelGGL(k_reduce_chunks, grid, dim3(64 * RC_W), 0, ctx->stream, part_t, part_s,
                      (const int*)m->fine.d_blk_start, m->n, d_t, d_ssq_g, d_ssq_p, d_ssq_x, part_d, nd, d_d, d_amp,
                      ctx->dpar);

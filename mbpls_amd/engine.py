@@ -136,12 +136,12 @@ class HipEngine:
             self._gp = None
 
     # ------------------------------------------------------------------ slots (p x K device arrays)
-    def slot(self, name, K):
+    def slot(self, name, K, zero=True):
         s = self.slots.get(name)
         if s is None or s.shape != (self.p, K):
             if s is not None:
                 s.free()
-            s = self.ctx.empty((self.p, K), zero=True)
+            s = self.ctx.empty((self.p, K), zero=zero)
             self.slots[name] = s
         return s
 
@@ -1168,7 +1168,7 @@ class _ResidentQueue:
         _capi.check(self.lib.mbpls_hip_cross_product_dev(self.ctx.handle, eng.p, A.ptr, eng.p, K, Bm.ptr, eng.p, K, dC.ptr))
         if eng.comm.is_distributed:
             eng.comm.allreduce_device(dC)
-        self.crossed = True
+        self.crossed = (pslot, wslot)
 
     def scale_col(self, src, dst, k):
         """dst = src * c_k with the scalar the step of component k left at scal[k][3][0]"""
@@ -1235,7 +1235,22 @@ class _ResidentQueue:
         scal = self._view(h, "scal").reshape(K, 4, B)
         # the attribute columns the helper thread is still copying / scaling must have landed before they are used:
         # the caller waits right before it hands them out (wait_copies), not here
-        self.result = dict(k_done=k_done, wait_copies=wait_copies, Ts=self._view(h, "Ts", (n, K)), U=self._view(h, "U", (n, K)),
+        finalised = None
+        if self.crossed and k_done == K:
+            # End-of-fit algebra right here, before anything else is unpacked: R_ = W (P^T W)^+, beta_ = R_ V^T
+            # (mbpls.py:988-989 / :569-570) with W = W~ diag(1/||W~[:, k]||) -- the K x K pinv on the host, the two p x K
+            # products on the device, their copies in the helper thread while the caller does its bookkeeping.
+            with eng._timed("finalise"):
+                Vq = self._view(h, "V", (q, K))
+                D = 1.0 / np.sqrt(scal[:, 0, :].sum(axis=1))
+                M = D[:, None] * np.linalg.pinv(self._view(h, "C").reshape(K, K) * D[None, :])
+                wslot = self.crossed[1]
+                eng.slot("R", K, zero=False)
+                eng.right_mul((wslot, 0, K), M, ("R", 0))
+                eng.slot("beta", q, zero=False)
+                eng.right_mul((wslot, 0, K), M.dot(Vq.T), ("beta", 0))
+                finalised = (eng.fetch_async("R")[1], eng.fetch_async("beta")[1])
+        self.result = dict(k_done=k_done, wait_copies=wait_copies, finalised=finalised, Ts=self._view(h, "Ts", (n, K)), U=self._view(h, "U", (n, K)),
                            V=self._view(h, "V", (q, K)), Tb=self._view(h, "Tb").reshape(K, B, n), scal=scal,
                            ssq_x=self._view(h, "ssqx").copy(), iters=self._view(h, "iters"), last_diff=float(par[4]),
                            PtW=self._view(h, "C").reshape(K, K).copy() if (self.crossed and k_done == K) else None)

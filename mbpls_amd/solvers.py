@@ -198,6 +198,19 @@ def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_hos
         return lambda: None
 
 
+def _finish_resident(eng, res, out, W_host, P_host):
+    """R_ / beta_ of a device-resident fit were computed and sent on their way by the queue itself (engine
+    _ResidentQueue.__exit__); returns the callable that waits for them and fills in the p-length attributes"""
+    wait_r, wait_b = out["finalised"]
+    offs = eng.block_offsets
+
+    def finish():
+        res.R_, res.beta_ = wait_r(), wait_b()
+        res.W_, res.P_ = _split(W_host, offs), _split(P_host, offs)
+
+    return finish
+
+
 # ----------------------------------------------------------------------------------- NIPALS
 def _prepare_products(eng, standardize):
     """a1 for the solvers whose X-sized work is products on a matrix that is never deflated (several-response NIPALS /
@@ -521,8 +534,11 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
             # the per-component bookkeeping below runs while they travel
             nu_all[:] = np.sqrt(out["scal"][:, 0, :].T)
             V[:] = out["V"]
-            finish = _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V, W_host=W_h,
-                                      P_host=P_h, fetch="async", C=out.get("PtW"))
+            if out.get("finalised"):
+                finish = _finish_resident(eng, res, out, W_h, P_h)      # (already launched by the queue)
+            else:
+                finish = _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V, W_host=W_h,
+                                          P_host=P_h, fetch="async", C=out.get("PtW"))
         if not whole:
             out["wait_copies"]()                            # the host loop below writes the same host columns
         for k in range(k_start):
@@ -760,7 +776,10 @@ def fit_unipals(eng, Y, K, standardize):
             Acorr[:, k] = _bip_corrected(A[:, k], sizes)    # (:542-553)
         res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, explained_var_x_=evx, explained_var_y_=evy,
                         explained_var_xblocks_=evxb, A_corrected_=Acorr)
-        _finalise_device(eng, res, "Wc", K, tot_nrm, blk_nrm, V, W_host=W_h, P_host=P_h, C=out.get("PtW"))   # (:569-572)
+        if out.get("finalised"):
+            _finish_resident(eng, res, out, W_h, P_h)()     # (:569-572, launched by the queue)
+        else:
+            _finalise_device(eng, res, "Wc", K, tot_nrm, blk_nrm, V, W_host=W_h, P_host=P_h, C=out.get("PtW"))
         out["wait_copies"]()                                # streamed columns of W, P complete
         return res
     varxb, m_raw, g_ssq = eng.prepare(standardize, v=y0 if fuse else None, alpha=1.0, g_slot=("S", 0) if fuse else None)

@@ -10,6 +10,8 @@ from mbpls_amd import MBPLS, DeviceMatrix
 
 n, p, K = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, 10
 ctx = mbpls_amd.get_context()
+if len(sys.argv) > 2 and sys.argv[2] == "rccl":       # the sharded code path with ONE rank: all-reduce behind every pass
+    mbpls_amd.set_comm(mbpls_amd.RcclComm(ctx, 0, 1, lambda payload: payload))
 Ts, Y = planted(n, 1, 32, 0)
 X = DeviceMatrix(ctx, n, p)
 X.fill_latent(ctx.from_host(Ts), 32, 0.5, 1234, 0)
