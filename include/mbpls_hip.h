@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 4   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host */
+#define MBPLS_HIP_ABI_VERSION 4   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights */
 
 enum {
   MBPLS_OK = 0,
@@ -442,6 +442,20 @@ int mbpls_hip_comm_info(mbpls_ctx* ctx, int* world_size, int* rank, int* rccl_ve
 int mbpls_hip_comm_query(mbpls_ctx* ctx, int* rccl_ranks, int* rccl_user_rank, int* rccl_device);
 int mbpls_hip_comm_destroy(mbpls_ctx* ctx);
 int mbpls_hip_allreduce(mbpls_ctx* ctx, double* d_buf, size_t count);   /* sum, in place, asynchronous */
+
+/* ---- cross-validation folds batched per read of X (mbpls_amd/cv_batch.py; the reference's callers run
+ * sklearn.model_selection.cross_val_predict(MBPLS(k), X, y, cv=n): n complete refits) ---------------------------------
+ * The p x F algebra of a NIPALS sweep for F folds at once, between the two many-right-hand-side products with the ONE
+ * raw matrix in HBM (mbpls_hip_xt_v, mbpls_hip_x_w with F columns).  Fold f has its own column statistics d_mu / d_rs
+ * (mean and 1/scale of its training rows, p x F column-major).  From d_G = X^T U (U: the folds' sweep vectors, zero on
+ * their held-out rows; d_su[f] = sum_i U_if):
+ *     d_g[j,f] = d_alpha[f] (d_G[j,f] - d_mu[j,f] d_su[f]) d_rs[j,f]        (mbpls.py:856 on the fold's standardised X)
+ *     d_C[j,f] = d_g[j,f] d_rs[j,f]                                          (X_b d_C_b - const = X_b,std g_b, :875)
+ *     d_sums[(b F + f) 2 + 0] = sum_{j in block b} d_g[j,f]^2               (block norms, :860)
+ *     d_sums[(b F + f) 2 + 1] = sum_{j in block b} d_mu[j,f] d_C[j,f]       (that const)
+ * Asynchronous on the context's stream; fixed-order sums.                                                          */
+int mbpls_hip_cv_weights(const mbpls_mat* m, int F, const double* d_G, const double* d_mu, const double* d_rs,
+                         const double* d_su, const double* d_alpha, double* d_g, double* d_C, double* d_sums);
 
 /* ---- end-of-fit algebra on p x K device arrays (any K; 32-column tiles inside), column-major ---
  * h_out (c1 x c2 row-major, HOST) = A^T B for p x c1 / p x c2 device arrays: P_^T W (mbpls.py:988,

@@ -1,0 +1,84 @@
+// Cross-validation folds batched per read of X (mbpls_amd/cv_batch.py): the p x F algebra between the two
+// many-right-hand-side products of a NIPALS sweep, for F folds at once.  Fold f has its own column statistics mu_f,
+// 1/sigma_f (p x F, column-major like the p x F product G = X^T U it starts from):
+//
+//     g_jf = alpha_f (G_jf - mu_jf su_f) rs_jf          weights of fold f on the standardised columns   (mbpls.py:856)
+//     C_jf = g_jf rs_jf                                 what the raw matrix is multiplied with           (mbpls.py:875)
+//     ssq_bf = sum_{j in block b} g_jf^2,   cst_bf = sum_{j in block b} mu_jf C_jf      (block norms :860; the means' share
+//                                                                                        of X_b C_f, removed per fold)
+//
+// One workgroup per (column chunk, fold); chunks never straddle a block, a second kernel adds the chunks of a block in
+// fixed order.  Element-wise and HBM-bound: 4 p F doubles read, 2 p F written.
+#include "common.h"
+
+namespace mbpls {
+
+__global__ __launch_bounds__(256) void k_cv_weights(int64_t p, const int64_t* __restrict__ c0, const int64_t* __restrict__ c1,
+                                                    const double* __restrict__ G, const double* __restrict__ mu,
+                                                    const double* __restrict__ rs, const double* __restrict__ su,
+                                                    const double* __restrict__ alpha, double* __restrict__ g,
+                                                    double* __restrict__ C, double* __restrict__ part, int F) {
+  __shared__ double red[2 * 64];
+  int buf = 0;
+  const int f = blockIdx.y, chunk = blockIdx.x;
+  const int64_t base = (int64_t)f * p;
+  const double s = su[f], a = alpha[f];
+  double v[2] = {0.0, 0.0};
+  for (int64_t j = c0[chunk] + threadIdx.x; j < c1[chunk]; j += 256) {
+    const double r = rs[base + j], m = mu[base + j];
+    const double gj = a * ((G[base + j] - m * s) * r);
+    const double cj = gj * r;
+    g[base + j] = gj;
+    C[base + j] = cj;
+    v[0] = fma(gj, gj, v[0]);
+    v[1] = fma(m, cj, v[1]);
+  }
+  block_sum<2>(v, red, buf);
+  if (threadIdx.x == 0) {
+    part[((int64_t)chunk * F + f) * 2] = v[0];
+    part[((int64_t)chunk * F + f) * 2 + 1] = v[1];
+  }
+}
+
+// out[(b * F + f) * 2 + {0, 1}] = sum over the chunks of block b, fixed order; one wave per (block, fold)
+__global__ __launch_bounds__(64) void k_cv_block_sums(const double* __restrict__ part, const int* __restrict__ blk_start,
+                                                      int F, double* __restrict__ out) {
+  const int b = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  for (int c = blk_start[b] + lane; c < blk_start[b + 1]; c += 64) {
+    s0 += part[((int64_t)c * F + f) * 2];
+    s1 += part[((int64_t)c * F + f) * 2 + 1];
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (lane == 0) {
+    out[((int64_t)b * F + f) * 2] = s0;
+    out[((int64_t)b * F + f) * 2 + 1] = s1;
+  }
+}
+
+}  // namespace mbpls
+
+using namespace mbpls;
+
+extern "C" {
+
+int mbpls_hip_cv_weights(const mbpls_mat* m, int F, const double* d_G, const double* d_mu, const double* d_rs,
+                         const double* d_su, const double* d_alpha, double* d_g, double* d_C, double* d_sums) {
+  MB_ARG(m && d_G && d_mu && d_rs && d_su && d_alpha && d_g && d_C && d_sums, "NULL argument");
+  MB_ARG(F >= 1 && F <= 65535, "bad fold count %d", F);
+  mbpls_ctx* ctx = m->ctx;
+  const int nch = m->fine.nchunks;
+  MB_TRY(ensure_ws(ctx, sizeof(double) * (size_t)nch * (size_t)F * 2));
+  double* part = (double*)ctx->ws;
+  hipLaunchKernelGGL(k_cv_weights, dim3((unsigned)nch, (unsigned)F), dim3(256), 0, ctx->stream, m->p,
+                     (const int64_t*)m->fine.d_c0, (const int64_t*)m->fine.d_c1, d_G, d_mu, d_rs, d_su, d_alpha, d_g, d_C,
+                     part, F);
+  MB_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_cv_block_sums, dim3((unsigned)m->nblocks, (unsigned)F), dim3(64), 0, ctx->stream,
+                     (const double*)part, (const int*)m->fine.d_blk_start, F, d_sums);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+}  // extern "C"

@@ -177,11 +177,14 @@ class HipEngine:
         a = getattr(self, "_host_ready", {}).pop(name, None)
         return a if a is not None and a.shape == tuple(shape) else self.host_array(shape)
 
-    def fetch(self, name, overlapped=False):
+    def fetch(self, name, overlapped=False, out=None):
         """D2H of a whole slot.  overlapped=True: on the copy stream, not ordered behind the kernels queued on
-        the compute stream (the slot must be final); safe to call from a helper thread."""
+        the compute stream (the slot must be final); safe to call from a helper thread.  ``out``: an F-ordered host
+        array of the slot's shape to copy into (repeated fetches of a scratch slot)."""
         S = self.slots[name]
-        out = self._host_for_slot(name, S.shape)
+        if out is None:
+            out = self._host_for_slot(name, S.shape)
+        assert out.shape == S.shape and out.flags.f_contiguous
         if not overlapped:
             with self._timed("d2h_slots"):
                 _capi.check(self.ctx.lib.mbpls_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data, S.ptr, out.nbytes))

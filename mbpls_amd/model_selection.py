@@ -16,9 +16,10 @@ from .mbpls import MBPLS, _is_block_list
 
 
 def _resident(X):
-    """Upload host blocks once (feature-major, side by side); pass a DeviceMatrix through."""
+    """Upload host blocks once (feature-major, side by side); pass a DeviceMatrix through.
+    Returns (matrix, owned, host blocks or None)."""
     if isinstance(X, _capi.DeviceMatrix):
-        return X, False
+        return X, False, None
     blocks = X if _is_block_list(X) else [X]
     blocks = [np.asarray(b, dtype=np.float64) for b in blocks]
     n = blocks[0].shape[0]
@@ -27,14 +28,17 @@ def _resident(X):
     dm = _capi.DeviceMatrix(ctx, n, int(offs[-1]), offs)
     for b, o in zip(blocks, offs[:-1]):
         dm.upload(b, int(o))
-    return dm, True
+    return dm, True, blocks
 
 
-def cross_val_predict(estimator, X, y, cv=5, groups=None):
+def cross_val_predict(estimator, X, y, cv=5, groups=None, batch_folds=True):
     """Out-of-fold predictions of ``estimator`` (an ``MBPLS``), like sklearn's ``cross_val_predict``.
 
     cv: int (KFold without shuffling, as sklearn does for regressors), a CV splitter, or an iterable of
-    (train, test) index pairs.  Returns an (n, q) array (``predict``'s shape)."""
+    (train, test) index pairs.  Returns an (n, q) array (``predict``'s shape).
+
+    One-response NIPALS models of moderate width (p x K <= 30 000) are fitted up to 256 folds at a time, every pass over X serving all of them
+    (``cv_batch``; ``batch_folds=False`` forces the fold-by-fold loop, which everything else takes)."""
     if not isinstance(estimator, MBPLS):
         raise TypeError("cross_val_predict of mbpls_amd works on mbpls_amd.MBPLS estimators")
     y = np.asarray(y, dtype=np.float64)
@@ -45,10 +49,16 @@ def cross_val_predict(estimator, X, y, cv=5, groups=None):
         splits = list(check_cv(cv, y2, classifier=False).split(np.zeros((n, 1)), y2, groups))
     else:
         splits = [(np.asarray(tr), np.asarray(te)) for tr, te in cv]
-    Xdev, owned = _resident(X)
+    Xdev, owned, host_blocks = _resident(X)
     try:
         if Xdev.n != n:
             raise ValueError(f"Found input variables with inconsistent numbers of samples: [{Xdev.n}, {n}]")
+        from . import cv_batch
+        if (batch_folds and cv_batch.eligible(estimator, y2.shape[1], n, Xdev.p, len(splits))
+                and not runtime.get_comm().is_distributed and 8 * n * Xdev.p <= cv_batch.MAX_HOST_BYTES):
+            # (the per-fold column statistics and the predictions of the held-out rows are taken from the host copy)
+            X_host = np.hstack(host_blocks) if host_blocks is not None else Xdev.download()
+            return cv_batch.predict_folds(estimator, X_host, Xdev, runtime.get_context(), runtime.get_comm(), y2, splits)
         out = np.full((n, y2.shape[1]), np.nan)
         for train, test in splits:
             est = MBPLS(**{**estimator.get_params(), "copy": True})

@@ -449,6 +449,51 @@ def test_row_subset_fit_and_cross_val_predict(gpu_required):
     Xd.close()
 
 
+@pytest.mark.parametrize("blocks,std,cv", [(1, True, "loo"), (2, True, 7), (3, False, 5), (2, True, "thirds")])
+def test_cross_val_predict_batched_folds(gpu_required, blocks, std, cv):
+    """One-response NIPALS: up to 256 folds per pass over X (cv_batch) == the fold-by-fold loop == a loop of oracle fits,
+    for leave-one-out, k-fold and an explicit split list, one and several blocks, with and without standardisation; a
+    constant column and a column that is constant on one fold's training rows only included."""
+    from mbpls_amd import MBPLS, cv_batch
+    from mbpls_amd.model_selection import cross_val_predict
+    n, p, K = 60, 700, 4
+    X, Y = orc.make_latent(n, p, 1, r=6, seed=21)
+    X[:, 5] = 3.0                                    # constant everywhere
+    X[:, 9] = 1.0; X[0, 9] = 2.0                     # constant on the training rows of the fold that holds out row 0
+    cuts = np.linspace(0, p, blocks + 1).astype(int)
+    Xs = X if blocks == 1 else [np.ascontiguousarray(X[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    if cv == "loo":
+        cv_arg, splits = n, [(np.delete(np.arange(n), i), np.array([i])) for i in range(n)]
+    elif cv == "thirds":
+        splits = [(np.arange(n)[np.arange(n) % 3 != f], np.arange(n)[np.arange(n) % 3 == f]) for f in range(3)]
+        cv_arg = splits
+    else:
+        from sklearn.model_selection import KFold
+        cv_arg, splits = cv, list(KFold(cv).split(X))
+    est = MBPLS(n_components=K, standardize=std)
+    assert cv_batch.eligible(est, 1, n, p, len(splits))
+    calls = []
+    real = cv_batch.predict_folds
+    cv_batch.predict_folds = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = cross_val_predict(est, Xs, Y, cv=cv_arg)
+            loop = cross_val_predict(est, Xs, Y, cv=cv_arg, batch_folds=False)
+    finally:
+        cv_batch.predict_folds = real
+    assert calls == [1]                              # the batched path ran (once), the second call looped
+    sp = (lambda A, idx: A[idx]) if blocks == 1 else (lambda A, idx: [b[idx] for b in A])
+    want = np.empty_like(Y)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tr, te in splits:
+            r = orc.fit(sp(Xs, tr), Y[tr], n_components=K, standardize=std)
+            want[te] = orc.predict(r, sp(Xs, te))
+    assert util.relerr(got, want) < 1e-9
+    assert util.relerr(got, loop) < 1e-9
+
+
 @pytest.mark.parametrize("n,p,q,K", [(5, 1, 1, 1), (3, 2, 1, 1), (7, 3, 2, 2), (64, 1, 1, 1), (2, 5, 1, 1), (6, 4, 1, 3),
                                      (9, 300, 3, 3), (513, 2, 1, 2)])
 def test_tiny_and_ragged_shapes(gpu_required, n, p, q, K):
