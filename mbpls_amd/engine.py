@@ -16,10 +16,12 @@ import numpy as np
 
 from . import _capi
 from .comm import LocalComm
-from .plan import FitOptions
+from .engine_base import EngineBase
 
 
-class HipEngine:
+class HipEngine(EngineBase):
+    has_association_matrices = True
+    has_device_helpers = True
     KD = 40                     # == KD of csrc/colpass.hip (max lazily deflated components + 1)
     # Deflation strategy of the NIPALS / UNIPALS(p>n) drivers.  "lazy": X in HBM is never rewritten, the
     # rank-1 updates X <- X - ts p^T (mbpls.py:969) are applied algebraically inside the next passes
@@ -37,11 +39,9 @@ class HipEngine:
         self.mean = None
         self.scale = None
         self.G = None
-        self.timings = {}
+        self._init_base()
         # missing values (sparse_data=True): NaN-aware column passes (csrc/colpass_nan.hip); set before load_*
         self.sparse = False
-        self.opts = FitOptions.from_env()     # route switches, read once per engine (= per fit)
-        self.plan = {}                        # the route this fit took (MBPLS.fit_plan_)
 
     @contextlib.contextmanager
     def _timed(self, name):
@@ -254,6 +254,9 @@ class HipEngine:
             return None
         name, k = spec
         return self.slots[name].col(k)
+
+    def sync(self):
+        self.ctx.sync()
 
     def run_deferred(self, count=1, all_of_it=False):
         """Host chores queued by the estimator (releasing the attributes a refit replaces): a few per column

@@ -1,0 +1,54 @@
+"""The engine interface the solvers are written against.
+
+``solvers.py`` calls these methods unconditionally; an engine overrides what it accelerates.  ``HipEngine`` (the
+product: HIP kernels through the C ABI) overrides all of it; the test-only numpy engine of ``tests/numpy_engine.py``
+(kernel semantics of include/mbpls_hip.h in numpy, for the CPU tests of the host drivers and of the column sharding)
+overrides the products and passes and inherits the plain defaults below -- no optional fast path is taken, every fit
+goes through the host-driven loops.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .plan import FitOptions
+
+
+class EngineBase:
+    sparse = False
+    rowmask = None
+    # capabilities that change the solver route (plain data, decided by the engine class)
+    has_association_matrices = False     # gram_blocks / gram_power_loop (several-response NIPALS on per-block Grams)
+    has_device_helpers = False           # asynchronous slot algebra with a device context (helper-thread fetches)
+
+    def _init_base(self):
+        self.opts = FitOptions.from_env()     # route switches, read once per engine (= per fit)
+        self.plan = {}                        # the route this fit took (MBPLS.fit_plan_)
+        self.timings = {}
+
+    # ---- host buffers
+    def host_array(self, shape, reserve=None, prefault=True):
+        return np.empty(shape, order="F")
+
+    def fetch_async(self, name):
+        out = self.fetch(name)
+        return out, (lambda: out)
+
+    # ---- routes an engine may offer
+    def use_lazy_deflation(self, K, pslot, prefer=None):
+        return False
+
+    def resident_supported(self, q, K, norm_kind):
+        return False
+
+    def stats_only_ok(self):
+        return False
+
+    def nipals_subspace_loop(self, G, Y, c0, norm_kind, tol, max_iter):
+        return None                           # "outside the kernel's range": the caller iterates on the host
+
+    def sync(self):
+        pass
+
+    def xt_self(self, slot):
+        """slot (p x p) = X^T X"""
+        self.xt_v(self.X.download(order="F"), 1.0, slot, 0)

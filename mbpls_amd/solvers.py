@@ -108,20 +108,9 @@ class _Responses:
         return u / np.linalg.norm(u)
 
 
-def _opts(eng):
-    """route switches of this fit (plan.FitOptions; engines without them -- the test-only numpy engine -- get defaults)"""
-    o = getattr(eng, "opts", None)
-    if o is None:
-        from .plan import FitOptions
-        o = FitOptions.from_env()
-    return o
-
-
 def _plan(eng, **kw):
     """record the route the fit takes (MBPLS.fit_plan_)"""
-    p = getattr(eng, "plan", None)
-    if p is not None:
-        p.update(kw)
+    eng.plan.update(kw)
 
 
 class FitResult(dict):
@@ -134,22 +123,13 @@ class FitResult(dict):
 def _host_array(eng, shape):
     """F-ordered host array for a p x K attribute that is filled column by column DURING the fit (the copies' own page
     faults hide behind the passes: no helper-thread mapping for these)"""
-    return eng.host_array(shape, prefault=False) if hasattr(eng, "host_array") else np.empty(shape, order="F")
+    return eng.host_array(shape, prefault=False)
 
 
 def _global_sizes(eng):
     """Block sizes of the WHOLE problem (summed over shards) for the BIP correction."""
     s = np.asarray(eng.block_sizes, dtype=np.float64)
     return eng.comm.allreduce_host(s)
-
-
-def _finalise(eng, res, Wcols, P, V):
-    """R_ = W (P^T W)^+,  beta_ = R_ V^T   (mbpls.py:988-989, :569-570, :737-738).
-    The K x K cross product is a sum over features -> all-reduced when sharded."""
-    PtW = eng.comm.allreduce_host(P.T.dot(Wcols))
-    res.R_ = Wcols.dot(np.linalg.pinv(PtW))
-    res.beta_ = res.R_.dot(V.T)
-    res.P_ = _split(P, eng.block_offsets)
 
 
 def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_host=None, P_host=None, fetch=True, C=None):
@@ -182,7 +162,7 @@ def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_hos
         res.W_ = _split(W_host if W_host is not None else eng.fetch("Wblk", **kw), offs)
         res.P_ = _split(P_host if P_host is not None else eng.fetch(pslot, **kw), offs)
 
-    if fetch == "async" and hasattr(eng, "fetch_async") and W_host is not None and P_host is not None:
+    if fetch == "async" and W_host is not None and P_host is not None:
         # R_ and beta_ leave through the helper thread while the caller does its host-side bookkeeping
         (_, wait_r), (_, wait_b) = eng.fetch_async("R"), eng.fetch_async("beta")
 
@@ -217,7 +197,7 @@ def _prepare_products(eng, standardize):
     UNIPALS, SIMPLS): a standardised working copy when it fits -- else (or when forced, MBPLS_KERNEL_IMPLICIT)
     statistics only: the products standardise their operand in registers and the caller's matrix is never written.
     Returns the per-block sums of squares of the standardised matrix."""
-    if hasattr(eng, "prepare_stats") and eng.stats_only_ok():
+    if eng.stats_only_ok():
         return eng.prepare_stats(standardize)
     return eng.prepare(standardize)[0]
 
@@ -228,8 +208,7 @@ def _nipals_on_subspace(eng, q):
     G = P X (X^T (P Y)) -- two many-right-hand-side products over X per COMPONENT -- the whole loop is n x q algebra:
     ts = G c / ||G c||.  X is standardised once and never deflated; a component costs three passes over X whatever its
     iteration count."""
-    return (q > 1 and q <= 16 and hasattr(eng, "x_w_slot") and not getattr(eng, "sparse", False)
-            and _opts(eng).nipals_subspace)
+    return q > 1 and q <= 16 and not eng.sparse and eng.opts.nipals_subspace
 
 
 def _subspace_loop_host(G, Y, c0, norm, tol, max_iter):
@@ -294,9 +273,8 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     q = Y.shape[1]
     sizes = _global_sizes(eng)
     eng.slot("Wn", K); eng.slot("P", K); eng.slot("S", q)
-    if hasattr(eng, "use_lazy_deflation"):
-        eng.use_lazy_deflation(K, "P", prefer="explicit")   # X is never deflated here: the plain (stored) passes
-        eng._lazy_pslot = None
+    eng.use_lazy_deflation(K, "P", prefer="explicit")       # X is never deflated here: the plain (stored) passes
+    eng._lazy_pslot = None
     varxb = _prepare_products(eng, standardize)
     varx = varxb.sum()
     vary = (Y ** 2).sum()
@@ -313,7 +291,7 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
         eng.xt_v(PY, 1.0, "S", 0)                           # X^T (P Y)
         G0 = eng.x_w_slot("S", 0, q)                        # X X^T P Y
         G = G0 - Tp.dot(Tp.T.dot(G0))
-        out = eng.nipals_subspace_loop(G, Y, c0, kind, max_tol, max_iter) if hasattr(eng, "nipals_subspace_loop") else None
+        out = eng.nipals_subspace_loop(G, Y, c0, kind, max_tol, max_iter)
         if out is None and kind == 0 and n > 8192:
             out = _subspace_loop_qspace(G, Y, c0, max_tol, max_iter)
         if out is None:
@@ -357,7 +335,7 @@ def _nipals_on_grams(eng, q):
     p > n the same iterates can be had from the per-block association matrices A_b = X_b X_b^T (n x n each):
     t_b = X_b w_b = A_b u / sqrt(u^T A_b u), so an iteration touches B n^2 doubles instead of n p.  Worth it once the
     fit needs more than about n/75 passes (the Gram costs n(n+1)p flop) -- always the case for q > 1 in practice."""
-    if (q == 1 or not hasattr(eng, "gram_blocks") or getattr(eng, "sparse", False) or not _opts(eng).nipals_gram):
+    if q == 1 or not eng.has_association_matrices or eng.sparse or not eng.opts.nipals_gram:
         return False
     p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
     return p_total > eng.n and eng.n <= 16384 and 8.0 * eng.nblocks * eng.n ** 2 <= 16 * 2 ** 30
@@ -384,7 +362,7 @@ def _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     # inf -> max |d|; -inf -> min |d|; anything else raises exactly as in the reference
     _norm(np.zeros((2, 1)), norm)
     kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
-    on_device = (kind is not None and hasattr(eng, "gram_power_loop") and K <= 16 and q <= 16)
+    on_device = kind is not None and K <= 16 and q <= 16
     Yc = np.asfortranarray(Y)
     for k in range(K):
         Tp = Ts[:, :k]
@@ -477,23 +455,20 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     alpha0 = 1.0 / u0.T.dot(u0).item()
     eng.slot("Wn", K)
     eng.slot("P", K)
-    if hasattr(eng, "use_lazy_deflation"):
-        # One response converges in two passes per component: lazy deflation (no rewrite of X) wins.  Several
-        # responses iterate 50-500 times per component (paper protocol, q = 10): every sweep then pays the lazy
-        # correction (~6 %), far more than one rewrite of X per component (measured 7.05 s -> 6.72 s).
-        eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
-    q1_fixed_point = (q == 1 and _opts(eng).q1_fixed_point and not getattr(eng, "sparse", False)
-                      and hasattr(eng, "right_mul"))
+    # One response converges in two passes per component: lazy deflation (no rewrite of X) wins.  Several
+    # responses iterate 50-500 times per component (paper protocol, q = 10): every sweep then pays the lazy
+    # correction (~6 %), far more than one rewrite of X per component (measured 7.05 s -> 6.72 s).
+    eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
+    q1_fixed_point = q == 1 and eng.opts.q1_fixed_point and not eng.sparse
     Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
     T = [np.empty((n, K)) for _ in range(B)]
     nu_all = np.empty((B, K))
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
     converged = []          # per component: the stop rule of mbpls.py:841 was met (not a cap / noise-floor stop)
-    if hasattr(eng, "host_array"):
-        # host buffers of the attributes that only exist at the very end of the fit (nothing hides THEIR page faults):
-        # allocated now, their pages mapped by the helper thread while the GPU has 2K + 1 passes to do
-        eng.host_array((eng.p, K), reserve="R")
-        eng.host_array((eng.p, q), reserve="beta")
+    # host buffers of the attributes that only exist at the very end of the fit (nothing hides THEIR page faults):
+    # allocated now, their pages mapped by the helper thread while the GPU has 2K + 1 passes to do
+    eng.host_array((eng.p, K), reserve="R")
+    eng.host_array((eng.p, q), reserve="beta")
     # host copies of the p x K attributes, filled column by column while later passes run on the GPU
     Wn_h, W_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
     vary = resp.ssq
@@ -501,8 +476,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     _norm(np.zeros((2, 1)), norm)
     kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
     k_start = 0
-    if (not q1_fixed_point and not resp.sparse and max_iter >= 2 and hasattr(eng, "resident_supported")
-            and eng.resident_supported(q, K, kind)):
+    if not q1_fixed_point and not resp.sparse and max_iter >= 2 and eng.resident_supported(q, K, kind):
         # One response: the whole fit is queued on the device (two iterations per component -- what one response takes),
         # the host reads the results once.  Components the speculation did not hold for are resumed below.
         first = eng.deferred_first_pass(standardize, u0, alpha0, ("Wn", 0))
@@ -590,8 +564,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
                 # and the reference's second sweep (:841, run 2) only re-derives it.  Skip it, rescale w~.
                 ynorm = float(np.linalg.norm(u0))
                 eng.right_mul(("Wn", k, 1), np.array([[ynorm]]), ("Wn", k))
-                if hasattr(eng, "ctx"):
-                    eng.ctx.sync()      # the column is streamed to the host on another stream right after
+                eng.sync()              # the column is streamed to the host on another stream right after
                 nu = nu * ynorm
                 diff = 0.0
             if run - 1 >= max_iter and diff > max_tol:
@@ -666,9 +639,8 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
     q = Y.shape[1]
     sizes = _global_sizes(eng)
     eng.slot("Wc", K); eng.slot("P", K); eng.slot("S", q)
-    if hasattr(eng, "use_lazy_deflation"):
-        eng.use_lazy_deflation(K, "P", prefer="explicit")   # plain passes on the stored X; nothing is deflated
-        eng._lazy_pslot = None
+    eng.use_lazy_deflation(K, "P", prefer="explicit")       # plain passes on the stored X; nothing is deflated
+    eng._lazy_pslot = None
     varxb = _prepare_products(eng, standardize)
     varx = varxb.sum()
     vary = (Y ** 2).sum()
@@ -717,8 +689,7 @@ def fit_unipals(eng, Y, K, standardize):
     # X (X^T y) / ||.|| of the p > n branch (:489-503) -- the same component up to the sign convention of the SVD --
     # so tall data takes the one-pass-per-component path as well (device-resident queue, X never written).
     wide = p_total > n or q == 1
-    if (wide and q > 1 and hasattr(eng, "x_w_slot") and not getattr(eng, "sparse", False)
-            and _opts(eng).unipals_nodeflate):
+    if wide and q > 1 and not eng.sparse and eng.opts.unipals_nodeflate:
         _plan(eng, solver="unipals: never-deflated products (several responses)")
         return _fit_unipals_wide_multi(eng, Y, K, standardize)
     sizes = _global_sizes(eng)
@@ -726,7 +697,7 @@ def fit_unipals(eng, Y, K, standardize):
     eng.slot("P", K)
     eng.slot("S", max(q, 1))
     y0 = Y[:, 0:1]
-    if wide and hasattr(eng, "use_lazy_deflation"):
+    if wide:
         # one response: every pass is a sweep / deflate_sweep, lazy deflation applies.  Several responses: X (X^T Y)
         # goes through the many-right-hand-side products, which need the deflated matrix itself -> explicit.
         # (the n >= p branch mixes in xt_v / x_w on the deflated X as well: explicit)
@@ -740,7 +711,7 @@ def fit_unipals(eng, Y, K, standardize):
     # p > n: W_ and P_ are streamed to the host column by column while the deflation passes run (as in NIPALS)
     W_h = _host_array(eng, (eng.p, K)) if wide else None
     P_h = _host_array(eng, (eng.p, K)) if wide else None
-    if fuse and hasattr(eng, "unipals_resident") and eng.resident_supported(q, K, 0):
+    if fuse and eng.resident_supported(q, K, 0):
         # one response: a component is ONE pass and everything between two passes is n x B algebra -- the whole fit
         # is queued on the device (engine.unipals_resident), the host reads the results once
         first = eng.deferred_first_pass(standardize, y0, 1.0, ("S", 0))
@@ -790,7 +761,7 @@ def fit_unipals(eng, Y, K, standardize):
         if wide:
             if fuse:
                 M = m_raw.sum(axis=1, keepdims=True)        # X (X^T y) = sum_b X_b g_b
-            elif getattr(eng, "_lazy_pslot", None) is None and hasattr(eng, "x_w_slot"):
+            elif getattr(eng, "_lazy_pslot", None) is None:
                 # X (X^T Y) for all q responses in two reads of the (explicitly deflated) X: matrix-core xt_v, x_w
                 eng.xt_v(Y, 1.0, "S", 0)
                 M = eng.x_w_slot("S", 0, q)
@@ -802,7 +773,7 @@ def fit_unipals(eng, Y, K, standardize):
             ts = _tlsv(M.dot(F))                            # (:489-493)
             v = Y.T.dot(ts) / ts.T.dot(ts)                  # (:496)
             u = Y.dot(v); u = u / np.linalg.norm(u)         # (:499-500)
-            if fuse and hasattr(eng, "right_mul"):
+            if fuse:
                 # one response: u = Y v / ||Y v|| is c y with a scalar c, so the weights w_raw = X^T u (:503) and the
                 # block scores X_b w_raw_b (:515-517) are c times the X^T y and X_b (X^T y)_b that the fused pass just
                 # produced for M = X (X^T y) -- the same products, not taken twice
@@ -921,7 +892,7 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
-    if p_total > n and hasattr(eng, "prepare_stats") and eng.stats_only_ok():
+    if p_total > n and eng.stats_only_ok():
         # p > n: every X-sized operation below is a matrix product (Gram, X^T [U Ts], X_b W_b) that can standardise
         # its operand in registers -- statistics only, X is neither copied nor written
         varxb = eng.prepare_stats(standardize)
@@ -950,60 +921,47 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
             Ts = np.hstack((Ts, ts)); U = np.hstack((U, u))
         eng.slot("UT", 2 * K)
         ssq = eng.xt_v(np.hstack((U, Ts)), 1.0, "UT", 0, want_ssq=True)   # X^T [U Ts] in one call (:731, :734)
-        if hasattr(eng, "right_mul"):
-            # post-processing on the device: only K x K matrices visit the host, every p x K attribute is
-            # fetched once
-            wnorm2 = ssq[:, :K]                             # per-block ||(X^T U)_b||^2, all shards
-            cn = np.sqrt(wnorm2.sum(axis=0))
-            G = np.linalg.pinv(Ts.T.dot(Ts))
-            V = Y.T.dot(Ts).dot(G)                          # (:735)
-            eng.slot("P", K)
-            eng.right_mul(("UT", K, K), G, ("P", 0))        # P = X^T Ts (Ts^T Ts)^+ (:734)
-            eng.slot("Wc", K)
-            eng.right_mul(("UT", 0, K), np.diag(1.0 / cn), ("Wc", 0))     # column-normalised weights (:733)
-            res.update(Ts_=Ts, U_=U, V_=V)
-            # R_, beta_ (:737-738), W_b, P_ on the device; their D2H (five p x K arrays) runs on the copy stream
-            # in a helper thread while the block-score passes of calc_all stream X on the compute stream
-            fetch_all = _finalise_device(eng, res, "UT", K, cn, np.sqrt(wnorm2), V, fetch=False)
-            if calc_all and hasattr(eng, "ctx"):
-                import threading
-                eng.ctx.sync()                              # every slot the helper reads is final
-                err = []
-
-                def helper():
-                    try:
-                        fetch_all(overlapped=True)
-                        res.W_concat_ = eng.fetch("Wc", overlapped=True)
-                    except BaseException as e:              # re-raised on the calling thread
-                        err.append(e)
-
-                th = threading.Thread(target=helper)
-                th.start()
-                try:
-                    _kernel_extras_device(eng, res, Y, V, Ts, varxb, "UT", wnorm2)
-                finally:
-                    th.join()
-                if err:
-                    raise err[0]
-                return res
-            fetch_all()
-            res.W_concat_ = eng.fetch("Wc")
-            if calc_all:
-                _kernel_extras_device(eng, res, Y, V, Ts, varxb, "UT", wnorm2)
-            else:
-                res.update(empty_blocks)
-            return res
-        UT = eng.fetch("UT")
-        wnorm2 = ssq[:, :K]                                 # per-block ||(X^T U)_b||^2, all shards
-        Wc = UT[:, :K] / np.sqrt(wnorm2.sum(axis=0))        # (:733)
+        # post-processing on the device: only K x K matrices visit the host, every p x K attribute is
+        # fetched once
+        wnorm2 = ssq[:, :K]                             # per-block ||(X^T U)_b||^2, all shards
+        cn = np.sqrt(wnorm2.sum(axis=0))
         G = np.linalg.pinv(Ts.T.dot(Ts))
-        P = UT[:, K:].dot(G)                                # (:734)
-        V = Y.T.dot(Ts).dot(G)                              # (:735)
-        res.update(Ts_=Ts, U_=U, V_=V, W_concat_=Wc)
-        res.update(empty_blocks)
+        V = Y.T.dot(Ts).dot(G)                          # (:735)
+        eng.slot("P", K)
+        eng.right_mul(("UT", K, K), G, ("P", 0))        # P = X^T Ts (Ts^T Ts)^+ (:734)
+        eng.slot("Wc", K)
+        eng.right_mul(("UT", 0, K), np.diag(1.0 / cn), ("Wc", 0))     # column-normalised weights (:733)
+        res.update(Ts_=Ts, U_=U, V_=V)
+        # R_, beta_ (:737-738), W_b, P_ on the device; their D2H (five p x K arrays) runs on the copy stream
+        # in a helper thread while the block-score passes of calc_all stream X on the compute stream
+        fetch_all = _finalise_device(eng, res, "UT", K, cn, np.sqrt(wnorm2), V, fetch=False)
+        if calc_all and eng.has_device_helpers:
+            import threading
+            eng.sync()                                  # every slot the helper reads is final
+            err = []
+
+            def helper():
+                try:
+                    fetch_all(overlapped=True)
+                    res.W_concat_ = eng.fetch("Wc", overlapped=True)
+                except BaseException as e:              # re-raised on the calling thread
+                    err.append(e)
+
+            th = threading.Thread(target=helper)
+            th.start()
+            try:
+                _kernel_extras_device(eng, res, Y, V, Ts, varxb, "UT", wnorm2)
+            finally:
+                th.join()
+            if err:
+                raise err[0]
+            return res
+        fetch_all()
+        res.W_concat_ = eng.fetch("Wc")
         if calc_all:
-            _kernel_extras(eng, res, Y, P, V, Ts, varxb, "UT", wnorm2)
-        _finalise(eng, res, Wc, P, V)                       # (:737-738)
+            _kernel_extras_device(eng, res, Y, V, Ts, varxb, "UT", wnorm2)
+        else:
+            res.update(empty_blocks)
         return res
     # ---- n >= p (:580-692): everything is p x p, p <= n <= a few thousand -> host algebra on X^T X, X^T Y
     eng.slot("C", q)
@@ -1047,10 +1005,7 @@ def _xtx(eng):
     own columns, so the p x p product is the many-right-hand-side product X^T V with V = X itself: matrix cores, 64
     right-hand sides per read of X, nothing leaves the device (the host only fetches the p x p result)."""
     eng.slot("XtX", eng.p)
-    if hasattr(eng, "xt_self"):
-        eng.xt_self("XtX")
-    else:                                                   # test-only engines without device pointers
-        eng.xt_v(eng.X.download(order="F"), 1.0, "XtX", 0)
+    eng.xt_self("XtX")
     return eng.fetch("XtX")
 
 
@@ -1062,7 +1017,7 @@ def fit_simpls(eng, Y, K, standardize):
     k x 1 matrices visit the host."""
     n = eng.n
     q = Y.shape[1]
-    if K + 1 + q > 32 or not hasattr(eng, "right_mul"):
+    if K + 1 + q > 32:
         return _fit_simpls_hostvec(eng, Y, K, standardize)
     _prepare_products(eng, standardize)
     nz = K + 1 + q

@@ -8,12 +8,14 @@ kernel-level semantics of include/mbpls_hip.h, nothing more.  The product never 
 import numpy as np
 
 from mbpls_amd.comm import LocalComm
+from mbpls_amd.engine_base import EngineBase
 
 _EPS = np.finfo(np.float64).eps
 
 
-class NumpyEngine:
+class NumpyEngine(EngineBase):
     def __init__(self, comm=None):
+        self._init_base()
         self.comm = comm if comm is not None else LocalComm()
         self.slots = {}
         self.mean = self.scale = None
