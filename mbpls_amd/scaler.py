@@ -8,16 +8,26 @@ from __future__ import annotations
 
 import numpy as np
 
+try:        # the reference stores sklearn StandardScaler objects: be one (isinstance checks, sklearn's own tooling)
+    from sklearn.preprocessing import StandardScaler as _Base
+except Exception:  # pragma: no cover
+    _Base = object
+
 _EPS = np.finfo(np.float64).eps
 
 
-class ColumnScaler:
-    with_mean = True
-    with_std = True
+class ColumnScaler(_Base):
+    """A ``sklearn.preprocessing.StandardScaler`` (when scikit-learn is importable) whose fitted statistics were
+    produced elsewhere -- for X by the HIP standardise pass -- with lean ``fit`` / ``transform`` for small host arrays."""
 
-    copy = True
+    def __init__(self, mean=None, scale=None, n_samples=None, var=None, *, copy=True, with_mean=True, with_std=True):
+        self.copy, self.with_mean, self.with_std = copy, with_mean, with_std      # StandardScaler's parameters
+        self._set(mean, scale, n_samples, var)
 
-    def __init__(self, mean=None, scale=None, n_samples=None, var=None):
+    def get_params(self, deep=True):
+        return {"copy": self.copy, "with_mean": self.with_mean, "with_std": self.with_std}
+
+    def _set(self, mean, scale, n_samples, var):
         """the fitted attributes of sklearn's StandardScaler: ``mean_``, ``scale_``, ``var_`` (0 for a constant
         column, whose ``scale_`` is 1), ``n_samples_seen_`` (an int, or one count per column when the data had
         missing values), ``n_features_in_``"""
@@ -29,7 +39,7 @@ class ColumnScaler:
             self.n_samples_seen_ = n_samples
             self.n_features_in_ = self.mean_.size
 
-    def fit(self, X):
+    def fit(self, X, y=None, sample_weight=None):
         """mean, then corrected two-pass variance (sklearn ``_incremental_mean_and_var``); NaN entries are ignored, as
         sklearn does (the statistics of a column are taken over its present samples)."""
         X = np.asarray(X, dtype=np.float64)

@@ -121,3 +121,26 @@ def test_subspace_loop_in_q_space_matches_the_n_vector_loop(n, q, seed):
     assert abs(a[0] - b[0]) <= 2, (a[0], b[0])               # the stop test sits at the rounding floor of both forms
     for i in (2, 3, 4, 5):
         assert np.abs(a[i] - b[i]).max() <= 1e-11 * np.abs(a[i]).max()
+
+
+def test_scalers_are_sklearn_standard_scalers():
+    """x_scalers_ / y_scaler_ of the reference are sklearn StandardScaler objects (mbpls.py:307,316,325): the product's
+    carry the statistics of the HIP passes but ARE StandardScalers (isinstance, clone, pickle) with the same fitted
+    attributes and the same numbers as sklearn's own fit."""
+    import pickle
+    from sklearn.base import clone
+    from sklearn.preprocessing import StandardScaler
+    from mbpls_amd.scaler import ColumnScaler
+    rng = np.random.RandomState(0)
+    X = rng.rand(40, 5) * 3 + 7
+    X[:, 2] = 4.0                                   # constant: scale_ 1, var_ 0
+    mine, ref = ColumnScaler().fit(X), StandardScaler().fit(X)
+    assert isinstance(mine, StandardScaler)
+    for attr in ("mean_", "scale_", "var_"):
+        np.testing.assert_allclose(getattr(mine, attr), getattr(ref, attr), rtol=1e-13, atol=1e-15)
+    assert mine.n_samples_seen_ == ref.n_samples_seen_ and mine.n_features_in_ == ref.n_features_in_
+    np.testing.assert_allclose(mine.transform(X), ref.transform(X), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(mine.inverse_transform(mine.transform(X)), X, rtol=1e-12)
+    carried = ColumnScaler(ref.mean_, ref.scale_, 40, ref.var_)          # statistics produced elsewhere (the GPU passes)
+    np.testing.assert_allclose(pickle.loads(pickle.dumps(carried)).transform(X), ref.transform(X), rtol=1e-12, atol=1e-13)
+    assert isinstance(clone(carried), ColumnScaler)
