@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 4   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights */
+#define MBPLS_HIP_ABI_VERSION 4   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev */
 
 enum {
   MBPLS_OK = 0,
@@ -467,6 +467,16 @@ int mbpls_hip_cross_product(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_
  * together with its other results.                                                                                  */
 int mbpls_hip_cross_product_dev(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1,
                                 const double* d_B, int64_t ldb, int c2, double* d_out);
+/* The K x K end-of-fit algebra on the device (no host round trip between the last pass and the p x K products):
+ * d_M (K x K row-major) = D (d_C D)^+ and d_MV (K x q row-major) = d_M d_V^T, with d_C = P^T W~ (K x K row-major),
+ * D = diag(1 / ||W~[:, k]||), ||W~[:, k]||^2 = sum_b d_scal[(k 4 + 0) nblocks + b], d_V q x K column-major -- so that
+ * R_ = W~ d_M (mbpls.py:988 / :569) and beta_ = W~ d_MV (:989 / :570).  The pseudo-inverse follows numpy.linalg.pinv
+ * (singular values <= 1e-15 sigma_max dropped; one-sided Jacobi SVD on one wave).  K <= 32.                          */
+int mbpls_hip_finalise_small(mbpls_ctx* ctx, int K, int nblocks, int q, const double* d_C, const double* d_scal,
+                             const double* d_V, double* d_M, double* d_MV);
+/* mbpls_hip_right_multiply with the c1 x c2 matrix (row-major, c1, c2 <= 32) already on the device.                  */
+int mbpls_hip_right_multiply_dev(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1, const double* d_M,
+                                 int c2, double* d_C, int64_t ldc);
 /* d_C (p x c2, ldc) = d_A (p x c1, lda) @ h_M (c1 x c2 row-major HOST matrix):
  * R_ = W (P^T W)^+ and beta_ = R_ V^T (mbpls.py:988-989), column scalings W_b = W~_b diag(1/||w~_b||)
  * (:860) with a diagonal M on the row range of block b. */

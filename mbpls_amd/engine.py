@@ -1081,8 +1081,9 @@ class _ResidentQueue:
         # copy.
         sizes = [("u_cur", n), ("Y", n * q), ("ts_old", n), ("par", 8), ("scal", K * 4 * B), ("iters", K), ("ssqx", B),
                  ("C", K * K), ("V", q * K), ("Ts", n * K), ("U", n * K), ("Tb", n * B * K)] \
-            + ([("Tsc", n * K)] if self.istd else [])
+            + ([("Tsc", n * K)] if self.istd else []) + [("M", K * K), ("MV", K * q)]
         self.crossed = False
+        self.finalised = None
         self.off, o = {}, 0
         for key, sz in sizes:
             self.off[key] = (o, sz)
@@ -1175,6 +1176,18 @@ class _ResidentQueue:
         if eng.comm.is_distributed:
             eng.comm.allreduce_device(dC)
         self.crossed = (pslot, wslot)
+        # ... and the rest of the end-of-fit algebra right behind it, all on the device: M = D (C D)^+ (one-wave Jacobi
+        # SVD, numpy.linalg.pinv's cutoff), R_ = W~ M, beta_ = W~ M V^T (:988-989 / :569-570); their copies start in the
+        # helper thread as soon as the products have run -- no host round trip between the last pass and the attributes
+        q = self.st.q
+        _capi.check(self.lib.mbpls_hip_finalise_small(self.ctx.handle, K, eng.nblocks, q, self.ptr["C"], self.ptr["scal"],
+                                                      self.ptr["V"], self.ptr["M"], self.ptr["MV"]))
+        R, Bt = eng.slot("R", K, zero=False), eng.slot("beta", q, zero=False)
+        _capi.check(self.lib.mbpls_hip_right_multiply_dev(self.ctx.handle, eng.p, Bm.ptr, eng.p, K, self.ptr["M"], K,
+                                                          R.ptr, eng.p))
+        _capi.check(self.lib.mbpls_hip_right_multiply_dev(self.ctx.handle, eng.p, Bm.ptr, eng.p, K, self.ptr["MV"], q,
+                                                          Bt.ptr, eng.p))
+        self.finalised = (eng.fetch_async("R")[1], eng.fetch_async("beta")[1])
 
     def scale_col(self, src, dst, k):
         """dst = src * c_k with the scalar the step of component k left at scal[k][3][0]"""
@@ -1241,21 +1254,11 @@ class _ResidentQueue:
         scal = self._view(h, "scal").reshape(K, 4, B)
         # the attribute columns the helper thread is still copying / scaling must have landed before they are used:
         # the caller waits right before it hands them out (wait_copies), not here
-        finalised = None
-        if self.crossed and k_done == K:
-            # End-of-fit algebra right here, before anything else is unpacked: R_ = W (P^T W)^+, beta_ = R_ V^T
-            # (mbpls.py:988-989 / :569-570) with W = W~ diag(1/||W~[:, k]||) -- the K x K pinv on the host, the two p x K
-            # products on the device, their copies in the helper thread while the caller does its bookkeeping.
-            with eng._timed("finalise"):
-                Vq = self._view(h, "V", (q, K))
-                D = 1.0 / np.sqrt(scal[:, 0, :].sum(axis=1))
-                M = D[:, None] * np.linalg.pinv(self._view(h, "C").reshape(K, K) * D[None, :])
-                wslot = self.crossed[1]
-                eng.slot("R", K, zero=False)
-                eng.right_mul((wslot, 0, K), M, ("R", 0))
-                eng.slot("beta", q, zero=False)
-                eng.right_mul((wslot, 0, K), M.dot(Vq.T), ("beta", 0))
-                finalised = (eng.fetch_async("R")[1], eng.fetch_async("beta")[1])
+        # (R_ / beta_ were computed and sent on their way by the queue itself: cross())
+        finalised = self.finalised if (self.finalised and k_done == K) else None
+        if self.finalised and finalised is None:
+            for w in self.finalised:                  # a failed speculation: let the (meaningless) copies land, drop them
+                w()
         self.result = dict(k_done=k_done, wait_copies=wait_copies, finalised=finalised, Ts=self._view(h, "Ts", (n, K)), U=self._view(h, "U", (n, K)),
                            V=self._view(h, "V", (q, K)), Tb=self._view(h, "Tb").reshape(K, B, n), scal=scal,
                            ssq_x=self._view(h, "ssqx").copy(), iters=self._view(h, "iters"), last_diff=float(par[4]),
