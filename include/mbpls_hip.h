@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 4   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev */
+#define MBPLS_HIP_ABI_VERSION 4   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev */
 
 enum {
   MBPLS_OK = 0,
@@ -453,9 +453,22 @@ int mbpls_hip_allreduce(mbpls_ctx* ctx, double* d_buf, size_t count);   /* sum, 
  *     d_C[j,f] = d_g[j,f] d_rs[j,f]                                          (X_b d_C_b - const = X_b,std g_b, :875)
  *     d_sums[(b F + f) 2 + 0] = sum_{j in block b} d_g[j,f]^2               (block norms, :860)
  *     d_sums[(b F + f) 2 + 1] = sum_{j in block b} d_mu[j,f] d_C[j,f]       (that const)
- * Asynchronous on the context's stream; fixed-order sums.                                                          */
-int mbpls_hip_cv_weights(const mbpls_mat* m, int F, const double* d_G, const double* d_mu, const double* d_rs,
+ * predict != 0: d_G holds the folds' regression vectors beta_f on the standardised columns; d_g = d_C = beta rs is what the
+ * raw matrix is multiplied with and d_sums[..1] = sum mu (beta rs) the constant to remove (mbpls.py:1369-1386); d_su /
+ * d_alpha unused.  Asynchronous on the context's stream; fixed-order sums.                                          */
+int mbpls_hip_cv_weights(const mbpls_mat* m, int F, int predict, const double* d_G, const double* d_mu, const double* d_rs,
                          const double* d_su, const double* d_alpha, double* d_g, double* d_C, double* d_sums);
+/* d_G (p x c) = ((X - 1 d_mean^T) [o (X - 1 d_mean^T) when square])^T d_V: centred sums / sums of squares over row sets
+ * given as indicator columns (the held-out rows of cross-validation folds); matrix cores, X read once.               */
+int mbpls_hip_xt_v_centred(const mbpls_mat* m, const double* d_mean, int square, const double* d_V, int64_t ldv, int c,
+                           double* d_G, int64_t ldg);
+/* Column statistics of the training rows of F folds (StandardScaler on X[train_f], mbpls.py:307-314) from the full-data
+ * mean / variance (d_mu0, d_var0: p) and the held-out rows' centred sums d_h1, d_h2 (p x F, mbpls_hip_xt_v_centred with
+ * the held-out indicators; d_nf[f] = training rows of fold f): d_mean, d_rs = 1 / scale (p x F; scale 1 for a constant
+ * column).  Entries whose variance is lost to cancellation get d_rs = -1 and are counted in *d_risky (uint64): the
+ * caller takes those from the rows themselves.                                                                     */
+int mbpls_hip_cv_fold_stats(const mbpls_mat* m, int F, const double* d_mu0, const double* d_var0, const double* d_h1,
+                            const double* d_h2, const double* d_nf, double* d_mean, double* d_rs, double* d_risky);
 
 /* ---- end-of-fit algebra on p x K device arrays (any K; 32-column tiles inside), column-major ---
  * h_out (c1 x c2 row-major, HOST) = A^T B for p x c1 / p x c2 device arrays: P_^T W (mbpls.py:988,

@@ -111,7 +111,9 @@ SIGNATURES = {
     "mbpls_hip_memcpy_d2h_after": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "mbpls_hip_event_destroy": (_int, [_vp, _vp]),
     "mbpls_hip_cross_product": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp]),
-    "mbpls_hip_cv_weights": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbpls_hip_cv_weights": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbpls_hip_xt_v_centred": (_int, [_vp, _vp, _int, _vp, _i64, _int, _vp, _i64]),
+    "mbpls_hip_cv_fold_stats": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_cross_product_dev": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp]),
     "mbpls_hip_finalise_small": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_right_multiply_dev": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _int, _vp, _i64]),

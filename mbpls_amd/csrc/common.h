@@ -134,7 +134,7 @@ int build_chunks(mbpls_ctx* ctx, const std::vector<int64_t>& offs, int target, C
 void free_chunks(ChunkTable* t);
 // xtv_mfma.hip: G = alpha X^T V on the f64 matrix cores (any n, any c)
 int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv, int c, double alpha, double* d_G,
-             int64_t ldg, double* d_ssq, const double* d_mean = nullptr, const double* d_rscale = nullptr);
+             int64_t ldg, double* d_ssq, const double* d_mean = nullptr, const double* d_rscale = nullptr, int square = 0);
 
 // xw_mfma.hip: OUT = X W on the f64 matrix cores, X read once per 64 right-hand sides
 int xw_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_W, int64_t ldw, int c, int per_block,

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void k_cv_weights(int64_t p, const int64_t* __
                                                     const double* __restrict__ G, const double* __restrict__ mu,
                                                     const double* __restrict__ rs, const double* __restrict__ su,
                                                     const double* __restrict__ alpha, double* __restrict__ g,
-                                                    double* __restrict__ C, double* __restrict__ part, int F) {
+                                                    double* __restrict__ C, double* __restrict__ part, int F, int predict) {
   __shared__ double red[2 * 64];
   int buf = 0;
   const int f = blockIdx.y, chunk = blockIdx.x;
@@ -26,8 +26,8 @@ __global__ __launch_bounds__(256) void k_cv_weights(int64_t p, const int64_t* __
   double v[2] = {0.0, 0.0};
   for (int64_t j = c0[chunk] + threadIdx.x; j < c1[chunk]; j += 256) {
     const double r = rs[base + j], m = mu[base + j];
-    const double gj = a * ((G[base + j] - m * s) * r);
-    const double cj = gj * r;
+    const double gj = predict ? G[base + j] * r : a * ((G[base + j] - m * s) * r);
+    const double cj = predict ? gj : gj * r;       // predict: G = beta (standardised space), X is multiplied with beta rs
     g[base + j] = gj;
     C[base + j] = cj;
     v[0] = fma(gj, gj, v[0]);
@@ -57,26 +57,76 @@ __global__ __launch_bounds__(64) void k_cv_block_sums(const double* __restrict__
   }
 }
 
+// Column statistics of the training rows of every fold from the full-data statistics and the held-out rows' centred
+// sums h1 = sum_held (x - mu0), h2 = sum_held (x - mu0)^2 (two many-right-hand-side products with the held-out
+// indicators): mean_f = mu0 - h1 / n_f, n_f var_f = n var0 - h2 - h1^2 / n_f (corrected two-pass form around mu0),
+// sklearn's constant-column rule (scale 1).  Entries whose variance is lost to cancellation (< 1e-9 of the full-data sum
+// of squares: a column that is all but constant on one fold's training rows) get rs = -1 and are counted: the host takes
+// those few from the rows themselves.
+__global__ __launch_bounds__(256) void k_cv_fold_stats(int64_t p, int F, double n, const double* __restrict__ mu0,
+                                                       const double* __restrict__ var0, const double* __restrict__ h1,
+                                                       const double* __restrict__ h2, const double* __restrict__ nf,
+                                                       double* __restrict__ mean, double* __restrict__ rs,
+                                                       unsigned long long* __restrict__ risky) {
+  const int f = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  const int64_t e = (int64_t)f * p + j;
+  const double n_f = nf[f], ss0 = n * var0[j];
+  const double dm = -h1[e] / n_f;
+  const double ssq = ss0 - h2[e] - n_f * dm * dm;
+  const double m = mu0[j] + dm;
+  mean[e] = m;
+  if (ss0 > 0.0 && ssq <= 1e-9 * ss0) {
+    rs[e] = -1.0;
+    atomicAdd(risky, 1ull);
+    return;
+  }
+  const double var = fmax(ssq, 0.0) / n_f;
+  const double eps = 2.220446049250313e-16;
+  const double nme = n_f * m * eps;
+  rs[e] = (var <= n_f * eps * var + nme * nme) ? 1.0 : 1.0 / sqrt(var);
+}
+
 }  // namespace mbpls
 
 using namespace mbpls;
 
 extern "C" {
 
-int mbpls_hip_cv_weights(const mbpls_mat* m, int F, const double* d_G, const double* d_mu, const double* d_rs,
+int mbpls_hip_cv_weights(const mbpls_mat* m, int F, int predict, const double* d_G, const double* d_mu, const double* d_rs,
                          const double* d_su, const double* d_alpha, double* d_g, double* d_C, double* d_sums) {
-  MB_ARG(m && d_G && d_mu && d_rs && d_su && d_alpha && d_g && d_C && d_sums, "NULL argument");
+  MB_ARG(m && d_G && d_mu && d_rs && d_g && d_C && d_sums && (predict || (d_su && d_alpha)), "NULL argument");
   MB_ARG(F >= 1 && F <= 65535, "bad fold count %d", F);
   mbpls_ctx* ctx = m->ctx;
   const int nch = m->fine.nchunks;
   MB_TRY(ensure_ws(ctx, sizeof(double) * (size_t)nch * (size_t)F * 2));
   double* part = (double*)ctx->ws;
   hipLaunchKernelGGL(k_cv_weights, dim3((unsigned)nch, (unsigned)F), dim3(256), 0, ctx->stream, m->p,
-                     (const int64_t*)m->fine.d_c0, (const int64_t*)m->fine.d_c1, d_G, d_mu, d_rs, d_su, d_alpha, d_g, d_C,
-                     part, F);
+                     (const int64_t*)m->fine.d_c0, (const int64_t*)m->fine.d_c1, d_G, d_mu, d_rs, predict ? d_rs : d_su,
+                     predict ? d_rs : d_alpha, d_g, d_C, part, F, predict);
   MB_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_cv_block_sums, dim3((unsigned)m->nblocks, (unsigned)F), dim3(64), 0, ctx->stream,
                      (const double*)part, (const int*)m->fine.d_blk_start, F, d_sums);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+int mbpls_hip_xt_v_centred(const mbpls_mat* m, const double* d_mean, int square, const double* d_V, int64_t ldv, int c,
+                           double* d_G, int64_t ldg) {
+  MB_ARG(m && d_mean && d_V && d_G, "NULL argument");
+  MB_ARG(c >= 1 && ldv >= m->n && ldg >= m->p, "bad shape (c=%d ldv=%lld ldg=%lld)", c, (long long)ldv, (long long)ldg);
+  return xtv_mfma(m->ctx, m, d_V, ldv, c, 1.0, d_G, ldg, nullptr, d_mean, nullptr, square ? 1 : 0);
+}
+
+int mbpls_hip_cv_fold_stats(const mbpls_mat* m, int F, const double* d_mu0, const double* d_var0, const double* d_h1,
+                            const double* d_h2, const double* d_nf, double* d_mean, double* d_rs, double* d_risky) {
+  MB_ARG(m && d_mu0 && d_var0 && d_h1 && d_h2 && d_nf && d_mean && d_rs && d_risky, "NULL argument");
+  MB_ARG(F >= 1 && F <= 65535, "bad fold count %d", F);
+  mbpls_ctx* ctx = m->ctx;
+  MB_HIP(hipMemsetAsync(d_risky, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(k_cv_fold_stats, dim3((unsigned)((m->p + 255) / 256), (unsigned)F), dim3(256), 0, ctx->stream, m->p, F,
+                     (double)m->n, d_mu0, d_var0, d_h1, d_h2, d_nf, d_mean, d_rs, (unsigned long long*)d_risky);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void k_xtv_mfma(const double* __restrict__ 
                                                   const double* __restrict__ Vp, int c, double alpha,
                                                   double* __restrict__ G, int64_t ldg, int64_t ks_per_slice,
                                                   int64_t slice_stride, const double* __restrict__ mean,
-                                                  const double* __restrict__ rscale) {
+                                                  const double* __restrict__ rscale, int square) {
   constexpr int FT = xtv_ft(NT);
   constexpr int CH = XTV_KC * 4 * NT * 64;      // doubles of V per chunk
   constexpr int NV2 = CH / 2 / 256;             // double2 per thread and chunk
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void k_xtv_mfma(const double* __restrict__ 
       xrow[t] = X + j * ld + 4 * g;
       if constexpr (SCALE) {
         mu[t] = mean[j];
-        rs[t] = rscale[j];
+        rs[t] = rscale ? rscale[j] : 1.0;           // (NULL: centring only)
       }
     }
     double4_t acc[FT][NT];
@@ -134,6 +134,12 @@ __global__ __launch_bounds__(256, 2) void k_xtv_mfma(const double* __restrict__ 
         for (int t = 0; t < FT; ++t)
 #pragma unroll
           for (int m = 0; m < 4; ++m) cur[t][m] = (cur[t][m] - mu[t]) * rs[t];
+        if (square) {                                // wave-uniform: G = alpha (Z o Z)^T V (sums of squares over row sets)
+#pragma unroll
+          for (int t = 0; t < FT; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) cur[t][m] = cur[t][m] * cur[t][m];
+        }
       }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -208,13 +214,13 @@ __global__ __launch_bounds__(256) void k_block_colssq(const double* __restrict__
 }
 
 int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv, int c, double alpha, double* d_G,
-             int64_t ldg, double* d_ssq, const double* d_mean, const double* d_rscale) {
+             int64_t ldg, double* d_ssq, const double* d_mean, const double* d_rscale, int square) {
   const int NT = (c + 15) / 16;
   if (NT > 4) {   // more than 64 right-hand sides: process in groups of 64
     for (int k0 = 0; k0 < c; k0 += 64) {
       const int cb = std::min(64, c - k0);
       MB_TRY(xtv_mfma(ctx, m, d_V + (int64_t)k0 * ldv, ldv, cb, alpha, d_G + (int64_t)k0 * ldg, ldg,
-                      d_ssq ? d_ssq + (int64_t)k0 * m->nblocks : nullptr, d_mean, d_rscale));
+                      d_ssq ? d_ssq + (int64_t)k0 * m->nblocks : nullptr, d_mean, d_rscale, square));
     }
     return MBPLS_OK;
   }
@@ -243,7 +249,7 @@ int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv,
 #define MB_XTV_(NT_, SC_)                                                                                              \
   hipLaunchKernelGGL((k_xtv_mfma<NT_, SC_>), dim3(grid, (unsigned)S), dim3(256), 0, ctx->stream, (const double*)m->data, \
                      m->ld, m->n, m->p, (const double*)Vp, c, alpha, S > 1 ? part : d_G, S > 1 ? m->p : ldg,           \
-                     ks_per_slice, S > 1 ? slice_stride : (int64_t)0, d_mean, d_rscale)
+                     ks_per_slice, S > 1 ? slice_stride : (int64_t)0, d_mean, d_rscale, square)
 #define MB_XTV(NT_)                 \
   do {                              \
     if (d_mean) MB_XTV_(NT_, true); \

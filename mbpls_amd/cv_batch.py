@@ -8,25 +8,30 @@ standardised, deflated matrix is never formed:
 
 (the rank-one deflations X <- X - ts p^T with p = X^T ts, mbpls.py:928/:969, are projections: the scores are
 orthonormal), so the two X-sized products of a NIPALS iteration (:856, :875) for ALL folds are two many-right-hand-side
-products with the one RAW matrix resident in HBM,
+products with the one RAW matrix resident in HBM (matrix cores, X read once per 64 folds),
 
     X_k,f^T u_f   = (X^T u'_f - mu_f (1^T u'_f)) / sigma_f,    u'_f = u_f - Ts_f (Ts_f^T u_f)            [xt_v, F columns]
     X_k,f,b w_fb  = (I - Ts_f Ts_f^T) [ m_f o (X_b (w_fb / sigma_fb) - mu_fb^T (w_fb / sigma_fb)) ]       [x_w, F columns]
 
-(u_f, ts_fl vanish on the held-out rows).  Between the two products, the element-wise p x F algebra and its block
-sums run on the device (csrc/cv_batch.hip, mbpls_hip_cv_weights); the n x F x K algebra -- the deflation is far cheaper
-on the n side than through the loadings -- stays on the host like the n x B algebra of a single fit.  Only n x F arrays
-and a few scalars per fold cross PCIe per sweep; the finished weight / loading columns are fetched once per batch.  Per-fold statistics come from the full-data centred sums minus the held-out rows' share (corrected
-two-pass form, sklearn's constant-column rule).  A batch of up to 256 folds costs 5 K product launches instead of that many
-complete fits of ~110 launches each -- what leave-one-out on a small data set (n = 150, p = 3000, K = 5: the
-reference's notebooks) spends its time on.
+(u_f, ts_fl vanish on the held-out rows).  Everything p-sized stays on the device (csrc/cv_batch.hip):
+* the folds' statistics: full-data mean / variance from one statistics pass, the held-out rows' centred sums and sums of
+  squares from two products with the held-out indicators (``mbpls_hip_xt_v_centred``), ``mbpls_hip_cv_fold_stats``
+  (corrected two-pass form around the full-data mean, sklearn's constant-column rule; the few entries that lose their
+  variance to cancellation are taken again from the rows themselves);
+* the p x F algebra between the two products and its block sums (``mbpls_hip_cv_weights``);
+* the finished weight / loading columns of every fold and the end-of-fit algebra: P_f^T W_f per fold
+  (``mbpls_hip_cross_product_dev`` on column-strided views), the K x K pseudo-inverses on the host (one stacked call),
+  beta_f = W_f M_f V_f^T (``mbpls_hip_right_multiply_dev``), and the predictions of ALL rows for all folds as one more
+  product, of which every fold keeps its held-out rows.
+Only n x F arrays and K x K matrices cross PCIe; the n x F x K algebra -- with the deflation on the n side it is far
+cheaper than through the loadings -- stays on the host like the n x B algebra of a single fit.
 
-Used by ``model_selection.cross_val_predict`` for method='NIPALS', one response, the 2-norm stop rule, complete data, a
-host copy of X (per-fold statistics, held-out rows), p <= 16384 and p x K small enough for at least 16 folds per batch
-(32 MB of fetched columns) -- the regime of the reference's notebooks, where a fit is all launches.  Wider matrices take
-the fold-by-fold loop: their passes hide the launches, and the per-fold statistics / end-of-fit algebra of a batch are
-still host numpy here (on the device they would make this the faster path at any width: next step).  Same numbers as a loop of
-fits (tests/test_gpu_parity.py) to ~1e-12.
+A batch of F folds costs 5 K + 3 products instead of F complete fits: leave-one-out on a small data set (n = 150,
+p = 3000, K = 5: all launches) and k-fold on a matrix that fills the GPU (every read of X serves all folds) alike.
+
+Used by ``model_selection.cross_val_predict`` for method='NIPALS', one response, the 2-norm stop rule, complete data,
+K <= 32 and at least 8 folds' worth of device memory; anything else takes the fold-by-fold loop.  Same numbers as that
+loop and as a loop of oracle fits (tests/test_gpu_parity.py) to ~1e-12.
 """
 from __future__ import annotations
 
@@ -34,90 +39,81 @@ import warnings
 
 import numpy as np
 
-from . import solvers
+from . import _capi, solvers
 from .engine import HipEngine
 
 _EPS = np.finfo(np.float64).eps
 MAX_FOLDS = 256                   # folds per batch (the matrix-core products read X once per 64 right-hand sides)
-MAX_STACK_BYTES = 32 << 20        # the two p x F x K stacks of finished columns are fetched once per batch
-MAX_P = 16384                     # (per-fold statistics and the end-of-fit algebra of a batch are host numpy on p x F arrays)
-MAX_HOST_BYTES = 1 << 30          # host copy of X (statistics of the folds, held-out rows)
+MIN_FOLDS = 8                     # fewer folds per read of X than this: fold-by-fold fits
 
 
-def eligible(estimator, q, n, p, n_folds):
+def _folds_per_batch(ctx, p, K, n_folds):
+    """as many folds per batch as a quarter of the free device memory holds: (2 K + 6) p x F arrays"""
+    free = ctx.info()["free_bytes"] + ctx._pool_bytes
+    return int(max(0, min(MAX_FOLDS, n_folds, (free // 4) // (8 * p * (2 * K + 6)))))
+
+
+def eligible(estimator, q, n, p, n_folds, ctx=None):
     K = int(estimator.n_components)
-    return (estimator.method == "NIPALS" and estimator.sparse_data is not True and q == 1 and n_folds >= 2
-            and estimator.nipals_convergence_norm in (2, -2, "fro", "nuc")
-            and p <= MAX_P and 8 * p * K * min(n_folds, 16) <= MAX_STACK_BYTES)
+    ok = (estimator.method == "NIPALS" and estimator.sparse_data is not True and q == 1 and n_folds >= 2 and K <= 32
+          and estimator.nipals_convergence_norm in (2, -2, "fro", "nuc"))
+    if ok and ctx is not None:
+        ok = _folds_per_batch(ctx, p, K, n_folds) >= min(MIN_FOLDS, n_folds)
+    return ok
 
 
-def predict_folds(estimator, X_host, Xdev, ctx, comm, y, splits, batch=None):
+def predict_folds(estimator, Xdev, ctx, comm, y, splits, batch=None):
     """out-of-fold predictions (n x 1) of a one-response NIPALS model for every (train, test) pair of ``splits``;
-    X_host: the n x p host matrix (blocks side by side), Xdev: the same, raw, resident in HBM"""
-    n, p = X_host.shape
+    Xdev: the raw matrix resident in HBM (blocks side by side); it is only ever read"""
+    n, p = Xdev.n, Xdev.p
     K = int(estimator.n_components)
-    if batch is None:                                # as many folds per read of X as the fetched stacks allow
-        batch = int(max(1, min(MAX_FOLDS, MAX_STACK_BYTES // (8 * p * K))))
+    if batch is None:
+        batch = max(1, _folds_per_batch(ctx, p, K, len(splits)))
     std = bool(estimator.standardize)
-    tol = float(estimator.max_tol)
-    offs = list(Xdev.block_offsets)
     y = np.asarray(y, dtype=np.float64).reshape(n)
     out = np.full((n, 1), np.nan)
-    mu0 = X_host.mean(axis=0) if std else np.zeros(p)
-    Xc = X_host - mu0 if std else X_host
-    Xc2 = Xc * Xc if std else None
     eng = HipEngine(ctx=ctx, comm=comm)
-    eng.load_device(Xdev, copy=False)                # raw matrix, only ever read
+    eng.load_device(Xdev, copy=False)
     from . import runtime
     try:
         with runtime.host_threads():                 # BLAS pools sized to the CPU quota, not to the visible CPUs
+            if std:
+                eng.prepare_stats(True)              # full-data mean / variance: one read, nothing written
+                eng._kscale = False                  # (the products below take the RAW matrix)
             for s0 in range(0, len(splits), batch):
-                _one_batch(eng, X_host, Xc, Xc2, mu0, y, splits[s0:s0 + batch], out, K, std, tol, offs)
+                _one_batch(eng, Xdev, y, splits[s0:s0 + batch], out, K, std, float(estimator.max_tol))
     finally:
         eng.X = None                                 # the caller owns the matrix
         eng.close()
     return out
 
 
-def _fold_stats(X_host, Xc, Xc2, mu0, M, std):
-    """mean / scale (p x F) of the training rows of every fold: full-data centred sums minus the held-out rows' share
-    (corrected two-pass form), sklearn's constant-column rule; columns whose downdated variance is lost to cancellation
-    (a column that is constant on one fold's training rows) are taken again from the rows themselves"""
-    n, p = X_host.shape
-    F = M.shape[1]
-    if not std:
-        return np.zeros((p, F)), np.ones((p, F))
-    n_f = M.sum(axis=0)
-    H = 1.0 - M
-    hsum = Xc.T.dot(H)                               # sums of the held-out rows, centred at the full-data mean
-    dmean = -hsum / n_f                              # mean_f - mu0
-    ss0 = Xc2.sum(axis=0)
-    ssq = ss0[:, None] - Xc2.T.dot(H) - n_f * dmean * dmean
-    mean = mu0[:, None] + dmean
-    risky = ssq <= 1e-9 * ss0[:, None]               # cancellation: what is left is rounding of the full-data sums
-    for j, f in zip(*np.nonzero(risky)):
-        col = X_host[M[:, f] != 0.0, j]
-        mean[j, f] = col.mean()
-        d = col - mean[j, f]
-        ssq[j, f] = np.sum(d * d) - np.sum(d) ** 2 / n_f[f]
-    var = np.maximum(ssq, 0.0) / n_f
-    bound = n_f * _EPS * var + (n_f * mean * _EPS) ** 2
-    scale = np.sqrt(var)
-    scale[var <= bound] = 1.0                        # sklearn: a constant column keeps scale 1
-    return mean, scale
+def _fix_risky(Xdev, M, n_f, dmu, drs, p, F):
+    """the (column, fold) entries whose downdated variance was lost to cancellation: statistics from the rows"""
+    rs = drs.get()
+    lib, ctx = Xdev.ctx.lib, Xdev.ctx
+    for j, f in zip(*np.nonzero(rs < 0.0)):
+        col = Xdev.download(int(j), 1)[M[:, f] != 0.0, 0]
+        mean = col.mean()
+        d = col - mean
+        var = (np.sum(d * d) - np.sum(d) ** 2 / n_f[f]) / n_f[f]
+        scale = 1.0 if var <= n_f[f] * _EPS * var + (n_f[f] * mean * _EPS) ** 2 else np.sqrt(var)
+        fix = np.array([mean, 1.0 / scale])
+        off = 8 * (int(f) * p + int(j))
+        _capi.check(lib.mbpls_hip_memcpy_h2d(ctx.handle, dmu.ptr + off, fix[0:1].ctypes.data, 8))
+        _capi.check(lib.mbpls_hip_memcpy_h2d(ctx.handle, drs.ptr + off, fix[1:2].ctypes.data, 8))
+        ctx.sync()
 
 
-def _one_batch(eng, X_host, Xc, Xc2, mu0, y, part, out, K, std, tol, offs):
-    from . import _capi
-    n, p = X_host.shape
+def _one_batch(eng, Xdev, y, part, out, K, std, tol):
+    n, p = Xdev.n, Xdev.p
+    offs = list(Xdev.block_offsets)
     F, B = len(part), len(offs) - 1
     ctx, lib = eng.ctx, eng.ctx.lib
     M = np.zeros((n, F))
     for f, (tr, te) in enumerate(part):
         M[np.asarray(tr), f] = 1.0
     n_f = M.sum(axis=0)
-    mu, sig = _fold_stats(X_host, Xc, Xc2, mu0, M, std)
-    rs = 1.0 / sig
     if std:                                          # ColumnScaler.fit on the training responses of every fold
         ymu = (y[:, None] * M).sum(axis=0) / n_f
         d = (y[:, None] - ymu) * M
@@ -126,52 +122,64 @@ def _one_batch(eng, X_host, Xc, Xc2, mu0, y, part, out, K, std, tol, offs):
     else:
         ymu, ysig = np.zeros(F), np.ones(F)
     Ys = (y[:, None] - ymu) / ysig * M               # n x F, zero on the held-out rows
-    # everything p-sized stays in HBM: the folds' statistics, the product X^T U, weights, what X is multiplied with,
-    # and the K finished weight / loading columns of every fold (component-major: block k holds the p x F columns)
-    dmu, drs = ctx.from_host(mu), ctx.from_host(rs)
-    dsu, dal, dsums = ctx.empty(F), ctx.empty(F), ctx.empty(B * F * 2)
-    G, Cs, dg = eng.slot("cvG", F, zero=False), eng.slot("cvC", F, zero=False), ctx.empty((p, F))
-    Wst, Pst = eng.slot("cvW", F * K, zero=False), eng.slot("cvP", F * K, zero=False)
     pf8 = 8 * p * F
-
-    def weights(U, alpha):
-        """g = alpha (X^T U - mu su) rs, C = g rs on the device for every fold; returns the block sums (B x F x 2)"""
-        eng.xt_v(U, 1.0, "cvG", 0)                                           # X^T U (p x F), raw X
-        dsu.set(U.sum(axis=0)); dal.set(alpha)
-        _capi.check(lib.mbpls_hip_cv_weights(eng.X.handle, F, G.ptr, dmu.ptr, drs.ptr, dsu.ptr, dal.ptr, dg.ptr, Cs.ptr,
-                                             dsums.ptr))
-
-    def keep(stack, k, cols):
-        """finished columns of component k (all folds, or the folds in ``cols``) from dg into a stack"""
-        if cols is None:
-            _capi.check(lib.mbpls_hip_memcpy_d2d(ctx.handle, stack.ptr + k * pf8, dg.ptr, pf8))
-        else:
-            for f in cols:
-                _capi.check(lib.mbpls_hip_memcpy_d2d(ctx.handle, stack.ptr + k * pf8 + 8 * p * int(f), dg.ptr + 8 * p * int(f),
-                                                     8 * p))
-
-    Ts = np.zeros((F, n, K))                                                 # fold-major: the deflation is n x K algebra
-    nu_all = np.ones((B, F, K)); V = np.zeros((F, K))
-
-    def deflate(A, k):
-        """(I - Ts_f Ts_f^T) a_f for every fold (columns of the n x F array A): n x k algebra per fold"""
-        if not k:
-            return A
-        T = Ts[:, :, :k]                                                     # F x n x k
-        c = np.matmul(T.transpose(0, 2, 1), A.T[:, :, None])                 # F x k x 1
-        return A - np.matmul(T, c)[:, :, 0].T
-
-    def sweep(U, alpha, k):
-        """block sums of squares of g = alpha X_k^T u (left on the device) and t~_b = X_k,b g_b -- for every fold"""
-        weights(deflate(U, k), alpha)
-        XC = eng.x_w_slot("cvC", 0, F, per_block=True)                       # per block: X_b C_b (n x F)
-        sums = dsums.get().reshape(B, F, 2)
-        t = np.empty((B, n, F))
-        for b in range(B):
-            t[b] = deflate((XC[b] - sums[b, :, 1]) * M, k)
-        return sums[:, :, 0], t
-
+    G, Cs = eng.slot("cvG", F, zero=False), eng.slot("cvC", F, zero=False)
+    Wst, Pst = eng.slot("cvW", F * K, zero=False), eng.slot("cvP", F * K, zero=False)
+    dg, dmu, drs = ctx.empty((p, F)), ctx.empty((p, F)), ctx.empty((p, F))
+    dsu, dal, dsums = ctx.empty(F), ctx.empty(F), ctx.empty(B * F * 2)
+    tmp = []
     try:
+        # ---- column statistics of every fold's training rows, on the device
+        if std:
+            dH, dnf, drisky = ctx.from_host(1.0 - M), ctx.from_host(n_f), ctx.empty(1)
+            tmp += [dH, dnf, drisky]
+            _capi.check(lib.mbpls_hip_xt_v_centred(Xdev.handle, eng.mean.ptr, 0, dH.ptr, n, F, G.ptr, p))    # h1 -> cvG
+            _capi.check(lib.mbpls_hip_xt_v_centred(Xdev.handle, eng.mean.ptr, 1, dH.ptr, n, F, dg.ptr, p))   # h2 -> dg
+            _capi.check(lib.mbpls_hip_cv_fold_stats(Xdev.handle, F, eng.mean.ptr, eng.var.ptr, G.ptr, dg.ptr, dnf.ptr,
+                                                    dmu.ptr, drs.ptr, drisky.ptr))
+            if drisky.get().view(np.uint64)[0]:
+                _fix_risky(Xdev, M, n_f, dmu, drs, p, F)
+        else:
+            _capi.check(lib.mbpls_hip_memset(ctx.handle, dmu.ptr, 0, pf8))
+            drs.set(np.ones((p, F)))
+
+        def weights(U, alpha):
+            """sweep: g = alpha (X^T U - mu su) rs, C = g rs for every fold, block sums in dsums (all on the device)"""
+            eng.xt_v(U, 1.0, "cvG", 0)                                       # X^T U (p x F), raw X
+            dsu.set(U.sum(axis=0)); dal.set(alpha)
+            _capi.check(lib.mbpls_hip_cv_weights(Xdev.handle, F, 0, G.ptr, dmu.ptr, drs.ptr, dsu.ptr, dal.ptr, dg.ptr,
+                                                 Cs.ptr, dsums.ptr))
+
+        def keep(stack, k, cols):
+            """finished columns of component k (all folds, or the folds in ``cols``) from dg into a stack"""
+            if cols is None:
+                _capi.check(lib.mbpls_hip_memcpy_d2d(ctx.handle, stack.ptr + k * pf8, dg.ptr, pf8))
+            else:
+                for f in cols:
+                    _capi.check(lib.mbpls_hip_memcpy_d2d(ctx.handle, stack.ptr + k * pf8 + 8 * p * int(f),
+                                                         dg.ptr + 8 * p * int(f), 8 * p))
+
+        Ts = np.zeros((F, n, K))                                             # fold-major: the deflation is n x K algebra
+        nu_all = np.ones((B, F, K)); V = np.zeros((F, K))
+
+        def deflate(A, k):
+            """(I - Ts_f Ts_f^T) a_f for every fold (columns of the n x F array A): n x k algebra per fold"""
+            if not k:
+                return A
+            T = Ts[:, :, :k]                                                 # F x n x k
+            c = np.matmul(T.transpose(0, 2, 1), A.T[:, :, None])             # F x k x 1
+            return A - np.matmul(T, c)[:, :, 0].T
+
+        def sweep(U, alpha, k):
+            """block sums of squares of g = alpha X_k^T u (left on the device) and t~_b = X_k,b g_b -- for every fold"""
+            weights(deflate(U, k), alpha)
+            XC = eng.x_w_slot("cvC", 0, F, per_block=True)                   # per block: X_b C_b (n x F)
+            sums = dsums.get().reshape(B, F, 2)
+            t = np.empty((B, n, F))
+            for b in range(B):
+                t[b] = deflate((XC[b] - sums[b, :, 1]) * M, k)
+            return sums[:, :, 0], t
+
         for k in range(K):
             u = Ys.copy()
             active = np.ones(F, dtype=bool)
@@ -208,19 +216,32 @@ def _one_batch(eng, X_host, Xc, Xc2, mu0, y, part, out, K, std, tol, offs):
             weights(deflate(ts_fin, k), np.ones(F))
             keep(Pst, k, None)
             Ts[:, :, k] = ts_fin.T; nu_all[:, :, k] = nu_fin; V[:, k] = v_fin
-        # every fold: R = W (P^T W)^+, beta = R V^T (:986-989) -- stacked K x K algebra on the host -- and the
-        # predictions of its held-out rows (:1369-1408)
-        Wh, Ph = Wst.get(), Pst.get()                                        # p x (K F): column k F + f
+
+        # ---- every fold: C_f = P_f^T W_f on the device (column k of fold f is column k F + f of the stacks: a p x K
+        # matrix with leading dimension p F), the K x K pseudo-inverses stacked on the host, beta_f = W_f M_f V_f^T on the
+        # device (:986-989)
+        dC = ctx.empty(F * K * K)
+        tmp.append(dC)
+        for f in range(F):
+            _capi.check(lib.mbpls_hip_cross_product_dev(ctx.handle, p, Pst.ptr + 8 * p * f, p * F, K, Wst.ptr + 8 * p * f,
+                                                        p * F, K, dC.ptr + 8 * K * K * f))
+        Cm = dC.get().reshape(F, K, K)
         D = 1.0 / np.sqrt((nu_all ** 2).sum(axis=0))                         # F x K: 1 / ||W~[:, k]||
-        Cm = np.empty((F, K, K))
-        for f in range(F):                           # P_f^T W_f on column-strided views (leading dimension p F: no copies)
-            Cm[f] = Ph[:, f::F].T.dot(Wh[:, f::F])
         Mv = np.matmul(D[:, :, None] * np.linalg.pinv(Cm * D[:, None, :]), V[:, :, None])[:, :, 0]   # F x K
+        dMv = ctx.from_host(np.ascontiguousarray(Mv).ravel())
+        tmp.append(dMv)
+        for f in range(F):                                                   # beta_f -> column f of cvG
+            _capi.check(lib.mbpls_hip_right_multiply_dev(ctx.handle, p, Wst.ptr + 8 * p * f, p * F, K, dMv.ptr + 8 * K * f, 1,
+                                                         G.ptr + 8 * p * f, p))
+        # ---- predictions of all rows for all folds: one more product (:1369-1408); a fold keeps its held-out rows
+        _capi.check(lib.mbpls_hip_cv_weights(Xdev.handle, F, 1, G.ptr, dmu.ptr, drs.ptr, None, None, dg.ptr, Cs.ptr,
+                                             dsums.ptr))
+        XC = eng.x_w_slot("cvC", 0, F, per_block=True)
+        sums = dsums.get().reshape(B, F, 2)
+        yhat = sum(XC[b] - sums[b, :, 1] for b in range(B)) * ysig + ymu     # n x F
         for f, (tr, te) in enumerate(part):
             te = np.asarray(te)
-            beta = Wh[:, f::F].dot(Mv[f])                                    # R_f V_f^T (p)
-            Zt = (X_host[te] - mu[:, f]) * rs[:, f]
-            out[te, 0] = Zt.dot(beta) * ysig[f] + ymu[f]
+            out[te, 0] = yhat[te, f]
     finally:
-        for a_ in (dmu, drs, dsu, dal, dsums, dg):
+        for a_ in [dg, dmu, drs, dsu, dal, dsums] + tmp:
             a_.free()

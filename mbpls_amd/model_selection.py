@@ -37,7 +37,8 @@ def cross_val_predict(estimator, X, y, cv=5, groups=None, batch_folds=True):
     cv: int (KFold without shuffling, as sklearn does for regressors), a CV splitter, or an iterable of
     (train, test) index pairs.  Returns an (n, q) array (``predict``'s shape).
 
-    One-response NIPALS models of moderate width (p x K <= 30 000) are fitted up to 256 folds at a time, every pass over X serving all of them
+    One-response NIPALS models are fitted up to 256 folds at a time (as many as device memory holds), every pass over X
+    serving all of them
     (``cv_batch``; ``batch_folds=False`` forces the fold-by-fold loop, which everything else takes)."""
     if not isinstance(estimator, MBPLS):
         raise TypeError("cross_val_predict of mbpls_amd works on mbpls_amd.MBPLS estimators")
@@ -54,11 +55,9 @@ def cross_val_predict(estimator, X, y, cv=5, groups=None, batch_folds=True):
         if Xdev.n != n:
             raise ValueError(f"Found input variables with inconsistent numbers of samples: [{Xdev.n}, {n}]")
         from . import cv_batch
-        if (batch_folds and cv_batch.eligible(estimator, y2.shape[1], n, Xdev.p, len(splits))
-                and not runtime.get_comm().is_distributed and 8 * n * Xdev.p <= cv_batch.MAX_HOST_BYTES):
-            # (the per-fold column statistics and the predictions of the held-out rows are taken from the host copy)
-            X_host = np.hstack(host_blocks) if host_blocks is not None else Xdev.download()
-            return cv_batch.predict_folds(estimator, X_host, Xdev, runtime.get_context(), runtime.get_comm(), y2, splits)
+        if (batch_folds and not runtime.get_comm().is_distributed
+                and cv_batch.eligible(estimator, y2.shape[1], n, Xdev.p, len(splits), runtime.get_context())):
+            return cv_batch.predict_folds(estimator, Xdev, runtime.get_context(), runtime.get_comm(), y2, splits)
         out = np.full((n, y2.shape[1]), np.nan)
         for train, test in splits:
             est = MBPLS(**{**estimator.get_params(), "copy": True})
