@@ -31,7 +31,7 @@ p = 3000, K = 5: all launches) and k-fold on a matrix that fills the GPU (every 
 
 Used by ``model_selection.cross_val_predict`` for method='NIPALS', one response, the 2-norm stop rule, complete data,
 K <= 32 and at least 8 folds' worth of device memory; anything else takes the fold-by-fold loop.  Same numbers as that
-loop and as a loop of oracle fits (tests/test_gpu_parity.py) to ~1e-12.
+loop and as a loop of fits of the CPU oracle (tests/test_gpu_parity.py) to ~1e-12.
 """
 from __future__ import annotations
 
