@@ -15,8 +15,8 @@ template <int TI, int TJ>
 __global__ __launch_bounds__(256) void k_cross_partial(int64_t p, const double* __restrict__ A, int64_t lda, int c1,
                                                        const double* __restrict__ B, int64_t ldb, int c2,
                                                        double* __restrict__ partial) {
-  __shared__ double red[2 * 64];
-  int buf = 0;
+  static_assert(TI * TJ <= 256, "one thread per element of a pass finishes the sums");
+  __shared__ double red[4 * TI * TJ];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int i0 = 0; i0 < c1; i0 += TI) {
     double acc[TI][TJ];
@@ -36,20 +36,24 @@ __global__ __launch_bounds__(256) void k_cross_partial(int64_t p, const double* 
           for (int i = 0; i < TI; ++i) acc[i][j] = fma(a[i], b, acc[i][j]);
         }
     }
+    // all TI x TJ sums of this pass at once: DPP wave sums, one LDS exchange between the four waves
 #pragma unroll
-    for (int j = 0; j < TJ; ++j)
-      if (j < c2) {
-        double v[TI];
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int i = 0; i < TI; ++i) v[i] = acc[i][j];
-        block_sum<TI>(v, red, buf);
-        if (threadIdx.x == 0) {
-          double* out = partial + (int64_t)blockIdx.x * c1 * c2;
-#pragma unroll
-          for (int i = 0; i < TI; ++i)
-            if (i0 + i < c1) out[(i0 + i) * c2 + j] = v[i];
-        }
+      for (int j = 0; j < TJ; ++j) {
+        const double w = wave_sum_last_row(acc[i][j]);
+        if ((threadIdx.x & 63) == 63) red[(threadIdx.x >> 6) * (TI * TJ) + i * TJ + j] = w;
       }
+    __syncthreads();
+    if (threadIdx.x < TI * TJ) {
+      const int i = threadIdx.x / TJ, j = threadIdx.x % TJ;
+      if (i0 + i < c1 && j < c2) {
+        const int e = threadIdx.x;
+        partial[(int64_t)blockIdx.x * c1 * c2 + (i0 + i) * c2 + j] =
+            (red[e] + red[TI * TJ + e]) + (red[2 * TI * TJ + e] + red[3 * TI * TJ + e]);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -202,11 +206,17 @@ int mbpls_hip_scale_rows(mbpls_ctx* ctx, int64_t p, int c, const double* d_A, in
 //     M = D (C D)^+,   MV = M V^T,      C = P^T W~ (K x K),  D = diag(1 / ||W~[:, k]||),  ||W~[:, k]||^2 = sum_b scal[k][0][b]
 // so that R_ = W~ M and beta_ = W~ MV.  The pseudo-inverse is numpy's (SVD, singular values <= 1e-15 sigma_max dropped),
 // the SVD a one-sided Jacobi iteration (Hestenes) on one wave: lane i owns row i of A = C D and of the accumulated right
-// rotations; the three sums of a column pair are wave reductions.  K <= 32; ~50 us at K = 10 against ~0.3 ms for the round
-// trip through numpy.linalg.pinv between the last pass and the two p x K products.
+// rotations; the three sums of a column pair are wave reductions (~180 us at K = 10).  A well-conditioned C D -- every
+// ordinary fit -- is inverted by Gauss-Jordan elimination instead (~10 us).  K <= 32; the round trip through
+// numpy.linalg.pinv between the last pass and the two p x K products cost ~0.3 ms.
 namespace mbpls {
 
 constexpr int FS_K = 32;
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
 __global__ __launch_bounds__(64) void k_finalise_small(int K, int B, int q, const double* __restrict__ Cg,
                                                        const double* __restrict__ scal, const double* __restrict__ Vg,
                                                        double* __restrict__ Mg, double* __restrict__ MVg) {
@@ -227,6 +237,70 @@ __global__ __launch_bounds__(64) void k_finalise_small(int K, int B, int q, cons
       R[c][i] = (c == i) ? 1.0 : 0.0;
     }
   __syncthreads();
+  // Fast path: a well-conditioned C D (P^T W of a PLS fit is close to unit upper triangular) is inverted by Gauss-Jordan
+  // elimination with partial pivoting on the augmented matrix [C D | I] -- lane j owns column j, a row operation is one
+  // broadcast read and one fused multiply-add per lane -- and accepted when the 1-norm condition number
+  // ||A||_1 ||A^-1||_1 it yields is below 1e8: pseudo-inverse and inverse then agree to that number times the rounding
+  // unit, the accuracy either algorithm has.  Anything else (rank deficient, ill conditioned) takes the Jacobi SVD below.
+  {
+    __shared__ double Ga[FS_K][2 * FS_K];     // [row][column of the augmented matrix]
+    const bool col_lane = i < 2 * K;
+    for (int r = 0; r < K; ++r)
+      if (col_lane) Ga[r][i] = i < K ? A[i][r] : (i - K == r ? 1.0 : 0.0);
+    double cs = 0.0;
+    if (i < K)
+      for (int r = 0; r < K; ++r) cs += fabs(A[i][r]);
+    const double norm_a = wave_max(cs);
+    __syncthreads();
+    bool ok = norm_a > 0.0 && norm_a < 1e300;
+    for (int c = 0; c < K && ok; ++c) {
+      const double v = (i >= c && i < K) ? fabs(Ga[i][c]) : -1.0;
+      const double m = wave_max(v);
+      const int piv = __ffsll((unsigned long long)__ballot(v == m)) - 1;
+      if (!(m > 0.0)) { ok = false; break; }                            // wave-uniform
+      __syncthreads();
+      double pr = 0.0;
+      if (col_lane) {
+        const double top = Ga[c][i];
+        pr = Ga[piv][i];
+        Ga[piv][i] = top;
+      }
+      const double pivot = __shfl(pr, c);
+      pr = pr / pivot;
+      if (col_lane) Ga[c][i] = pr;
+      __syncthreads();
+      for (int r = 0; r < K; ++r) {
+        if (r == c) continue;
+        const double f = Ga[r][c];                                      // broadcast read, before lane c zeroes it
+        __syncthreads();
+        if (col_lane) Ga[r][i] -= f * pr;
+      }
+      __syncthreads();
+    }
+    if (ok) {
+      double is = 0.0;
+      if (i >= K && i < 2 * K)
+        for (int r = 0; r < K; ++r) is += fabs(Ga[r][i]);
+      const double norm_inv = wave_max(is);
+      ok = norm_a * norm_inv < 1e8;
+    }
+    if (ok) {
+      if (i < K)
+        for (int c = 0; c < K; ++c) {
+          const double m = Dk[i] * Ga[i][K + c];
+          Ms[i][c] = m;
+          Mg[i * K + c] = m;
+        }
+      __syncthreads();
+      if (i < K)
+        for (int j = 0; j < q; ++j) {
+          double m = 0.0;
+          for (int k = 0; k < K; ++k) m += Ms[i][k] * Vg[(int64_t)k * q + j];
+          MVg[i * q + j] = m;
+        }
+      return;
+    }
+  }
   for (int sweep = 0; sweep < 40; ++sweep) {
     int rotated = 0;
     for (int pc = 0; pc < K - 1; ++pc)
