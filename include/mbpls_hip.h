@@ -344,6 +344,15 @@ int mbpls_hip_nipals_subspace_loop(mbpls_ctx* ctx, int64_t n, int q, const doubl
                                    const double* d_c0, int norm_kind, double tol, int max_iter, double* d_ts,
                                    double* d_u, double* d_v, double* d_c_used, double* d_state);
 
+/* The same loop for the 2-norm stop rule (nipals_convergence_norm = 2, the default) and ANY n, in q x q algebra: with
+ * M1 = G^T G, M2 = Y^T G, M3 = Y^T Y (formed here, three small products into d_moments[3 q q]) an iteration is
+ * c~ = c / sqrt(c^T M1 c) (ts = G c~, :882-883), diff = sqrt(d^T M1 d) with d = c~_old - c~ (:887), v = M2 c~ (:899),
+ * c = v / v^T v / (sqrt(v^T M3 v) / v^T v) (:911-913) -- ~1 us on one wave instead of ~34 us of n x q work -- and ts, u, v
+ * are formed from G and Y once the loop has stopped.  Same outputs as mbpls_hip_nipals_subspace_loop.  q <= 16.          */
+int mbpls_hip_nipals_subspace_qloop(mbpls_ctx* ctx, int64_t n, int q, const double* d_G, const double* d_Y,
+                                    const double* d_c0, double tol, int max_iter, double* d_ts, double* d_u,
+                                    double* d_v, double* d_c_used, double* d_state, double* d_moments);
+
 /* ---- device-resident NIPALS: a whole one-response fit queued without a host round trip -----------------------
  * Between two passes over X the reference does n x (B + q) algebra on the host (mbpls.py:860-913: norms of the
  * block weights, block scores t_b, super weights sw, super score ts, the stop rule ||ts_old - ts|| <= max_tol,

@@ -76,6 +76,7 @@ SIGNATURES = {
     "mbpls_hip_nipals_gram_step": (_int, [_vp, _i64, _vp, _vp, _int, _vp, _int, _int, _dbl, _int, _vp, _vp, _vp, _vp, _int,
                                           _vp]),
     "mbpls_hip_nipals_subspace_loop": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _int, _dbl, _int, _vp, _vp, _vp, _vp, _vp]),
+    "mbpls_hip_nipals_subspace_qloop": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_scale_rows": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _vp, _i64]),
     "mbpls_hip_sweep_lazy_scaled": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "mbpls_hip_loadings_sweep_lazy_scaled": (_int, [_vp, _vp, _dbl, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i64, _int,

@@ -358,6 +358,131 @@ __global__ __launch_bounds__(SS_T) void k_nipals_subspace_loop(SubspaceArgs s) {
   }
 }
 
+
+// The same loop for the 2-norm stop rule in q x q algebra (any n): with M1 = G^T G, M2 = Y^T G, M3 = Y^T Y every quantity
+// of an iteration is a function of the coefficient vector c -- ||G c||^2 = c^T M1 c, v = M2 c~ (c~ = c / ||G c||, so
+// ts = G c~ has unit length), ||Y v||^2 = v^T M3 v -- and the stop rule ||ts_old - ts|| = ||G (c~_old - c~)|| is taken on
+// the DIFFERENCE of the coefficient vectors, sqrt(d^T M1 d) (formed in q dimensions it resolves 1e-14, where 2 - 2 cos
+// would stop at 1e-8).  One wave iterates -- lane j owns row j of the three matrices, a mat-vec is q lane broadcasts
+// and q fused multiply-adds, a quadratic form one DPP wave sum: ~1 us per iteration against ~34 us for the n-space loop
+// above -- then the whole workgroup forms ts = G c~ (:882-883), u = Y v / v^T v (:911-913) and v = Y^T ts / ts^T ts (:899).
+struct QLoopArgs {
+  int64_t n;
+  int q, max_iter;
+  double tol;
+  const double* G;      // n x q
+  const double* Y;      // n x q
+  const double* M;      // [3][q][q] row-major: G^T G, Y^T G, Y^T Y
+  const double* c0;
+  double* ts;
+  double* u;
+  double* v;
+  double* c_used;
+  double* state;
+};
+
+__device__ __forceinline__ double lane_value(double x, int k) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), k), __builtin_amdgcn_readlane(__double2loint(x), k));
+}
+
+__global__ __launch_bounds__(SS_T) void k_nipals_subspace_qloop(QLoopArgs s) {
+  constexpr int M = 2 + SS_QMAX;
+  __shared__ double red[(SS_T / 64) * M];
+  __shared__ double tot[M];
+  __shared__ double s_ct[SS_QMAX], s_v[SS_QMAX], s_sc[4];
+  const int tid = threadIdx.x;
+  const int64_t n = s.n;
+  const int q = s.q;
+  if (tid < 64) {
+    const int j = tid;
+    double m1[SS_QMAX], m2[SS_QMAX], m3[SS_QMAX];
+#pragma unroll
+    for (int k = 0; k < SS_QMAX; ++k) {
+      const bool in = j < q && k < q;
+      m1[k] = in ? s.M[j * q + k] : 0.0;
+      m2[k] = in ? s.M[q * q + j * q + k] : 0.0;
+      m3[k] = in ? s.M[2 * q * q + j * q + k] : 0.0;
+    }
+    auto matvec = [&](const double (&m)[SS_QMAX], double x) {
+      double y = 0.0;
+#pragma unroll
+      for (int k = 0; k < SS_QMAX; ++k) y = fma(m[k], lane_value(x, k), y);
+      return y;
+    };
+    double c = j < q ? s.c0[j] : 0.0, cu = c, ct = 0.0, ct_old = 0.0, v = 0.0, vv = 1.0, diff = 1.0, flag = 0.0;
+    int iters = 0;
+    while (true) {
+      ++iters;
+      cu = c;
+      ct = c / sqrt(wave_sum(c * matvec(m1, c)));                       // ts = G c~, unit length (:882-883)
+      if (iters > 1) {
+        const double d = ct_old - ct;
+        diff = sqrt(fmax(wave_sum(d * matvec(m1, d)), 0.0));            // (:887)
+      }
+      ct_old = ct;
+      v = matvec(m2, ct);                                               // (:899)
+      vv = wave_sum(v * v);
+      const double un = sqrt(wave_sum(v * matvec(m3, v))) / vv;         // ||Y v / v^T v|| (:911-913)
+      c = v / vv / un;
+      if (iters >= 2 && diff <= s.tol) {
+        flag = 1.0;
+        break;
+      }
+      if (iters >= s.max_iter) {
+        flag = 2.0;
+        break;
+      }
+    }
+    if (j < SS_QMAX) {
+      s_ct[j] = ct;
+      s_v[j] = v;
+    }
+    if (j < q) s.c_used[j] = cu;
+    if (j == 0) {
+      s_sc[0] = vv;
+      s.state[0] = flag;
+      s.state[1] = (double)iters;
+      s.state[2] = diff;
+    }
+  }
+  __syncthreads();
+  // ts = G c~ / ||G c~||,  u = (Y v / v^T v) / || . ||: the norms first, the vectors in a second pass over G and Y
+  double rv[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) rv[k] = 0.0;
+  const double vv = s_sc[0];
+  for (int64_t i = tid; i < n; i += SS_T) {
+    double a = 0.0, b = 0.0;
+    for (int j = 0; j < q; ++j) {
+      a = fma(s.G[(int64_t)j * n + i], s_ct[j], a);
+      b = fma(s.Y[(int64_t)j * n + i], s_v[j], b);
+    }
+    b = b / vv;
+    rv[0] = fma(a, a, rv[0]);
+    rv[1] = fma(b, b, rv[1]);
+  }
+  ss_reduce<M>(rv, 2, red, tot);
+  const double na = sqrt(rv[0]), nb = sqrt(rv[1]);
+#pragma unroll
+  for (int k = 0; k < M; ++k) rv[k] = 0.0;
+  for (int64_t i = tid; i < n; i += SS_T) {
+    double a = 0.0, b = 0.0;
+    for (int j = 0; j < q; ++j) {
+      a = fma(s.G[(int64_t)j * n + i], s_ct[j], a);
+      b = fma(s.Y[(int64_t)j * n + i], s_v[j], b);
+    }
+    const double t = a / na;
+    s.ts[i] = t;
+    s.u[i] = b / vv / nb;
+    rv[0] = fma(t, t, rv[0]);
+#pragma unroll
+    for (int j = 0; j < SS_QMAX; ++j)
+      if (j < q) rv[2 + j] = fma(s.Y[(int64_t)j * n + i], t, rv[2 + j]);
+  }
+  ss_reduce<M>(rv, 2 + q, red, tot);
+  if (tid < q) s.v[tid] = tot[2 + tid] / tot[0];
+}
+
 }  // namespace mbpls
 
 extern "C" int mbpls_hip_nipals_subspace_loop(mbpls_ctx* ctx, int64_t n, int q, const double* d_G, const double* d_Y,
@@ -374,6 +499,21 @@ extern "C" int mbpls_hip_nipals_subspace_loop(mbpls_ctx* ctx, int64_t n, int q, 
     lds_attr_set = true;
   }
   hipLaunchKernelGGL(k_nipals_subspace_loop, dim3(1), dim3(SS_T), (size_t)(16 * n), ctx->stream, s);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+extern "C" int mbpls_hip_nipals_subspace_qloop(mbpls_ctx* ctx, int64_t n, int q, const double* d_G, const double* d_Y,
+                                               const double* d_c0, double tol, int max_iter, double* d_ts, double* d_u,
+                                               double* d_v, double* d_c_used, double* d_state, double* d_moments) {
+  using namespace mbpls;
+  MB_ARG(ctx && d_G && d_Y && d_c0 && d_ts && d_u && d_v && d_c_used && d_state && d_moments, "NULL argument");
+  MB_ARG(n >= 1 && q >= 1 && q <= SS_QMAX && max_iter >= 1, "q-space loop covers q <= %d", SS_QMAX);
+  MB_TRY(mbpls_hip_cross_product_dev(ctx, n, d_G, n, q, d_G, n, q, d_moments));
+  MB_TRY(mbpls_hip_cross_product_dev(ctx, n, d_Y, n, q, d_G, n, q, d_moments + q * q));
+  MB_TRY(mbpls_hip_cross_product_dev(ctx, n, d_Y, n, q, d_Y, n, q, d_moments + 2 * q * q));
+  QLoopArgs s{n, q, max_iter, tol, d_G, d_Y, d_moments, d_c0, d_ts, d_u, d_v, d_c_used, d_state};
+  hipLaunchKernelGGL(k_nipals_subspace_qloop, dim3(1), dim3(SS_T), 0, ctx->stream, s);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }

@@ -127,7 +127,7 @@ class HipEngine(EngineBase):
                     a.free()
             self.Gb = None
         if getattr(self, "_ss", None) is not None:
-            for key in ("Y", "G", "c0", "ts", "u", "v", "c", "state"):
+            for key in ("Y", "G", "c0", "ts", "u", "v", "c", "state", "moments"):
                 self._ss[key].free()
             self._ss = None
         if getattr(self, "_gp", None) is not None:
@@ -940,20 +940,29 @@ class HipEngine(EngineBase):
         """The multi-response NIPALS inner loop of one component inside ONE kernel launch (csrc/nipals_step.hip,
         k_nipals_subspace_loop): G = P X (X^T (P Y)) (n x q, host), every sweep vector is u = Y c.  Returns
         (iterations, capped, ts, u, v, c_used) -- c_used: coefficients of the sweep vector of the last iteration.
-        None when the shape is outside the kernel's range (the caller iterates on the host then)."""
+        With the 2-norm stop rule the loop runs in q x q algebra (k_nipals_subspace_qloop: ~1 us per iteration, any n).
+        None when the shape is outside the kernels' range (the caller iterates on the host then)."""
         n, q = G.shape
-        if n > 8192 or q > 16 or norm_kind is None:
+        qspace = norm_kind == 0 and self.opts.nipals_qspace        # 2-norm: the loop in q x q algebra, any n
+        if q > 16 or norm_kind is None or (n > 8192 and not qspace):
             return None
         ctx = self.ctx
         st = getattr(self, "_ss", None)
         if st is None or st["q"] != q:
             st = self._ss = dict(q=q, Y=ctx.from_host(np.asfortranarray(Y)), G=ctx.empty((n, q)), c0=ctx.empty(q),
-                                 ts=ctx.empty(n), u=ctx.empty(n), v=ctx.empty(q), c=ctx.empty(q), state=ctx.empty(3))
+                                 ts=ctx.empty(n), u=ctx.empty(n), v=ctx.empty(q), c=ctx.empty(q), state=ctx.empty(3),
+                                 moments=ctx.empty(3 * q * q))
         st["G"].set(G)
         st["c0"].set(np.ascontiguousarray(c0, dtype=np.float64).ravel())
-        _capi.check(ctx.lib.mbpls_hip_nipals_subspace_loop(ctx.handle, n, q, st["G"].ptr, st["Y"].ptr, st["c0"].ptr,
-                                                           int(norm_kind), float(tol), int(max_iter), st["ts"].ptr,
-                                                           st["u"].ptr, st["v"].ptr, st["c"].ptr, st["state"].ptr))
+        if qspace:
+            _capi.check(ctx.lib.mbpls_hip_nipals_subspace_qloop(ctx.handle, n, q, st["G"].ptr, st["Y"].ptr, st["c0"].ptr,
+                                                                float(tol), int(max_iter), st["ts"].ptr, st["u"].ptr,
+                                                                st["v"].ptr, st["c"].ptr, st["state"].ptr,
+                                                                st["moments"].ptr))
+        else:
+            _capi.check(ctx.lib.mbpls_hip_nipals_subspace_loop(ctx.handle, n, q, st["G"].ptr, st["Y"].ptr, st["c0"].ptr,
+                                                               int(norm_kind), float(tol), int(max_iter), st["ts"].ptr,
+                                                               st["u"].ptr, st["v"].ptr, st["c"].ptr, st["state"].ptr))
         state = st["state"].get()
         return (int(state[1]), state[0] == 2.0, st["ts"].get().reshape(-1, 1), st["u"].get().reshape(-1, 1),
                 st["v"].get().reshape(-1, 1), st["c"].get().reshape(-1, 1))

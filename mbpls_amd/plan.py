@@ -26,6 +26,7 @@ class FitOptions:
     resident: bool = True               # MBPLS_RESIDENT=0: host-driven loop instead of the device-resident queue
     stream_stats: bool = True           # MBPLS_STREAM_STATS=0: scaler statistics fetched at the end of the fit
     nipals_subspace: bool = True        # MBPLS_NIPALS_SUBSPACE=0: several responses without the q-space inner loop
+    nipals_qspace: bool = True          # MBPLS_NIPALS_QSPACE=0: that loop on n-vectors (the reference's own formulas) for the 2-norm too
     nipals_gram: bool = True            # MBPLS_NIPALS_GRAM=0: ... and without the association-matrix form either
     unipals_nodeflate: bool = True      # MBPLS_UNIPALS_NODEFLATE=0: UNIPALS, several responses, on the deflated X
     q1_fixed_point: bool = False        # MBPLS_NIPALS_Q1_FIXED_POINT=1: opt-in, skip the redundant second iteration
@@ -39,6 +40,7 @@ class FitOptions:
                    resident=_flag("MBPLS_RESIDENT", True),
                    stream_stats=_flag("MBPLS_STREAM_STATS", True),
                    nipals_subspace=_flag("MBPLS_NIPALS_SUBSPACE", True),
+                   nipals_qspace=_flag("MBPLS_NIPALS_QSPACE", True),
                    nipals_gram=_flag("MBPLS_NIPALS_GRAM", True),
                    unipals_nodeflate=_flag("MBPLS_UNIPALS_NODEFLATE", True),
                    q1_fixed_point=os.environ.get("MBPLS_NIPALS_Q1_FIXED_POINT", "0") == "1")

@@ -910,15 +910,20 @@ def test_multi_response_nipals_on_association_matrices(gpu_required, monkeypatch
         assert all(abs(a - b) <= 2 for a, b in zip(mdl.nipals_iterations_, ref.nipals_iterations_))
 
 
-@pytest.mark.parametrize("n,q,kind,k", [(300, 2, 0, 0), (1000, 4, 1, 2), (4096, 10, 0, 5), (8192, 16, 2, 3), (777, 3, 3, 1)])
-def test_nipals_subspace_loop_kernel(ctx, n, q, kind, k):
-    """The whole multi-response NIPALS loop of a component in one launch (k_nipals_subspace_loop) against its numpy
-    statement (solvers._subspace_loop_host): iteration count, ts, u, v, the coefficients of the last sweep vector."""
+@pytest.mark.parametrize("n,q,kind,k,qspace", [(300, 2, 0, 0, False), (1000, 4, 1, 2, False), (4096, 10, 0, 5, False),
+                                               (8192, 16, 2, 3, False), (777, 3, 3, 1, False), (300, 2, 0, 0, True),
+                                               (4096, 10, 0, 5, True), (8192, 16, 0, 3, True), (20000, 5, 0, 2, True),
+                                               (64, 1, 0, 0, True)])
+def test_nipals_subspace_loop_kernel(ctx, n, q, kind, k, qspace):
+    """The whole multi-response NIPALS loop of a component in one launch against its numpy statement
+    (solvers._subspace_loop_host): iteration count, ts, u, v, the coefficients of the last sweep vector -- on n-vectors
+    (k_nipals_subspace_loop, every norm) and in q x q algebra (k_nipals_subspace_qloop, 2-norm, any n)."""
     from mbpls_amd import solvers
     from mbpls_amd.engine import HipEngine
     rng = np.random.RandomState(n + q)
     Yl = rng.standard_normal((n, q)); Yl -= Yl.mean(axis=0)
-    Xl = rng.standard_normal((n, 3 * n // 2 + 7)) @ np.diag(0.97 ** np.arange(3 * n // 2 + 7))
+    pl = min(3 * n // 2 + 7, 3000)
+    Xl = rng.standard_normal((n, pl)) * (0.97 ** np.arange(pl))
     Tp = np.linalg.qr(rng.standard_normal((n, k)))[0] if k else np.zeros((n, 0))
     PY = Yl - Tp @ (Tp.T @ Yl)
     G = Xl @ (Xl.T @ PY)
@@ -928,8 +933,9 @@ def test_nipals_subspace_loop_kernel(ctx, n, q, kind, k):
     want = solvers._subspace_loop_host(G, Yl, c0, norm, 1e-14, 5000)
     eng = HipEngine(ctx=ctx)
     eng.n = n
+    eng.opts.nipals_qspace = qspace
     got = eng.nipals_subspace_loop(G, Yl, c0, kind, 1e-14, 5000)
-    eng._ss and [eng._ss[key].free() for key in ("Y", "G", "c0", "ts", "u", "v", "c", "state")]
+    eng._ss and [a.free() for key, a in eng._ss.items() if key != "q"]
     assert got is not None
     assert abs(got[0] - want[0]) <= max(2, want[0] // 50) and got[1] == want[1], (got[0], want[0])
     for a, b, nm in zip(got[2:], want[2:], ("ts", "u", "v", "c_used")):
