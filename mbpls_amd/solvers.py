@@ -126,6 +126,35 @@ def _host_array(eng, shape):
     return eng.host_array(shape, prefault=False)
 
 
+class _StreamedColumns:
+    """The p x K attributes of a host-driven fit leaving the device one column at a time: the columns of component k
+    are final once its last pass has completed, and are copied (copy stream) while the first pass of component k + 1
+    runs -- the end of the fit then fetches R_ and beta_ only.  W_b[:, k] = w_b / ||w_b|| (:860, :510-512) is formed on
+    the host from the fetched raw column."""
+
+    def __init__(self, eng, K, wslot, pslot="P", keep_raw=False):
+        self.eng, self.wslot, self.pslot, self.pending = eng, wslot, pslot, None
+        self.W = _host_array(eng, (eng.p, K))
+        self.P = _host_array(eng, (eng.p, K))
+        self.W_raw = _host_array(eng, (eng.p, K)) if keep_raw else None
+
+    def component_done(self, k, blk_norm):
+        self.flush()
+        self.pending = (k, np.array(blk_norm, dtype=np.float64).ravel())
+
+    def flush(self):
+        """call with a pass over X in flight (or at the end of the fit)"""
+        if self.pending is None:
+            return
+        (k, nu), self.pending = self.pending, None
+        eng, offs = self.eng, self.eng.block_offsets
+        raw = self.W_raw if self.W_raw is not None else self.W
+        eng.fetch_col(self.wslot, k, raw)
+        for b in range(eng.nblocks):
+            np.divide(raw[offs[b]:offs[b + 1], k], nu[b], out=self.W[offs[b]:offs[b + 1], k])
+        eng.fetch_col(self.pslot, k, self.P)
+
+
 def _global_sizes(eng):
     """Block sizes of the WHOLE problem (summed over shards) for the BIP correction."""
     s = np.asarray(eng.block_sizes, dtype=np.float64)
@@ -285,10 +314,12 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     _norm(np.zeros((2, 1)), norm)                           # raises for invalid orders exactly as the reference (:887)
     kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
     c0 = np.zeros((q, 1)); c0[0, 0] = 1.0                   # the start vector Y[:, 0] (:838)
+    cols = _StreamedColumns(eng, K, "Wn", keep_raw=True)
     for k in range(K):
         Tp = Ts[:, :k]
         PY = Y - Tp.dot(Tp.T.dot(Y))
         eng.xt_v(PY, 1.0, "S", 0)                           # X^T (P Y)
+        cols.flush()                                        # (the previous component's columns, beside this pass)
         G0 = eng.x_w_slot("S", 0, q)                        # X X^T P Y
         G = G0 - Tp.dot(Tp.T.dot(G0))
         out = eng.nipals_subspace_loop(G, Y, c0, kind, max_tol, max_iter)
@@ -311,6 +342,7 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
         sw = nu.reshape(-1, 1) / np.linalg.norm(nu)         # sw_b ~ t_b^T u = ||w~_b|| uu (:879-880)
         Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u; V[:, k:k + 1] = v; A[:, k:k + 1] = sw ** 2
         nu_all[:, k] = nu
+        cols.component_done(k, nu)
         for b in range(B):
             T[b][:, k] = Tm[:, b]
         if calc_all:                                        # (:932-964)
@@ -325,8 +357,9 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     else:
         res.update(explained_var_x_=[], explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)),
                    A_corrected_=np.empty((B, 0)))
-    _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V)
-    res.W_non_normal_ = _split(eng.fetch("Wn"), eng.block_offsets)
+    cols.flush()
+    _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V, W_host=cols.W, P_host=cols.P)
+    res.W_non_normal_ = _split(cols.W_raw, eng.block_offsets)
     return res
 
 
@@ -649,10 +682,12 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
     T = [np.empty((n, K)) for _ in range(B)]
     blk_nrm = np.empty((B, K)); tot_nrm = np.empty(K)
     evx, evy, evxb, Acorr = [], [], np.empty((B, K)), np.empty((B, K))
+    cols = _StreamedColumns(eng, K, "Wc")
     for k in range(K):
         Tp = Ts[:, :k]
         PY = Y - Tp.dot(Tp.T.dot(Y))
         eng.xt_v(PY, 1.0, "S", 0)
+        cols.flush()                                        # (the previous component's columns, beside this pass)
         M = eng.x_w_slot("S", 0, q)
         M = M - Tp.dot(Tp.T.dot(M))                         # X_k X_k^T Y (:489)
         ts = _tlsv(M.dot(F))                                # (:489-493)
@@ -664,6 +699,7 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
         t_raw = t_raw - Tp.dot(Tp.T.dot(t_raw))             # X_k,b w_raw,b = P X_0,b w_raw,b (:515-517)
         tot = ssq.sum()
         blk_nrm[:, k] = np.sqrt(ssq); tot_nrm[k] = np.sqrt(tot)
+        cols.component_done(k, blk_nrm[:, k])
         A[:, k] = ssq / tot                                 # ||w_b||^2 of the unit-length w (:512)
         Tm = t_raw / np.sqrt(ssq)
         Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u; V[:, k:k + 1] = v
@@ -675,7 +711,8 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
         Acorr[:, k] = _bip_corrected(A[:, k], sizes)        # (:542-553)
     res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, explained_var_x_=evx, explained_var_y_=evy,
                     explained_var_xblocks_=evxb, A_corrected_=Acorr)
-    _finalise_device(eng, res, "Wc", K, tot_nrm, blk_nrm, V)                            # (:569-572)
+    cols.flush()
+    _finalise_device(eng, res, "Wc", K, tot_nrm, blk_nrm, V, W_host=cols.W, P_host=cols.P)    # (:569-572)
     return res
 
 
@@ -1027,6 +1064,12 @@ def fit_simpls(eng, Y, K, standardize):
     rm = getattr(eng, "rowmask", None)
     inc = None if rm is None else (np.asarray(rm).ravel() != 0)
     Ts = np.empty((n, K)); U = np.empty((n, K)); Q = np.empty((q, K))
+    W_h, R_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
+
+    def fetch_cols(c):          # columns of a finished component leave on the copy stream, beside a pass over X
+        for name, h in (("W", W_h), ("R", R_h), ("P", P_h)):
+            eng.fetch_col(name, c, h)
+
     for comp in range(K):
         if q == 1:
             qv = np.array([[1.0]])                          # the 1 x 1 S^T S has the singular vector [1]
@@ -1040,6 +1083,8 @@ def fit_simpls(eng, Y, K, standardize):
         t = t / nt                                          # (:1008-1009)
         eng.right_mul(("W", comp, 1), np.array([[1.0 / nt]]), ("R", comp))   # r / ||t|| (:1010)
         eng.xt_v(t, 1.0, "Z", K)                            # p = X^T t (:1011) into the scratch column
+        if comp > 0:
+            fetch_cols(comp - 1)
         eng.right_mul(("Z", K, 1), np.array([[1.0]]), ("P", comp))
         qk = Y.T.dot(t)                                     # (:1012)
         u = Y.dot(qk)                                       # (:1013)
@@ -1059,8 +1104,9 @@ def fit_simpls(eng, Y, K, standardize):
         M[comp, :] = -vS
         eng.right_mul(("Z", 0, nz), M, ("Z", cS))           # S <- S - v (v^T S) (:1019), in place
         Ts[:, comp:comp + 1] = t; U[:, comp:comp + 1] = u / np.linalg.norm(u); Q[:, comp:comp + 1] = qk
-    P = eng.fetch("P")
-    res = FitResult(P_=_split(P, eng.block_offsets), Ts_=Ts, U_=U, R_=eng.fetch("R"), V_=Q, W_=eng.fetch("W"))
+    eng.sync()
+    fetch_cols(K - 1)
+    res = FitResult(P_=_split(P_h, eng.block_offsets), Ts_=Ts, U_=U, R_=R_h, V_=Q, W_=W_h)
     res.beta_ = res.R_.dot(res.V_.T)                        # (:1044)
     return res
 
