@@ -798,9 +798,9 @@ class HipEngine(EngineBase):
         S = self.slots[slot]
         self.X.xt_v(self.X.data_ptr, self.p, 1.0, S, None, ldv=self.X.ld, ldg=self.p)
 
-    def _xw(self, Wdev, c, per_block, mean=None, scale=None, mat=None, nan=None):
+    def _xw(self, Wdev, c, per_block, mean=None, scale=None, mat=None, nan=None, overlap=None):
         """nan: None dense; "skip" missing entries contribute nothing; "indicator" sums of W over the present
-        columns of every row (csrc/gemv.hip k_xw NANM)."""
+        columns of every row (csrc/gemv.hip k_xw NANM).  ``overlap``: host work to do while the kernel runs."""
         if mat is None and self._kscale and mean is None:
             mean, scale = self.mean, self.scale          # raw working matrix: standardise on the fly
         mat = mat if mat is not None else self.X
@@ -813,6 +813,8 @@ class HipEngine(EngineBase):
             mat.x_w_nan(Wdev, c, buf, per_block=per_block, mean=mean, scale=scale, indicator=(nan == "indicator"),
                         ldw=mat.p, ldo=n)
         self.comm.allreduce_device(buf)
+        if overlap is not None:
+            overlap()
         h = buf.get()
         if hasattr(buf, "free"):
             buf.free()
@@ -827,9 +829,9 @@ class HipEngine(EngineBase):
         ones.free()
         return np.column_stack([c[:, 0] for c in cnt])
 
-    def x_w_slot(self, slot, k0, c, per_block=False):
+    def x_w_slot(self, slot, k0, c, per_block=False, overlap=None):
         """X @ slot[:, k0:k0+c]  -> n x c (or one n x c per block)."""
-        return self._xw(self.slots[slot].col(k0, c), c, per_block)
+        return self._xw(self.slots[slot].col(k0, c), c, per_block, overlap=overlap)
 
     def x_w_host(self, W, per_block=False):
         W = np.asarray(W, dtype=np.float64)

@@ -126,6 +126,14 @@ def _host_array(eng, shape):
     return eng.host_array(shape, prefault=False)
 
 
+def _project_out_component(eng, sslot, q, pcol, tsY):
+    """S <- S - p (ts^T Y) for S = X^T (P Y) (p x q, columns 0..q-1 of slot ``sslot``) with the loadings
+    p = X^T ts / ts^T ts the last pass left in column q of that slot; p is also stored as column ``pcol``"""
+    eng.right_mul((sslot, q, 1), np.array([[1.0]]), pcol)
+    M = np.vstack([np.eye(q), -np.asarray(tsY, dtype=np.float64).reshape(1, q)])
+    eng.right_mul((sslot, 0, q + 1), M, (sslot, 0))         # (in place: a row is read whole before it is written)
+
+
 class _StreamedColumns:
     """The p x K attributes of a host-driven fit leaving the device one column at a time: the columns of component k
     are final once its last pass has completed, and are copied (copy stream) while the first pass of component k + 1
@@ -295,13 +303,16 @@ def _subspace_loop_qspace(G, Y, c0, tol, max_iter):
 
 def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter):
     """mbpls.py:809-993 with the inner loop (:841-913) in the q-dimensional space of its iterates.  Per component:
-    G = P X (X^T (P Y)) (xt_v + x_w with q right-hand sides), the loop (one kernel launch / numpy), then ONE more pass:
+    G = P X (X^T (P Y)) (x_w with q right-hand sides), the loop (one kernel launch), then ONE more pass:
     loadings p = X^T ts (:928) together with the weights w~ = X^T (P u)/(u^T u) (:856) and the block products
-    X_b w~_b of the last sweep vector -- t_b = P X_b w~_b / ||w~_b|| (:875-877), sw_b ~ ||w~_b|| (:879)."""
+    X_b w~_b of the last sweep vector -- t_b = P X_b w~_b / ||w~_b|| (:875-877), sw_b ~ ||w~_b|| (:879).
+    X^T (P Y) itself is a pass over X for the first component only: P_{k+1} = P_k - ts ts^T / ts^T ts gives
+    X^T P_{k+1} Y = X^T P_k Y - p_k (ts^T Y) with the loadings p_k = X^T ts / ts^T ts the last pass has just produced --
+    p-sized algebra on the device (_project_out_component).  Two passes over X per component."""
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     sizes = _global_sizes(eng)
-    eng.slot("Wn", K); eng.slot("P", K); eng.slot("S", q)
+    eng.slot("Wn", K); eng.slot("P", K); eng.slot("S", q + 1)      # S = [X^T (P Y) | the loadings of the component]
     eng.use_lazy_deflation(K, "P", prefer="explicit")       # X is never deflated here: the plain (stored) passes
     eng._lazy_pslot = None
     varxb = _prepare_products(eng, standardize)
@@ -315,12 +326,10 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
     c0 = np.zeros((q, 1)); c0[0, 0] = 1.0                   # the start vector Y[:, 0] (:838)
     cols = _StreamedColumns(eng, K, "Wn", keep_raw=True)
+    eng.xt_v(Y, 1.0, "S", 0)                                # X^T Y: the only product of this kind (see below)
     for k in range(K):
         Tp = Ts[:, :k]
-        PY = Y - Tp.dot(Tp.T.dot(Y))
-        eng.xt_v(PY, 1.0, "S", 0)                           # X^T (P Y)
-        cols.flush()                                        # (the previous component's columns, beside this pass)
-        G0 = eng.x_w_slot("S", 0, q)                        # X X^T P Y
+        G0 = eng.x_w_slot("S", 0, q, overlap=cols.flush)    # X X^T P Y (the previous component's columns leave meanwhile)
         G = G0 - Tp.dot(Tp.T.dot(G0))
         out = eng.nipals_subspace_loop(G, Y, c0, kind, max_tol, max_iter)
         if out is None and kind == 0 and n > 8192:
@@ -336,7 +345,8 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
         uu = u_used.T.dot(u_used).item()
         z = u_used - Tp.dot(Tp.T.dot(u_used))               # P u
         # one pass: p = X^T ts (ts is orthogonal to the earlier scores), w~ = X^T z / uu, X_b w~_b, ||w~_b||^2, ||p_b||^2
-        ssq_p, t_raw, ssq = eng.deflate_sweep(ts, 1.0, False, ("P", k), z, 1.0 / uu, ("Wn", k))
+        ssq_p, t_raw, ssq = eng.deflate_sweep(ts, 1.0, False, ("S", q), z, 1.0 / uu, ("Wn", k))
+        _project_out_component(eng, "S", q, ("P", k), ts.T.dot(Y))
         nu = np.sqrt(ssq)
         Tm = (t_raw - Tp.dot(Tp.T.dot(t_raw))) / nu         # t_b = P X_b w_b (:875-877)
         sw = nu.reshape(-1, 1) / np.linalg.norm(nu)         # sw_b ~ t_b^T u = ||w~_b|| uu (:879-880)
@@ -664,14 +674,16 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
 def _fit_unipals_wide_multi(eng, Y, K, standardize):
     """UNIPALS, p > n, several responses (mbpls.py:481-572) without ever deflating X.  The deflation :535 is
     X_k = (I - ts ts^T) X_{k-1} = P X_0 with P = I - Ts Ts^T (successive ts are orthonormal), so
-      S-factor :489   X_k X_k^T Y = P X_0 (X_0^T (P Y))         -- xt_v + x_w with q right-hand sides on X_0
+      S-factor :489   X_k X_k^T Y = P X_0 (X_0^T (P Y))         -- x_w with q right-hand sides on X_0; X_0^T (P Y) is a
+                                                                   pass for the first component only, then updated
+                                                                   with the loadings: X_0^T P_k+1 Y = X_0^T P_k Y - p_k ts^T Y
       weights  :503   X_k^T u = X_0^T (P u),  block scores :515-517  X_k,b w_b = P X_0,b w_b,
       loadings :520   X_k^T ts / ts^T ts = X_0^T ts / ts^T ts     (ts is orthogonal to the earlier scores)
-    and the last three are ONE fused read-only pass: three passes per component instead of four plus a rewrite."""
+    and the last three are ONE fused read-only pass: two passes per component instead of four plus a rewrite."""
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     sizes = _global_sizes(eng)
-    eng.slot("Wc", K); eng.slot("P", K); eng.slot("S", q)
+    eng.slot("Wc", K); eng.slot("P", K); eng.slot("S", q + 1)      # S = [X^T (P Y) | the loadings of the component]
     eng.use_lazy_deflation(K, "P", prefer="explicit")       # plain passes on the stored X; nothing is deflated
     eng._lazy_pslot = None
     varxb = _prepare_products(eng, standardize)
@@ -683,19 +695,18 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
     blk_nrm = np.empty((B, K)); tot_nrm = np.empty(K)
     evx, evy, evxb, Acorr = [], [], np.empty((B, K)), np.empty((B, K))
     cols = _StreamedColumns(eng, K, "Wc")
+    eng.xt_v(Y, 1.0, "S", 0)                                # X_0^T Y; later: X_0^T P Y by p-sized updates (below)
     for k in range(K):
         Tp = Ts[:, :k]
-        PY = Y - Tp.dot(Tp.T.dot(Y))
-        eng.xt_v(PY, 1.0, "S", 0)
-        cols.flush()                                        # (the previous component's columns, beside this pass)
-        M = eng.x_w_slot("S", 0, q)
+        M = eng.x_w_slot("S", 0, q, overlap=cols.flush)     # (the previous component's columns leave meanwhile)
         M = M - Tp.dot(Tp.T.dot(M))                         # X_k X_k^T Y (:489)
         ts = _tlsv(M.dot(F))                                # (:489-493)
         tt = ts.T.dot(ts).item()
         v = Y.T.dot(ts) / tt                                # (:496)
         u = Y.dot(v); u = u / np.linalg.norm(u)             # (:499-500)
         z = u - Tp.dot(Tp.T.dot(u))
-        ssq_p, t_raw, ssq = eng.deflate_sweep(ts, 1.0 / tt, False, ("P", k), z, 1.0, ("Wc", k))
+        ssq_p, t_raw, ssq = eng.deflate_sweep(ts, 1.0 / tt, False, ("S", q), z, 1.0, ("Wc", k))
+        _project_out_component(eng, "S", q, ("P", k), ts.T.dot(Y))     # X_0^T P_{k+1} Y = X_0^T P_k Y - p_k (ts^T Y)
         t_raw = t_raw - Tp.dot(Tp.T.dot(t_raw))             # X_k,b w_raw,b = P X_0,b w_raw,b (:515-517)
         tot = ssq.sum()
         blk_nrm[:, k] = np.sqrt(ssq); tot_nrm[k] = np.sqrt(tot)

@@ -130,7 +130,9 @@ class NumpyEngine(EngineBase):
         if want_ssq:
             return self.comm.allreduce_host(np.array([(G[s:e] ** 2).sum(axis=0) for s, e in self._ranges()]))
 
-    def x_w_slot(self, slot, k0, c, per_block=False):
+    def x_w_slot(self, slot, k0, c, per_block=False, overlap=None):
+        if overlap is not None:
+            overlap()
         return self.x_w_host(self.slots[slot][:, k0:k0 + c], per_block)
 
     def x_w_host(self, W, per_block=False):
