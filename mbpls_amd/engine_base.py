@@ -40,7 +40,7 @@ class EngineBase:
     def resident_supported(self, q, K, norm_kind):
         return False
 
-    def stats_only_ok(self):
+    def stats_only_ok(self, prefer=False):
         return False
 
     def nipals_subspace_loop(self, G, Y, c0, norm_kind, tol, max_iter):

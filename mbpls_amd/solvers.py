@@ -229,12 +229,12 @@ def _finish_resident(eng, res, out, W_host, P_host):
 
 
 # ----------------------------------------------------------------------------------- NIPALS
-def _prepare_products(eng, standardize):
+def _prepare_products(eng, standardize, prefer_stats_only=False):
     """a1 for the solvers whose X-sized work is products on a matrix that is never deflated (several-response NIPALS /
     UNIPALS, SIMPLS): a standardised working copy when it fits -- else (or when forced, MBPLS_KERNEL_IMPLICIT)
     statistics only: the products standardise their operand in registers and the caller's matrix is never written.
     Returns the per-block sums of squares of the standardised matrix."""
-    if eng.stats_only_ok():
+    if eng.stats_only_ok(prefer_stats_only):
         return eng.prepare_stats(standardize)
     return eng.prepare(standardize)[0]
 
@@ -315,7 +315,7 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     eng.slot("Wn", K); eng.slot("P", K); eng.slot("S", q + 1)      # S = [X^T (P Y) | the loadings of the component]
     eng.use_lazy_deflation(K, "P", prefer="explicit")       # X is never deflated here: the plain (stored) passes
     eng._lazy_pslot = None
-    varxb = _prepare_products(eng, standardize)
+    varxb = _prepare_products(eng, standardize, prefer_stats_only=True)
     varx = varxb.sum()
     vary = (Y ** 2).sum()
     Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
@@ -686,7 +686,7 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
     eng.slot("Wc", K); eng.slot("P", K); eng.slot("S", q + 1)      # S = [X^T (P Y) | the loadings of the component]
     eng.use_lazy_deflation(K, "P", prefer="explicit")       # plain passes on the stored X; nothing is deflated
     eng._lazy_pslot = None
-    varxb = _prepare_products(eng, standardize)
+    varxb = _prepare_products(eng, standardize, prefer_stats_only=True)
     varx = varxb.sum()
     vary = (Y ** 2).sum()
     F = _psd_factor(Y.T.dot(Y))
