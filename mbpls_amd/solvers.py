@@ -1059,14 +1059,97 @@ def _xtx(eng):
 
 # ----------------------------------------------------------------------------------- SIMPLS
 def fit_simpls(eng, Y, K, standardize):
-    """mbpls.py:995-1048 (de Jong 1993).  X is never deflated: S = X^T Y once, then per component
+    """mbpls.py:995-1048 (de Jong 1993) with ONE pass over X per component.  X is never deflated: S = X^T Y, and per
+    component the reference computes t = X r (:1006, r = S q) and p = X^T t (:1011) -- two reads of X.  Here the fused
+    sweep pass (the NIPALS one: g = X^T v and X g in the same read) takes v = t: it returns the loadings p = X^T t AND
+    a = X p.  Everything r is built from is a combination of vectors whose products with X are then known:
+        S_0 = X^T Y, X S_0                (one fused pass per response: v = Y[:, j])
+        v = p - V_s (V_s^T p)  (:1016)  ->  X v = a - (X V_s)(V_s^T p)
+        S <- S - v (v^T S)     (:1019)  ->  X S <- X S - (X v)(v^T S)
+    so t = X r = (X S) q needs no pass.  All p-length algebra (r = S q, the Gram-Schmidt step on v, the update of S)
+    runs on the device in one p x (K+1+q) slot  Z = [V_s | p | S]; only n- and q-sized matrices visit the host.
+    With standardised data nothing is written: the passes standardise in registers (engine: lazy / implicit mode with
+    no component ever deflated)."""
+    n = eng.n
+    q = Y.shape[1]
+    if K + 1 + q > 32:
+        return _fit_simpls_hostvec(eng, Y, K, standardize)
+    if q > K + 2:
+        return _fit_simpls_products(eng, Y, K, standardize)
+    nz = K + 1 + q
+    cS = K + 1                                              # first S column inside Z
+    eng.slot("Z", nz); eng.slot("R", K); eng.slot("W", K); eng.slot("P", K)
+    eng.use_lazy_deflation(K, "P", prefer="lazy")           # (never deflates: the never-writes-X passes when they apply)
+    XS = np.empty((n, q)); XV = np.empty((n, K))
+    _, tb, _ = eng.prepare(standardize, v=Y[:, 0:1], alpha=1.0, g_slot=("Z", cS))       # S[:, 0] = X^T y_0 (:998), X S[:, 0]
+    XS[:, 0] = tb.sum(axis=1)
+    for j in range(1, q):
+        tb, _ = eng.sweep(Y[:, j:j + 1], 1.0, ("Z", cS + j))
+        XS[:, j] = tb.sum(axis=1)
+    rm = getattr(eng, "rowmask", None)
+    inc = None if rm is None else (np.asarray(rm).ravel() != 0)
+    Ts = np.empty((n, K)); U = np.empty((n, K)); Q = np.empty((q, K))
+    W_h, R_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
+
+    def fetch_cols(c):          # columns of a finished component leave on the copy stream, beside a pass over X
+        for name, h in (("W", W_h), ("R", R_h), ("P", P_h)):
+            eng.fetch_col(name, c, h)
+
+    for comp in range(K):
+        if q == 1:
+            qv = np.array([[1.0]])                          # the 1 x 1 S^T S has the singular vector [1]
+        else:
+            StS = eng.cross(("Z", cS, q), ("Z", cS, q))
+            qv = np.linalg.svd(StS, full_matrices=True)[0][:, 0:1]  # (:1001)
+        eng.right_mul(("Z", cS, q), qv, ("W", comp))        # w = r = S q (:1004-1005)
+        t = XS.dot(qv)                                      # X r (:1006), no pass
+        t = t - np.mean(t) if inc is None else np.where(inc[:, None], t - t[inc].mean(), 0.0)   # (:1007)
+        nt = np.sqrt(t.T.dot(t)).item()
+        t = t / nt                                          # (:1008-1009)
+        eng.right_mul(("W", comp, 1), np.array([[1.0 / nt]]), ("R", comp))   # r / ||t|| (:1010)
+        # p = X^T t (:1011) into the scratch column of Z, and a = X p
+        tb, _ = eng.sweep(t, 1.0, ("Z", K), overlap=(lambda c=comp - 1: fetch_cols(c)) if comp > 0 else None)
+        a = tb.sum(axis=1, keepdims=True)
+        eng.right_mul(("Z", K, 1), np.array([[1.0]]), ("P", comp))
+        qk = Y.T.dot(t)                                     # (:1012)
+        u = Y.dot(qk)                                       # (:1013)
+        coef = np.zeros((nz, 1))
+        coef[K, 0] = 1.0
+        xv = a
+        if comp > 0:
+            c = eng.cross(("Z", 0, comp), ("Z", K, 1))      # V_s^T p
+            coef[:comp] = -c                                # v = p - V_s (V_s^T p) (:1016)
+            xv = a - XV[:, :comp].dot(c)
+            u = u - Ts[:, :comp].dot(Ts[:, :comp].T.dot(u))            # (:1017)
+        eng.right_mul(("Z", 0, nz), coef, ("Z", comp))
+        # one reduction for v^T v and v^T S (columns comp .. end of Z; the columns in between are not used)
+        row = eng.cross(("Z", comp, 1), ("Z", comp, nz - comp))
+        vv = row[0, 0]
+        eng.right_mul(("Z", comp, 1), np.array([[1.0 / np.sqrt(vv)]]), ("Z", comp))     # (:1018)
+        xv = xv / np.sqrt(vv)
+        vS = row[:, cS - comp:] / np.sqrt(vv)               # v^T S of the unit-length v (1 x q)
+        M = np.zeros((nz, q))
+        M[cS:, :] = np.eye(q)
+        M[comp, :] = -vS
+        eng.right_mul(("Z", 0, nz), M, ("Z", cS))           # S <- S - v (v^T S) (:1019), in place
+        XS -= xv.dot(vS)
+        XV[:, comp:comp + 1] = xv
+        Ts[:, comp:comp + 1] = t; U[:, comp:comp + 1] = u / np.linalg.norm(u); Q[:, comp:comp + 1] = qk
+    eng.sync()
+    fetch_cols(K - 1)
+    res = FitResult(P_=_split(P_h, eng.block_offsets), Ts_=Ts, U_=U, R_=R_h, V_=Q, W_=W_h)
+    res.beta_ = res.R_.dot(res.V_.T)                        # (:1044)
+    return res
+
+
+def _fit_simpls_products(eng, Y, K, standardize):
+    """The two-reads-per-component form (many responses, few components: q > K + 2).
+    mbpls.py:995-1048 (de Jong 1993).  X is never deflated: S = X^T Y once, then per component
     t = X r and p = X^T t (two reads of X).  All p-length algebra (r = S q, the Gram-Schmidt step on v,
     S <- S - v v^T S) runs on the device in one p x (K+1+q) slot  Z = [V_s | p | S]; only q x q and
     k x 1 matrices visit the host."""
     n = eng.n
     q = Y.shape[1]
-    if K + 1 + q > 32:
-        return _fit_simpls_hostvec(eng, Y, K, standardize)
     _prepare_products(eng, standardize)
     nz = K + 1 + q
     cS = K + 1                                              # first S column inside Z
