@@ -441,10 +441,13 @@ class HipEngine(EngineBase):
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
         return x, t, g
 
-    def stats_only_ok(self, prefer=False):
-        """``prefer``: the caller's products lose less to standardising in registers than the read-only statistics pass
-        saves (several-response NIPALS / UNIPALS: two passes per component; profiles/r03_ab_stats_only_products.txt).
-        Otherwise: the products of this fit (Gram, X^T V, X W) can standardise their operand in registers -- and should: the
+    def scaled_products(self):
+        """after an implicit first pass (raw matrix, statistics known): the many-right-hand-side products X^T V / X W
+        standardise their operand in registers as well"""
+        self._kscale = bool(self._istd)
+
+    def stats_only_ok(self):
+        """The products of this fit (Gram, X^T V, X W) can standardise their operand in registers -- and should: the
         Gram pays ~6 % for it (a fifth load per k-step plus the operand arithmetic: 2.00 s instead of 1.88 s at
         BASELINE config[3]), more than the read-only statistics pass saves (27 ms instead of 57 ms), so the stored path
         is kept whenever a standardised working copy comfortably fits beside the caller's matrix (or copy=False lets
@@ -455,8 +458,6 @@ class HipEngine(EngineBase):
             return False
         if self.opts.kernel_implicit is not None:
             return self.opts.kernel_implicit == "1"
-        if prefer:
-            return True
         if self._src is None:
             return False                              # the matrix is ours to overwrite: standardise in place
         need = self.X.nbytes + 8 * self.n * self.n * 3 + (17 << 30)     # working copy + Gram + its split-K slices

@@ -40,7 +40,10 @@ class EngineBase:
     def resident_supported(self, q, K, norm_kind):
         return False
 
-    def stats_only_ok(self, prefer=False):
+    def scaled_products(self):
+        pass
+
+    def stats_only_ok(self):
         return False
 
     def nipals_subspace_loop(self, G, Y, c0, norm_kind, tol, max_iter):

@@ -126,12 +126,62 @@ def _host_array(eng, shape):
     return eng.host_array(shape, prefault=False)
 
 
-def _project_out_component(eng, sslot, q, pcol, tsY):
-    """S <- S - p (ts^T Y) for S = X^T (P Y) (p x q, columns 0..q-1 of slot ``sslot``) with the loadings
-    p = X^T ts / ts^T ts the last pass left in column q of that slot; p is also stored as column ``pcol``"""
-    eng.right_mul((sslot, q, 1), np.array([[1.0]]), pcol)
-    M = np.vstack([np.eye(q), -np.asarray(tsY, dtype=np.float64).reshape(1, q)])
-    eng.right_mul((sslot, 0, q + 1), M, (sslot, 0))         # (in place: a row is read whole before it is written)
+class _ResponseProducts:
+    """S = X^T (P Y) (p x q: columns 0..q-1 of a device slot, column q receives the loadings of the component at hand) and
+    the per-block products X_b S_b (n x q each, host), kept up to date WITHOUT passes over X.  P = I - Ts Ts^T carries
+    the deflation (:969, :535): P_{k+1} = P_k - ts ts^T / ts^T ts gives
+        X^T P_{k+1} Y = S - p (ts^T Y),      X_b S_b <- X_b S_b - (X_b p_b)(ts^T Y),      p = X^T ts / ts^T ts,
+    and the ONE pass a component needs is the fused sweep with v = ts: it returns the loadings p AND X_b p_b.  Every
+    other X-sized quantity of a component is a combination of the columns of S -- the weights X^T (P Y c) = S c, their
+    block products X_b (S c)_b = (X_b S_b) c, the matrix X X^T P Y the scores come from = sum_b X_b S_b.
+    Set-up: column 0 together with the statistics pass (fused sweep, v = Y[:, 0]), the other columns by one X^T Y and one
+    per-block X W product (or one more sweep when q = 2): 3 + K passes per fit."""
+
+    def __init__(self, eng, Y, standardize, sslot="S"):
+        n, B, q = eng.n, eng.nblocks, Y.shape[1]
+        self.eng, self.q, self.sslot, self.Y = eng, q, sslot, Y
+        self.varxb, tb, _ = eng.prepare(standardize, v=Y[:, 0:1], alpha=1.0, g_slot=(sslot, 0))
+        self.XS = [np.empty((n, q)) for _ in range(B)]
+        for b in range(B):
+            self.XS[b][:, 0] = tb[:, b]
+        if q == 2:
+            tb, _ = eng.sweep(Y[:, 1:2], 1.0, (sslot, 1))
+            for b in range(B):
+                self.XS[b][:, 1] = tb[:, b]
+        elif q > 2:
+            eng.scaled_products()                           # (raw matrix: the products standardise in registers too)
+            eng.xt_v(Y[:, 1:], 1.0, sslot, 1)
+            for b, blk in enumerate(eng.x_w_slot(sslot, 1, q - 1, per_block=True)):
+                self.XS[b][:, 1:] = blk
+
+    def total(self):
+        """X X^T P Y (before the projection of its rows)"""
+        out = self.XS[0].copy()
+        for blk in self.XS[1:]:
+            out += blk
+        return out
+
+    def combination(self, coef, dst):
+        """column ``dst`` = S coef (device);  returns X_b (S coef)_b (n x B) and ||(S coef)_b||^2 (B)"""
+        eng, offs = self.eng, self.eng.block_offsets
+        coef = np.asarray(coef, dtype=np.float64).reshape(self.q, 1)
+        eng.right_mul((self.sslot, 0, self.q), coef, dst)
+        ssq = np.array([eng.cross((dst[0], dst[1], 1), (dst[0], dst[1], 1), rows=(offs[b], offs[b + 1]))[0, 0]
+                        for b in range(eng.nblocks)])
+        return np.column_stack([blk.dot(coef) for blk in self.XS]), ssq
+
+    def component(self, ts, inv_tt, pcol, overlap=None):
+        """the pass of a component: p = X^T ts / ts^T ts (stored as column ``pcol``), then S and X_b S_b without ts;
+        returns ||p_b||^2 (B)"""
+        eng, q = self.eng, self.q
+        tb, ssq_p = eng.sweep(ts, inv_tt, (self.sslot, q), overlap=overlap)
+        eng.right_mul((self.sslot, q, 1), np.array([[1.0]]), pcol)
+        r = np.asarray(ts, dtype=np.float64).reshape(1, -1).dot(self.Y)          # ts^T Y (1 x q)
+        M = np.vstack([np.eye(q), -r])
+        eng.right_mul((self.sslot, 0, q + 1), M, (self.sslot, 0))               # (in place: a row is read whole first)
+        for b, blk in enumerate(self.XS):
+            blk -= tb[:, b:b + 1].dot(r)
+        return ssq_p
 
 
 class _StreamedColumns:
@@ -229,12 +279,12 @@ def _finish_resident(eng, res, out, W_host, P_host):
 
 
 # ----------------------------------------------------------------------------------- NIPALS
-def _prepare_products(eng, standardize, prefer_stats_only=False):
+def _prepare_products(eng, standardize):
     """a1 for the solvers whose X-sized work is products on a matrix that is never deflated (several-response NIPALS /
     UNIPALS, SIMPLS): a standardised working copy when it fits -- else (or when forced, MBPLS_KERNEL_IMPLICIT)
     statistics only: the products standardise their operand in registers and the caller's matrix is never written.
     Returns the per-block sums of squares of the standardised matrix."""
-    if eng.stats_only_ok(prefer_stats_only):
+    if eng.stats_only_ok():
         return eng.prepare_stats(standardize)
     return eng.prepare(standardize)[0]
 
@@ -303,19 +353,17 @@ def _subspace_loop_qspace(G, Y, c0, tol, max_iter):
 
 def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter):
     """mbpls.py:809-993 with the inner loop (:841-913) in the q-dimensional space of its iterates.  Per component:
-    G = P X (X^T (P Y)) (x_w with q right-hand sides), the loop (one kernel launch), then ONE more pass:
-    loadings p = X^T ts (:928) together with the weights w~ = X^T (P u)/(u^T u) (:856) and the block products
-    X_b w~_b of the last sweep vector -- t_b = P X_b w~_b / ||w~_b|| (:875-877), sw_b ~ ||w~_b|| (:879).
-    X^T (P Y) itself is a pass over X for the first component only: P_{k+1} = P_k - ts ts^T / ts^T ts gives
-    X^T P_{k+1} Y = X^T P_k Y - p_k (ts^T Y) with the loadings p_k = X^T ts / ts^T ts the last pass has just produced --
-    p-sized algebra on the device (_project_out_component).  Two passes over X per component."""
+    G = P X (X^T (P Y)), the loop (one kernel launch), the weights of the last sweep vector w~ = X^T (P u)/(u^T u) (:856)
+    with u = Y c, their block products X_b w~_b -- t_b = P X_b w~_b / ||w~_b|| (:875-877), sw_b ~ ||w~_b|| (:879) -- all
+    from the maintained products of _ResponseProducts (no pass), then ONE pass: the loadings p = X^T ts (:928).
+    X is never written (implicit standardisation, nothing deflated).  3 + K passes per fit."""
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     sizes = _global_sizes(eng)
     eng.slot("Wn", K); eng.slot("P", K); eng.slot("S", q + 1)      # S = [X^T (P Y) | the loadings of the component]
-    eng.use_lazy_deflation(K, "P", prefer="explicit")       # X is never deflated here: the plain (stored) passes
-    eng._lazy_pslot = None
-    varxb = _prepare_products(eng, standardize, prefer_stats_only=True)
+    eng.use_lazy_deflation(K, "P", prefer="lazy")           # (never deflates: the never-writes-X passes when they apply)
+    prod = _ResponseProducts(eng, Y, standardize)
+    varxb = prod.varxb
     varx = varxb.sum()
     vary = (Y ** 2).sum()
     Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
@@ -326,10 +374,9 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
     c0 = np.zeros((q, 1)); c0[0, 0] = 1.0                   # the start vector Y[:, 0] (:838)
     cols = _StreamedColumns(eng, K, "Wn", keep_raw=True)
-    eng.xt_v(Y, 1.0, "S", 0)                                # X^T Y: the only product of this kind (see below)
     for k in range(K):
         Tp = Ts[:, :k]
-        G0 = eng.x_w_slot("S", 0, q, overlap=cols.flush)    # X X^T P Y (the previous component's columns leave meanwhile)
+        G0 = prod.total()                                   # X X^T P Y
         G = G0 - Tp.dot(Tp.T.dot(G0))
         out = eng.nipals_subspace_loop(G, Y, c0, kind, max_tol, max_iter)
         if out is None and kind == 0 and n > 8192:
@@ -343,10 +390,11 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
         iters.append(n_it)
         u_used = Y.dot(c_used)                              # sweep vector of the last iteration
         uu = u_used.T.dot(u_used).item()
-        z = u_used - Tp.dot(Tp.T.dot(u_used))               # P u
-        # one pass: p = X^T ts (ts is orthogonal to the earlier scores), w~ = X^T z / uu, X_b w~_b, ||w~_b||^2, ||p_b||^2
-        ssq_p, t_raw, ssq = eng.deflate_sweep(ts, 1.0, False, ("S", q), z, 1.0 / uu, ("Wn", k))
-        _project_out_component(eng, "S", q, ("P", k), ts.T.dot(Y))
+        # w~ = X^T (P u) / uu = S c / uu, X_b w~_b, ||w~_b||^2: combinations of maintained products
+        t_raw, ssq = prod.combination(c_used / uu, ("Wn", k))
+        # the pass of the component: p = X^T ts (ts is orthogonal to the earlier scores), ||p_b||^2; the previous
+        # component's attribute columns leave meanwhile
+        ssq_p = prod.component(ts, 1.0, ("P", k), overlap=cols.flush)
         nu = np.sqrt(ssq)
         Tm = (t_raw - Tp.dot(Tp.T.dot(t_raw))) / nu         # t_b = P X_b w_b (:875-877)
         sw = nu.reshape(-1, 1) / np.linalg.norm(nu)         # sw_b ~ t_b^T u = ||w~_b|| uu (:879-880)
@@ -674,19 +722,18 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
 def _fit_unipals_wide_multi(eng, Y, K, standardize):
     """UNIPALS, p > n, several responses (mbpls.py:481-572) without ever deflating X.  The deflation :535 is
     X_k = (I - ts ts^T) X_{k-1} = P X_0 with P = I - Ts Ts^T (successive ts are orthonormal), so
-      S-factor :489   X_k X_k^T Y = P X_0 (X_0^T (P Y))         -- x_w with q right-hand sides on X_0; X_0^T (P Y) is a
-                                                                   pass for the first component only, then updated
-                                                                   with the loadings: X_0^T P_k+1 Y = X_0^T P_k Y - p_k ts^T Y
+      S-factor :489   X_k X_k^T Y = P X_0 (X_0^T (P Y))         -- maintained (_ResponseProducts): no pass
       weights  :503   X_k^T u = X_0^T (P u),  block scores :515-517  X_k,b w_b = P X_0,b w_b,
       loadings :520   X_k^T ts / ts^T ts = X_0^T ts / ts^T ts     (ts is orthogonal to the earlier scores)
-    and the last three are ONE fused read-only pass: two passes per component instead of four plus a rewrite."""
+    and only the loadings need a pass -- the fused sweep with v = ts, which also returns X_0,b p_b for the maintained
+    products: ONE pass per component instead of four plus a rewrite."""
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     sizes = _global_sizes(eng)
     eng.slot("Wc", K); eng.slot("P", K); eng.slot("S", q + 1)      # S = [X^T (P Y) | the loadings of the component]
-    eng.use_lazy_deflation(K, "P", prefer="explicit")       # plain passes on the stored X; nothing is deflated
-    eng._lazy_pslot = None
-    varxb = _prepare_products(eng, standardize, prefer_stats_only=True)
+    eng.use_lazy_deflation(K, "P", prefer="lazy")           # (never deflates: the never-writes-X passes when they apply)
+    prod = _ResponseProducts(eng, Y, standardize)
+    varxb = prod.varxb
     varx = varxb.sum()
     vary = (Y ** 2).sum()
     F = _psd_factor(Y.T.dot(Y))
@@ -695,18 +742,18 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
     blk_nrm = np.empty((B, K)); tot_nrm = np.empty(K)
     evx, evy, evxb, Acorr = [], [], np.empty((B, K)), np.empty((B, K))
     cols = _StreamedColumns(eng, K, "Wc")
-    eng.xt_v(Y, 1.0, "S", 0)                                # X_0^T Y; later: X_0^T P Y by p-sized updates (below)
     for k in range(K):
         Tp = Ts[:, :k]
-        M = eng.x_w_slot("S", 0, q, overlap=cols.flush)     # (the previous component's columns leave meanwhile)
+        M = prod.total()
         M = M - Tp.dot(Tp.T.dot(M))                         # X_k X_k^T Y (:489)
         ts = _tlsv(M.dot(F))                                # (:489-493)
         tt = ts.T.dot(ts).item()
         v = Y.T.dot(ts) / tt                                # (:496)
-        u = Y.dot(v); u = u / np.linalg.norm(u)             # (:499-500)
-        z = u - Tp.dot(Tp.T.dot(u))
-        ssq_p, t_raw, ssq = eng.deflate_sweep(ts, 1.0 / tt, False, ("S", q), z, 1.0, ("Wc", k))
-        _project_out_component(eng, "S", q, ("P", k), ts.T.dot(Y))     # X_0^T P_{k+1} Y = X_0^T P_k Y - p_k (ts^T Y)
+        u = Y.dot(v); un = np.linalg.norm(u); u = u / un    # (:499-500)
+        # w_raw = X_k^T u = X_0^T P Y v / ||Y v|| = S v / ||Y v|| (:503), X_0,b w_raw,b, ||w_raw,b||^2: maintained products
+        t_raw, ssq = prod.combination(v / un, ("Wc", k))
+        # the pass of the component: p = X_0^T ts / ts^T ts (:520); the previous component's columns leave meanwhile
+        ssq_p = prod.component(ts, 1.0 / tt, ("P", k), overlap=cols.flush)
         t_raw = t_raw - Tp.dot(Tp.T.dot(t_raw))             # X_k,b w_raw,b = P X_0,b w_raw,b (:515-517)
         tot = ssq.sum()
         blk_nrm[:, k] = np.sqrt(ssq); tot_nrm[k] = np.sqrt(tot)

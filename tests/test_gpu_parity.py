@@ -813,8 +813,9 @@ def test_kernel_method_never_writes_x(gpu_required, monkeypatch, offset, standar
     ("UNIPALS", 0.0, True, 640), ("UNIPALS", 300.0, True, 200), ("SIMPLS", 0.0, True, 640), ("SIMPLS", 300.0, True, 200),
     ("SIMPLS", 0.0, False, 640), ("UNIPALS", 0.0, True, 9000), ("SIMPLS", 0.0, True, 9000), ("KERNEL", 0.0, True, 9000)])
 def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, method, offset, standardize, n):
-    """Several responses (NIPALS, UNIPALS; SIMPLS: its own never-writes-X passes) without a standardised working copy: statistics-only
-    preparation, then per component X (X^T P Y) with the operand standardised in registers and ONE raw-space
+    """Several responses (NIPALS, UNIPALS) and SIMPLS without a standardised working copy: one fused raw-space sweep pass per
+    component (loadings p = X^T ts and X p, everything else from maintained products); KERNEL: statistics-only
+    preparation, products with the operand standardised in registers.  Earlier form of this test: ONE raw-space
     pass for the loadings, the weights of the last sweep vector and their block scores (mbpls_hip_loadings_sweep_raw:
     no deflation) -- against the oracle and the stored path, with the caller's matrix bit-identical afterwards.
     n = 9000: the two-phase long-column form of the same pass."""
@@ -840,7 +841,7 @@ def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, meth
     Xd = DeviceMatrix(ctx, n, p, offs)
     Xd.upload(X)
     mdl = MBPLS(n_components=3, method=method, standardize=standardize, full_svd=True).fit(Xd, Y)
-    if method == "SIMPLS":      # one fused sweep pass per component (p = X^T t and X p), standardising in registers
+    if method != "KERNEL":      # one fused sweep pass per component (p = X^T t and X p), standardising in registers
         assert used == [] and "never written" in mdl.fit_plan_["standardisation"], mdl.fit_plan_
     else:
         assert used == [True]
@@ -850,8 +851,7 @@ def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, meth
     if method == "NIPALS":
         assert [abs(a - b) <= 2 for a, b in zip(mdl.nipals_iterations_, ref.nipals_iterations_)] == [True] * 3
     monkeypatch.setenv("MBPLS_KERNEL_IMPLICIT", "0")
-    if method == "SIMPLS":
-        monkeypatch.setenv("MBPLS_IMPLICIT_STD", "0")
+    monkeypatch.setenv("MBPLS_IMPLICIT_STD", "0")
     used.clear()
     m2 = MBPLS(n_components=3, method=method, standardize=standardize, full_svd=True).fit(Xd, Y)
     assert used == []
