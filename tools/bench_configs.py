@@ -26,14 +26,15 @@ def run(name, n, p, K, q, method, offs, copy, calc_all=True, steps=2):
     dT = ctx.from_host(Ts)
     X.fill_latent(dT, 32, 0.5, 1234, 0)
     ctx.sync()
-    m = MBPLS(n_components=K, method=method, calc_all=calc_all, copy=copy)
-    times = []
+    times, models = [], []
     for s in range(steps + 1):
         if not copy and s > 0:
             X.fill_latent(dT, 32, 0.5, 1234, 0)
             ctx.sync()
         if s == 1:
             ctx.profile(True); ctx.profile_reset()
+        m = MBPLS(n_components=K, method=method, calc_all=calc_all, copy=copy)     # a fresh estimator per fit, as bench.py
+        models.append(m)
         t0 = time.perf_counter()
         m.fit(X, Y)
         ctx.sync()
