@@ -290,3 +290,77 @@ def test_c4_kernel_full_size(gpu_required, monkeypatch):
     finally:
         X.close()
         ctx.trim_pool()
+
+
+# ------------------------------------------------------------------------------- several responses at C2 size
+def test_c2_several_responses_full_size(gpu_required, monkeypatch):
+    """The secondary q = 10 configuration (paper protocol at BASELINE size; n=4096, p=1,000,000, 2 blocks,
+    K=10) for the solvers that keep X^T (P Y) and X_b S_b up to date instead of passing over X (one fused sweep per
+    component): NIPALS and UNIPALS with ten responses, SIMPLS.  Checked through (a) the generic products behind
+    transform / predict, (b) sampled columns through the reference recurrence, (c) orthonormal scores, and (d) the
+    same fit through a DIFFERENT solver route (NIPALS on per-block association matrices; UNIPALS on the explicitly
+    deflated matrix)."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS
+    ctx = mbpls_amd.get_context()
+    ctx.trim_pool()
+    n, p, K, q = 4096, 1_000_000, 10, 10
+    offs = [0, 500_000, p]
+    X, Y = device_problem(ctx, n, p, offs, q=q)
+    try:
+        ranges, width = sample_ranges(X)
+        cols, data = download_sample(X, ranges, width)
+        # ---- NIPALS
+        mdl = MBPLS(n_components=K, method="NIPALS").fit(X, Y)
+        assert "never written" in mdl.fit_plan_["standardisation"]
+        check_orthonormal(mdl.Ts_)
+        check_generic_products(mdl, X, Y)
+        Z = check_statistics(mdl, cols, data)
+        _, P = recurrence(Z, mdl.Ts_, mdl.U_)
+        assert util.relerr(np.vstack(mdl.P_)[cols], P) < TOL
+        Wn = np.vstack(mdl.W_non_normal_)
+        for b in range(2):
+            nu = np.linalg.norm(mdl.W_non_normal_[b], axis=0)
+            assert util.relerr(mdl.W_[b], mdl.W_non_normal_[b] / nu) < 1e-12
+        Wc = Wn / np.linalg.norm(Wn, axis=0)
+        R = Wc.dot(np.linalg.pinv(np.vstack(mdl.P_).T.dot(Wc)))                     # (:988)
+        assert util.relerr(mdl.R_, R) < TOL and util.relerr(mdl.beta_, R.dot(mdl.V_.T)) < TOL
+        monkeypatch.setenv("MBPLS_NIPALS_SUBSPACE", "0")                            # per-block association matrices
+        m2 = MBPLS(n_components=K, method="NIPALS").fit(X, Y)
+        monkeypatch.delenv("MBPLS_NIPALS_SUBSPACE")
+        assert m2.fit_plan_["solver"] != mdl.fit_plan_["solver"], m2.fit_plan_
+        assert all(abs(a - b) <= 2 for a, b in zip(m2.nipals_iterations_, mdl.nipals_iterations_))
+        assert util.compare(util.model_to_flat(m2), util.model_to_flat(mdl), 1e-7, what="Gram route vs maintained") < 1e-7
+        del m2
+        # ---- UNIPALS
+        mu = MBPLS(n_components=K, method="UNIPALS").fit(X, Y)
+        check_orthonormal(mu.Ts_)
+        # (no Z R_ == Ts_ check here: with several responses the reference takes ts as the first LEFT SINGULAR vector of
+        # the non-symmetric X X^T Y Y^T (:489-493), which is not X w / ||X w|| for its weights w = X^T u (:503))
+        Wraw, P = recurrence(Z, mu.Ts_, mu.U_)
+        assert util.relerr(np.vstack(mu.P_)[cols], P) < TOL
+        Wfit = np.vstack(mu.W_)
+        for b in range(2):
+            sel = (cols >= offs[b]) & (cols < offs[b + 1])
+            for k in range(K):
+                c = Wfit[cols[sel], k].dot(Wraw[sel, k]) / Wraw[sel, k].dot(Wraw[sel, k])
+                assert np.max(np.abs(Wfit[cols[sel], k] - c * Wraw[sel, k])) < TOL * np.max(np.abs(Wfit[cols[sel], k]))
+        monkeypatch.setenv("MBPLS_UNIPALS_NODEFLATE", "0")                          # explicitly deflated working copy
+        m2 = MBPLS(n_components=K, method="UNIPALS").fit(X, Y)
+        monkeypatch.delenv("MBPLS_UNIPALS_NODEFLATE")
+        assert util.compare(util.model_to_flat(m2), util.model_to_flat(mu), 1e-7, what="deflating vs maintained") < 1e-7
+        del m2, mu
+        # ---- SIMPLS (never deflates: P = Z^T Ts, Ts = Z R_, orthonormal scores, beta_ = R_ V_^T)
+        ms = MBPLS(n_components=K, method="SIMPLS").fit(X, Y)
+        check_orthonormal(ms.Ts_)
+        check_generic_products(ms, X, Y, blocks=False, check_u=False)
+        Pfit = np.vstack(ms.P_) if isinstance(ms.P_, list) else ms.P_
+        assert util.relerr(Pfit[cols], Z.T.dot(ms.Ts_)) < TOL
+        Ys = (Y - Y.mean(axis=0)) / Y.std(axis=0)
+        assert util.relerr(ms.V_, Ys.T.dot(ms.Ts_)) < TOL
+        assert util.relerr(ms.beta_, ms.R_.dot(ms.V_.T)) < 1e-12
+        cols2, data2 = download_sample(X, ranges[:3], width)
+        assert np.array_equal(data2, data[:, :cols2.size])                # the caller's matrix is intact
+    finally:
+        X.close()
+        ctx.trim_pool()
