@@ -441,6 +441,10 @@ class HipEngine(EngineBase):
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
         return x, t, g
 
+    def sweep_reads_once(self):
+        """a fused sweep (g = X^T v and X g) is ONE read of X: register-resident columns (not the two-phase long-column form)"""
+        return self.n <= min(8192, getattr(self.ctx, "long_columns_from", 8192)) or self.sparse
+
     def scaled_products(self):
         """after an implicit first pass (raw matrix, statistics known): the many-right-hand-side products X^T V / X W
         standardise their operand in registers as well"""

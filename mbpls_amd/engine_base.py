@@ -43,6 +43,9 @@ class EngineBase:
     def scaled_products(self):
         pass
 
+    def sweep_reads_once(self):
+        return True
+
     def stats_only_ok(self):
         return False
 

@@ -1110,7 +1110,7 @@ def fit_simpls(eng, Y, K, standardize):
     component the reference computes t = X r (:1006, r = S q) and p = X^T t (:1011) -- two reads of X.  Here the fused
     sweep pass (the NIPALS one: g = X^T v and X g in the same read) takes v = t: it returns the loadings p = X^T t AND
     a = X p.  Everything r is built from is a combination of vectors whose products with X are then known:
-        S_0 = X^T Y, X S_0                (one fused pass per response: v = Y[:, j])
+        S_0 = X^T Y, X S_0                (the first response with the statistics pass, the others by two products)
         v = p - V_s (V_s^T p)  (:1016)  ->  X v = a - (X V_s)(V_s^T p)
         S <- S - v (v^T S)     (:1019)  ->  X S <- X S - (X v)(v^T S)
     so t = X r = (X S) q needs no pass.  All p-length algebra (r = S q, the Gram-Schmidt step on v, the update of S)
@@ -1121,8 +1121,8 @@ def fit_simpls(eng, Y, K, standardize):
     q = Y.shape[1]
     if K + 1 + q > 32:
         return _fit_simpls_hostvec(eng, Y, K, standardize)
-    if q > K + 2:
-        return _fit_simpls_products(eng, Y, K, standardize)
+    if not eng.sweep_reads_once():
+        return _fit_simpls_products(eng, Y, K, standardize)     # tall data: a fused sweep is two reads there as well
     nz = K + 1 + q
     cS = K + 1                                              # first S column inside Z
     eng.slot("Z", nz); eng.slot("R", K); eng.slot("W", K); eng.slot("P", K)
@@ -1130,9 +1130,13 @@ def fit_simpls(eng, Y, K, standardize):
     XS = np.empty((n, q)); XV = np.empty((n, K))
     _, tb, _ = eng.prepare(standardize, v=Y[:, 0:1], alpha=1.0, g_slot=("Z", cS))       # S[:, 0] = X^T y_0 (:998), X S[:, 0]
     XS[:, 0] = tb.sum(axis=1)
-    for j in range(1, q):
-        tb, _ = eng.sweep(Y[:, j:j + 1], 1.0, ("Z", cS + j))
-        XS[:, j] = tb.sum(axis=1)
+    if q == 2:
+        tb, _ = eng.sweep(Y[:, 1:2], 1.0, ("Z", cS + 1))
+        XS[:, 1] = tb.sum(axis=1)
+    elif q > 2:                                             # the other responses: one X^T Y and one X W product
+        eng.scaled_products()
+        eng.xt_v(Y[:, 1:], 1.0, "Z", cS + 1)
+        XS[:, 1:] = eng.x_w_slot("Z", cS + 1, q - 1)
     rm = getattr(eng, "rowmask", None)
     inc = None if rm is None else (np.asarray(rm).ravel() != 0)
     Ts = np.empty((n, K)); U = np.empty((n, K)); Q = np.empty((q, K))
@@ -1190,7 +1194,8 @@ def fit_simpls(eng, Y, K, standardize):
 
 
 def _fit_simpls_products(eng, Y, K, standardize):
-    """The two-reads-per-component form (many responses, few components: q > K + 2).
+    """The two-reads-per-component form (tall data, n > 8192: the column passes are two streaming phases there, a fused
+    sweep would read X twice as well, and the matrix-core products stream faster).
     mbpls.py:995-1048 (de Jong 1993).  X is never deflated: S = X^T Y once, then per component
     t = X r and p = X^T t (two reads of X).  All p-length algebra (r = S q, the Gram-Schmidt step on v,
     S <- S - v v^T S) runs on the device in one p x (K+1+q) slot  Z = [V_s | p | S]; only q x q and

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -k several 2>&1 | tail -15
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "never_writes" 2>&1 | tail -4
