@@ -534,7 +534,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     q = Y.shape[1]
     max_iter = NIPALS_MAX_ITER if max_iter is None else max_iter
     if _nipals_on_subspace(eng, q):
-        _plan(eng, solver="nipals: inner loop in the q-space of its iterates, three passes per component")
+        _plan(eng, solver="nipals: inner loop in the q-space of its iterates, one pass per component (maintained products)")
         return _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     if _nipals_on_grams(eng, q):
         _plan(eng, solver="nipals: inner loop on per-block association matrices")
@@ -785,7 +785,7 @@ def fit_unipals(eng, Y, K, standardize):
     # so tall data takes the one-pass-per-component path as well (device-resident queue, X never written).
     wide = p_total > n or q == 1
     if wide and q > 1 and not eng.sparse and eng.opts.unipals_nodeflate:
-        _plan(eng, solver="unipals: never-deflated products (several responses)")
+        _plan(eng, solver="unipals: several responses, one pass per component (maintained products)")
         return _fit_unipals_wide_multi(eng, Y, K, standardize)
     sizes = _global_sizes(eng)
     eng.slot("Wc", K)
