@@ -190,8 +190,11 @@ class _StreamedColumns:
     runs -- the end of the fit then fetches R_ and beta_ only.  W_b[:, k] = w_b / ||w_b|| (:860, :510-512) is formed on
     the host from the fetched raw column."""
 
-    def __init__(self, eng, K, wslot, pslot="P", keep_raw=False):
+    def __init__(self, eng, K, wslot, pslot="P", keep_raw=False, q=None):
         self.eng, self.wslot, self.pslot, self.pending = eng, wslot, pslot, None
+        if q is not None:       # R_ / beta_ only exist at the very end: their pages are mapped while the GPU works
+            eng.host_array((eng.p, K), reserve="R")
+            eng.host_array((eng.p, q), reserve="beta")
         self.W = _host_array(eng, (eng.p, K))
         self.P = _host_array(eng, (eng.p, K))
         self.W_raw = _host_array(eng, (eng.p, K)) if keep_raw else None
@@ -362,6 +365,7 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     sizes = _global_sizes(eng)
     eng.slot("Wn", K); eng.slot("P", K); eng.slot("S", q + 1)      # S = [X^T (P Y) | the loadings of the component]
     eng.use_lazy_deflation(K, "P", prefer="lazy")           # (never deflates: the never-writes-X passes when they apply)
+    cols = _StreamedColumns(eng, K, "Wn", keep_raw=True, q=q)
     prod = _ResponseProducts(eng, Y, standardize)
     varxb = prod.varxb
     varx = varxb.sum()
@@ -373,7 +377,6 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     _norm(np.zeros((2, 1)), norm)                           # raises for invalid orders exactly as the reference (:887)
     kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
     c0 = np.zeros((q, 1)); c0[0, 0] = 1.0                   # the start vector Y[:, 0] (:838)
-    cols = _StreamedColumns(eng, K, "Wn", keep_raw=True)
     for k in range(K):
         Tp = Ts[:, :k]
         G0 = prod.total()                                   # X X^T P Y
@@ -732,6 +735,7 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
     sizes = _global_sizes(eng)
     eng.slot("Wc", K); eng.slot("P", K); eng.slot("S", q + 1)      # S = [X^T (P Y) | the loadings of the component]
     eng.use_lazy_deflation(K, "P", prefer="lazy")           # (never deflates: the never-writes-X passes when they apply)
+    cols = _StreamedColumns(eng, K, "Wc", q=q)
     prod = _ResponseProducts(eng, Y, standardize)
     varxb = prod.varxb
     varx = varxb.sum()
@@ -741,7 +745,6 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
     T = [np.empty((n, K)) for _ in range(B)]
     blk_nrm = np.empty((B, K)); tot_nrm = np.empty(K)
     evx, evy, evxb, Acorr = [], [], np.empty((B, K)), np.empty((B, K))
-    cols = _StreamedColumns(eng, K, "Wc")
     for k in range(K):
         Tp = Ts[:, :k]
         M = prod.total()
