@@ -410,14 +410,16 @@ def test_q1_fixed_point_option(gpu_required, monkeypatch):
     assert w < 1e-9
 
 
-def test_row_subset_fit_and_cross_val_predict(gpu_required):
+@pytest.mark.parametrize("q", [2, 4])
+def test_row_subset_fit_and_cross_val_predict(gpu_required, q):
     """Fits on a ROW SUBSET of a resident matrix == the oracle on the sliced arrays; cross_val_predict on the
-    device == a loop of oracle fits (what sklearn's cross_val_predict does with the reference)."""
+    device == a loop of oracle fits (what sklearn's cross_val_predict does with the reference).  Two and four
+    responses: the two ways the several-response solvers set up their maintained products."""
     import mbpls_amd
     from mbpls_amd import MBPLS, DeviceMatrix
     from mbpls_amd.model_selection import cross_val_predict
     n, p = 120, 900
-    X, Y = orc.make_latent(n, p, 2, r=6, seed=4)
+    X, Y = orc.make_latent(n, p, q, r=6, seed=4)
     blocks = [np.ascontiguousarray(X[:, :400]), np.ascontiguousarray(X[:, 400:])]
     ctx = mbpls_amd.get_context()
     Xd = DeviceMatrix(ctx, n, p, [0, 400, p])
