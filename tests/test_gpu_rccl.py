@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("which,q", [("torch", 2), ("torch", 1), ("rccl", 2), ("rccl", 1)])
+@pytest.mark.parametrize("which,q", [("torch", 2), ("torch", 1), ("rccl", 2), ("rccl", 1), ("rccl", 3)])
 def test_rccl_sharded_fit(gpu_required, which, q):
     """All four methods column-sharded over the visible GPUs, the exchange through torch.distributed ("nccl" = RCCL)
     or through the C ABI's own RCCL communicator (ncclAllReduce on the context's stream; with one response the whole
