@@ -22,6 +22,9 @@ value = ACHIEVED HBM traffic of the whole job / wall time [GB/s]: the X bytes th
         (sum of their algorithmic bytes, 8np per read-only pass -- PMC-measured traffic is 1.003x that,
         profiles/) x ranks / time per fit.  fit_wall_s and fits_per_s are printed beside it; the reference
         algorithm's un-fused byte count ("effective" GB/s) is an extra key, never `value`.
+Side legs of the N = 1 line (never `value`): shard_proxy (this problem / 8 through the RCCL communicator), explicit
+        deflation, end to end from host arrays, other_solvers_same_matrix (ten responses with NIPALS / UNIPALS, SIMPLS
+        and UNIPALS with one response on the same resident matrix), cpu_baseline.
 """
 import argparse
 import json
@@ -221,6 +224,8 @@ def main():
         extras = nipals_extras(ctx, mdl, X, Y, n, p, barrier_sync)
     if not a.no_extras and dist is None and a.method == "NIPALS" and q == 1 and p >= 8 * 1024:
         extras["shard_proxy"] = shard_proxy(ctx, mbpls_amd, dT, Y, r, n, p // 8, K, dt / a.steps)
+    if not a.no_extras and dist is None and a.method == "NIPALS" and q == 1 and len(offs) == 2:
+        extras["other_solvers_same_matrix"] = other_solvers(ctx, X, n, K, r)
     if dist is not None and not a.no_extras:
         extras["allreduce"] = time_allreduce(ctx, mbpls_amd.get_comm(), n * B + 3 * B + B * 40)
         extras["strong_scaling_c2"] = strong_scaling(ctx, mbpls_amd, dT, Y, r, rank, world, n, a.p, K, a.method,
@@ -512,6 +517,41 @@ def strong_scaling(ctx, mbpls_amd, dT, Y, r, rank, world, n, p_total, K, method,
     Xs.close()
     return {"workload": f"single-block NIPALS n={n} p={p_total} K={K} split over {world} GPUs", "fit_wall_s": round(dt, 5),
             "fits_per_s": round(1.0 / dt, 3), "nipals_iterations": list(getattr(mdl, "nipals_iterations_", []))}
+
+
+def other_solvers(ctx, X, n, K, r):
+    """The secondary configurations of SURVEY 8d on the SAME resident matrix (never `value`): ten responses (the paper
+    protocol's q) with NIPALS and UNIPALS, SIMPLS and UNIPALS with one response.  A fresh estimator per fit, one
+    warm-up and three timed fits each; passes = launches of X-sized kernels per fit (HIP-event profile)."""
+    from mbpls_amd import MBPLS
+    out = {}
+    for name, method, q in (("nipals_q10", "NIPALS", 10), ("unipals_q10", "UNIPALS", 10), ("simpls_q1", "SIMPLS", 1),
+                            ("unipals_q1", "UNIPALS", 1)):
+        Yq = planted(n, q, r, 0)[1]                      # the same latent scores as X (seed 0), q response columns
+        try:
+            MBPLS(n_components=K, method=method).fit(X, Yq)
+            ctx.profile(True); ctx.profile_reset()
+            walls, keep = [], []
+            for _ in range(3):
+                ctx.sync()
+                t1 = time.perf_counter()
+                keep.append(MBPLS(n_components=K, method=method).fit(X, Yq))
+                ctx.sync()
+                walls.append(time.perf_counter() - t1)
+            pr = ctx.profile_get(); ctx.profile(False)
+            m = keep[-1]
+            out[name] = {"fit_wall_s": round(float(np.median(walls)), 5),
+                         "passes_per_fit": sum(v["launches"] for v in pr.values()) // 3,
+                         "sum_of_passes_ms": round(sum(v["total_ms"] for v in pr.values()) / 3, 2),
+                         "solver": getattr(m, "fit_plan_", {}).get("solver"),
+                         "standardisation": getattr(m, "fit_plan_", {}).get("standardisation")}
+            if hasattr(m, "nipals_iterations_"):
+                out[name]["nipals_iterations_total"] = int(sum(m.nipals_iterations_))
+            del keep, m
+        except Exception as e:                           # noqa: BLE001 -- a side leg must not cost the line
+            ctx.profile(False)
+            out[name] = {"skipped": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def shard_proxy(ctx, mbpls_amd, dT, Y, r, n, p_shard, K, full_fit_s):

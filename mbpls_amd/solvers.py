@@ -1125,7 +1125,9 @@ def fit_simpls(eng, Y, K, standardize):
     if K + 1 + q > 32:
         return _fit_simpls_hostvec(eng, Y, K, standardize)
     if not eng.sweep_reads_once():
+        _plan(eng, solver="simpls: two products per component")
         return _fit_simpls_products(eng, Y, K, standardize)     # tall data: a fused sweep is two reads there as well
+    _plan(eng, solver="simpls: one fused sweep per component (maintained products)")
     nz = K + 1 + q
     cS = K + 1                                              # first S column inside Z
     eng.slot("Z", nz); eng.slot("R", K); eng.slot("W", K); eng.slot("P", K)
