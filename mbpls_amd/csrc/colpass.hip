@@ -124,9 +124,10 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   const double* prow = mine ? a.Pm + (int64_t)tid * a.ldp : nullptr;
   double dacc = 0.0, dk = 0.0;
 
-  // The statistics-only pass masks at the point of use (e = real ? x - K : 0): its loads stay select-free for ragged n
-  // as well, so the compiler's s_waitcnt lands one column later (n = 3000: 3.0 -> TB/s of the n = 4096 case).
-  constexpr bool LFULL = FULL || (STD && ISTD && SWEEP);
+  // Every pass masks at the point of USE (the statistics-only pass inside its own arithmetic, e = real ? x - K : 0; the
+  // others right where a column becomes the current one, below): the loads stay select-free for ragged n as well -- a
+  // select right behind the load forces the s_waitcnt there and the prefetched column stops overlapping the current one.
+  constexpr bool LFULL = true;
   double x[D][R];
   __shared__ double s_out[(STD && ISTD) ? 4 : 1][64];   // statistics-only pass: per-column outputs of 64 columns
   __shared__ double s_go[2][64];                          // g_j / p_j of up to 64 columns (see flush_outputs)
@@ -150,6 +151,14 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
       const int64_t jj = j + d;
       if (jj >= j1) break;
       double(&xc)[R] = x[d];
+      if constexpr (!FULL && !(STD && ISTD && SWEEP)) {
+        // rows beyond n, excluded samples (row mask) and the padding element of an odd n: zero, now that the column is needed
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const bool real = (((k & 1) ? rm.in_n1 : rm.in_n0) >> (k >> 1)) & 1u;
+          xc[k] = real ? xc[k] : 0.0;
+        }
+      }
       // STD + ISTD = statistics-only flavour of the standardise pass: nothing is stored, the column stays RAW in
       // registers and the first sweep runs in raw-column space exactly like the implicit-standardisation passes that
       // follow (same arithmetic on the same inputs: the second NIPALS pass reproduces ts to a few ulp).  ONE
@@ -526,7 +535,7 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   ProfScope prof(ctx, kind, 8.0 * (double)a.n * (double)p * (writes ? 2.0 : 1.0));
   Cfg cfg;
   int T = 0;
-  if (!pick_cfg(ctx, a.n, &cfg, &T, STD || (DEFL && SWEEP))) {
+  if (!pick_cfg(ctx, a.n, &cfg, &T, STD || (DEFL && SWEEP), true)) {
     set_error("column passes support n <= 65536 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;
   }
@@ -583,6 +592,7 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   else if (cfg.R == 8 && cfg.TMAX == 512) MB_LAUNCH_D(8, 512);
   else if (cfg.R == 8) MB_LAUNCH_D(8, 1024);
   else if (cfg.R == 16 && cfg.TMAX == 512) MB_LAUNCH_D(16, 512);
+  else if (cfg.R == 10) MB_LAUNCH(10, 512, 2);      // 4096 < n <= 5120, single-reduction passes: eight full waves
   else if (istd) {
     set_error("implicit standardisation / statistics-only passes need n <= 8192 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;

@@ -103,11 +103,11 @@ struct Cfg {
 };
 
 // Choose rows-per-thread R and the workgroup size T = roundup(ceil(n/R), 64) <= TMAX.
-static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std_pass = false) {
+static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std_pass = false, bool has_r10 = false) {
   // preference order: smallest register footprint that still covers n with <= TMAX threads
   // the last two are correctness fallbacks for very long columns (8192 < n <= 65536): the column no longer
   // fits the register budget of 1024 threads, the compiler spills to scratch -> slow but exact
-  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}, {4, 1024}, {32, 1024}, {64, 1024}};
+  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}, {10, 512}, {4, 1024}, {32, 1024}, {64, 1024}};
   auto fits = [&](const Cfg& c, int* t) {
     int64_t need = (n + c.R - 1) / c.R;
     need = (need + 63) / 64 * 64;
@@ -124,6 +124,13 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
   // table vs R=16: n=2048 sweep 4.99 vs 3.78 ms, n=6000 5.09 vs 4.30 ms; n=4096 loadings-only 4.64 vs 5.05 ms).
   // Rule: the largest R in {16, 8, 4, 2} that still gives a full wave of real threads.
   const bool tuned8 = !std_pass && n > 3584 && n <= 4096;
+  // just above 4096 the single-reduction passes do better with ten rows per thread -- eight full waves -- than with sixteen
+  // on five (measured, 8 GB matrices, R = 10 vs 16: n = 4500 sweep 5.80 vs 5.48 TB/s, loadings only 6.73 vs 6.04; n = 5000
+  // 6.08 vs 5.78, 6.62 vs 6.30; from n = 6000 on there is nothing in it; the two-reduction passes lose 8 % with R = 10)
+  if (has_r10 && ctx->rows_per_thread <= 0 && !std_pass && n > 4096 && n <= 5120) {   // (colpass.hip only)
+    *cfg = Cfg{10, 512};
+    return fits(*cfg, T);
+  }
   if (ctx->rows_per_thread <= 0 && !tuned8) {
     static const Cfg fat[] = {{16, 512}, {8, 512}, {4, 512}, {2, 256}};
     for (const Cfg& c : fat)
@@ -134,13 +141,13 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
   }
   if (ctx->rows_per_thread > 0) {
     for (const Cfg& c : table)
-      if (c.R == ctx->rows_per_thread && fits(c, T)) {
+      if (c.R == ctx->rows_per_thread && (has_r10 || c.R != 10) && fits(c, T)) {
         *cfg = c;
         return true;
       }
   }
   for (const Cfg& c : table)
-    if (fits(c, T)) {
+    if ((has_r10 || c.R != 10) && fits(c, T)) {
       *cfg = c;
       return true;
     }

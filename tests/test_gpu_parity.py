@@ -1052,3 +1052,26 @@ def test_large_host_to_device_copies_round_trip(gpu_required, mbytes):
     assert np.array_equal(d1.get(), a)
     assert np.array_equal(d2.get(), a)
     d1.free(); d2.free()
+
+
+@pytest.mark.parametrize("n", [4097, 4500, 5119, 5121, 6001, 8191])
+def test_ragged_sample_counts_above_4096(gpu_required, monkeypatch, n):
+    """4096 < n < 8192: columns that do not fill their workgroup (loads without selects, masked where a column becomes the
+    current one; ten rows per thread for the single-reduction passes up to n = 5120, sixteen otherwise), odd n (one padding
+    element per column), never-writes-X and stored / explicitly deflating passes -- against the oracle."""
+    from mbpls_amd import MBPLS
+    X, Y = orc.make_latent(n, 1500, 1, seed=n)
+    X = X + 3.0
+    blocks = [np.ascontiguousarray(X[:, :700]), np.ascontiguousarray(X[:, 700:])]
+    ref = orc.fit(blocks, Y, n_components=3, method="NIPALS")
+    mdl = MBPLS(n_components=3).fit(blocks, Y)
+    assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * 3
+    assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"ragged n={n}") < 1e-9
+    assert util.relerr(mdl.predict(blocks), orc.predict(ref, blocks)) < 1e-9
+    monkeypatch.setenv("MBPLS_DEFLATION", "explicit")
+    monkeypatch.setenv("MBPLS_IMPLICIT_STD", "0")
+    m2 = MBPLS(n_components=3).fit(blocks, Y)
+    assert util.compare(util.model_to_flat(m2), util.model_to_flat(ref), TOL, what=f"ragged n={n}, stored") < 1e-9
+    mu = MBPLS(n_components=3, method="UNIPALS").fit(blocks, Y)
+    ru = orc.fit(blocks, Y, n_components=3, method="UNIPALS", full_svd=True)
+    assert util.compare(util.model_to_flat(mu), util.model_to_flat(ru), TOL, what=f"ragged n={n}, UNIPALS") < 1e-9

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python3 bench.py --cpu-cols 0 --e2e-cols 0 > gpurun_out/bench_quick.log 2>&1; echo rc=$?
-tail -1 gpurun_out/bench_quick.log | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['fit_wall_s']); print(json.dumps(d['other_solvers_same_matrix'], indent=1))"
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "ragged_sample" 2>&1 | tail -6
+timeout 600 python tools/ab_rows.py 4500,5000 2>&1 | grep "^n=\|failed"
