@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "ragged_sample" 2>&1 | tail -6
-timeout 600 python tools/ab_rows.py 4500,5000 2>&1 | grep "^n=\|failed"
+mkdir -p gpurun_out/shapes
+timeout 900 python tools/time_shapes.py 8 NIPALS 1 2>/dev/null | grep "^n=" > gpurun_out/shapes/r03_shapes.txt
+timeout 600 python tools/time_shapes.py 8 UNIPALS 1 1200,2500,3000,5000,6000,7000 2>/dev/null | grep "^n=" >> gpurun_out/shapes/r03_shapes.txt
+cat gpurun_out/shapes/r03_shapes.txt | cut -c1-120

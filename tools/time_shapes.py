@@ -24,10 +24,12 @@ for n in sizes:
     X = DeviceMatrix(ctx, n, p, [0, p // 3, p])
     X.fill_latent(ctx.from_host(Ts), 16, 0.5, 1234, 0)
     ctx.sync()
-    m = MBPLS(n_components=5, method=method)
+    keep = []
     for rep in range(3):
         ctx.profile(rep == 2)
         ctx.profile_reset()
+        m = MBPLS(n_components=5, method=method)      # a fresh estimator per fit (as bench.py), released after the timing
+        keep.append(m)
         t0 = time.perf_counter(); m.fit(X, Y); ctx.sync(); t1 = time.perf_counter()
     prof = ctx.profile_get()
     ctx.profile(False)
@@ -35,4 +37,4 @@ for n in sizes:
           "  ".join(f"{k}: {v['avg_ms']:.2f} ms {v['GBps']:.0f} GB/s x{v['launches']}" for k, v in prof.items()),
           flush=True)
     X.close()
-    del X
+    del X, keep, m
