@@ -25,7 +25,8 @@ __global__ __launch_bounds__(TMAX) void k_axpy_cols(const double* __restrict__ X
   double x[D][R];
 #pragma unroll
   for (int d = 0; d < D; ++d)
-    if (j0 + d < j1) load_col<R, FULL>(x[d], X + (j0 + d) * ld, rm);
+    // select-free loads for ragged n too: rows beyond n only ever reach accumulators that are never stored
+    if (j0 + d < j1) load_col<R, true>(x[d], X + (j0 + d) * ld, rm);
   // the weights of 64 columns at a time: one coalesced load per wave, then a lane broadcast per column (a global
   // load of g[j] per column would sit on the critical path of every column)
   const int lane = tid & 63;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(TMAX) void k_axpy_cols(const double* __restrict__ X
       const double gj = __longlong_as_double((long long)(((unsigned long long)ghi << 32) | glo));
 #pragma unroll
       for (int k = 0; k < R; ++k) acc[k] = fma(gj, x[d][k], acc[k]);
-      if (jj + D < j1) load_col<R, FULL>(x[d], X + (jj + D) * ld, rm);
+      if (jj + D < j1) load_col<R, true>(x[d], X + (jj + D) * ld, rm);
     }
     // keep the waves of the workgroup on the same columns: without any reduction they drift apart and the eight
     // 1 KB pieces of a column stop arriving at HBM together
