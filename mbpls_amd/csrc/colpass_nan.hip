@@ -99,7 +99,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   double x[D][R];
 #pragma unroll
   for (int d = 0; d < D; ++d)
-    if (j0 + d < j1) load_col<R, FULL>(x[d], a.src + (j0 + d) * ld, rm);
+    if (j0 + d < j1) load_col<R, true>(x[d], a.src + (j0 + d) * ld, rm);   // select-free; masked at the point of use
 
   for (int64_t j = j0; j < j1; j += D) {
 #pragma unroll
@@ -107,7 +107,15 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
       const int64_t jj = j + d;
       if (jj >= j1) break;
       double(&xc)[R] = x[d];
-      // rows beyond n were loaded as 0: present, and without weight in any sum
+      if constexpr (!FULL) {
+        // rows beyond n / excluded samples become 0 now that the column is needed (a select right behind the load would
+        // stall the prefetch): present, and without weight in any sum
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const bool real = (((k & 1) ? rm.in_n1 : rm.in_n0) >> (k >> 1)) & 1u;
+          xc[k] = real ? xc[k] : 0.0;
+        }
+      }
       unsigned pm = 0u;
 #pragma unroll
       for (int k = 0; k < R; ++k) pm |= ((xc[k] == xc[k]) ? 1u : 0u) << k;
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
           dac[k] += pr ? g2 : 0.0;
         }
       }
-      if (jj + D < j1) load_col<R, FULL>(xc, a.src + (jj + D) * ld, rm);
+      if (jj + D < j1) load_col<R, true>(xc, a.src + (jj + D) * ld, rm);
     }
   }
 
