@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_sparse.py -x -q 2>&1 | tail -3
+PYTHONPATH=$GRAFT_REPO_ROOT/_ab_old timeout 300 python tools/_ab_explicit.py 2>/dev/null | tail -5
+PYTHONPATH=$GRAFT_REPO_ROOT timeout 300 python tools/_ab_explicit.py 2>/dev/null | tail -5
+PYTHONPATH=$GRAFT_REPO_ROOT/_ab_old timeout 300 python tools/_ab_explicit.py 2>/dev/null | tail -5
