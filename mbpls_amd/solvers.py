@@ -529,6 +529,27 @@ def _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     return res
 
 
+def _fit_nipals_q1_fixed_point(eng, Y, K, standardize, calc_all):
+    """OPT-IN (MBPLS_NIPALS_Q1_FIXED_POINT=1, off by default).  One response: u after the first pass of a component is
+    sign(v) y/||y|| whatever ts was (v is 1 x 1, and v = y^T ts > 0: a sum of squares), so the second pass of the
+    reference's loop (:841) computes w~_2 = ||y|| w~_1 and reproduces ts exactly -- the iteration is at its fixed point
+    after ONE pass and the second only re-derives it.  Without it a component is: weights X_k^T u with u = y/||y||, block
+    scores, ts, loadings -- which is UNIPALS with one response (:481-572: sw_b = t_b^T u / u^T u is proportional to
+    ||w~_b||, so ts = T sw is X w / ||X w||): the same model, fitted by the one-pass-per-component queue of fit_unipals.
+    NIPALS' own attributes on top: W_non_normal_ (the raw weights of the last sweep vector, :975) and the iteration count,
+    reported as 1 per component."""
+    res = fit_unipals(eng, Y, K, standardize)
+    _plan(eng, solver="nipals, one response, fixed point after one pass: " + str(eng.plan.get("solver", "")).replace("unipals: ", ""))
+    res.W_non_normal_ = _split(eng.fetch("Wc"), eng.block_offsets)
+    res.nipals_iterations_ = [1] * K
+    res.nipals_converged_ = [True] * K
+    if not calc_all:                                        # (:932-964 are skipped by the reference then)
+        B = eng.nblocks
+        res.update(explained_var_x_=[], explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)),
+                   A_corrected_=np.empty((B, 0)))
+    return res
+
+
 def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max_iter=None):
     """mbpls.py:809-993.  Per component: iterate {sweep(u) -> T -> sw, ts -> v -> u} until
     ||ts_old - ts|| <= max_tol (never on the first pass, :884), then p = X^T ts and
@@ -545,6 +566,9 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     sizes = _global_sizes(eng)
     resp = _Responses(Y)
     Y = resp.Y                                              # missing responses (sparse_data=True) as zeros + masks
+    if q == 1 and eng.opts.q1_fixed_point and not eng.sparse and not resp.sparse and max_iter >= 1:
+        _norm(np.zeros((2, 1)), norm)                       # raises for invalid orders exactly as the reference (:887)
+        return _fit_nipals_q1_fixed_point(eng, Y, K, standardize, calc_all)
     u0 = resp.start()
     alpha0 = 1.0 / u0.T.dot(u0).item()
     eng.slot("Wn", K)
@@ -553,7 +577,6 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     # responses iterate 50-500 times per component (paper protocol, q = 10): every sweep then pays the lazy
     # correction (~6 %), far more than one rewrite of X per component (measured 7.05 s -> 6.72 s).
     eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
-    q1_fixed_point = q == 1 and eng.opts.q1_fixed_point and not eng.sparse
     Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
     T = [np.empty((n, K)) for _ in range(B)]
     nu_all = np.empty((B, K))
@@ -570,7 +593,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     _norm(np.zeros((2, 1)), norm)
     kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
     k_start = 0
-    if not q1_fixed_point and not resp.sparse and max_iter >= 2 and eng.resident_supported(q, K, kind):
+    if not resp.sparse and max_iter >= 2 and eng.resident_supported(q, K, kind):
         # One response: the whole fit is queued on the device (two iterations per component -- what one response takes),
         # the host reads the results once.  Components the speculation did not hold for are resumed below.
         first = eng.deferred_first_pass(standardize, u0, alpha0, ("Wn", 0))
@@ -651,16 +674,6 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
             v = resp.loadings(ts)                           # (:899)
             u = resp.scores(v)                              # (:911-913)
             run += 1
-            if q1_fixed_point and run == 2:
-                # OPT-IN (off by default).  One response: u after the first pass is sign(v) Y/||Y|| whatever ts
-                # was (v is 1 x 1, and v = Y^T ts > 0 because Y^T ts is a sum of squares), so the second pass
-                # would compute w~_2 = ||Y|| w~_1 and reproduce ts exactly: the iteration is at its fixed point
-                # and the reference's second sweep (:841, run 2) only re-derives it.  Skip it, rescale w~.
-                ynorm = float(np.linalg.norm(u0))
-                eng.right_mul(("Wn", k, 1), np.array([[ynorm]]), ("Wn", k))
-                eng.sync()              # the column is streamed to the host on another stream right after
-                nu = nu * ynorm
-                diff = 0.0
             if run - 1 >= max_iter and diff > max_tol:
                 warnings.warn(f"NIPALS component {k}: no convergence to max_tol={max_tol} after {max_iter} "
                               f"iterations (last diff {diff:.3e}); the reference would loop forever here.")
