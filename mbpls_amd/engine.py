@@ -175,7 +175,11 @@ class HipEngine(EngineBase):
 
     def _host_for_slot(self, name, shape):
         a = getattr(self, "_host_ready", {}).pop(name, None)
-        return a if a is not None and a.shape == tuple(shape) else self.host_array(shape)
+        if a is not None and a.shape == tuple(shape):
+            return a
+        # not reserved ahead: the copy that follows at once maps the pages itself -- handing the array to the helper
+        # thread as well would only keep that thread busy (80 MB: ~50 ms) when the NEXT fit wants its R_ / beta_ mapped
+        return self.host_array(shape, prefault=False)
 
     def fetch(self, name, overlapped=False, out=None):
         """D2H of a whole slot.  overlapped=True: on the copy stream, not ordered behind the kernels queued on
