@@ -9,7 +9,7 @@ from oracle import mbpls_oracle_sparse as ors
 from tests import util
 
 
-def run(cases, seed, verbose=True):
+def run(cases, seed, verbose=True, big=False):
     from mbpls_amd import MBPLS
     warnings.filterwarnings("ignore")
     rng = np.random.RandomState(seed)
@@ -17,8 +17,10 @@ def run(cases, seed, verbose=True):
     worst, bad = 0.0, 0
     for c in range(cases):
         n = int(rng.choice([rng.randint(3, 40), rng.randint(40, 700), rng.choice([64, 128, 256, 512, 1024])]))
+        if big:      # register-resident columns (1024 < n <= 8192), ragged and odd sample counts included
+            n = int(rng.choice([rng.randint(1025, 4096), rng.randint(4097, 8192), rng.choice([2048, 4096, 4097, 8191, 8192])]))
         p = int(rng.choice([rng.randint(1, 30), rng.randint(30, 3000)]))
-        q = int(rng.choice([1, 1, 2, 3]))
+        q = int(rng.choice([1, 1, 2, 3, 5])) if big else int(rng.choice([1, 1, 2, 3]))
         K = int(min(rng.randint(1, 5), max(1, min(n - 1, p))))
         method = str(rng.choice(["NIPALS", "NIPALS", "UNIPALS", "KERNEL", "SIMPLS"]))
         std = bool(rng.rand() < 0.7)

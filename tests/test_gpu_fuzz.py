@@ -11,3 +11,10 @@ def test_random_problems(gpu_required):
     bad, worst = fuzz.run(150, seed=11, verbose=False)
     assert bad == 0
     assert worst < 1e-8, worst
+
+
+def test_random_problems_register_resident_columns(gpu_required):
+    """the same sweep on 1024 < n <= 8192 (ragged and odd sample counts, up to five responses)"""
+    bad, worst = fuzz.run(25, seed=5, verbose=False, big=True)
+    assert bad == 0
+    assert worst < 1e-8, worst

@@ -1,4 +1,5 @@
-"""Randomised parity sweep on the GPU (see tests/fuzz.py):  python tools/fuzz_parity.py [cases] [seed]"""
+"""Randomised parity sweep on the GPU (see tests/fuzz.py):  python tools/fuzz_parity.py [cases] [seed] [big]
+(big: 1024 < n <= 8192 instead of the few-samples shapes)"""
 import os
 import sys
 
@@ -6,5 +7,5 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import fuzz
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-bad, worst = fuzz.run(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad, worst = fuzz.run(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0, big=len(sys.argv) > 3 and sys.argv[3] == "big")
 print(f"{cases} cases, {bad} failures, worst relerr {worst:.2e}")
