@@ -127,7 +127,7 @@ class HipEngine(EngineBase):
                     a.free()
             self.Gb = None
         if getattr(self, "_ss", None) is not None:
-            for key in ("Y", "G", "c0", "ts", "u", "v", "c", "state", "moments"):
+            for key in ("Y", "inp", "out", "moments"):
                 self._ss[key].free()
             self._ss = None
         if getattr(self, "_gp", None) is not None:
@@ -964,23 +964,28 @@ class HipEngine(EngineBase):
         ctx = self.ctx
         st = getattr(self, "_ss", None)
         if st is None or st["q"] != q:
-            st = self._ss = dict(q=q, Y=ctx.from_host(np.asfortranarray(Y)), G=ctx.empty((n, q)), c0=ctx.empty(q),
-                                 ts=ctx.empty(n), u=ctx.empty(n), v=ctx.empty(q), c=ctx.empty(q), state=ctx.empty(3),
-                                 moments=ctx.empty(3 * q * q))
-        st["G"].set(G)
-        st["c0"].set(np.ascontiguousarray(c0, dtype=np.float64).ravel())
+            # inputs [G | c0] and outputs [state(3) | v(q) | c_used(q) | ts(n) | u(n)] as ONE device array each: one
+            # upload and one download per component instead of two and five blocking copies
+            st = self._ss = dict(q=q, Y=ctx.from_host(np.asfortranarray(Y)), inp=ctx.empty(n * q + q),
+                                 out=ctx.empty(3 + 2 * q + 2 * n), moments=ctx.empty(3 * q * q),
+                                 host_in=np.empty(n * q + q))
+        hin = st["host_in"]
+        hin[:n * q] = np.asarray(G, dtype=np.float64).T.ravel()          # column-major n x q
+        hin[n * q:] = np.asarray(c0, dtype=np.float64).ravel()
+        st["inp"].set(hin)
+        dG, dc0, o = st["inp"].ptr, st["inp"].ptr + 8 * n * q, st["out"].ptr
+        dstate, dv, dc, dts, du = o, o + 8 * 3, o + 8 * (3 + q), o + 8 * (3 + 2 * q), o + 8 * (3 + 2 * q + n)
         if qspace:
-            _capi.check(ctx.lib.mbpls_hip_nipals_subspace_qloop(ctx.handle, n, q, st["G"].ptr, st["Y"].ptr, st["c0"].ptr,
-                                                                float(tol), int(max_iter), st["ts"].ptr, st["u"].ptr,
-                                                                st["v"].ptr, st["c"].ptr, st["state"].ptr,
-                                                                st["moments"].ptr))
+            _capi.check(ctx.lib.mbpls_hip_nipals_subspace_qloop(ctx.handle, n, q, dG, st["Y"].ptr, dc0, float(tol),
+                                                                int(max_iter), dts, du, dv, dc, dstate, st["moments"].ptr))
         else:
-            _capi.check(ctx.lib.mbpls_hip_nipals_subspace_loop(ctx.handle, n, q, st["G"].ptr, st["Y"].ptr, st["c0"].ptr,
-                                                               int(norm_kind), float(tol), int(max_iter), st["ts"].ptr,
-                                                               st["u"].ptr, st["v"].ptr, st["c"].ptr, st["state"].ptr))
-        state = st["state"].get()
-        return (int(state[1]), state[0] == 2.0, st["ts"].get().reshape(-1, 1), st["u"].get().reshape(-1, 1),
-                st["v"].get().reshape(-1, 1), st["c"].get().reshape(-1, 1))
+            _capi.check(ctx.lib.mbpls_hip_nipals_subspace_loop(ctx.handle, n, q, dG, st["Y"].ptr, dc0, int(norm_kind),
+                                                               float(tol), int(max_iter), dts, du, dv, dc, dstate))
+        h = st["out"].get()
+        state = h[:3]
+        return (int(state[1]), state[0] == 2.0, h[3 + 2 * q:3 + 2 * q + n].reshape(-1, 1).copy(),
+                h[3 + 2 * q + n:].reshape(-1, 1).copy(), h[3:3 + q].reshape(-1, 1).copy(),
+                h[3 + q:3 + 2 * q].reshape(-1, 1).copy())
 
     def gram_apply(self, Z):
         """A @ Z for a host n x c matrix (A symmetric, so the feature-major product X W is A Z)."""
