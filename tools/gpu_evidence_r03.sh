@@ -1,4 +1,5 @@
-# Round-3 evidence (everything named profiles/r03_*): run on the GPU box from the repo root, e.g.
+# Round-3 evidence (everything named profiles/r03_* except the paper protocol, tools/paper_protocol.py, and the A/B notes):
+# run on the GPU box from the repo root, e.g.
 #   gpurun --timeout 3000 -- 'bash tools/gpu_evidence_r03.sh'
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03ev
@@ -10,6 +11,7 @@ timeout 600 python3 bench.py --dist --p 250000 --steps 5 --warmup 3 --cpu-cols 0
 timeout 300 python tools/iters_deep.py 1000000 20 30 38 2>&1 | grep "^K=" > $O/r03_deep_iterations.txt
 timeout 900 python tools/time_cv.py > $O/r03_time_cv.txt 2>&1
 for c in c3 c4 simpls nipals_q10 unipals_q10 nipals_mb; do timeout 600 python tools/bench_configs.py $c 2>/dev/null | tail -1 >> $O/r03_other_configs_lines.jsonl; done
+( timeout 900 python tools/time_shapes.py 8 NIPALS 1 2>/dev/null | grep '^n='; timeout 600 python tools/time_shapes.py 8 UNIPALS 1 1200,2500,3000,5000,6000,7000 2>/dev/null | grep '^n=' ) > $O/r03_shapes.txt
 timeout 600 python tools/time_long.py 1000000 2000 > $O/r03_long_columns.txt 2>&1; timeout 600 python tools/time_long.py 16384 100000 >> $O/r03_long_columns.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 6 --cpu-cols 0 --e2e-cols 0 --no-extras > $O/bench_under_rocprof.log 2>&1; echo stats rc=$?
