@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 4   /* 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
+#define MBPLS_HIP_ABI_VERSION 5   /* 5: mbpls_hip_cluster_status (one-read passes for long columns); 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
 
 enum {
   MBPLS_OK = 0,
@@ -73,9 +73,18 @@ int mbpls_hip_device_info(mbpls_ctx* ctx, char* name, size_t name_len, int* comp
  * "long_columns_from" (0..65536, default 8192: matrices with more samples than this use the two-phase long-column
  * passes instead of the register-resident ones, which spill above 8192 and have no lazy / implicit flavour there),
  * "sub_columns" (default 1: matrices with n <= 1024 samples run the column passes with several columns per wave;
- * 0 = one column per workgroup at every n -- same results, kept for A/B tests).
+ * 0 = one column per workgroup at every n -- same results, kept for A/B tests),
+ * "cluster_passes" (default 1: the never-writes-X passes of long columns -- statistics + sweep, sweep, loadings + sweep
+ * on the raw matrix -- run on clusters of workgroups that share a column and read X ONCE, csrc/colpass_cluster.hip;
+ * 0 = the two-phase passes, two reads), "cluster_slab_rows" (128..8192, default 8192: rows of a column held by one
+ * workgroup of a cluster), "cluster_spin_limit" (polls before a hand-off between the workgroups of a cluster gives up).
  * Returns MBPLS_ERR_ARG for unknown keys. */
 int mbpls_hip_set_tunable(mbpls_ctx* ctx, const char* key, int value);
+/* Cluster passes (long columns, one read of X; replaces the two visits numpy's X.T.dot(u) :856 and X.dot(w) :875 make):
+ * the workgroups of a cluster hand partial column sums to each other inside the launch, every wait bounded by
+ * "cluster_spin_limit".  Drains the stream and returns in *timeouts how many waits gave up since the last call
+ * (0 on a healthy device; results of a pass that gave up are garbage and the caller must raise). */
+int mbpls_hip_cluster_status(mbpls_ctx* ctx, int* timeouts);
 
 /* ---- raw device memory (so a host needs nothing but this library) ------------------------- */
 int mbpls_hip_malloc(mbpls_ctx* ctx, size_t bytes, void** d_ptr);

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmbpls_hip.so")
 ROW_MAJOR, COL_MAJOR = 0, 1
 COMM_ID_BYTES = 128
 SCALE_FIT, SCALE_APPLY, SCALE_NONE = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i64, _dbl, _int, _sz = C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
@@ -46,6 +46,7 @@ SIGNATURES = {
     "mbpls_hip_sync": (_int, [_vp]),
     "mbpls_hip_device_info": (_int, [_vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_sz), C.POINTER(_sz)]),
     "mbpls_hip_set_tunable": (_int, [_vp, C.c_char_p, _int]),
+    "mbpls_hip_cluster_status": (_int, [_vp, C.POINTER(_int)]),
     "mbpls_hip_malloc": (_int, [_vp, _sz, _pp]),
     "mbpls_hip_free": (_int, [_vp, _vp]),
     "mbpls_hip_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
@@ -272,12 +273,21 @@ class Context:
         check(self.lib.mbpls_hip_device_info(self.handle, name, 256, C.byref(cus), C.byref(tot), C.byref(free)))
         return dict(name=name.value.decode(), compute_units=cus.value, total_bytes=tot.value, free_bytes=free.value)
 
-    long_columns_from = 8192     # mirrors the C default; n above it -> two-phase long-column passes
+    long_columns_from = 8192     # mirrors the C default; n above it -> long-column passes
+    cluster_passes = 0 if os.environ.get("MBPLS_HIP_CLUSTER_PASSES", "1") == "0" else 1   # ... on clusters of workgroups
 
     def set_tunable(self, key, value):
         check(self.lib.mbpls_hip_set_tunable(self.handle, key.encode(), int(value)))
         if key == "long_columns_from":
             self.long_columns_from = max(0, min(int(value), 65536))
+        if key == "cluster_passes":
+            self.cluster_passes = 1 if value else 0
+
+    def cluster_status(self):
+        """hand-offs of the cluster passes (long columns) that gave up since the last call; drains the stream"""
+        v = _int(0)
+        check(self.lib.mbpls_hip_cluster_status(self.handle, C.byref(v)))
+        return int(v.value)
 
     def timer_start(self):
         check(self.lib.mbpls_hip_timer_start(self.handle))

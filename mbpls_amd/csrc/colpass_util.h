@@ -158,7 +158,8 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
 // the per-chunk scalars [ssq_g, ssq_p, ssq_x, -] into the d_ssq_* outputs, lazy-deflation sums into d_d)
 int reduce_chunks(mbpls_ctx* ctx, const mbpls_mat* m, const double* part_t, const double* part_s,
                   double* d_t, double* d_ssq_g, double* d_ssq_p, double* d_ssq_x,
-                  const double* part_d = nullptr, int nd = 0, double* d_d = nullptr, double* d_amp = nullptr);
+                  const double* part_d = nullptr, int nd = 0, double* d_d = nullptr, double* d_amp = nullptr,
+                  const ChunkTable* table = nullptr /* default: the matrix's fine table */);
 
 
 // Arguments of a column pass (colpass.hip; colpass_sub.hip for few samples).
@@ -282,5 +283,22 @@ int long_loadings_sweep_raw(const mbpls_mat* m, const double* d_ts, double inv_t
 int long_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_mean, double* d_scale, double* d_rscale,
                                  double* d_r2, double* d_ssq_x, double* d_amp, const double* d_v, double alpha,
                                  double* d_g, double* d_t, double* d_ssq_g);
+
+
+// colpass_cluster.hip: the never-writes-X passes for long columns with ONE read of X -- a cluster of workgroups shares
+// a column (same arguments as the mbpls_hip_*_lazy_scaled / _stats_sweep entry points; true-space outputs written by
+// the kernel itself)
+bool cluster_columns(const mbpls_ctx* ctx, int64_t n);
+int cluster_sweep_lazy(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g,
+                       const double* d_P, int64_t ldp, int kprev, const double* d_cu, double* d_d, const double* d_r2,
+                       const double* d_mean);
+int cluster_loadings_sweep(const mbpls_mat* m, const double* d_ts, double inv_tt, int deflate, double* d_p,
+                           double* d_ssq_p, const double* d_v, double alpha, double* d_g, double* d_t, double* d_ssq_g,
+                           const double* d_P, int64_t ldp, int kprev, const double* d_cu, const double* d_ce,
+                           double* d_d, const double* d_r2, const double* d_mean);
+int cluster_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_mean, double* d_scale, double* d_r2,
+                                    double* d_ssq_x, double* d_amp, const double* d_v, double alpha, double* d_g,
+                                    double* d_t, double* d_ssq_g);
+int cluster_stats_reduce(const mbpls_mat* src, double* d_t, double* d_ssq_g, double* d_ssq_x, double* d_amp);
 
 }  // namespace mbpls

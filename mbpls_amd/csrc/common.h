@@ -68,6 +68,13 @@ struct mbpls_ctx {
   int64_t gram_slice_features = 131072;   // Gram: features per split-K slice for long feature ranges (0 = off)
   int sub_columns = 1;       // n <= 256: several columns per wave (colpass_sub.hip); 0 = the one-column-per-workgroup kernels
   int64_t long_columns_from = 8192;    // n above this: streamed-column kernels (colpass_long.hip)
+  // ... and among those, the never-writes-X passes run on CLUSTERS of workgroups that share a column and read X once
+  // (colpass_cluster.hip); 0 = the two-phase passes of colpass_long.hip for everything
+  int cluster_passes = 1;
+  int64_t cluster_slab_rows = 8192;    // rows of a column held by one workgroup of a cluster (tests lower it)
+  unsigned cluster_spin_limit = 1u << 24;   // polls before a cluster hand-off gives up
+  void* cl_ws = nullptr;               // fine-grained: [error word | exchange slots] of the cluster passes
+  size_t cl_ws_bytes = 0;
   // workspace for chunk partials (grown on demand, never shrunk)
   void* ws = nullptr;
   size_t ws_bytes = 0;
@@ -125,6 +132,8 @@ struct mbpls_mat {
   bool owns = false;
   mbpls::ChunkTable fine;    // column-pass kernels (one workgroup per chunk, full columns)
   mbpls::ChunkTable coarse;  // row-slab kernels (x_w)
+  mbpls::ChunkTable cluster; // cluster passes (colpass_cluster.hip): one chunk per cluster of workgroups, built on demand
+  int cluster_G = 0;         // ... for this many clusters
 };
 
 namespace mbpls {

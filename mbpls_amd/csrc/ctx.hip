@@ -214,6 +214,7 @@ int mbpls_hip_create(int device, void* stream, mbpls_ctx** out) {
   if (const char* e = getenv("MBPLS_HIP_ROWS_PER_THREAD")) ctx->rows_per_thread = atoi(e);
   if (const char* e = getenv("MBPLS_HIP_PREFETCH")) ctx->prefetch = atoi(e);
   if (const char* e = getenv("MBPLS_HIP_XW_CHUNKS_PER_CU")) ctx->xw_chunks_per_cu = std::max(1, atoi(e));
+  if (const char* e = getenv("MBPLS_HIP_CLUSTER_PASSES")) ctx->cluster_passes = atoi(e) ? 1 : 0;
   hipError_t e0 = hipEventCreate(&ctx->ev0), e1 = hipEventCreate(&ctx->ev1);
   if (e0 != hipSuccess || e1 != hipSuccess) {
     delete ctx;
@@ -233,6 +234,7 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->small_m) (void)hipFree(ctx->small_m);
   if (ctx->step_ws) (void)hipFree(ctx->step_ws);
+  if (ctx->cl_ws) (void)hipFree(ctx->cl_ws);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   for (hipEvent_t e : ctx->pin_ev)
     if (e) (void)hipEventDestroy(e);
@@ -287,6 +289,9 @@ int mbpls_hip_set_tunable(mbpls_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "step_reg")) ctx->step_reg = value ? 1 : 0;
   else if (!strcmp(key, "step_spin_limit")) ctx->step_spin_limit = (unsigned)std::max(1, value);
   else if (!strcmp(key, "long_columns_from")) ctx->long_columns_from = std::max(0, std::min(value, 65536));
+  else if (!strcmp(key, "cluster_passes")) ctx->cluster_passes = value ? 1 : 0;
+  else if (!strcmp(key, "cluster_slab_rows")) ctx->cluster_slab_rows = std::max(128, std::min(value, 8192)) / 128 * 128;
+  else if (!strcmp(key, "cluster_spin_limit")) ctx->cluster_spin_limit = (unsigned)std::max(1, value);
   else MB_ARG(false, "unknown tunable '%s'", key);
   return MBPLS_OK;
 }
@@ -506,6 +511,7 @@ int mbpls_hip_mat_destroy(mbpls_mat* m) {
   (void)hipStreamSynchronize(m->ctx->stream);
   free_chunks(&m->fine);
   free_chunks(&m->coarse);
+  free_chunks(&m->cluster);
   if (m->d_block_offsets) (void)hipFree(m->d_block_offsets);
   if (m->owns && m->data) (void)hipFree(m->data);
   delete m;

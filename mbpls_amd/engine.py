@@ -446,8 +446,24 @@ class HipEngine(EngineBase):
         return x, t, g
 
     def sweep_reads_once(self):
-        """a fused sweep (g = X^T v and X g) is ONE read of X: register-resident columns (not the two-phase long-column form)"""
-        return self.n <= min(8192, getattr(self.ctx, "long_columns_from", 8192)) or self.sparse
+        """a fused sweep (g = X^T v and X g) is ONE read of X: register-resident columns, or long columns shared by a
+        cluster of workgroups (csrc/colpass_cluster.hip) -- not the two-phase long-column form"""
+        return self.n <= min(8192, getattr(self.ctx, "long_columns_from", 8192)) or self.sparse or self.cluster_passes
+
+    @property
+    def cluster_passes(self):
+        """the never-writes-X passes of this matrix run on clusters of workgroups (long columns, one read of X)"""
+        return (not self.sparse and self.n > getattr(self.ctx, "long_columns_from", 8192)
+                and bool(getattr(self.ctx, "cluster_passes", 0)) and hasattr(self.ctx, "cluster_status"))
+
+    def check_cluster_passes(self):
+        """Long columns: the workgroups of a cluster hand partial sums to each other inside a launch, every wait
+        bounded; a wait that gave up leaves garbage behind -- never hand that to the caller."""
+        if self.cluster_passes:
+            bad = self.ctx.cluster_status()
+            if bad:
+                raise _capi.HipError(f"{bad} hand-off(s) between the workgroups of a column cluster timed out "
+                                     "(csrc/colpass_cluster.hip); set_tunable('cluster_passes', 0) selects the two-phase passes")
 
     def scaled_products(self):
         """after an implicit first pass (raw matrix, statistics known): the many-right-hand-side products X^T V / X W

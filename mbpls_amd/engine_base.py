@@ -49,6 +49,9 @@ class EngineBase:
     def stats_only_ok(self):
         return False
 
+    def check_cluster_passes(self):
+        pass
+
     def nipals_subspace_loop(self, G, Y, c0, norm_kind, tol, max_iter):
         return None                           # "outside the kernel's range": the caller iterates on the host
 

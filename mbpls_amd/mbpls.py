@@ -214,6 +214,7 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
                 res = solvers.fit_kernel(eng, Ys, K, self.standardize, self.calc_all)
             else:
                 res = solvers.fit_simpls(eng, Ys, K, self.standardize)
+            eng.check_cluster_passes()                      # long columns: a hand-off between workgroups gave up -> raise
             if row_mask is not None:                        # n-row outputs: included samples only
                 for key in ("Ts_", "U_"):
                     if key in res:
@@ -236,6 +237,7 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             n_ = getattr(eng, "n", 0)
             fam = ("few samples (column groups per wave)" if n_ <= 1024 else
                    "register-resident columns" if n_ <= getattr(eng.ctx, "long_columns_from", 8192) else
+                   "long columns (clusters of workgroups, one read per pass)" if getattr(eng, "cluster_passes", False) else
                    "long columns (two streaming phases)")
             self.fit_plan_ = dict(method=self.method, **eng.plan, kernels=fam, centred_in_registers=bool(getattr(eng, "_cen", False)),
                                   column_shards=int(getattr(eng.comm, "world_size", 1)), sparse=bool(sparse))

@@ -1,5 +1,6 @@
-"""GPU parity for LONG columns (n beyond the register-resident column passes): csrc/colpass_long.hip -- the
-two-phase passes in their storing and their never-writes-X forms, the multi-workgroup step kernel of csrc/resident.hip.
+"""GPU parity for LONG columns (n beyond the register-resident column passes): csrc/colpass_cluster.hip -- clusters of
+workgroups that share a column, ONE read of X per pass (the never-writes-X forms) --, csrc/colpass_long.hip -- the
+two-phase passes in their storing and their never-writes-X forms --, the multi-workgroup step kernel of csrc/resident.hip.
 
 Tall data -- many samples, few features -- is what the reference's n >= p branches exist for
 (mbpls.py:388-479 UNIPALS, :580-692 KERNEL); NIPALS / SIMPLS take the same passes.  Checked (a) with the
@@ -16,13 +17,23 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-6
 
 
-@pytest.fixture()
-def forced_long(gpu_required):
+def _long_mode(ctx, mode):
+    """"cluster": one-read passes with 128-row slabs (several workgroups per column even on small problems);
+    "two_phase": the streamed passes of colpass_long.hip; None: the defaults"""
+    ctx.set_tunable("cluster_passes", 0 if mode == "two_phase" else 1)
+    ctx.set_tunable("cluster_slab_rows", 128 if mode == "cluster" else 8192)
+
+
+@pytest.fixture(params=["cluster", "two_phase"])
+def forced_long(gpu_required, request):
     import mbpls_amd
     ctx = mbpls_amd.get_context()
     ctx.set_tunable("long_columns_from", 0)
+    _long_mode(ctx, request.param)
     yield ctx
     ctx.set_tunable("long_columns_from", 8192)
+    _long_mode(ctx, None)
+    assert ctx.cluster_status() == 0
 
 
 def _oracle_flat(ref, Xn, Yn, method):
@@ -61,20 +72,28 @@ def test_fixture_matrix_with_streamed_columns(forced_long, fixture):
     assert worst < 1e-8, worst
 
 
-@pytest.mark.parametrize("method,n,p,q,K,blocks", [
-    ("NIPALS", 1001, 3000, 2, 3, [1000, 2000]),
-    ("UNIPALS", 777, 2500, 1, 3, [2500]),
-    ("NIPALS", 100_000, 300, 1, 3, [100, 200]),       # genuinely long columns (n > 65536), n >= p
-    ("NIPALS", 30_000, 260, 3, 2, [100, 160]),         # several responses: the inner loop in q x q algebra
-    ("UNIPALS", 100_000, 240, 2, 3, [240]),
-    ("KERNEL", 70_001, 200, 1, 3, [80, 120]),
-    ("SIMPLS", 90_000, 150, 2, 3, [150]),
+@pytest.mark.parametrize("method,n,p,q,K,blocks,mode", [
+    ("NIPALS", 1001, 3000, 2, 3, [1000, 2000], "cluster"),        # 8 workgroups per column
+    ("NIPALS", 1001, 3000, 2, 3, [1000, 2000], "two_phase"),
+    ("UNIPALS", 777, 2500, 1, 3, [2500], "cluster"),
+    ("UNIPALS", 777, 2500, 1, 3, [2500], "two_phase"),
+    ("NIPALS", 1500, 1300, 1, 4, [300, 400, 600], "cluster"),     # one response: lazy deflation, three blocks
+    ("SIMPLS", 1203, 700, 1, 3, [700], "cluster"),
+    ("NIPALS", 100_000, 300, 1, 3, [100, 200], None),       # genuinely long columns (n > 65536), n >= p
+    ("NIPALS", 100_000, 300, 1, 3, [100, 200], "two_phase"),
+    ("NIPALS", 30_000, 260, 3, 2, [100, 160], None),         # several responses: the inner loop in q x q algebra
+    ("UNIPALS", 100_000, 240, 2, 3, [240], None),
+    ("KERNEL", 70_001, 200, 1, 3, [80, 120], None),
+    ("SIMPLS", 90_000, 150, 2, 3, [150], None),
+    ("NIPALS", 20_000, 1000, 1, 3, [1000], None),            # the paper protocol's shape: three workgroups per column
+    ("UNIPALS", 16_384, 2100, 1, 3, [700, 1400], None),      # two full slabs
 ])
-def test_vs_oracle(gpu_required, method, n, p, q, K, blocks):
+def test_vs_oracle(gpu_required, method, n, p, q, K, blocks, mode):
     import mbpls_amd
     from mbpls_amd import MBPLS
     ctx = mbpls_amd.get_context()
     ctx.set_tunable("long_columns_from", 0 if n <= 8192 else 8192)
+    _long_mode(ctx, mode)
     try:
         X, Y = orc.make_latent(n, p, q, seed=n + p)
         Xn, Yn = orc.make_latent(64, p, q, seed=1)
@@ -86,8 +105,12 @@ def test_vs_oracle(gpu_required, method, n, p, q, K, blocks):
         w = util.compare(_fit_flat(mdl, sp(Xn), Yn), _oracle_flat(ref, sp(Xn), Yn, method), TOL,
                          what=f"{method} n={n} p={p}")
         assert w < 1e-8, w
+        assert ctx.cluster_status() == 0
+        if mode != "two_phase":
+            assert "clusters of workgroups" in mdl.fit_plan_["kernels"], mdl.fit_plan_
     finally:
         ctx.set_tunable("long_columns_from", 8192)
+        _long_mode(ctx, None)
 
 
 def test_row_subset_fit_with_streamed_columns(forced_long):
@@ -113,14 +136,19 @@ def test_register_resident_configs_above_8192(gpu_required):
     from mbpls_amd import MBPLS
     ctx = mbpls_amd.get_context()
     X, Y = orc.make_latent(10_000, 2000, 1, seed=12)
-    a = MBPLS(n_components=3).fit(X, Y)                      # two-phase long-column passes (never write X)
+    a = MBPLS(n_components=3).fit(X, Y)                      # clusters of two workgroups per column (never write X)
     ctx.set_tunable("long_columns_from", 65536)
     try:
         b = MBPLS(n_components=3).fit(X, Y)                  # register-resident, lazy deflation
     finally:
         ctx.set_tunable("long_columns_from", 8192)
+    ctx.set_tunable("cluster_passes", 0)
+    try:
+        c = MBPLS(n_components=3).fit(X, Y)                  # two-phase long-column passes
+    finally:
+        ctx.set_tunable("cluster_passes", 1)
     ref = orc.fit(X, Y, n_components=3)
-    for mdl in (a, b):
+    for mdl in (a, b, c):
         w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="n=10000")
         assert w < 1e-8, w
 
