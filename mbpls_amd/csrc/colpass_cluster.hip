@@ -41,16 +41,10 @@
 
 namespace mbpls {
 
-#ifndef MB_CL_R
-#define MB_CL_R 16
-#define MB_CL_T 512
-#define MB_CL_D 3
-#define MB_CL_L 2
-#endif
-constexpr int CL_R = MB_CL_R;       // rows per thread
-constexpr int CL_TMAX = MB_CL_T;    // threads per workgroup
-constexpr int CL_D = MB_CL_D;       // register-resident columns per workgroup (ring)
-constexpr int CL_L = MB_CL_L;       // columns between the production of partial sums and their consumption
+// Two launch shapes (ctx->cluster_rows): 16 rows per thread with a ring of 3 columns, partial sums 2 columns ahead of
+// their consumption; 12 rows per thread with a ring of 4 columns, 3 ahead (the exchange wave's loads for the next column
+// are then issued one iteration before they are looked at).  512 threads: 7 compute waves + the exchange wave.
+constexpr int CL_TMAX = 512;
 constexpr int CL_NV = 4;       // doubles per (column, workgroup) exchange slot
 constexpr unsigned long long CL_SENT = 0x7FF8C0DEC0DEC0DEull;   // "not yet published"
 
@@ -79,46 +73,71 @@ __global__ __launch_bounds__(256) void k_cl_fill(int64_t count, unsigned long lo
   }
 }
 
-// wave 0: wait for the W partials of every value of a slot and add them in slab order
-template <int NVX>
-__device__ __forceinline__ void cl_poll(const ClArgs& c, int64_t slot, int lane, double (&tot)[NVX],
-                                        volatile unsigned* s_dead) {
-  const int W = c.W;
-  const double* base = c.xch + slot * (int64_t)(CL_NV * W);
-#pragma unroll
-  for (int k = 0; k < NVX; ++k) tot[k] = 0.0;
-  for (int r0 = 0; r0 < W; r0 += 64) {
-    const int wi = r0 + lane;
-    const bool act = wi < W;
-    double val[NVX];
-    unsigned spins = 0;
-    while (true) {
-      bool ok = true;
-#pragma unroll
-      for (int k = 0; k < NVX; ++k)
-        val[k] = act ? __hip_atomic_load(base + k * W + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-      for (int k = 0; k < NVX; ++k)
-        ok = ok && (unsigned long long)__double_as_longlong(val[k]) != CL_SENT;
-      if (__all(ok ? 1 : 0) || *s_dead != 0u) break;
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > c.spin_limit) {
-        if (lane == 0) {
-          *s_dead = 1u;
-          atomicAdd(c.err, 1u);
-          if (c.par) {
-            c.par[7] = 1.0;
-            c.par[2] = 1.0;            // everything queued behind becomes a no-op
-          }
-        }
-        break;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NVX; ++k) tot[k] += wave_sum(val[k]);
-  }
-}
+// The exchange wave's view of one slot: the NV x W partial sums, flattened (value-major, as they lie in memory) over the
+// lanes in rounds of 64.  Loads of up to CL_PRE rounds can be issued AHEAD (cl_prefetch) and looked at one iteration
+// later, so the 1-2 us round trip of a fine-grained load is not on the critical path of a column.
+constexpr int CL_PRE = 4;
 
+template <int NVX>
+struct ClPoll {
+  double pre[CL_PRE];
+  __device__ __forceinline__ void prefetch(const ClArgs& c, int64_t slot, int lane) {
+    const int nflat = NVX * c.W;
+    const double* base = c.xch + slot * (int64_t)(CL_NV * c.W);
+#pragma unroll
+    for (int r = 0; r < CL_PRE; ++r) {
+      const int idx = r * 64 + lane;
+      pre[r] = (idx < nflat) ? __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+  }
+  // totals of the slot (fixed order: slab order within 64-lane rounds); have_pre: prefetch() was called for this slot
+  __device__ __forceinline__ void collect(const ClArgs& c, int64_t slot, int lane, bool have_pre, double* s_xv,
+                                          double (&tot)[NVX], volatile unsigned* s_dead) {
+    const int W = c.W, nflat = NVX * W;
+    const double* base = c.xch + slot * (int64_t)(CL_NV * W);
+    for (int r0 = 0; r0 < nflat; r0 += 64) {
+      const int idx = r0 + lane, r = r0 >> 6;
+      const bool act = idx < nflat;
+      double val = 0.0;
+      bool fresh = !(have_pre && r < CL_PRE);
+      if (!fresh) {
+#pragma unroll
+        for (int q = 0; q < CL_PRE; ++q)
+          if (q == r) val = pre[q];
+      }
+      unsigned spins = 0;
+      while (true) {
+        if (fresh) val = act ? __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        const bool ok = !act || (unsigned long long)__double_as_longlong(val) != CL_SENT;
+        if (__all(ok ? 1 : 0) || *s_dead != 0u) break;
+        fresh = true;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > c.spin_limit) {
+          if (lane == 0) {
+            *s_dead = 1u;
+            atomicAdd(c.err, 1u);
+            if (c.par) {
+              c.par[7] = 1.0;
+              c.par[2] = 1.0;            // everything queued behind becomes a no-op
+            }
+          }
+          break;
+        }
+      }
+      if (act) s_xv[idx] = val;
+    }
+    // (one wave: LDS writes above are visible to its own reads below in program order)
+#pragma unroll
+    for (int k = 0; k < NVX; ++k) {
+      double t = 0.0;
+      for (int w0 = 0; w0 < W; w0 += 64) t += wave_sum((w0 + lane < W) ? s_xv[k * W + w0 + lane] : 0.0);
+      tot[k] = t;
+    }
+  }
+};
+
+// R rows per thread, TMAX threads: TMAX / 64 - 1 COMPUTE waves that hold the columns, and one EXCHANGE wave (the last)
+// that publishes the workgroup's partial sums and collects the cluster's totals while the others work.
 template <int R, int TMAX, int D, int L, bool STATS, bool DEFL, bool SWEEP, bool CEN>
 __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
   static_assert(L >= 1 && L < D, "lookahead");
@@ -134,9 +153,12 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
   __shared__ double s_tot[2][4];
   __shared__ double s_out[4][64];
   __shared__ double s_go[2][64];
+  __shared__ double s_xv[3 * 256];
   __shared__ unsigned s_dead;
   extern __shared__ double2 s_dyn[];
-  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = T >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = (int)blockDim.x >> 6;
+  const int ncw = nw - 1, T = ncw * 64;                                // compute waves / threads
+  const bool xw = wv == ncw;                                           // this wave is the exchange wave
   const int W = c.W;
   const int cluster = (int)blockIdx.x / W, w = (int)blockIdx.x - cluster * W;
   const int64_t n = a.n, ld = a.ld;
@@ -145,22 +167,24 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
   RowMap<R> rm;
   {
     const int64_t ld_slab = (ns + 1) & ~(int64_t)1;                    // never load beyond the slab: one read of X
-    rm.init(ns, (ld - slab0 < ld_slab) ? ld - slab0 : ld_slab, tid, T);
+    rm.init(ns, (ld - slab0 < ld_slab) ? ld - slab0 : ld_slab, xw ? 0 : tid, T);
   }
   double2* s_v = s_dyn;                                                // [R/2][T] row pairs of the sweep vector
   double2* s_ts = s_dyn + (SWEEP ? (R / 2) * T : 0);                   // ... of the score vector
   if (tid == 0) s_dead = 0u;
-  if constexpr (SWEEP) {
-    double tmp[R];
-    load_vec<R>(tmp, a.v + slab0, ns, tid, T);
+  if (!xw) {
+    if constexpr (SWEEP) {
+      double tmp[R];
+      load_vec<R>(tmp, a.v + slab0, ns, tid, T);
 #pragma unroll
-    for (int k = 0; k < R / 2; ++k) s_v[k * T + tid] = make_double2(tmp[2 * k], tmp[2 * k + 1]);
-  }
-  if constexpr (DEFL) {
-    double tmp[R];
-    load_vec<R>(tmp, a.ts + slab0, ns, tid, T);
+      for (int k = 0; k < R / 2; ++k) s_v[k * T + tid] = make_double2(tmp[2 * k], tmp[2 * k + 1]);
+    }
+    if constexpr (DEFL) {
+      double tmp[R];
+      load_vec<R>(tmp, a.ts + slab0, ns, tid, T);
 #pragma unroll
-    for (int k = 0; k < R / 2; ++k) s_ts[k * T + tid] = make_double2(tmp[2 * k], tmp[2 * k + 1]);
+      for (int k = 0; k < R / 2; ++k) s_ts[k * T + tid] = make_double2(tmp[2 * k], tmp[2 * k + 1]);
+    }
   }
   __syncthreads();
   const bool fit = STATS && a.mode == MBPLS_SCALE_FIT;
@@ -171,8 +195,10 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
   const double ce_i = (lazy_c && a.ce) ? a.ce[tid] : 0.0;
   const double* prow = lazy_c ? a.Pm + (int64_t)tid * a.ldp : nullptr;
   const bool outs = !STATS && a.ir2 != nullptr && a.rs != nullptr;     // true-space g / p written here
-  const int ow = nw > 1 ? 1 : 0;                                       // the wave that writes per-column outputs
-  const bool writer = w == 0 && wv == ow;
+  const bool writer = w == 0 && wv == 0;                               // the wave that writes per-column outputs
+  ClPoll<NV> poll;
+#pragma unroll
+  for (int r = 0; r < CL_PRE; ++r) poll.pre[r] = 0.0;
 
   for (int chunk = cluster; chunk < c.nchunks; chunk += c.G) {
     const int64_t j0 = uniform64(a.c0[chunk]), j1 = uniform64(a.c1[chunk]);
@@ -186,25 +212,28 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
     double tsv = 0.0;
     if constexpr (DEFL && SWEEP) {
       if (a.deflate) {
-        double s = 0.0;
+        if (!xw) {
+          double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < R / 2; ++k) {
-          const double2 t2 = s_ts[k * T + tid], v2 = s_v[k * T + tid];
-          s = fma(t2.x, v2.x, s);
-          s = fma(t2.y, v2.y, s);
+          for (int k = 0; k < R / 2; ++k) {
+            const double2 t2 = s_ts[k * T + tid], v2 = s_v[k * T + tid];
+            s = fma(t2.x, v2.x, s);
+            s = fma(t2.y, v2.y, s);
+          }
+          s = wave_sum_last_row(s);
+          if (lane == 63) s_part[0][wv][0] = s;
         }
-        s = wave_sum_last_row(s);
-        if (lane == 63) s_part[0][wv][0] = s;
         __syncthreads();
-        if (wv == 0) {
+        if (xw) {
           const int64_t slot = c.p + chunk;
           if (lane == 0) {
             double t = s_part[0][0][0];
-            for (int i = 1; i < nw; ++i) t += s_part[0][i][0];
+            for (int i = 1; i < ncw; ++i) t += s_part[0][i][0];
             __hip_atomic_store(c.xch + slot * (int64_t)(CL_NV * W) + w, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+          ClPoll<1> p1;
           double tot[1];
-          cl_poll<1>(c, slot, lane, tot, &s_dead);
+          p1.collect(c, slot, lane, false, s_xv, tot, &s_dead);
           if (lane == 0) s_tot[0][0] = tot[0];
         }
         __syncthreads();
@@ -228,8 +257,9 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       pp[d] = 0.0;
-      if (d < ncols) fetch(d, j0 + d);
+      if (!xw && d < ncols) fetch(d, j0 + d);
     }
+    bool have_pre = false;           // exchange wave: loads of the next slot's partial sums are in flight
 
     for (int64_t base = -L; base < ncols; base += D) {
 #pragma unroll
@@ -237,13 +267,11 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
         const int64_t i = base + d;           // the column consumed in this iteration (from iteration 0 on)
         const int64_t ip = i + L;             // the column whose partial sums are produced: slot d (base + L = 0 mod D)
         if (i >= ncols) break;
-        constexpr int dummy = 0;
-        (void)dummy;
         const int sp = d;
         const int sc = (d + D - (L % D)) % D;
         const int pb = (int)(ip & 1);
-        // ---- produce: partial sums of column ip over the rows of this workgroup
-        if (ip < ncols) {
+        // ---- compute waves, produce: partial sums of column ip over the rows of this workgroup
+        if (!xw && ip < ncols) {
           double(&xp)[R] = x[sp];
           double s[NV];
 #pragma unroll
@@ -274,6 +302,9 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
             // zero and their accumulators are never stored, so nothing is masked here
 #pragma unroll
             for (int k = 0; k < R / 2; ++k) {
+              // (keeps the LDS reads of at most two row pairs in flight: hoisted to the top of the loop they hold
+              // 64 registers and the x ring spills)
+              if ((DEFL && SWEEP) && (k & 1) == 0 && k) __builtin_amdgcn_sched_barrier(0);
               double e0 = xp[2 * k], e1 = xp[2 * k + 1];
               if constexpr (CEN) {
                 e0 -= muj;
@@ -300,26 +331,33 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
             for (int k = 0; k < NV; ++k) s_part[pb][wv][k] = s[k];
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        // ---- wave 0: publish column ip, collect the totals of column i + 1 (consumed in the next iteration)
-        if (wv == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (xw) {
+          // ---- exchange wave: publish column ip, collect the totals of column i + 1 (consumed in the next iteration;
+          // its loads were issued one iteration ago), issue the loads for column i + 2
           if (ip < ncols && lane < NV) {
             double t = s_part[pb][0][lane];
-            for (int q = 1; q < nw; ++q) t += s_part[pb][q][lane];
+            for (int q = 1; q < ncw; ++q) t += s_part[pb][q][lane];
             __hip_atomic_store(c.xch + (j0 + ip) * (int64_t)(CL_NV * W) + (int64_t)lane * W + w, t, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
           }
           if (i + 1 >= 0 && i + 1 < ncols) {
             double tot[NV];
-            cl_poll<NV>(c, j0 + i + 1, lane, tot, &s_dead);
+            poll.collect(c, j0 + i + 1, lane, have_pre, s_xv, tot, &s_dead);
             if (lane == 0) {
 #pragma unroll
               for (int k = 0; k < NV; ++k) s_tot[(i + 1) & 1][k] = tot[k];
             }
           }
-        }
-        // ---- consume: totals of column i (left in LDS by wave 0 one iteration ago, before this iteration's barrier)
-        if (i >= 0) {
+          have_pre = false;
+          if (L >= 2 && i + 2 >= 0 && i + 2 < ncols) {      // (published by every workgroup L - 2 iterations ago or now)
+            poll.prefetch(c, j0 + i + 2, lane);
+            have_pre = true;
+          }
+        } else if (i >= 0) {
+          // ---- compute waves, consume: totals of column i (left in LDS by the exchange wave one iteration ago)
           const int64_t jj = j0 + i;
           double(&xc)[R] = x[sc];
           const int cb = (int)(i & 1);
@@ -425,12 +463,14 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
 
     // ---- the chunk's outputs: this workgroup's rows of the partial score vector, the scalars from workgroup 0
     if constexpr (SWEEP) {
-      double* out = a.part_t + (int64_t)chunk * n + slab0;
+      if (!xw) {
+        double* out = a.part_t + (int64_t)chunk * n + slab0;
 #pragma unroll
-      for (int k = 0; k < R / 2; ++k) {
-        const int64_t r0 = 2 * ((int64_t)k * T + tid);
-        if (r0 + 1 < ns) *reinterpret_cast<double2*>(out + r0) = make_double2(acc[2 * k], acc[2 * k + 1]);
-        else if (r0 < ns) out[r0] = acc[2 * k];
+        for (int k = 0; k < R / 2; ++k) {
+          const int64_t r0 = 2 * ((int64_t)k * T + tid);
+          if (r0 + 1 < ns) *reinterpret_cast<double2*>(out + r0) = make_double2(acc[2 * k], acc[2 * k + 1]);
+          else if (r0 < ns) out[r0] = acc[2 * k];
+        }
       }
     }
     if (w == 0) {
@@ -459,15 +499,16 @@ struct ClPlan {
 };
 
 static bool cl_plan(const mbpls_ctx* ctx, int64_t n, ClPlan* pl) {
-  const int64_t slab = std::max<int64_t>(128, std::min<int64_t>(ctx->cluster_slab_rows, (int64_t)CL_R * CL_TMAX)) / 128 * 128;
+  const int CL_R = ctx->cluster_rows == 12 ? 12 : 16;
+  const int64_t slab = std::max<int64_t>(128, std::min<int64_t>(ctx->cluster_slab_rows, (int64_t)CL_R * (CL_TMAX - 64))) / 128 * 128;
   const int cap = ctx->cus;                                   // one workgroup per CU (128 KB of LDS)
   const int64_t wmin = (n + slab - 1) / slab;
-  if (wmin > cap || wmin < 1) return false;
+  if (wmin > cap || wmin > 256 || wmin < 1) return false;
   pl->G = (int)(cap / wmin);
   const int64_t wuse = cap / pl->G;                           // spread the rows over every CU the clusters can use
   pl->S = ((n + wuse - 1) / wuse + 127) / 128 * 128;
   pl->W = (int)((n + pl->S - 1) / pl->S);
-  pl->T = (int)(((pl->S + CL_R - 1) / CL_R + 63) / 64 * 64);
+  pl->T = (int)(((pl->S + CL_R - 1) / CL_R + 63) / 64 * 64) + 64;        // compute waves + the exchange wave
   return pl->T <= CL_TMAX;
 }
 
@@ -595,24 +636,31 @@ static int cl_launch(mbpls_ctx* ctx, const mbpls_mat* mc, PassArgs a, bool cen) 
   hipLaunchKernelGGL(k_cl_fill, dim3((unsigned)((xd / 2 + 256) / 256)), dim3(256), 0, ctx->stream, (int64_t)xd,
                      (unsigned long long*)c.xch, ctx->dpar);
   MB_HIP(hipGetLastError());
-  const unsigned dyn = (unsigned)((SWEEP ? 1 : 0) + (DEFL ? 1 : 0)) * (unsigned)pl.T * (CL_R / 2) * 16u;
+  const int rows = ctx->cluster_rows == 12 ? 12 : 16;
+  const unsigned dyn = (unsigned)((SWEEP ? 1 : 0) + (DEFL ? 1 : 0)) * (unsigned)(pl.T - 64) * (unsigned)(rows / 2) * 16u;
   dim3 grid((unsigned)(c.G * c.W)), block((unsigned)pl.T);
-#define MB_CL(CEN_)                                                                                         \
+#define MB_CL(R_, D_, L_, CEN_)                                                                             \
   do {                                                                                                      \
-    auto fn = k_colpass_cl<CL_R, CL_TMAX, CL_D, CL_L, STATS, DEFL, SWEEP, CEN_>;                                                 \
+    auto fn = k_colpass_cl<R_, CL_TMAX, D_, L_, STATS, DEFL, SWEEP, CEN_>;                                  \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
-      MB_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CL_TMAX * (CL_R / 2) * 16)); \
+      MB_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CL_TMAX * (R_ / 2) * 16)); \
       attr_set = true;                                                                                      \
     }                                                                                                       \
     hipLaunchKernelGGL(fn, grid, block, dyn, ctx->stream, c);                                               \
   } while (0)
-  if constexpr (STATS) {
-    MB_CL(false);
-  } else {
-    if (cen) MB_CL(true);
-    else MB_CL(false);
-  }
+#define MB_CL_CEN(R_, D_, L_)                     \
+  do {                                            \
+    if constexpr (STATS) {                        \
+      MB_CL(R_, D_, L_, false);                   \
+    } else {                                      \
+      if (cen) MB_CL(R_, D_, L_, true);           \
+      else MB_CL(R_, D_, L_, false);              \
+    }                                             \
+  } while (0)
+  if (rows == 12) MB_CL_CEN(12, 4, 3);
+  else MB_CL_CEN(16, 3, 2);
+#undef MB_CL_CEN
 #undef MB_CL
   MB_HIP(hipGetLastError());
   return MBPLS_OK;

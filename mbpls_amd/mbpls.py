@@ -235,10 +235,10 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             # the route this fit took (not in the reference): solver form, deflation, standardisation, kernel family,
             # centring of offset data, column shards -- decided in engine / solvers from plan.FitOptions, recorded here
             n_ = getattr(eng, "n", 0)
-            fam = ("few samples (column groups per wave)" if n_ <= 1024 else
-                   "register-resident columns" if n_ <= getattr(eng.ctx, "long_columns_from", 8192) else
-                   "long columns (clusters of workgroups, one read per pass)" if getattr(eng, "cluster_passes", False) else
-                   "long columns (two streaming phases)")
+            long_from = getattr(eng.ctx, "long_columns_from", 8192)
+            fam = (("long columns (clusters of workgroups, one read per pass)" if getattr(eng, "cluster_passes", False)
+                    else "long columns (two streaming phases)") if n_ > long_from else
+                   "few samples (column groups per wave)" if n_ <= 1024 else "register-resident columns")
             self.fit_plan_ = dict(method=self.method, **eng.plan, kernels=fam, centred_in_registers=bool(getattr(eng, "_cen", False)),
                                   column_shards=int(getattr(eng.comm, "world_size", 1)), sparse=bool(sparse))
         return self
