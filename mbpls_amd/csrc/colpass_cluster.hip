@@ -41,9 +41,8 @@
 
 namespace mbpls {
 
-// Two launch shapes (ctx->cluster_rows): 16 rows per thread with a ring of 3 columns, partial sums 2 columns ahead of
-// their consumption; 12 rows per thread with a ring of 4 columns, 3 ahead (the exchange wave's loads for the next column
-// are then issued one iteration before they are looked at).  512 threads: 7 compute waves + the exchange wave.
+// 16 rows per thread, a ring of 3 columns, partial sums 2 columns ahead of their consumption; 512 threads = 8 waves,
+// 2 per SIMD: 256 registers per lane (a ring of 4 columns of 12 rows, 3 ahead, measured 10-20 % slower).
 constexpr int CL_TMAX = 512;
 constexpr int CL_NV = 4;       // doubles per (column, workgroup) exchange slot
 constexpr unsigned long long CL_SENT = 0x7FF8C0DEC0DEC0DEull;   // "not yet published"
@@ -74,9 +73,11 @@ __global__ __launch_bounds__(256) void k_cl_fill(int64_t count, unsigned long lo
 }
 
 // The exchange wave's view of one slot: the NV x W partial sums, flattened (value-major, as they lie in memory) over the
-// lanes in rounds of 64.  Loads of up to CL_PRE rounds can be issued AHEAD (cl_prefetch) and looked at one iteration
-// later, so the 1-2 us round trip of a fine-grained load is not on the critical path of a column.
+// lanes in rounds of 64.  Loads of up to CL_PRE rounds can be issued AHEAD (prefetch) and looked at one iteration later,
+// so the 1-2 us round trip of a fine-grained load is not on the critical path of a column; the loads of all rounds of
+// a group are in flight together (a slot of W = 128 workgroups x 3 values is six rounds).
 constexpr int CL_PRE = 4;
+constexpr int CL_RND = 6;
 
 template <int NVX>
 struct ClPoll {
@@ -95,22 +96,27 @@ struct ClPoll {
                                           double (&tot)[NVX], volatile unsigned* s_dead) {
     const int W = c.W, nflat = NVX * W;
     const double* base = c.xch + slot * (int64_t)(CL_NV * W);
-    for (int r0 = 0; r0 < nflat; r0 += 64) {
-      const int idx = r0 + lane, r = r0 >> 6;
-      const bool act = idx < nflat;
-      double val = 0.0;
-      bool fresh = !(have_pre && r < CL_PRE);
-      if (!fresh) {
-#pragma unroll
-        for (int q = 0; q < CL_PRE; ++q)
-          if (q == r) val = pre[q];
-      }
+    for (int g0 = 0; g0 < nflat; g0 += 64 * CL_RND) {
+      double val[CL_RND];
+      bool first = true;
       unsigned spins = 0;
       while (true) {
-        if (fresh) val = act ? __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        const bool ok = !act || (unsigned long long)__double_as_longlong(val) != CL_SENT;
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < CL_RND; ++r) {
+          const int idx = g0 + r * 64 + lane;
+          if (idx < nflat) {
+            if (first && have_pre && g0 == 0 && r < CL_PRE) val[r] = pre[r];
+            else if (first || (unsigned long long)__double_as_longlong(val[r]) == CL_SENT)
+              val[r] = __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            val[r] = 0.0;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < CL_RND; ++r) ok = ok && (unsigned long long)__double_as_longlong(val[r]) != CL_SENT;
+        first = false;
         if (__all(ok ? 1 : 0) || *s_dead != 0u) break;
-        fresh = true;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > c.spin_limit) {
           if (lane == 0) {
@@ -124,9 +130,13 @@ struct ClPoll {
           break;
         }
       }
-      if (act) s_xv[idx] = val;
+#pragma unroll
+      for (int r = 0; r < CL_RND; ++r) {
+        const int idx = g0 + r * 64 + lane;
+        if (idx < nflat) s_xv[idx] = val[r];
+      }
     }
-    // (one wave: LDS writes above are visible to its own reads below in program order)
+    // (one wave: the LDS writes above are visible to its own reads below in program order)
 #pragma unroll
     for (int k = 0; k < NVX; ++k) {
       double t = 0.0;
@@ -136,9 +146,12 @@ struct ClPoll {
   }
 };
 
-// R rows per thread, TMAX threads: TMAX / 64 - 1 COMPUTE waves that hold the columns, and one EXCHANGE wave (the last)
-// that publishes the workgroup's partial sums and collects the cluster's totals while the others work.
-template <int R, int TMAX, int D, int L, bool STATS, bool DEFL, bool SWEEP, bool CEN>
+// R rows per thread, TMAX threads.  DED: TMAX / 64 - 1 COMPUTE waves hold the columns and one dedicated EXCHANGE wave
+// (the last) publishes the workgroup's partial sums and collects the cluster's totals while the others work (measured
+// at n = 20 000, three workgroups per column: sweep 4.6 -> 5.6 TB/s against wave 0 doing both).  !DED: every wave
+// computes and wave 0 also does the exchange -- 8192 instead of 7168 rows per workgroup, which pays where it saves a
+// workgroup per column (n = 16 384: two instead of three) or lets a second cluster run (n = 10^6: 2 x 128 workgroups).
+template <int R, int TMAX, int D, int L, bool DED, bool STATS, bool DEFL, bool SWEEP, bool CEN>
 __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
   static_assert(L >= 1 && L < D, "lookahead");
   static_assert(!STATS || (SWEEP && !DEFL && !CEN), "the statistics pass carries the first sweep");
@@ -157,8 +170,10 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
   __shared__ unsigned s_dead;
   extern __shared__ double2 s_dyn[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = (int)blockDim.x >> 6;
-  const int ncw = nw - 1, T = ncw * 64;                                // compute waves / threads
-  const bool xw = wv == ncw;                                           // this wave is the exchange wave
+  const int ncw = DED ? nw - 1 : nw, T = ncw * 64;                     // compute waves / threads
+  constexpr int TC = DED ? TMAX - 64 : TMAX;                           // row-pair stride of the vectors in LDS
+  const bool xw = DED ? wv == ncw : wv == 0;                           // this wave does the exchange
+  const bool cw = DED ? !xw : true;                                    // this wave holds rows of the columns
   const int W = c.W;
   const int cluster = (int)blockIdx.x / W, w = (int)blockIdx.x - cluster * W;
   const int64_t n = a.n, ld = a.ld;
@@ -167,23 +182,23 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
   RowMap<R> rm;
   {
     const int64_t ld_slab = (ns + 1) & ~(int64_t)1;                    // never load beyond the slab: one read of X
-    rm.init(ns, (ld - slab0 < ld_slab) ? ld - slab0 : ld_slab, xw ? 0 : tid, T);
+    rm.init(ns, (ld - slab0 < ld_slab) ? ld - slab0 : ld_slab, cw ? tid : 0, T);
   }
-  double2* s_v = s_dyn;                                                // [R/2][T] row pairs of the sweep vector
-  double2* s_ts = s_dyn + (SWEEP ? (R / 2) * T : 0);                   // ... of the score vector
+  double2* s_v = s_dyn;                                                // [R/2][TC] row pairs of the sweep vector
+  double2* s_ts = s_dyn + (SWEEP ? (R / 2) * TC : 0);                  // ... of the score vector
   if (tid == 0) s_dead = 0u;
-  if (!xw) {
+  if (cw) {
     if constexpr (SWEEP) {
       double tmp[R];
       load_vec<R>(tmp, a.v + slab0, ns, tid, T);
 #pragma unroll
-      for (int k = 0; k < R / 2; ++k) s_v[k * T + tid] = make_double2(tmp[2 * k], tmp[2 * k + 1]);
+      for (int k = 0; k < R / 2; ++k) s_v[k * TC + tid] = make_double2(tmp[2 * k], tmp[2 * k + 1]);
     }
     if constexpr (DEFL) {
       double tmp[R];
       load_vec<R>(tmp, a.ts + slab0, ns, tid, T);
 #pragma unroll
-      for (int k = 0; k < R / 2; ++k) s_ts[k * T + tid] = make_double2(tmp[2 * k], tmp[2 * k + 1]);
+      for (int k = 0; k < R / 2; ++k) s_ts[k * TC + tid] = make_double2(tmp[2 * k], tmp[2 * k + 1]);
     }
   }
   __syncthreads();
@@ -195,7 +210,7 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
   const double ce_i = (lazy_c && a.ce) ? a.ce[tid] : 0.0;
   const double* prow = lazy_c ? a.Pm + (int64_t)tid * a.ldp : nullptr;
   const bool outs = !STATS && a.ir2 != nullptr && a.rs != nullptr;     // true-space g / p written here
-  const bool writer = w == 0 && wv == 0;                               // the wave that writes per-column outputs
+  const bool writer = w == 0 && wv == ((DED || nw == 1) ? 0 : 1);      // the wave that writes per-column outputs
   ClPoll<NV> poll;
 #pragma unroll
   for (int r = 0; r < CL_PRE; ++r) poll.pre[r] = 0.0;
@@ -212,11 +227,11 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
     double tsv = 0.0;
     if constexpr (DEFL && SWEEP) {
       if (a.deflate) {
-        if (!xw) {
+        if (cw) {
           double s = 0.0;
 #pragma unroll
           for (int k = 0; k < R / 2; ++k) {
-            const double2 t2 = s_ts[k * T + tid], v2 = s_v[k * T + tid];
+            const double2 t2 = s_ts[k * TC + tid], v2 = s_v[k * TC + tid];
             s = fma(t2.x, v2.x, s);
             s = fma(t2.y, v2.y, s);
           }
@@ -257,7 +272,7 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       pp[d] = 0.0;
-      if (!xw && d < ncols) fetch(d, j0 + d);
+      if (cw && d < ncols) fetch(d, j0 + d);
     }
     bool have_pre = false;           // exchange wave: loads of the next slot's partial sums are in flight
 
@@ -271,7 +286,7 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
         const int sc = (d + D - (L % D)) % D;
         const int pb = (int)(ip & 1);
         // ---- compute waves, produce: partial sums of column ip over the rows of this workgroup
-        if (!xw && ip < ncols) {
+        if (cw && ip < ncols) {
           double(&xp)[R] = x[sp];
           double s[NV];
 #pragma unroll
@@ -280,7 +295,7 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
             const double K0 = fit ? uniform_f64(k0v[sp]) : 0.0;
 #pragma unroll
             for (int k = 0; k < R / 2; ++k) {
-              const double2 v2 = s_v[k * T + tid];
+              const double2 v2 = s_v[k * TC + tid];
               const bool r0 = (rm.in_n0 >> k) & 1u, r1 = (rm.in_n1 >> k) & 1u;
               const double e0 = r0 ? xp[2 * k] - K0 : 0.0, e1 = r1 ? xp[2 * k + 1] - K0 : 0.0;
               xp[2 * k] = e0;                  // the shifted column serves the accumulation too
@@ -313,12 +328,12 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
                 xp[2 * k + 1] = e1;
               }
               if constexpr (DEFL) {
-                const double2 t2 = s_ts[k * T + tid];
+                const double2 t2 = s_ts[k * TC + tid];
                 s[0] = fma(e0, t2.x, s[0]);
                 s[0] = fma(e1, t2.y, s[0]);
               }
               if constexpr (SWEEP) {
-                const double2 v2 = s_v[k * T + tid];
+                const double2 v2 = s_v[k * TC + tid];
                 s[DEFL ? 1 : 0] = fma(e0, v2.x, s[DEFL ? 1 : 0]);
                 s[DEFL ? 1 : 0] = fma(e1, v2.y, s[DEFL ? 1 : 0]);
               }
@@ -356,7 +371,8 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
             poll.prefetch(c, j0 + i + 2, lane);
             have_pre = true;
           }
-        } else if (i >= 0) {
+        }
+        if (cw && i >= 0) {
           // ---- compute waves, consume: totals of column i (left in LDS by the exchange wave one iteration ago)
           const int64_t jj = j0 + i;
           double(&xc)[R] = x[sc];
@@ -463,11 +479,13 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
 
     // ---- the chunk's outputs: this workgroup's rows of the partial score vector, the scalars from workgroup 0
     if constexpr (SWEEP) {
-      if (!xw) {
+      if (cw) {
         double* out = a.part_t + (int64_t)chunk * n + slab0;
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));     // (the store addresses are computed here, not carried through the loop)
 #pragma unroll
         for (int k = 0; k < R / 2; ++k) {
-          const int64_t r0 = 2 * ((int64_t)k * T + tid);
+          const int64_t r0 = 2 * ((int64_t)k * T + tid_e);
           if (r0 + 1 < ns) *reinterpret_cast<double2*>(out + r0) = make_double2(acc[2 * k], acc[2 * k + 1]);
           else if (r0 < ns) out[r0] = acc[2 * k];
         }
@@ -496,20 +514,38 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
 struct ClPlan {
   int W, G, T;
   int64_t S;
+  bool ded;      // dedicated exchange wave (7 compute waves) or wave 0 doing both (8 compute waves)
 };
 
-static bool cl_plan(const mbpls_ctx* ctx, int64_t n, ClPlan* pl) {
-  const int CL_R = ctx->cluster_rows == 12 ? 12 : 16;
-  const int64_t slab = std::max<int64_t>(128, std::min<int64_t>(ctx->cluster_slab_rows, (int64_t)CL_R * (CL_TMAX - 64))) / 128 * 128;
-  const int cap = ctx->cus;                                   // one workgroup per CU (128 KB of LDS)
+constexpr int CL_R = 16;
+
+static bool cl_plan_for(const mbpls_ctx* ctx, int64_t n, bool ded, ClPlan* pl) {
+  const int tc = ded ? CL_TMAX - 64 : CL_TMAX;
+  const int64_t slab = std::max<int64_t>(128, std::min<int64_t>(ctx->cluster_slab_rows, (int64_t)CL_R * tc)) / 128 * 128;
+  const int cap = ctx->cus;                                   // one workgroup per CU (the vectors fill the LDS)
   const int64_t wmin = (n + slab - 1) / slab;
   if (wmin > cap || wmin > 256 || wmin < 1) return false;
+  pl->ded = ded;
   pl->G = (int)(cap / wmin);
   const int64_t wuse = cap / pl->G;                           // spread the rows over every CU the clusters can use
   pl->S = ((n + wuse - 1) / wuse + 127) / 128 * 128;
   pl->W = (int)((n + pl->S - 1) / pl->S);
-  pl->T = (int)(((pl->S + CL_R - 1) / CL_R + 63) / 64 * 64) + 64;        // compute waves + the exchange wave
+  pl->T = (int)(((pl->S + CL_R - 1) / CL_R + 63) / 64 * 64) + (ded ? 64 : 0);
   return pl->T <= CL_TMAX;
+}
+
+// Dedicated exchange wave unless giving its rows to an eighth compute wave saves a workgroup per column or lets
+// another cluster run beside the others (ctx->cluster_exchange: 0 = this rule, 1 = always dedicated, 2 = never).
+static bool cl_plan(const mbpls_ctx* ctx, int64_t n, ClPlan* pl) {
+  ClPlan d, s;
+  const bool okd = cl_plan_for(ctx, n, true, &d), oks = cl_plan_for(ctx, n, false, &s);
+  if (!okd && !oks) return false;
+  bool ded = okd;
+  if (okd && oks && (s.W < d.W || s.G > d.G)) ded = false;
+  if (ctx->cluster_exchange == 1 && okd) ded = true;
+  if (ctx->cluster_exchange == 2 && oks) ded = false;
+  *pl = ded ? d : s;
+  return true;
 }
 
 bool cluster_columns(const mbpls_ctx* ctx, int64_t n) {
@@ -636,30 +672,30 @@ static int cl_launch(mbpls_ctx* ctx, const mbpls_mat* mc, PassArgs a, bool cen) 
   hipLaunchKernelGGL(k_cl_fill, dim3((unsigned)((xd / 2 + 256) / 256)), dim3(256), 0, ctx->stream, (int64_t)xd,
                      (unsigned long long*)c.xch, ctx->dpar);
   MB_HIP(hipGetLastError());
-  const int rows = ctx->cluster_rows == 12 ? 12 : 16;
-  const unsigned dyn = (unsigned)((SWEEP ? 1 : 0) + (DEFL ? 1 : 0)) * (unsigned)(pl.T - 64) * (unsigned)(rows / 2) * 16u;
+  const int tc = pl.ded ? CL_TMAX - 64 : CL_TMAX;
+  const unsigned dyn = (unsigned)((SWEEP ? 1 : 0) + (DEFL ? 1 : 0)) * (unsigned)tc * (unsigned)(CL_R / 2) * 16u;
   dim3 grid((unsigned)(c.G * c.W)), block((unsigned)pl.T);
-#define MB_CL(R_, D_, L_, CEN_)                                                                             \
+#define MB_CL(DED_, CEN_)                                                                                   \
   do {                                                                                                      \
-    auto fn = k_colpass_cl<R_, CL_TMAX, D_, L_, STATS, DEFL, SWEEP, CEN_>;                                  \
+    auto fn = k_colpass_cl<CL_R, CL_TMAX, 3, 2, DED_, STATS, DEFL, SWEEP, CEN_>;                            \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
-      MB_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CL_TMAX * (R_ / 2) * 16)); \
+      MB_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CL_TMAX * (CL_R / 2) * 16)); \
       attr_set = true;                                                                                      \
     }                                                                                                       \
     hipLaunchKernelGGL(fn, grid, block, dyn, ctx->stream, c);                                               \
   } while (0)
-#define MB_CL_CEN(R_, D_, L_)                     \
+#define MB_CL_CEN(DED_)                           \
   do {                                            \
     if constexpr (STATS) {                        \
-      MB_CL(R_, D_, L_, false);                   \
+      MB_CL(DED_, false);                         \
     } else {                                      \
-      if (cen) MB_CL(R_, D_, L_, true);           \
-      else MB_CL(R_, D_, L_, false);              \
+      if (cen) MB_CL(DED_, true);                 \
+      else MB_CL(DED_, false);                    \
     }                                             \
   } while (0)
-  if (rows == 12) MB_CL_CEN(12, 4, 3);
-  else MB_CL_CEN(16, 3, 2);
+  if (pl.ded) MB_CL_CEN(true);
+  else MB_CL_CEN(false);
 #undef MB_CL_CEN
 #undef MB_CL
   MB_HIP(hipGetLastError());

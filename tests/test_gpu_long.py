@@ -21,7 +21,9 @@ def _long_mode(ctx, mode):
     """"cluster": one-read passes with 128-row slabs (several workgroups per column even on small problems);
     "two_phase": the streamed passes of colpass_long.hip; None: the defaults"""
     ctx.set_tunable("cluster_passes", 0 if mode == "two_phase" else 1)
-    ctx.set_tunable("cluster_slab_rows", 128 if mode == "cluster" else 8192)
+    ctx.set_tunable("cluster_slab_rows", 128 if mode in ("cluster", "cluster_shared") else 8192)
+    # "cluster": a dedicated exchange wave per workgroup; "cluster_shared": wave 0 computes and exchanges; None: by shape
+    ctx.set_tunable("cluster_exchange", {"cluster": 1, "cluster_shared": 2}.get(mode, 0))
 
 
 @pytest.fixture(params=["cluster", "two_phase"])
@@ -78,6 +80,8 @@ def test_fixture_matrix_with_streamed_columns(forced_long, fixture):
     ("UNIPALS", 777, 2500, 1, 3, [2500], "cluster"),
     ("UNIPALS", 777, 2500, 1, 3, [2500], "two_phase"),
     ("NIPALS", 1500, 1300, 1, 4, [300, 400, 600], "cluster"),     # one response: lazy deflation, three blocks
+    ("NIPALS", 1500, 1300, 1, 4, [300, 400, 600], "cluster_shared"),
+    ("UNIPALS", 999, 1100, 3, 3, [500, 600], "cluster_shared"),
     ("SIMPLS", 1203, 700, 1, 3, [700], "cluster"),
     ("NIPALS", 100_000, 300, 1, 3, [100, 200], None),       # genuinely long columns (n > 65536), n >= p
     ("NIPALS", 100_000, 300, 1, 3, [100, 200], "two_phase"),

@@ -18,9 +18,9 @@ X = DeviceMatrix(ctx, n, p)
 X.fill_latent(ctx.from_host(Ts), 32, 0.5, 1234, 0)
 ctx.sync()
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-for thr in (0, 16, 12):
-    ctx.set_tunable("cluster_passes", 1 if thr else 0)
-    ctx.set_tunable("cluster_rows", thr or 16)
+for thr in (-1, 0, 1, 2):
+    ctx.set_tunable("cluster_passes", 0 if thr < 0 else 1)
+    ctx.set_tunable("cluster_exchange", max(thr, 0))
     for method in ("NIPALS", "UNIPALS"):
         m = MBPLS(n_components=K, method=method)
         for rep in range(3):
@@ -29,7 +29,7 @@ for thr in (0, 16, 12):
             t0 = time.perf_counter(); m.fit(X, Y); ctx.sync(); t1 = time.perf_counter()
         prof = ctx.profile_get()
         ctx.profile(False)
-        print(f"n={n} p={p} cluster_rows={thr} {method}: fit {1e3 * (t1 - t0):.1f} ms  " +
+        print(f"n={n} p={p} cluster_exchange={thr} {method}: fit {1e3 * (t1 - t0):.1f} ms  " +
               "  ".join(f"{k}: {v['avg_ms']:.2f} ms {v['GBps']:.0f} GB/s x{v['launches']}" for k, v in prof.items()),
               flush=True)
         print("    host phases (ms):", {k: round(1e3 * v, 1) for k, v in m.fit_timings_.items()}, "timeouts", ctx.cluster_status(), flush=True)
