@@ -162,8 +162,11 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
     a.alpha = uniform_f64(a.dpar[0]);
     a.inv_tt = uniform_f64(a.dpar[1]);
   }
-  __shared__ double s_part[2][TMAX / 64][4];
-  __shared__ double s_tot[2][4];
+  constexpr int Q = 4;                       // ring of per-column staging slots in LDS
+  __shared__ double s_part[Q][TMAX / 64][4];
+  __shared__ double s_tot[Q][4];
+  __shared__ unsigned s_seq[TMAX / 64];      // DED: columns whose partial sums compute wave q has left in s_part
+  __shared__ unsigned s_rdy;                 // DED: columns whose totals the exchange wave has left in s_tot
   __shared__ double s_out[4][64];
   __shared__ double s_go[2][64];
   __shared__ double s_xv[3 * 256];
@@ -186,7 +189,12 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
   }
   double2* s_v = s_dyn;                                                // [R/2][TC] row pairs of the sweep vector
   double2* s_ts = s_dyn + (SWEEP ? (R / 2) * TC : 0);                  // ... of the score vector
-  if (tid == 0) s_dead = 0u;
+  if (tid == 0) {
+    s_dead = 0u;
+    s_rdy = 0u;
+  }
+  if (tid < TMAX / 64) s_seq[tid] = 0u;
+  unsigned cbase = 0u;                                                 // columns of the chunks walked so far
   if (cw) {
     if constexpr (SWEEP) {
       double tmp[R];
@@ -276,7 +284,58 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
     }
     bool have_pre = false;           // exchange wave: loads of the next slot's partial sums are in flight
 
-    for (int64_t base = -L; base < ncols; base += D) {
+    // LDS hand-offs between the compute waves and a dedicated exchange wave: plain stores / loads of one LDS word,
+    // in program order per wave (the LDS executes a wave's instructions in order); bounded like the global polls.
+    volatile unsigned* v_seq = s_seq;
+    volatile unsigned* v_rdy = &s_rdy;
+    volatile unsigned* v_dead = &s_dead;
+    auto give_up = [&]() {
+      *v_dead = 1u;
+      atomicAdd(c.err, 1u);
+      if (c.par) {
+        c.par[7] = 1.0;
+        c.par[2] = 1.0;
+      }
+    };
+    if (DED && xw) {
+      // ---- dedicated exchange wave: its own loop, no workgroup barrier.  Step s: publish column s as soon as every
+      // compute wave has left its partial sums, then collect the totals of column s - (L - 1) and release them.
+      for (int64_t st = 0; st < ncols + (L - 1); ++st) {
+        if (st < ncols) {
+          const unsigned want = cbase + (unsigned)st + 1u;
+          unsigned spins = 0;
+          while (true) {
+            const bool ok = lane >= ncw || (int)(v_seq[lane < ncw ? lane : 0] - want) >= 0;
+            if (__all(ok ? 1 : 0) || *v_dead != 0u) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 26)) {
+              if (lane == 0) give_up();
+              break;
+            }
+          }
+          if (lane < NV) {
+            const int pb = (int)(st & (Q - 1));
+            double t = ((volatile double*)&s_part[pb][0][0])[lane];
+            for (int q = 1; q < ncw; ++q) t += ((volatile double*)&s_part[pb][q][0])[lane];
+            __hip_atomic_store(c.xch + (j0 + st) * (int64_t)(CL_NV * W) + (int64_t)lane * W + w, t, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        const int64_t cc = st - (L - 1);
+        if (cc >= 0) {
+          double tot[NV];
+          poll.collect(c, j0 + cc, lane, false, s_xv, tot, &s_dead);
+          if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) ((volatile double*)&s_tot[cc & (Q - 1)][0])[k] = tot[k];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            *v_rdy = cbase + (unsigned)cc + 1u;
+          }
+        }
+      }
+    }
+
+    for (int64_t base = -L; (!DED || cw) && base < ncols; base += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const int64_t i = base + d;           // the column consumed in this iteration (from iteration 0 on)
@@ -284,7 +343,7 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
         if (i >= ncols) break;
         const int sp = d;
         const int sc = (d + D - (L % D)) % D;
-        const int pb = (int)(ip & 1);
+        const int pb = (int)(ip & (DED ? Q - 1 : 1));
         // ---- compute waves, produce: partial sums of column ip over the rows of this workgroup
         if (cw && ip < ncols) {
           double(&xp)[R] = x[sp];
@@ -343,13 +402,19 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
           for (int k = 0; k < NV; ++k) s[k] = wave_sum_last_row(s[k]);
           if (lane == 63) {
 #pragma unroll
-            for (int k = 0; k < NV; ++k) s_part[pb][wv][k] = s[k];
+            for (int k = 0; k < NV; ++k) ((volatile double*)&s_part[pb][wv][0])[k] = s[k];
+            if constexpr (DED) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              v_seq[wv] = cbase + (unsigned)ip + 1u;
+            }
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-        if (xw) {
+        if constexpr (!DED) {
+          __builtin_amdgcn_sched_barrier(0);
+          __syncthreads();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!DED && xw) {
           // ---- exchange wave: publish column ip, collect the totals of column i + 1 (consumed in the next iteration;
           // its loads were issued one iteration ago), issue the loads for column i + 2
           if (ip < ncols && lane < NV) {
@@ -376,11 +441,23 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
           // ---- compute waves, consume: totals of column i (left in LDS by the exchange wave one iteration ago)
           const int64_t jj = j0 + i;
           double(&xc)[R] = x[sc];
-          const int cb = (int)(i & 1);
+          const int cb = (int)(i & (DED ? Q - 1 : 1));
+          if constexpr (DED) {
+            const unsigned want = cbase + (unsigned)i + 1u;
+            unsigned spins = 0;
+            while ((int)(*v_rdy - want) < 0 && *v_dead == 0u) {
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > (1u << 26)) {
+                if (lane == 0) give_up();
+                break;
+              }
+            }
+          }
           const int oslot = (int)(i & 63);
           double cj = 0.0;
           if constexpr (STATS) {
-            const double S1 = s_tot[cb][0], S2 = s_tot[cb][1], Sv = s_tot[cb][2];
+            const volatile double* tq = &s_tot[cb][0];
+            const double S1 = tq[0], S2 = tq[1], Sv = tq[2];
             if (fit) {
               const double K0 = uniform_f64(k0v[sc]);
               const double inv_n = 1.0 / dn;
@@ -427,13 +504,14 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
               }
             }
           } else {
+            const volatile double* tq = &s_tot[cb][0];
             const double r2c = uniform_f64(r2v[sc]);
             double gj = 0.0, pj = 0.0, pjk = 0.0;
             if constexpr (DEFL) {
-              pj = s_tot[cb][0] * a.inv_tt;               // raw-space loading p~_j
+              pj = tq[0] * a.inv_tt;               // raw-space loading p~_j
               ssq_p = fma(pj * pj, r2c, ssq_p);
               if constexpr (SWEEP) {
-                const double b = s_tot[cb][1];
+                const double b = tq[1];
                 if (a.deflate) {
                   gj = a.alpha * fma(-pj, tsv, b);        // <x - p ts, v> = <x, v> - p <ts, v>
                   pjk = pj;
@@ -442,7 +520,7 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
                 }
               }
             } else {
-              gj = a.alpha * s_tot[cb][0];
+              gj = a.alpha * tq[0];
             }
             if constexpr (SWEEP) {
               cj = gj * r2c;
@@ -505,6 +583,7 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
         if (tid == 0) pd[a.kprev] = dk;
       }
     }
+    cbase += (unsigned)ncols;
     __syncthreads();          // LDS staging (s_part / s_tot / s_go) is reused by the next chunk
   }
 }

@@ -73,7 +73,7 @@ struct mbpls_ctx {
   int cluster_passes = 1;
   int64_t cluster_slab_rows = 8192;    // rows of a column held by one workgroup of a cluster (tests lower it)
   int cluster_exchange = 0;            // 0: dedicated exchange wave unless sharing saves workgroups; 1: always; 2: never
-  unsigned cluster_spin_limit = 1u << 24;   // polls before a cluster hand-off gives up
+  unsigned cluster_spin_limit = 1u << 22;   // polls before a cluster hand-off gives up
   void* cl_ws = nullptr;               // fine-grained: [error word | exchange slots] of the cluster passes
   size_t cl_ws_bytes = 0;
   // workspace for chunk partials (grown on demand, never shrunk)
