@@ -316,23 +316,64 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def launch_ranks(world, argv, timeout=None, python=None):
+def count_gpus_without_hip():
+    """GPUs of this node, counted WITHOUT initialising the HIP / HSA runtime in this process (the launcher must stay a
+    GPU-free parent of the ranks): the KFD topology in sysfs (a node with simd_count > 0 is a GPU), else a throw-away
+    child process that asks the runtime; None when neither works (the caller then skips its check)."""
+    import glob
+    import subprocess
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if nodes:
+        n = 0
+        for f in nodes:
+            try:
+                props = dict(line.split()[:2] for line in open(f).read().splitlines() if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                pass
+        hide = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+        if hide is not None and hide.strip() != "":
+            n = min(n, len([x for x in hide.split(",") if x.strip() != ""]))
+        return n
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
+def _die_with_parent():
+    """preexec of a rank: SIGTERM when the launcher dies (PR_SET_PDEATHSIG) -- a killed launcher leaves no rank behind
+    in a collective with the GPUs leased"""
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM, 0, 0, 0)
+    except Exception:
+        pass
+
+
+DEFAULT_LAUNCH_TIMEOUT_S = 3000.0
+
+
+def launch_ranks(world, argv, timeout=DEFAULT_LAUNCH_TIMEOUT_S, python=None):
     """Start `world` child processes `python argv...`, one rank each (RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE /
     MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment -- what torch.distributed.run would export), wait for them,
     print the LAST line of rank 0's stdout that parses as JSON as the last line of this process's stdout, and return
     the exit status: 0 only when every rank returned 0.  Everything else the ranks print goes to stderr, prefixed.
-    The first rank that fails takes the others down (they would otherwise wait in a collective); the caller itself
-    never touches the GPU, so the children are ordinary fresh processes (no exec from a GPU-initialised process).
-    When the node shows fewer GPUs than ranks and MBPLS_BENCH_SHARED_GPU is not set, nothing is started."""
+    The first rank that fails takes the others down (they would otherwise wait in a collective); so does a SIGTERM /
+    SIGINT / SIGHUP sent to the launcher, its own death (PR_SET_PDEATHSIG in the ranks), a timeout, and any exception
+    on the way out (try / finally): every rank started here is signalled, then killed after a grace period.  The
+    caller itself never touches the GPU, so the children are ordinary fresh processes (no exec from a GPU-initialised
+    process).  When the node shows fewer GPUs than ranks and MBPLS_BENCH_SHARED_GPU is not set, nothing is started."""
+    import signal
     import subprocess
     import threading
     python = python or sys.executable
     if os.environ.get("MBPLS_BENCH_SHARED_GPU") != "1" and os.environ.get("MBPLS_BENCH_SKIP_GPU_COUNT") != "1":
-        try:
-            import torch
-            have = torch.cuda.device_count()           # counting devices does not initialise the GPU runtime
-        except Exception:
-            have = None
+        have = count_gpus_without_hip()
         if have is not None and have < world:
             print(f"[bench] --gpus {world} but only {have} GPU(s) visible (MBPLS_BENCH_SHARED_GPU=1 runs the ranks on "
                   f"one GPU over gloo as a dry run)", file=sys.stderr, flush=True)
@@ -351,42 +392,74 @@ def launch_ranks(world, argv, timeout=None, python=None):
             else:
                 print(f"[rank {rank}] {text}", file=sys.stderr, flush=True)
 
-    for r in range(world):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        pr = subprocess.Popen([python] + list(argv), env=e, stdout=subprocess.PIPE, stderr=None,
-                              start_new_session=True)
-        th = threading.Thread(target=pump, args=(pr.stdout, r, lines0 if r == 0 else None), daemon=True)
-        th.start()
-        procs.append(pr)
-        pumps.append(th)
-    t0 = time.time()
     rcs = [None] * world
-    failed = None
-    while any(rc is None for rc in rcs):
+
+    def take_down(grace=10.0):
+        """SIGTERM to the session of every rank still running, SIGKILL after the grace period"""
+        live = [(r, pr) for r, pr in enumerate(procs) if rcs[r] is None and pr.poll() is None]
+        for _, pr in live:
+            try:
+                os.killpg(pr.pid, signal.SIGTERM)
+            except (ProcessLookupError, PermissionError):
+                pass
+        deadline = time.time() + grace
+        for r, pr in live:
+            try:
+                rcs[r] = pr.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+                rcs[r] = pr.wait()
         for r, pr in enumerate(procs):
             if rcs[r] is None:
                 rcs[r] = pr.poll()
-                if rcs[r] not in (None, 0) and failed is None:
-                    failed = r
-        if failed is not None or (timeout is not None and time.time() - t0 > timeout):
-            for r, pr in enumerate(procs):           # exactly the processes started here (their own sessions)
-                if rcs[r] is None:
-                    try:
-                        os.killpg(pr.pid, 15)
-                    except ProcessLookupError:
-                        pass
-            deadline = time.time() + 10
+
+    got_signal = []
+    previous = {}
+
+    def on_signal(signum, frame):
+        got_signal.append(signum)
+
+    in_main_thread = threading.current_thread() is threading.main_thread()
+    if in_main_thread:
+        for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            previous[sg] = signal.signal(sg, on_signal)
+    failed = None
+    timed_out = False
+    try:
+        for r in range(world):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+            pr = subprocess.Popen([python] + list(argv), env=e, stdout=subprocess.PIPE, stderr=None,
+                                  start_new_session=True, preexec_fn=_die_with_parent)
+            th = threading.Thread(target=pump, args=(pr.stdout, r, lines0 if r == 0 else None), daemon=True)
+            th.start()
+            procs.append(pr)
+            pumps.append(th)
+        t0 = time.time()
+        while any(rc is None for rc in rcs):
             for r, pr in enumerate(procs):
                 if rcs[r] is None:
-                    try:
-                        rcs[r] = pr.wait(timeout=max(0.1, deadline - time.time()))
-                    except subprocess.TimeoutExpired:
-                        os.killpg(pr.pid, 9)
-                        rcs[r] = pr.wait()
-            break
-        time.sleep(0.05)
+                    rcs[r] = pr.poll()
+                    if rcs[r] not in (None, 0) and failed is None:
+                        failed = r
+            timed_out = timeout is not None and time.time() - t0 > timeout
+            if failed is not None or timed_out or got_signal:
+                take_down()
+                break
+            time.sleep(0.05)
+    finally:
+        take_down(grace=5.0)                          # nothing started here survives this call, whatever happened
+        if in_main_thread:
+            for sg, h in previous.items():
+                signal.signal(sg, h)
     for th in pumps:
         th.join(timeout=5)
+    if got_signal:
+        print(f"[bench] launcher received signal {got_signal[0]}: ranks taken down, exit codes {rcs}", file=sys.stderr,
+              flush=True)
+        return 128 + int(got_signal[0])
     line = None
     for text in lines0:
         try:
@@ -407,7 +480,7 @@ def launch_ranks(world, argv, timeout=None, python=None):
         return 1
     if ok:
         return 0
-    bad = rcs[failed] if failed is not None else next(rc for rc in rcs if rc)
+    bad = rcs[failed] if failed is not None else next((rc for rc in rcs if rc), 1)
     return bad if 0 < bad < 256 else 1
 
 

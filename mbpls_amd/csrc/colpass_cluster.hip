@@ -335,6 +335,189 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
       }
     }
 
+    // produce: the partial sums of column ip (ring slot sp) over this workgroup's rows, left in LDS for the exchange
+    auto produce = [&](const int sp, const int64_t ip) {
+      const int pb = (int)(ip & (DED ? Q - 1 : 1));
+      double(&xp)[R] = x[sp];
+      double s[NV];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) s[k] = 0.0;
+      if constexpr (STATS) {
+        const double K0 = fit ? uniform_f64(k0v[sp]) : 0.0;
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) {
+          const double2 v2 = s_v[k * TC + tid];
+          const bool r0 = (rm.in_n0 >> k) & 1u, r1 = (rm.in_n1 >> k) & 1u;
+          const double e0 = r0 ? xp[2 * k] - K0 : 0.0, e1 = r1 ? xp[2 * k + 1] - K0 : 0.0;
+          xp[2 * k] = e0;                  // the shifted column serves the accumulation too
+          xp[2 * k + 1] = e1;
+          s[0] += e0;
+          s[0] += e1;
+          s[1] = fma(e0, e0, s[1]);
+          s[1] = fma(e1, e1, s[1]);
+          s[2] = fma(e0, v2.x, s[2]);
+          s[2] = fma(e1, v2.y, s[2]);
+        }
+      } else {
+        const double muj = CEN ? uniform_f64(muv[sp]) : 0.0;
+        if (corr) {
+          if constexpr (DEFL) s[0] = -pp[sp] * ce_i;
+          if constexpr (SWEEP) s[DEFL ? 1 : 0] = -pp[sp] * cu_i;
+        }
+        // rows beyond the slab hold a re-read of its first pair (clamped offsets): their entries of v / ts are
+        // zero and their accumulators are never stored, so nothing is masked here
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) {
+          // (keeps the LDS reads of at most two row pairs in flight: hoisted to the top of the loop they hold
+          // 64 registers and the x ring spills)
+          if ((DEFL && SWEEP) && (k & 1) == 0 && k) __builtin_amdgcn_sched_barrier(0);
+          double e0 = xp[2 * k], e1 = xp[2 * k + 1];
+          if constexpr (CEN) {
+            e0 -= muj;
+            e1 -= muj;
+            xp[2 * k] = e0;
+            xp[2 * k + 1] = e1;
+          }
+          if constexpr (DEFL) {
+            const double2 t2 = s_ts[k * TC + tid];
+            s[0] = fma(e0, t2.x, s[0]);
+            s[0] = fma(e1, t2.y, s[0]);
+          }
+          if constexpr (SWEEP) {
+            const double2 v2 = s_v[k * TC + tid];
+            s[DEFL ? 1 : 0] = fma(e0, v2.x, s[DEFL ? 1 : 0]);
+            s[DEFL ? 1 : 0] = fma(e1, v2.y, s[DEFL ? 1 : 0]);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) s[k] = wave_sum_last_row(s[k]);
+      if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) ((volatile double*)&s_part[pb][wv][0])[k] = s[k];
+        if constexpr (DED) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          v_seq[wv] = cbase + (unsigned)ip + 1u;
+        }
+      }
+    };
+    // consume: the totals of column i (ring slot sc) -> weights / loadings, the accumulation, the slot's refill
+    auto consume = [&](const int sc, const int64_t i) {
+      // ---- compute waves, consume: totals of column i (left in LDS by the exchange wave one iteration ago)
+      const int64_t jj = j0 + i;
+      double(&xc)[R] = x[sc];
+      const int cb = (int)(i & (DED ? Q - 1 : 1));
+      if constexpr (DED) {
+        const unsigned want = cbase + (unsigned)i + 1u;
+        unsigned spins = 0;
+        while ((int)(*v_rdy - want) < 0 && *v_dead == 0u) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 26)) {
+            if (lane == 0) give_up();
+            break;
+          }
+        }
+      }
+      const int oslot = (int)(i & 63);
+      double cj = 0.0;
+      if constexpr (STATS) {
+        const volatile double* tq = &s_tot[cb][0];
+        const double S1 = tq[0], S2 = tq[1], Sv = tq[2];
+        if (fit) {
+          const double K0 = uniform_f64(k0v[sc]);
+          const double inv_n = 1.0 / dn;
+          const double m1 = S1 * inv_n;
+          const double mean = K0 + m1;
+          const double var = fmax((S2 - S1 * m1) * inv_n, 0.0);
+          const double eps = 2.220446049250313e-16;
+          const double nme = dn * mean * eps;
+          const bool constant = var <= dn * eps * var + nme * nme;
+          double rv = __builtin_amdgcn_rcp(var);
+          rv = fma(fma(-var, rv, 1.0), rv, rv);
+          rv = fma(fma(-var, rv, 1.0), rv, rv);
+          const double r2 = constant ? 0.0 : rv;
+          const double gt = a.alpha * Sv;             // raw-space weight g~_j
+          cj = gt * r2;
+          ssq_g = fma(gt, cj, ssq_g);
+          amp = fmax(amp, mean * mean * r2);
+          ssq_x = fma(dn * var, r2, ssq_x);
+          if (writer) {
+            if (lane == 0) {
+              s_out[0][oslot] = mean;
+              s_out[1][oslot] = var;
+              s_out[2][oslot] = r2;
+              s_out[3][oslot] = gt;
+            }
+            if (oslot == 63 || i == ncols - 1) {
+              const int64_t jb = jj - oslot;
+              if (lane <= oslot) {
+                a.mean[jb + lane] = s_out[0][lane];
+                a.scale[jb + lane] = s_out[1][lane];
+                if (a.r2_out) a.r2_out[jb + lane] = s_out[2][lane];
+                if (a.g) a.g[jb + lane] = s_out[3][lane];
+              }
+            }
+          }
+        } else {                                      // standardize=False: sums of squares and the sweep only
+          const double gj = a.alpha * Sv;
+          cj = gj;
+          ssq_g = fma(gj, gj, ssq_g);
+          ssq_x += S2;
+          if (writer) {
+            if (lane == 0) s_out[3][oslot] = gj;
+            if ((oslot == 63 || i == ncols - 1) && lane <= oslot && a.g) a.g[jj - oslot + lane] = s_out[3][lane];
+          }
+        }
+      } else {
+        const volatile double* tq = &s_tot[cb][0];
+        const double r2c = uniform_f64(r2v[sc]);
+        double gj = 0.0, pj = 0.0, pjk = 0.0;
+        if constexpr (DEFL) {
+          pj = tq[0] * a.inv_tt;               // raw-space loading p~_j
+          ssq_p = fma(pj * pj, r2c, ssq_p);
+          if constexpr (SWEEP) {
+            const double b = tq[1];
+            if (a.deflate) {
+              gj = a.alpha * fma(-pj, tsv, b);        // <x - p ts, v> = <x, v> - p <ts, v>
+              pjk = pj;
+            } else {
+              gj = a.alpha * b;
+            }
+          }
+        } else {
+          gj = a.alpha * tq[0];
+        }
+        if constexpr (SWEEP) {
+          cj = gj * r2c;
+          ssq_g = fma(gj, cj, ssq_g);
+          dacc = fma(cj, pp[sc], dacc);
+          if constexpr (DEFL) dk = fma(cj, pjk, dk);
+        }
+        if (writer) {
+          if (lane == 0) {
+            s_go[0][oslot] = gj;
+            s_go[1][oslot] = pj;
+          }
+          if (oslot == 63 || i == ncols - 1) {
+            const int64_t jb = jj - oslot;
+            if (lane <= oslot) {
+              const double r = outs ? a.rs[jb + lane] : 1.0;
+              if (SWEEP && a.g) a.g[jb + lane] = s_go[0][lane] * r;
+              if (DEFL && a.pvec) {
+                a.pvec[jb + lane] = s_go[1][lane];
+                if (outs && a.pvec_true) a.pvec_true[jb + lane] = s_go[1][lane] * r;
+              }
+            }
+          }
+        }
+      }
+      if constexpr (SWEEP) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) acc[k] = fma(cj, xc[k], acc[k]);
+      }
+      if (i + D < ncols) fetch(sc, jj + D);
+    };
+
     for (int64_t base = -L; (!DED || cw) && base < ncols; base += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
@@ -343,214 +526,41 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
         if (i >= ncols) break;
         const int sp = d;
         const int sc = (d + D - (L % D)) % D;
-        const int pb = (int)(ip & (DED ? Q - 1 : 1));
-        // ---- compute waves, produce: partial sums of column ip over the rows of this workgroup
-        if (cw && ip < ncols) {
-          double(&xp)[R] = x[sp];
-          double s[NV];
-#pragma unroll
-          for (int k = 0; k < NV; ++k) s[k] = 0.0;
-          if constexpr (STATS) {
-            const double K0 = fit ? uniform_f64(k0v[sp]) : 0.0;
-#pragma unroll
-            for (int k = 0; k < R / 2; ++k) {
-              const double2 v2 = s_v[k * TC + tid];
-              const bool r0 = (rm.in_n0 >> k) & 1u, r1 = (rm.in_n1 >> k) & 1u;
-              const double e0 = r0 ? xp[2 * k] - K0 : 0.0, e1 = r1 ? xp[2 * k + 1] - K0 : 0.0;
-              xp[2 * k] = e0;                  // the shifted column serves the accumulation too
-              xp[2 * k + 1] = e1;
-              s[0] += e0;
-              s[0] += e1;
-              s[1] = fma(e0, e0, s[1]);
-              s[1] = fma(e1, e1, s[1]);
-              s[2] = fma(e0, v2.x, s[2]);
-              s[2] = fma(e1, v2.y, s[2]);
-            }
-          } else {
-            const double muj = CEN ? uniform_f64(muv[sp]) : 0.0;
-            if (corr) {
-              if constexpr (DEFL) s[0] = -pp[sp] * ce_i;
-              if constexpr (SWEEP) s[DEFL ? 1 : 0] = -pp[sp] * cu_i;
-            }
-            // rows beyond the slab hold a re-read of its first pair (clamped offsets): their entries of v / ts are
-            // zero and their accumulators are never stored, so nothing is masked here
-#pragma unroll
-            for (int k = 0; k < R / 2; ++k) {
-              // (keeps the LDS reads of at most two row pairs in flight: hoisted to the top of the loop they hold
-              // 64 registers and the x ring spills)
-              if ((DEFL && SWEEP) && (k & 1) == 0 && k) __builtin_amdgcn_sched_barrier(0);
-              double e0 = xp[2 * k], e1 = xp[2 * k + 1];
-              if constexpr (CEN) {
-                e0 -= muj;
-                e1 -= muj;
-                xp[2 * k] = e0;
-                xp[2 * k + 1] = e1;
-              }
-              if constexpr (DEFL) {
-                const double2 t2 = s_ts[k * TC + tid];
-                s[0] = fma(e0, t2.x, s[0]);
-                s[0] = fma(e1, t2.y, s[0]);
-              }
-              if constexpr (SWEEP) {
-                const double2 v2 = s_v[k * TC + tid];
-                s[DEFL ? 1 : 0] = fma(e0, v2.x, s[DEFL ? 1 : 0]);
-                s[DEFL ? 1 : 0] = fma(e1, v2.y, s[DEFL ? 1 : 0]);
-              }
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < NV; ++k) s[k] = wave_sum_last_row(s[k]);
-          if (lane == 63) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k) ((volatile double*)&s_part[pb][wv][0])[k] = s[k];
-            if constexpr (DED) {
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-              v_seq[wv] = cbase + (unsigned)ip + 1u;
-            }
-          }
-        }
-        if constexpr (!DED) {
+        if constexpr (DED) {
+          // no barrier: the exchange wave runs its own loop.  Consume first -- the slot's refill then has a whole
+          // iteration (this produce, the next wait and consume) to arrive before the column is looked at.
+          if (i >= 0) consume(sc, i);
+          if (ip < ncols) produce(sp, ip);
+        } else {
+          const int pb = (int)(ip & 1);
+          if (ip < ncols) produce(sp, ip);
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();
           __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!DED && xw) {
-          // ---- exchange wave: publish column ip, collect the totals of column i + 1 (consumed in the next iteration;
-          // its loads were issued one iteration ago), issue the loads for column i + 2
-          if (ip < ncols && lane < NV) {
-            double t = s_part[pb][0][lane];
-            for (int q = 1; q < ncw; ++q) t += s_part[pb][q][lane];
-            __hip_atomic_store(c.xch + (j0 + ip) * (int64_t)(CL_NV * W) + (int64_t)lane * W + w, t, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-          }
-          if (i + 1 >= 0 && i + 1 < ncols) {
-            double tot[NV];
-            poll.collect(c, j0 + i + 1, lane, have_pre, s_xv, tot, &s_dead);
-            if (lane == 0) {
-#pragma unroll
-              for (int k = 0; k < NV; ++k) s_tot[(i + 1) & 1][k] = tot[k];
+          if (xw) {
+            // ---- exchange wave: publish column ip, collect the totals of column i + 1 (consumed in the next iteration;
+            // its loads were issued one iteration ago), issue the loads for column i + 2
+            if (ip < ncols && lane < NV) {
+              double t = s_part[pb][0][lane];
+              for (int q = 1; q < ncw; ++q) t += s_part[pb][q][lane];
+              __hip_atomic_store(c.xch + (j0 + ip) * (int64_t)(CL_NV * W) + (int64_t)lane * W + w, t, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
             }
-          }
-          have_pre = false;
-          if (L >= 2 && i + 2 >= 0 && i + 2 < ncols) {      // (published by every workgroup L - 2 iterations ago or now)
-            poll.prefetch(c, j0 + i + 2, lane);
-            have_pre = true;
-          }
-        }
-        if (cw && i >= 0) {
-          // ---- compute waves, consume: totals of column i (left in LDS by the exchange wave one iteration ago)
-          const int64_t jj = j0 + i;
-          double(&xc)[R] = x[sc];
-          const int cb = (int)(i & (DED ? Q - 1 : 1));
-          if constexpr (DED) {
-            const unsigned want = cbase + (unsigned)i + 1u;
-            unsigned spins = 0;
-            while ((int)(*v_rdy - want) < 0 && *v_dead == 0u) {
-              __builtin_amdgcn_s_sleep(1);
-              if (++spins > (1u << 26)) {
-                if (lane == 0) give_up();
-                break;
-              }
-            }
-          }
-          const int oslot = (int)(i & 63);
-          double cj = 0.0;
-          if constexpr (STATS) {
-            const volatile double* tq = &s_tot[cb][0];
-            const double S1 = tq[0], S2 = tq[1], Sv = tq[2];
-            if (fit) {
-              const double K0 = uniform_f64(k0v[sc]);
-              const double inv_n = 1.0 / dn;
-              const double m1 = S1 * inv_n;
-              const double mean = K0 + m1;
-              const double var = fmax((S2 - S1 * m1) * inv_n, 0.0);
-              const double eps = 2.220446049250313e-16;
-              const double nme = dn * mean * eps;
-              const bool constant = var <= dn * eps * var + nme * nme;
-              double rv = __builtin_amdgcn_rcp(var);
-              rv = fma(fma(-var, rv, 1.0), rv, rv);
-              rv = fma(fma(-var, rv, 1.0), rv, rv);
-              const double r2 = constant ? 0.0 : rv;
-              const double gt = a.alpha * Sv;             // raw-space weight g~_j
-              cj = gt * r2;
-              ssq_g = fma(gt, cj, ssq_g);
-              amp = fmax(amp, mean * mean * r2);
-              ssq_x = fma(dn * var, r2, ssq_x);
-              if (writer) {
-                if (lane == 0) {
-                  s_out[0][oslot] = mean;
-                  s_out[1][oslot] = var;
-                  s_out[2][oslot] = r2;
-                  s_out[3][oslot] = gt;
-                }
-                if (oslot == 63 || i == ncols - 1) {
-                  const int64_t jb = jj - oslot;
-                  if (lane <= oslot) {
-                    a.mean[jb + lane] = s_out[0][lane];
-                    a.scale[jb + lane] = s_out[1][lane];
-                    if (a.r2_out) a.r2_out[jb + lane] = s_out[2][lane];
-                    if (a.g) a.g[jb + lane] = s_out[3][lane];
-                  }
-                }
-              }
-            } else {                                      // standardize=False: sums of squares and the sweep only
-              const double gj = a.alpha * Sv;
-              cj = gj;
-              ssq_g = fma(gj, gj, ssq_g);
-              ssq_x += S2;
-              if (writer) {
-                if (lane == 0) s_out[3][oslot] = gj;
-                if ((oslot == 63 || i == ncols - 1) && lane <= oslot && a.g) a.g[jj - oslot + lane] = s_out[3][lane];
-              }
-            }
-          } else {
-            const volatile double* tq = &s_tot[cb][0];
-            const double r2c = uniform_f64(r2v[sc]);
-            double gj = 0.0, pj = 0.0, pjk = 0.0;
-            if constexpr (DEFL) {
-              pj = tq[0] * a.inv_tt;               // raw-space loading p~_j
-              ssq_p = fma(pj * pj, r2c, ssq_p);
-              if constexpr (SWEEP) {
-                const double b = tq[1];
-                if (a.deflate) {
-                  gj = a.alpha * fma(-pj, tsv, b);        // <x - p ts, v> = <x, v> - p <ts, v>
-                  pjk = pj;
-                } else {
-                  gj = a.alpha * b;
-                }
-              }
-            } else {
-              gj = a.alpha * tq[0];
-            }
-            if constexpr (SWEEP) {
-              cj = gj * r2c;
-              ssq_g = fma(gj, cj, ssq_g);
-              dacc = fma(cj, pp[sc], dacc);
-              if constexpr (DEFL) dk = fma(cj, pjk, dk);
-            }
-            if (writer) {
+            if (i + 1 >= 0 && i + 1 < ncols) {
+              double tot[NV];
+              poll.collect(c, j0 + i + 1, lane, have_pre, s_xv, tot, &s_dead);
               if (lane == 0) {
-                s_go[0][oslot] = gj;
-                s_go[1][oslot] = pj;
-              }
-              if (oslot == 63 || i == ncols - 1) {
-                const int64_t jb = jj - oslot;
-                if (lane <= oslot) {
-                  const double r = outs ? a.rs[jb + lane] : 1.0;
-                  if (SWEEP && a.g) a.g[jb + lane] = s_go[0][lane] * r;
-                  if (DEFL && a.pvec) {
-                    a.pvec[jb + lane] = s_go[1][lane];
-                    if (outs && a.pvec_true) a.pvec_true[jb + lane] = s_go[1][lane] * r;
-                  }
-                }
+  #pragma unroll
+                for (int k = 0; k < NV; ++k) s_tot[(i + 1) & 1][k] = tot[k];
               }
             }
+            have_pre = false;
+            if (L >= 2 && i + 2 >= 0 && i + 2 < ncols) {      // (published by every workgroup L - 2 iterations ago or now)
+              poll.prefetch(c, j0 + i + 2, lane);
+              have_pre = true;
+            }
           }
-          if constexpr (SWEEP) {
-#pragma unroll
-            for (int k = 0; k < R; ++k) acc[k] = fma(cj, xc[k], acc[k]);
-          }
-          if (i + D < ncols) fetch(sc, jj + D);
+          if (i >= 0) consume(sc, i);
         }
       }
     }

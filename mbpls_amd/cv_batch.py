@@ -186,6 +186,7 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol):
             ts_old = np.zeros((n, F))
             nu_fin = np.ones((B, F)); ts_fin = np.zeros((n, F)); v_fin = np.zeros(F)
             run = 1
+            prev_diff, stalls = None, np.zeros(F, dtype=np.int64)
             while active.any():
                 uu = (u * u).sum(axis=0)
                 ssq, t = sweep(u, 1.0 / uu, k)                               # (:856, :875)
@@ -199,11 +200,16 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol):
                 v = (Ys * ts).sum(axis=0) / (ts * ts).sum(axis=0)            # (:899)
                 un = Ys * (v / (v * v))                                      # (:911)
                 un /= np.sqrt((un * un).sum(axis=0))
-                floor_hit = run >= solvers.NIPALS_Q1_NOISE_FLOOR_ITER
+                # stagnation rule of the fold-by-fold loop (solvers.q1_noise_floor), per fold
+                floor_hit = np.zeros(F, dtype=bool)
+                if run >= 2:
+                    floor_hit, stalls = solvers.q1_noise_floor(run, diff, prev_diff, stalls)
+                    prev_diff = diff
+                floor_hit = floor_hit & active & (diff > tol)
                 done = active & ((diff <= tol) | floor_hit)
-                if floor_hit and (active & (diff > tol)).any():
+                if floor_hit.any():
                     warnings.warn(f"NIPALS component {k}: ||ts_old - ts|| stays above max_tol={tol} in "
-                                  f"{int((active & (diff > tol)).sum())} fold(s) (rounding noise of an exhausted "
+                                  f"{int(floor_hit.sum())} fold(s) (rounding noise of an exhausted "
                                   f"response); stopped after {run} iterations.")
                 if done.any():                                               # this iteration's g is their W~[:, k]
                     keep(Wst, k, None if done.all() else np.nonzero(done)[0])

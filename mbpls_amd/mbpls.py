@@ -11,10 +11,11 @@ Deliberate deviations from the reference (documented in DESIGN.md):
   host (n x q) for EVERY row, where the reference only patches the sparse rows of the last X block and fails on any
   other (mbpls.py:903): same numbers wherever the reference produces any.
 * NIPALS has an iteration cap (``solvers.NIPALS_MAX_ITER``) with a warning; the reference loops
-  forever on data without latent structure (mbpls.py:841).  With ONE complete response the loop also gives up after
-  ``solvers.NIPALS_Q1_NOISE_FLOOR_ITER`` iterations -- always with a warning, ``nipals_converged_[k] = False`` -- when
-  ``||ts_old - ts||`` is still above ``max_tol``: the iteration is at its fixed point after the first pass, what is
-  left is rounding noise of a response that is exhausted, and the reference does not terminate there either.
+  forever on data without latent structure (mbpls.py:841).  With ONE complete response the loop also gives up once
+  ``||ts_old - ts||`` STAGNATES above ``max_tol`` (``solvers.q1_noise_floor``: from the fourth iteration on, two
+  iterations in a row without halving it; twelve at most) -- always with a warning, ``nipals_converged_[k] = False``:
+  the iteration is at its fixed point after the first pass, what is left is rounding noise of a response that is
+  exhausted, and the reference does not terminate there either.  A difference that still shrinks is left to converge.
 * SIMPLS with one response and ``full_svd=False`` works (the reference raises inside scipy ``svds``).
 * X may also be a ``DeviceMatrix`` already resident in HBM (feature-major); ``copy`` then decides
   whether it is deflated in place.

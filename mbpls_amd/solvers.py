@@ -25,9 +25,26 @@ NIPALS_MAX_ITER = 5000
 # > 0.9999 -- that rounding is amplified by ||y|| / ||y residual|| and ||ts_old - ts|| <= 1e-14 (mbpls.py:841) is out of
 # reach for the reference too: its loop does not end (the CPU oracle, explicit deflation, shows 2 iterations for
 # components 0..28 and then 6, cap, cap, 4, cap, ... on the same data -- tools/deep_iterations_cpu.py).  More passes
-# only re-roll the rounding, so the one-response loop gives up after this many iterations, ALWAYS with a warning, and
-# the component is flagged in ``nipals_converged_``.  Listed among the deliberate deviations.
+# only re-roll the rounding, so the one-response loop gives up once the difference has STAGNATED -- not before this many
+# iterations, after two consecutive iterations without at least halving it, and in any case after
+# NIPALS_Q1_NOISE_FLOOR_MAX -- ALWAYS with a warning, and the component is flagged in ``nipals_converged_``.  (A fixed
+# cut-off at four iterations also stopped components the reference finishes in five: a difference that still shrinks is
+# convergence, not noise.)  Listed among the deliberate deviations.
 NIPALS_Q1_NOISE_FLOOR_ITER = 4
+NIPALS_Q1_NOISE_FLOOR_MAX = 12
+
+
+def q1_noise_floor(run, diff, prev_diff, stalls):
+    """One-response NIPALS, after iteration ``run`` (>= 2) with difference ``diff`` (``prev_diff``: the one before, or
+    None): returns (give_up, stalls).  Works element-wise on arrays (one entry per cross-validation fold)."""
+    if prev_diff is None:
+        return (np.zeros(np.shape(diff), dtype=bool) if np.ndim(diff) else False), stalls
+    stalled = np.asarray(diff) >= 0.5 * np.asarray(prev_diff)
+    stalls = np.where(stalled, np.asarray(stalls) + 1, 0)
+    give_up = ((run >= NIPALS_Q1_NOISE_FLOOR_ITER) & (stalls >= 2)) | (run >= NIPALS_Q1_NOISE_FLOOR_MAX)
+    if not np.ndim(diff):
+        return bool(give_up), int(stalls)
+    return give_up, stalls
 
 
 def _norm(x, order):
@@ -490,6 +507,7 @@ def _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
             ts = Tm.dot(sw)                                 # (:882)
             ts = ts / np.linalg.norm(ts)
             if run > 1:
+                prev_diff = diff if run > 2 else None
                 diff = _norm(ts_old - ts, norm)             # (:887)
             ts_old = ts.copy()
             z_used, uu_used = z, uu
@@ -658,6 +676,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     for k in range(k_start, K):
         u = u0
         diff, run, ts_old = 1.0, 1, None
+        prev_diff, stalls = None, 0
         while diff > max_tol:
             uu = u.T.dot(u).item()
             if run > 1:
@@ -669,6 +688,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
             ts = Tm.dot(sw)                                 # (:882)
             ts = ts / np.linalg.norm(ts)
             if run > 1:
+                prev_diff = diff if run > 2 else None
                 diff = _norm(ts_old - ts, norm)             # (:887)
             ts_old = ts.copy()
             v = resp.loadings(ts)                           # (:899)
@@ -678,7 +698,10 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
                 warnings.warn(f"NIPALS component {k}: no convergence to max_tol={max_tol} after {max_iter} "
                               f"iterations (last diff {diff:.3e}); the reference would loop forever here.")
                 break
-            if q == 1 and not resp.sparse and run - 1 >= NIPALS_Q1_NOISE_FLOOR_ITER and diff > max_tol:
+            floor_hit = False
+            if q == 1 and not resp.sparse and run - 1 >= 2 and diff > max_tol:
+                floor_hit, stalls = q1_noise_floor(run - 1, diff, prev_diff, stalls)
+            if floor_hit:
                 warnings.warn(f"NIPALS component {k}: ||ts_old - ts|| = {diff:.3e} stays above max_tol={max_tol} after "
                               f"{run - 1} iterations -- with one response the iteration has been at its fixed point "
                               f"since the first pass, the difference is rounding noise (y is nearly exhausted); "

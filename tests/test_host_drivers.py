@@ -144,3 +144,35 @@ def test_scalers_are_sklearn_standard_scalers():
     carried = ColumnScaler(ref.mean_, ref.scale_, 40, ref.var_)          # statistics produced elsewhere (the GPU passes)
     np.testing.assert_allclose(pickle.loads(pickle.dumps(carried)).transform(X), ref.transform(X), rtol=1e-12, atol=1e-13)
     assert isinstance(clone(carried), ColumnScaler)
+
+
+def test_one_response_noise_floor_is_a_stagnation_rule():
+    """advisor finding (round 3): a fixed cut-off at four iterations also stopped components the reference finishes in
+    five.  The one-response loop gives up only when ||ts_old - ts|| has STOPPED shrinking; iteration counts equal the
+    oracle's wherever the oracle converges, and a difference that still shrinks is never cut."""
+    import warnings
+    from oracle import mbpls_oracle as orc
+    st, pd = 0, None
+    for run, d in [(2, 1e-10), (3, 1e-12), (4, 3e-14), (5, 1.2e-14)]:       # shrinking: left to converge
+        give_up, st = solvers.q1_noise_floor(run, d, pd, st)
+        pd = d
+        assert not give_up
+    st, pd, stops = 0, None, []
+    for run, d in [(2, 3e-14), (3, 2.5e-14), (4, 4e-14), (5, 3e-14)]:       # a plateau: stopped at the fourth iteration
+        give_up, st = solvers.q1_noise_floor(run, d, pd, st)
+        pd = d
+        stops.append(give_up)
+    assert stops == [False, False, True, True]
+    g, st = solvers.q1_noise_floor(3, np.array([1e-14, 3e-14]), np.array([1e-10, 2e-14]), np.zeros(2, dtype=int))
+    assert list(st) == [0, 1] and not g.any()                               # per cross-validation fold
+    rng = np.random.RandomState(1)
+    X, Y = rng.standard_normal((60, 400)), rng.standard_normal((60, 1))     # p >> n: y is exhausted after five components
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = orc.fit(X, Y, n_components=6, method="NIPALS", faithful=False, max_iter=60)
+        res = run_driver(X, Y, "NIPALS", 6)
+    for it_ref, it, conv in zip(ref.nipals_iterations_, res["nipals_iterations_"], res["nipals_converged_"]):
+        if it_ref < 60:
+            assert it == it_ref and conv
+        else:
+            assert not conv and it <= solvers.NIPALS_Q1_NOISE_FLOOR_MAX
