@@ -42,7 +42,10 @@
 namespace mbpls {
 
 // 16 rows per thread, a ring of 3 columns, partial sums 2 columns ahead of their consumption; 512 threads = 8 waves,
-// 2 per SIMD: 256 registers per lane (a ring of 4 columns of 12 rows, 3 ahead, measured 10-20 % slower).
+// 2 per SIMD: 256 registers per lane.  What bounds these passes at 5.2-5.6 TB/s is the data a CU can hold while a
+// column waits: about two column times for the hand-off (a store and a load through the fabric while every CU streams)
+// plus one for the refill = 3 x 64 KB, all the registers there are (a ring of 4 columns spills 40-90 registers; 4
+// columns of 12 rows measured 10-20 % slower: smaller slabs need proportionally more columns in flight).
 constexpr int CL_TMAX = 512;
 constexpr int CL_NV = 4;       // doubles per (column, workgroup) exchange slot
 constexpr unsigned long long CL_SENT = 0x7FF8C0DEC0DEC0DEull;   // "not yet published"
@@ -54,6 +57,7 @@ struct ClArgs {
   int64_t p;
   double* xch;           // [(p + nchunks)][CL_NV][W]
   unsigned spin_limit;
+  int prefetch;          // shared exchange wave: issue the loads of the next slot one iteration ahead
   unsigned* err;         // device word: polls that gave up
   double* par;           // device-resident pass parameters (writable view of a.dpar) or NULL
 };
@@ -83,12 +87,28 @@ template <int NVX>
 struct ClPoll {
   double pre[CL_PRE];
   __device__ __forceinline__ void prefetch(const ClArgs& c, int64_t slot, int lane) {
-    const int nflat = NVX * c.W;
-    const double* base = c.xch + slot * (int64_t)(CL_NV * c.W);
+    const int W = c.W, nflat = NVX * W;
+    const double* base = c.xch + slot * (int64_t)(CL_NV * W);
+    if (W <= 64) {                 // one lane per workgroup, one load per value (the layout collect() takes directly)
+#pragma unroll
+      for (int k = 0; k < NVX; ++k)
+        pre[k] = (lane < W) ? __hip_atomic_load(base + k * W + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < CL_PRE; ++r) {
       const int idx = r * 64 + lane;
       pre[r] = (idx < nflat) ? __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+  }
+  __device__ __forceinline__ void gave_up(const ClArgs& c, int lane, volatile unsigned* s_dead) {
+    if (lane == 0) {
+      *s_dead = 1u;
+      atomicAdd(c.err, 1u);
+      if (c.par) {
+        c.par[7] = 1.0;
+        c.par[2] = 1.0;            // everything queued behind becomes a no-op
+      }
     }
   }
   // totals of the slot (fixed order: slab order within 64-lane rounds); have_pre: prefetch() was called for this slot
@@ -96,6 +116,33 @@ struct ClPoll {
                                           double (&tot)[NVX], volatile unsigned* s_dead) {
     const int W = c.W, nflat = NVX * W;
     const double* base = c.xch + slot * (int64_t)(CL_NV * W);
+    if (W <= 64) {
+      // the everyday case (n up to half a million rows): lane w' holds workgroup w's partial of every value
+      double val[NVX];
+      bool first = true;
+      unsigned spins = 0;
+      while (true) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) {
+          if (first && have_pre) val[k] = pre[k];
+          else if (first || (unsigned long long)__double_as_longlong(val[k]) == CL_SENT)
+            val[k] = (lane < W) ? __hip_atomic_load(base + k * W + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NVX; ++k) ok = ok && (unsigned long long)__double_as_longlong(val[k]) != CL_SENT;
+        first = false;
+        if (__all(ok ? 1 : 0) || *s_dead != 0u) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > c.spin_limit) {
+          gave_up(c, lane, s_dead);
+          break;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NVX; ++k) tot[k] = wave_sum(val[k]);
+      return;
+    }
     for (int g0 = 0; g0 < nflat; g0 += 64 * CL_RND) {
       double val[CL_RND];
       bool first = true;
@@ -119,14 +166,7 @@ struct ClPoll {
         if (__all(ok ? 1 : 0) || *s_dead != 0u) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > c.spin_limit) {
-          if (lane == 0) {
-            *s_dead = 1u;
-            atomicAdd(c.err, 1u);
-            if (c.par) {
-              c.par[7] = 1.0;
-              c.par[2] = 1.0;            // everything queued behind becomes a no-op
-            }
-          }
+          gave_up(c, lane, s_dead);
           break;
         }
       }
@@ -527,10 +567,11 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
         const int sp = d;
         const int sc = (d + D - (L % D)) % D;
         if constexpr (DED) {
-          // no barrier: the exchange wave runs its own loop.  Consume first -- the slot's refill then has a whole
-          // iteration (this produce, the next wait and consume) to arrive before the column is looked at.
-          if (i >= 0) consume(sc, i);
+          // no barrier: the exchange wave runs its own loop.  Produce first: the hand-off between the workgroups (a
+          // store and a load through the fabric under full streaming load) takes about two column times, more than
+          // the refill of a slot (consume first measured 5.5 -> 3.6 TB/s at n = 20 000).
           if (ip < ncols) produce(sp, ip);
+          if (i >= 0) consume(sc, i);
         } else {
           const int pb = (int)(ip & 1);
           if (ip < ncols) produce(sp, ip);
@@ -555,7 +596,7 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
               }
             }
             have_pre = false;
-            if (L >= 2 && i + 2 >= 0 && i + 2 < ncols) {      // (published by every workgroup L - 2 iterations ago or now)
+            if (c.prefetch && L >= 2 && i + 2 >= 0 && i + 2 < ncols) {      // (published by every workgroup about now)
               poll.prefetch(c, j0 + i + 2, lane);
               have_pre = true;
             }
@@ -753,6 +794,7 @@ static int cl_launch(mbpls_ctx* ctx, const mbpls_mat* mc, PassArgs a, bool cen) 
   c.a = a;
   c.W = pl.W; c.G = std::min(pl.G, ct.nchunks); c.nchunks = ct.nchunks; c.S = pl.S; c.p = m->p;
   c.spin_limit = ctx->cluster_spin_limit;
+  c.prefetch = ctx->cluster_prefetch;
   c.par = const_cast<double*>(ctx->dpar);
   const size_t slots = (size_t)m->p + (size_t)ct.nchunks;
   const size_t xd = slots * (size_t)CL_NV * (size_t)pl.W;
