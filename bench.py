@@ -79,7 +79,12 @@ def main():
     ap.add_argument("--e2e-cols", type=int, default=-1,
                     help="columns of the end-to-end (host numpy in) leg; -1 = all when host RAM allows, 0 = skip")
     ap.add_argument("--no-extras", action="store_true", help="skip the explicit-deflation / fixed-point extras")
+    ap.add_argument("--first-fit-child", action="store_true",
+                    help="(internal) fresh process: generate X, time the FIRST fit of the process and the second, print JSON")
+    ap.add_argument("--no-first-fit", action="store_true", help="skip the cold-start leg (a child process run first)")
     a = ap.parse_args()
+    if a.first_fit_child:
+        return first_fit_child(a)
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process only starts the N ranks (fresh processes,
@@ -90,6 +95,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # cold start: what a user who calls fit() once per process pays.  A CHILD process, started before this one has
+    # touched the GPU, generates the same matrix and times its first and second fit.
+    cold = None
+    if world == 1 and not a.dist and not a.no_first_fit and not a.no_extras:
+        cold = run_first_fit_child(a)
     import mbpls_amd
     from mbpls_amd import MBPLS, DeviceMatrix
 
@@ -265,6 +275,9 @@ def main():
                        "method": a.method, "standardize": True, "calc_all": True, "nipals_iterations": iters},
             "fit_wall_s": round(per_step, 5), "fits_per_s": round(1.0 / per_step, 4),
             "fit_wall_s_median": round(float(np.median(per_fit)), 5),
+            "fit_wall_s_max": round(float(np.max(per_fit)), 5),
+            "first_fit_wall_s": None if not cold else cold.get("first_fit_wall_s"),
+            "cold_start": cold,
             "estimator_per_step": "fresh (a new MBPLS object for every timed fit, warm process)",
             "fit_wall_s_same_estimator_refit": round(float(np.median(refit)), 5),
             "fit_wall_s_each": [round(t, 5) for t in per_fit],
@@ -286,8 +299,13 @@ def main():
         if rank == 0:
             out["end_to_end_host_numpy"] = e2e
     if rank == 0:
-        if dist is None and a.cpu_cols > 0:
+        if a.cpu_cols > 0 and dist is None:
             out["cpu_baseline"] = cpu_baseline(ctx, X, Y, n, p, min(a.cpu_cols, p), K, a.method, per_step)
+        elif a.cpu_cols > 0:
+            # N > 1: rank 0 times the oracle on a smaller sample of ITS columns (the other ranks wait at the barrier
+            # below); the GPU-vs-oracle comparison of this configuration is sharded_self_check, run before the timing
+            out["cpu_baseline"] = cpu_baseline(ctx, X, Y, n, p * world, min(a.cpu_cols // 2, p), K, a.method, per_step,
+                                               gpu_check=False)
         else:
             out["cpu_baseline"] = None
     X.close()
@@ -768,7 +786,52 @@ def pmc_traffic(kernel, n, p):
     return None, None
 
 
-def cpu_baseline(ctx, X, Y, n, p, cols, K, method, gpu_fit_s):
+def first_fit_child(a):
+    """bench.py --first-fit-child: a fresh process.  Times import, context, data generation, the FIRST fit (fresh
+    estimator, everything cold: code objects, pools, pinned buffers, helper threads) and the second."""
+    t_start = time.perf_counter()
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix
+    t_imp = time.perf_counter()
+    ctx = mbpls_amd.get_context()
+    t_ctx = time.perf_counter()
+    Ts, Y = planted(a.n, a.q, 32, seed=0)
+    dT = ctx.from_host(Ts)
+    X = DeviceMatrix(ctx, a.n, a.p, [0, a.p])
+    X.fill_latent(dT, 32, 0.5, 1234, 0)
+    ctx.sync()
+    t_gen = time.perf_counter()
+    walls, phases = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        m = MBPLS(n_components=a.K, method=a.method, standardize=True, calc_all=True, copy=True).fit(X, Y)
+        walls.append(time.perf_counter() - t0)
+        phases.append({k: round(1e3 * v, 2) for k, v in m.fit_timings_.items()})
+    print(json.dumps({"first_fit_wall_s": round(walls[0], 5), "second_fit_wall_s": round(walls[1], 5),
+                      "third_fit_wall_s": round(walls[2], 5), "import_s": round(t_imp - t_start, 3),
+                      "context_s": round(t_ctx - t_imp, 3), "generate_s": round(t_gen - t_ctx, 3),
+                      "host_phases_ms_first_fit": phases[0], "host_phases_ms_second_fit": phases[1],
+                      "protocol": "fresh process (child started before the parent touched the GPU), X generated in HBM, "
+                                  "fresh estimator per fit"}), flush=True)
+    X.close()
+    return 0
+
+
+def run_first_fit_child(a):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--first-fit-child", "--n", str(a.n), "--p", str(a.p), "--K", str(a.K),
+           "--q", str(a.q), "--method", a.method]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        for line in reversed(r.stdout.splitlines()):
+            if line.lstrip().startswith("{"):
+                return json.loads(line)
+        return {"error": f"child exited with {r.returncode}: {r.stderr[-300:]}"}
+    except Exception as e:                               # noqa: BLE001 -- reported in the line, never fatal
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def cpu_baseline(ctx, X, Y, n, p, cols, K, method, gpu_fit_s, gpu_check=True):
     """BASELINE.md section 3 protocol on the GPU box's host cores: the oracle in FAITHFUL mode (= the reference's numpy
     op sequence, n x p temporaries included) and in LEAN mode (the GPU's algorithm on the CPU) at three widths of the
     SAME device-generated matrix, after one warm-up fit; a line fitted in p gives the labelled extrapolation to the
@@ -778,13 +841,13 @@ def cpu_baseline(ctx, X, Y, n, p, cols, K, method, gpu_fit_s):
     from oracle import mbpls_oracle as orc
     from mbpls_amd.runtime import cpu_quota
     sizes = sorted({max(2048, cols // 2), cols})
-    big = 4 * cols                                   # one larger sample (single run) when the host has the memory for it
+    big = 4 * cols if gpu_check else 0               # one larger sample (single run) when the host has the memory for it
     try:
         with open("/proc/meminfo") as f:
             avail = next(int(line.split()[1]) * 1024 for line in f if line.startswith("MemAvailable"))
     except Exception:
         avail = 0
-    if big <= p and 6.5 * 8.0 * n * big < avail:     # faithful mode holds ~5 X-sized temporaries
+    if big and big <= p and 6.5 * 8.0 * n * big < avail:     # faithful mode holds ~5 X-sized temporaries
         sizes.append(big)
     Xs = X.download(0, sizes[-1])
     cols_checked = cols
@@ -813,7 +876,7 @@ def cpu_baseline(ctx, X, Y, n, p, cols, K, method, gpu_fit_s):
                     rec["faithful_s_each"] = [round(t, 3) for t in tt]
                     if c == cols_checked:
                         ref = mdl
-                    if c > cols_checked:                 # the large sample: the GPU fit of the same columns against it
+                    if c > cols_checked and gpu_check:   # the large sample: the GPU fit of the same columns against it
                         g = MBPLS(n_components=K, method=method).fit(Xc, Y)
                         sg = np.sign(np.sum(mdl.Ts_ * g.Ts_, axis=0))
                         rec["gpu_vs_oracle_relerr"] = float(max(
@@ -839,11 +902,13 @@ def cpu_baseline(ctx, X, Y, n, p, cols, K, method, gpu_fit_s):
         full = float(slope * p + icpt)
         fit[mode] = {"s_per_1e6_columns": round(float(slope) * 1e6, 2), "extrapolated_full_size_fit_s": round(full, 1),
                      "extrapolated_fits_per_s": round(1.0 / full, 6), "gpu_speedup_fits_per_s": round(full / gpu_fit_s, 1)}
-    mdl = MBPLS(n_components=K, method=method).fit(np.ascontiguousarray(Xs[:, :cols_checked]), Y)
-    s = np.sign(np.sum(ref.Ts_ * mdl.Ts_, axis=0))
-    err = max(np.max(np.abs(mdl.Ts_ * s - ref.Ts_)) / np.max(np.abs(ref.Ts_)),
-              np.max(np.abs(mdl.beta_ - ref.beta_)) / np.max(np.abs(ref.beta_)),
-              np.max(np.abs(mdl.P_[0] * s - ref.P_[0])) / np.max(np.abs(ref.P_[0])))
+    err = None
+    if gpu_check:
+        mdl = MBPLS(n_components=K, method=method).fit(np.ascontiguousarray(Xs[:, :cols_checked]), Y)
+        s = np.sign(np.sum(ref.Ts_ * mdl.Ts_, axis=0))
+        err = float(max(np.max(np.abs(mdl.Ts_ * s - ref.Ts_)) / np.max(np.abs(ref.Ts_)),
+                        np.max(np.abs(mdl.beta_ - ref.beta_)) / np.max(np.abs(ref.beta_)),
+                        np.max(np.abs(mdl.P_[0] * s - ref.P_[0])) / np.max(np.abs(ref.P_[0]))))
     return {"value": round(gbps, 3), "unit": "GB/s", "cores": thr, "kind": "port",
             "sample": f"oracle faithful mode (reference numpy op sequence) on the first {cols_timed} columns of the same "
                       f"matrix, n={n} K={K}: {t_cpu:.1f} s wall = {units} reference-algorithm units of 8np bytes / wall; "
@@ -851,7 +916,7 @@ def cpu_baseline(ctx, X, Y, n, p, cols, K, method, gpu_fit_s):
                       f"median of 3 runs at the two smaller widths, one run at the largest",
             "fit_wall_s": t_cpu, "runs": runs, "linear_fit_in_p": fit,
             "extrapolation": f"EXTRAPOLATED to p={p} from {len(runs)} sizes (linear in p); not measured at full size",
-            "gpu_vs_oracle_relerr_on_sample": float(err), "gpu_vs_oracle_sample_columns": cols_checked}
+            "gpu_vs_oracle_relerr_on_sample": err, "gpu_vs_oracle_sample_columns": cols_checked if gpu_check else None}
 
 
 if __name__ == "__main__":

@@ -72,7 +72,7 @@ struct mbpls_ctx {
   // (colpass_cluster.hip); 0 = the two-phase passes of colpass_long.hip for everything
   int cluster_passes = 1;
   int64_t cluster_slab_rows = 8192;    // rows of a column held by one workgroup of a cluster (tests lower it)
-  int cluster_prefetch = 1;            // shared exchange wave: loads of the next column's partial sums issued ahead
+  int cluster_prefetch = 0;            // shared exchange wave: loads of the next column's partial sums issued ahead
   int cluster_exchange = 0;            // 0: dedicated exchange wave unless sharing saves workgroups; 1: always; 2: never
   unsigned cluster_spin_limit = 1u << 22;   // polls before a cluster hand-off gives up
   void* cl_ws = nullptr;               // fine-grained: [error word | exchange slots] of the cluster passes

@@ -116,6 +116,10 @@ class HipEngine(EngineBase):
             if hasattr(self.G[1], "free"):
                 self.G[1].free()
             self.G = None
+        if getattr(self, "_xtx", None) is not None:
+            self._xtx[0].close()
+            self._xtx[1].free()
+            self._xtx = None
         if getattr(self, "Gsum", None) is not None:
             self.Gsum[0].close()
             self.Gsum[1].free()
@@ -827,6 +831,31 @@ class HipEngine(EngineBase):
         S = self.slots[slot]
         self.X.xt_v(self.X.data_ptr, self.p, 1.0, S, None, ldv=self.X.ld, ldg=self.p)
 
+    def xtx_operator(self):
+        """w -> (X^T X) w with the p x p matrix left where the matrix cores wrote it: it is wrapped as a p x p
+        'matrix' whose x_w product IS the symmetric matrix-vector product (KERNEL n >= p, mbpls.py:586-633).  Column
+        shards would need the cross products of different shards: the host form then."""
+        if self.comm.is_distributed:
+            return super().xtx_operator()
+        p = self.p
+        ldg = p + (p & 1)
+        store = self.ctx.empty(ldg * p, zero=True)
+        self.X.xt_v(self.X.data_ptr, p, 1.0, store, None, ldv=self.X.ld, ldg=ldg)
+        Vm = _capi.DeviceMatrix(self.ctx, p, p, [0, p], storage=store.ptr)
+        self._xtx = (Vm, store)
+
+        def apply(w):
+            w = np.ascontiguousarray(np.asarray(w, dtype=np.float64).reshape(p, -1).T)     # c x p: columns contiguous
+            c = w.shape[0]
+            dW = self.ctx.from_host(w.ravel())
+            buf = self.ctx.empty(p * c)
+            Vm.x_w(dW, c, buf, ldw=p, ldo=p)
+            out = buf.get().reshape(c, p).T.copy()
+            buf.free()
+            dW.free()
+            return out
+        return apply
+
     def _xw(self, Wdev, c, per_block, mean=None, scale=None, mat=None, nan=None, overlap=None):
         """nan: None dense; "skip" missing entries contribute nothing; "indicator" sums of W over the present
         columns of every row (csrc/gemv.hip k_xw NANM).  ``overlap``: host work to do while the kernel runs."""
@@ -937,6 +966,10 @@ class HipEngine(EngineBase):
         Gm = self.Gb[0]
         n, B, k, q = self.n, self.nblocks, Tp.shape[1], Y.shape[1]
         ctx = self.ctx
+        if getattr(self, "_xtx", None) is not None:
+            self._xtx[0].close()
+            self._xtx[1].free()
+            self._xtx = None
         if getattr(self, "Gsum", None) is not None:
             Gm, B = self.Gsum[0], 1         # iterate on the summed Gram: one n x n product per iteration
         if getattr(self, "_gp", None) is None or self._gp["q"] != q:

@@ -58,6 +58,13 @@ class EngineBase:
     def sync(self):
         pass
 
+    def xtx_operator(self):
+        """callable w (p x c host) -> (X^T X) w: here through a host copy of the p x p matrix"""
+        self.slot("XtX", self.p)
+        self.xt_self("XtX")
+        VAR = self.fetch("XtX")
+        return lambda w: VAR.dot(w)
+
     def xt_self(self, slot):
         """slot (p x p) = X^T X"""
         self.xt_v(self.X.download(order="F"), 1.0, slot, 0)

@@ -1097,24 +1097,35 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
         else:
             res.update(empty_blocks)
         return res
-    # ---- n >= p (:580-692): everything is p x p, p <= n <= a few thousand -> host algebra on X^T X, X^T Y
+    # ---- n >= p (:580-692).  The reference deflates the p x p matrices with dense products, D^T VAR D with
+    # D = I - w pl (:630-633): two p^3 GEMMs per component.  VAR is symmetric and pl = w^T VAR / den, so
+    #     D^T VAR D = VAR - g g^T / den,   g = VAR w,   den = w^T g          (a symmetric rank-1 update)
+    #     D^T COV   = COV - pl^T (w^T COV)
+    # and VAR_k = VAR_0 - sum_i g_i g_i^T / den_i never has to be formed: g_k = VAR_0 w_k - sum_i g_i (g_i^T w_k) / den_i
+    # costs ONE product with the p x p matrix X^T X where it lies in HBM (engine.xtx_operator: O(p^2), 3.2 GB at
+    # p = 20 000) plus O(p K) on the host -- the n >= p analogue of the rank updates of the p > n branch.  Nothing p x p
+    # visits the host.
     eng.slot("C", q)
     eng.xt_v(Y, 1.0, "C", 0)
     COV = eng.fetch("C")                                    # X^T Y (:587)
-    VAR = _xtx(eng)                                         # X^T X (:586)
+    var0 = eng.xtx_operator()                               # w -> (X^T X) w (:586)
     p = eng.p
     Wc = np.empty((p, 0)); P = np.empty((p, 0)); V = np.empty((q, 0)); U = np.empty((n, 0))
+    Gd = np.empty((p, 0)); dens = np.empty(0)
+    _plan(eng, solver="kernel n >= p: rank-1 deflation of X^T X, one p x p product per component")
     for k in range(K):
         w = _tlsv(COV)                                      # S = COV COV^T stays true under :631,:633
-        den = np.linalg.multi_dot([w.T, VAR, w]).item()     # (:595)
+        g = var0(w)                                         # VAR_0 w
+        if k:
+            g = g - Gd.dot(Gd.T.dot(w) / dens[:, None])     # ... - sum_i g_i (g_i^T w) / den_i  =  VAR_k w
+        den = w.T.dot(g).item()                             # (:595)
         v = w.T.dot(COV) / den                              # (:596)
-        pl = w.T.dot(VAR) / den                             # (:599)
+        pl = g.T / den                                      # (:599)  w^T VAR / den, VAR symmetric
         if calc_all:
             u = Y.dot(v.T) / v.dot(v.T)                     # (:624-625)
             U = np.hstack((U, u / np.linalg.norm(u)))
-        D = np.eye(p) - w.dot(pl)                           # (:630)
-        VAR = np.linalg.multi_dot([D.T, VAR, D])            # (:632)
-        COV = D.T.dot(COV)                                  # (:633)
+        COV = COV - pl.T.dot(w.T.dot(COV))                  # (:633)
+        Gd = np.hstack((Gd, g)); dens = np.append(dens, den)
         V = np.hstack((V, v.T)); P = np.hstack((P, pl.T)); Wc = np.hstack((Wc, w))
     R = Wc.dot(np.linalg.pinv(P.T.dot(Wc)))                 # (:642)
     beta = R.dot(V.T)                                       # (:643)
@@ -1132,15 +1143,6 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
     res.beta_ = beta
     res.P_ = _split(P, eng.block_offsets)
     return res
-
-
-def _xtx(eng):
-    """X^T X for the n >= p branch (mbpls.py:586).  The feature-major X in HBM IS the column-major n x p matrix of its
-    own columns, so the p x p product is the many-right-hand-side product X^T V with V = X itself: matrix cores, 64
-    right-hand sides per read of X, nothing leaves the device (the host only fetches the p x p result)."""
-    eng.slot("XtX", eng.p)
-    eng.xt_self("XtX")
-    return eng.fetch("XtX")
 
 
 # ----------------------------------------------------------------------------------- SIMPLS

@@ -343,6 +343,8 @@ def test_sklearn_plumbing(gpu_required):
     ("NIPALS", 8192, 9000, 1, 3, [4000, 5000]),
     ("NIPALS", 10000, 3000, 1, 2, [3000]),          # n > 8192: long-column fallback kernels
     ("UNIPALS", 4096, 12000, 2, 12, [12000]),       # K = 12 lazily deflated components, q = 2
+    ("KERNEL", 4096, 3000, 3, 6, [1000, 2000]),     # n >= p (mbpls.py:580-692): rank-1 deflation of X^T X on the device
+    ("KERNEL", 2500, 2500, 1, 4, [2500]),           # n == p takes the same branch
 ])
 def test_medium_vs_oracle(gpu_required, method, n, p, q, K, blocks):
     from mbpls_amd import MBPLS

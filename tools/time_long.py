@@ -20,8 +20,8 @@ ctx.sync()
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 for thr in (-1, 0, 1, 2, 3):
     ctx.set_tunable("cluster_passes", 0 if thr < 0 else 1)
-    ctx.set_tunable("cluster_exchange", min(max(thr, 0), 2))        # 3: shared exchange wave without prefetch
-    ctx.set_tunable("cluster_prefetch", 0 if thr == 3 else 1)
+    ctx.set_tunable("cluster_exchange", min(max(thr, 0), 2))        # 3: shared exchange wave WITH prefetch
+    ctx.set_tunable("cluster_prefetch", 1 if thr == 3 else 0)
     for method in ("NIPALS", "UNIPALS"):
         m = MBPLS(n_components=K, method=method)
         for rep in range(3):
