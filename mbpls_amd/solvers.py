@@ -391,6 +391,7 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     T = [np.empty((n, K)) for _ in range(B)]
     nu_all = np.empty((B, K))
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
+    converged = []
     _norm(np.zeros((2, 1)), norm)                           # raises for invalid orders exactly as the reference (:887)
     kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
     c0 = np.zeros((q, 1)); c0[0, 0] = 1.0                   # the start vector Y[:, 0] (:838)
@@ -408,6 +409,7 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
             warnings.warn(f"NIPALS component {k}: no convergence to max_tol={max_tol} after {max_iter} "
                           f"iterations; the reference would loop forever here.")
         iters.append(n_it)
+        converged.append(not capped)
         u_used = Y.dot(c_used)                              # sweep vector of the last iteration
         uu = u_used.T.dot(u_used).item()
         # w~ = X^T (P u) / uu = S c / uu, X_b w~_b, ||w~_b||^2: combinations of maintained products
@@ -429,7 +431,7 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
             evy.append(tt * v.T.dot(v).item() / vary)
             evxb[:, k] = tt * ssq_p / varxb
             Acorr[:, k] = _bip_corrected(sw ** 2, sizes)
-    res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, nipals_iterations_=iters)
+    res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, nipals_iterations_=iters, nipals_converged_=converged)
     if calc_all:
         res.update(explained_var_x_=evx, explained_var_y_=evy, explained_var_xblocks_=evxb, A_corrected_=Acorr)
     else:
@@ -469,6 +471,7 @@ def _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     T = [np.empty((n, K)) for _ in range(B)]
     nu_all = np.empty((B, K))
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
+    converged = []
     # norm of the n x 1 difference as numpy's MATRIX norm (:887): 2, 'fro', 'nuc', -2 -> ||d||_2; 1, -1 -> sum |d|;
     # inf -> max |d|; -inf -> min |d|; anything else raises exactly as in the reference
     _norm(np.zeros((2, 1)), norm)
@@ -507,7 +510,6 @@ def _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
             ts = Tm.dot(sw)                                 # (:882)
             ts = ts / np.linalg.norm(ts)
             if run > 1:
-                prev_diff = diff if run > 2 else None
                 diff = _norm(ts_old - ts, norm)             # (:887)
             ts_old = ts.copy()
             z_used, uu_used = z, uu
@@ -520,6 +522,7 @@ def _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
                               f"iterations (last diff {diff:.3e}); the reference would loop forever here.")
                 break
         iters.append(run - 1)
+        converged.append(bool(diff <= max_tol))
         # the converged component's p-length vectors: one read of X for both
         ssq = eng.xt_v(np.hstack((z_used / uu_used, ts - Tp.dot(Tp.T.dot(ts)))), 1.0, "WP", 0, want_ssq=True)
         eng.right_mul(("WP", 0, 1), np.array([[1.0]]), ("Wn", k))
@@ -536,7 +539,7 @@ def _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
             evy.append(tt * v.T.dot(v).item() / vary)
             evxb[:, k] = tt * ssq_p / varxb
             Acorr[:, k] = _bip_corrected(sw ** 2, sizes)
-    res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, nipals_iterations_=iters)
+    res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, nipals_iterations_=iters, nipals_converged_=converged)
     if calc_all:
         res.update(explained_var_x_=evx, explained_var_y_=evy, explained_var_xblocks_=evxb, A_corrected_=Acorr)
     else:

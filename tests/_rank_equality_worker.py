@@ -57,7 +57,7 @@ def main():
         mine = {k: np.asarray(getattr(mdl, k)) for k in REPLICATED}
         mine.update({f"T_{b}": t for b, t in enumerate(mdl.T_)})
         mine["nipals_iterations_"] = np.asarray(mdl.nipals_iterations_)
-        mine["nipals_converged_"] = np.asarray(mdl.nipals_converged_)
+        mine["nipals_converged_"] = np.asarray(getattr(mdl, "nipals_converged_", []))
         everyone = [None] * world
         dist.all_gather_object(everyone, mine)
         for other in everyone:                            # bit-equal on every rank

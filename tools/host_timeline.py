@@ -1,20 +1,36 @@
-"""Host-side timeline of ONE warm fit (microseconds from the start of fit): which Python / ctypes calls the head and
-the tail of a device-resident fit consist of.   python tools/host_timeline.py [p] [K]"""
+"""Host-side timeline of ONE fit (microseconds from the start of fit): which Python / ctypes calls the head, the tail and
+any stall of a device-resident fit consist of.
+    python tools/host_timeline.py [--n 4096] [--p 125000] [--K 10] [--method NIPALS] [--blocks 1] [--fits 4]
+                                  [--show first|last|slowest] [--fresh]
+--show first  = the cold fit of the process;  --fresh = a new estimator per fit (as bench.py), kept alive."""
+import argparse
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=4096)
+ap.add_argument("--p", type=int, default=125_000)
+ap.add_argument("--K", type=int, default=10)
+ap.add_argument("--method", default="NIPALS")
+ap.add_argument("--blocks", type=int, default=1)
+ap.add_argument("--fits", type=int, default=4)
+ap.add_argument("--show", default="last")
+ap.add_argument("--fresh", action="store_true")
+ap.add_argument("--min-us", type=float, default=0.0)
+a = ap.parse_args()
+
+import numpy as np
 import mbpls_amd
 from bench import planted
 from mbpls_amd import MBPLS, DeviceMatrix, _capi, engine, solvers, mbpls as mb
 
-n = 4096
-p = int(sys.argv[1]) if len(sys.argv) > 1 else 125_000
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+n, p, K = a.n, a.p, a.K
 ctx = mbpls_amd.get_context()
 Ts, Y = planted(n, 1, 32, 0)
-X = DeviceMatrix(ctx, n, p)
+offs = [int(round(b * p / a.blocks)) for b in range(a.blocks + 1)]
+X = DeviceMatrix(ctx, n, p, offs)
 X.fill_latent(ctx.from_host(Ts), 32, 0.5, 1234, 0)
 ctx.sync()
 log, depth = [], [0]
@@ -23,20 +39,20 @@ log, depth = [], [0]
 def wrap(obj, name, label=None):
     f = getattr(obj, name)
 
-    def g(*a, **k):
+    def g(*aa, **k):
         t0 = time.perf_counter()
         depth[0] += 1
         try:
-            return f(*a, **k)
+            return f(*aa, **k)
         finally:
             depth[0] -= 1
             log.append((t0, time.perf_counter(), depth[0], label or name))
     setattr(obj, name, g)
 
 
-for nm in ("load_device", "_set_matrix", "slot", "prepare", "_prepare_implicit", "nipals_resident", "use_lazy_deflation",
-           "fetch_async", "cross", "right_mul", "host_array", "stream_stats", "wait_stats", "close", "run_deferred",
-           "_res_sweep", "_res_loadings", "deferred_first_pass"):
+for nm in ("load_device", "_set_matrix", "slot", "prepare", "_prepare_implicit", "nipals_resident", "unipals_resident",
+           "use_lazy_deflation", "fetch", "fetch_async", "cross", "right_mul", "host_array", "stream_stats", "wait_stats",
+           "close", "run_deferred", "_res_sweep", "_res_loadings", "deferred_first_pass", "sync", "check_cluster_passes"):
     wrap(engine.HipEngine, nm)
 for nm in ("__init__", "__exit__", "step", "stream_out"):
     wrap(engine._ResidentQueue, nm, "rq." + nm)
@@ -47,15 +63,46 @@ wrap(mb.MBPLS, "_store")
 wrap(mb.MBPLS, "_engine")
 wrap(_capi.DeviceArray, "set", "DeviceArray.set")
 wrap(_capi.DeviceArray, "get", "DeviceArray.get")
-import numpy as np
+wrap(_capi.Context, "sync", "ctx.sync")
 wrap(np.linalg, "pinv")
-m = MBPLS(n_components=K)
-for i in range(4):
+# device allocations that miss the pool / frees that leave it (the runtime calls behind them may wait for the device)
+real_malloc, real_free = ctx.lib.mbpls_hip_malloc, ctx.lib.mbpls_hip_free
+
+
+def t_malloc(*aa):
+    t0 = time.perf_counter()
+    try:
+        return real_malloc(*aa)
+    finally:
+        log.append((t0, time.perf_counter(), depth[0], f"hipMalloc {int(aa[1]) / 1e6:.2f} MB (pool miss)"))
+
+
+def t_free(*aa):
+    t0 = time.perf_counter()
+    try:
+        return real_free(*aa)
+    finally:
+        log.append((t0, time.perf_counter(), depth[0], "hipFree (pool full)"))
+
+
+ctx.lib.mbpls_hip_malloc, ctx.lib.mbpls_hip_free = t_malloc, t_free
+runs, keep = [], []
+m = MBPLS(n_components=K, method=a.method)
+for i in range(a.fits):
     log.clear()
+    if a.fresh:
+        m = MBPLS(n_components=K, method=a.method)
+        keep.append(m)
     t0 = time.perf_counter(); m.fit(X, Y); t1 = time.perf_counter()
-print(f"fit: {1e6 * (t1 - t0):.0f} us")
+    runs.append((t1 - t0, t0, list(log), dict(m.fit_timings_)))
+print("fits (ms):", [round(1e3 * r[0], 2) for r in runs])
+pick = {"first": 0, "last": len(runs) - 1, "slowest": int(np.argmax([r[0] for r in runs]))}[a.show]
+dt, t0, lg, phases = runs[pick]
+print(f"fit #{pick}: {1e6 * dt:.0f} us   phases (ms): " + str({k: round(1e3 * v, 2) for k, v in phases.items()}))
 skip = {"_res_sweep", "_res_loadings", "rq.step", "rq.stream_out"}
-for a, b, d, nm in sorted(log):
-    if nm in skip and not (a - t0 < 700e-6):
+for s0, s1, d, nm in sorted(lg):
+    if nm in skip and not (s0 - t0 < 700e-6):
         continue
-    print(f"{1e6 * (a - t0):9.0f} {1e6 * (b - a):8.0f} us  {'  ' * d}{nm}")
+    if 1e6 * (s1 - s0) < a.min_us:
+        continue
+    print(f"{1e6 * (s0 - t0):9.0f} {1e6 * (s1 - s0):8.0f} us  {'  ' * d}{nm}")
