@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 5   /* 5: mbpls_hip_cluster_status (one-read passes for long columns); 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
+#define MBPLS_HIP_ABI_VERSION 5   /* 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
 
 enum {
   MBPLS_OK = 0,
@@ -64,6 +64,10 @@ int mbpls_hip_device_count(int* count);
  * against these kernels. */
 int mbpls_hip_create(int device, void* stream, mbpls_ctx** out);
 int mbpls_hip_destroy(mbpls_ctx* ctx);
+/* Optional: pay the process-wide first-use costs now instead of inside the first fit -- the code objects of the kernel
+ * translation units (loaded lazily otherwise), the pinned bounce buffers, the first event.  Thread-safe; the Python
+ * package calls it from a helper thread right after creating a context, so it overlaps with the caller's upload. */
+int mbpls_hip_warmup(mbpls_ctx* ctx);
 int mbpls_hip_sync(mbpls_ctx* ctx);
 int mbpls_hip_device_info(mbpls_ctx* ctx, char* name, size_t name_len, int* compute_units,
                           size_t* total_bytes, size_t* free_bytes);

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mbpls_hip_device_count": (_int, [C.POINTER(_int)]),
     "mbpls_hip_create": (_int, [_int, _vp, _pp]),
     "mbpls_hip_destroy": (_int, [_vp]),
+    "mbpls_hip_warmup": (_int, [_vp]),
     "mbpls_hip_sync": (_int, [_vp]),
     "mbpls_hip_device_info": (_int, [_vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_sz), C.POINTER(_sz)]),
     "mbpls_hip_set_tunable": (_int, [_vp, C.c_char_p, _int]),
@@ -237,6 +238,9 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            th = getattr(self, "_warmup_thread", None)
+            if th is not None and th.is_alive():
+                th.join()
             if getattr(self, "_mapped", None) is not None:
                 self.lib.mbpls_hip_host_free(self.handle, self._mapped[2])
                 self._mapped = None

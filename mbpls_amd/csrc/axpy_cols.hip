@@ -117,3 +117,8 @@ int axpy_cols(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_g, int per_blo
 }
 
 }  // namespace mbpls
+
+// one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)
+namespace mbpls {
+const void* anchor_axpy_cols() { return (const void*)&k_sum_blocks; }
+}  // namespace mbpls

@@ -910,3 +910,8 @@ extern "C" int mbpls_hip_cluster_status(mbpls_ctx* ctx, int* timeouts) {
   *timeouts = (int)v;
   return MBPLS_OK;
 }
+
+// one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)
+namespace mbpls {
+const void* anchor_colpass_cluster() { return (const void*)&k_cl_fill; }
+}  // namespace mbpls

@@ -689,3 +689,8 @@ int long_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_mean,
 }
 
 }  // namespace mbpls
+
+// one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)
+namespace mbpls {
+const void* anchor_colpass_long() { return (const void*)&k_slab_colreduce; }
+}  // namespace mbpls

@@ -614,3 +614,47 @@ int mbpls_hip_mat_copy(mbpls_mat* dst, const mbpls_mat* src) {
 }
 
 }  // extern "C"
+
+namespace mbpls {
+const void* anchor_colpass();
+const void* anchor_colpass_cluster();
+const void* anchor_colpass_long();
+const void* anchor_axpy_cols();
+const void* anchor_cv_batch();
+const void* anchor_gemv();
+const void* anchor_gen();
+const void* anchor_gram();
+const void* anchor_resident();
+const void* anchor_small();
+const void* anchor_step_reg();
+const void* anchor_xtv_mfma();
+const void* anchor_xw_mfma();
+}  // namespace mbpls
+
+extern "C" int mbpls_hip_warmup(mbpls_ctx* ctx) {
+  MB_ARG(ctx, "ctx is NULL");
+  MB_HIP(hipSetDevice(ctx->device));
+  // code objects are loaded lazily, one per translation unit, on the first use of one of their kernels: ~13 ms of
+  // the first fit of a process went there
+  const void* (*anchors[])() = {mbpls::anchor_colpass, mbpls::anchor_colpass_cluster, mbpls::anchor_colpass_long, mbpls::anchor_axpy_cols, mbpls::anchor_cv_batch, mbpls::anchor_gemv, mbpls::anchor_gen, mbpls::anchor_gram, mbpls::anchor_resident, mbpls::anchor_small, mbpls::anchor_step_reg, mbpls::anchor_xtv_mfma, mbpls::anchor_xw_mfma};
+  for (auto fn : anchors) {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, fn());
+  }
+  (void)hipGetLastError();
+  // the pinned bounce buffers of the small copies, an event (the first creation sets up runtime state)
+  {
+    std::lock_guard<std::mutex> lock(ctx->pin_mutex);
+    if (!ctx->pin) {
+      ctx->pin_half = (size_t)8 << 20;
+      MB_HIP(hipHostMalloc(&ctx->pin, PIN_SLOTS * ctx->pin_half, hipHostMallocDefault));
+      for (int i = 0; i < PIN_SLOTS; ++i) {
+        MB_HIP(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+        MB_HIP(hipEventRecord(ctx->pin_ev[i], ctx->stream));
+      }
+    }
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) (void)hipEventDestroy(e);
+  return MBPLS_OK;
+}

@@ -132,3 +132,8 @@ int mbpls_hip_cv_fold_stats(const mbpls_mat* m, int F, const double* d_mu0, cons
 }
 
 }  // extern "C"
+
+// one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)
+namespace mbpls {
+const void* anchor_cv_batch() { return (const void*)&k_cv_block_sums; }
+}  // namespace mbpls

@@ -411,3 +411,8 @@ int mbpls_hip_x_w_nan(const mbpls_mat* m, const double* d_W, int64_t ldw, int c,
 }
 
 }  // extern "C"
+
+// one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)
+namespace mbpls {
+const void* anchor_gemv() { return (const void*)&k_reduce_ssq; }
+}  // namespace mbpls

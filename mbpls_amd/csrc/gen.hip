@@ -126,3 +126,8 @@ extern "C" int mbpls_hip_mat_fill_latent(mbpls_mat* m, const double* d_T, int r,
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }
+
+// one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)
+namespace mbpls {
+const void* anchor_gen() { return (const void*)&k_fill_latent; }
+}  // namespace mbpls

@@ -312,3 +312,8 @@ extern "C" int mbpls_hip_gram_scaled(const mbpls_mat* m, const double* d_mean, c
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }
+
+// one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)
+namespace mbpls {
+const void* anchor_gram() { return (const void*)&k_gram_finish; }
+}  // namespace mbpls

@@ -633,3 +633,8 @@ int mbpls_hip_event_destroy(mbpls_ctx* ctx, void* event) {
 }
 
 }  // extern "C"
+
+// one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)
+namespace mbpls {
+const void* anchor_resident() { return (const void*)&k_block_unit_col; }
+}  // namespace mbpls

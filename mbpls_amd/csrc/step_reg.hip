@@ -481,3 +481,8 @@ int launch_step_reg(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
 }
 
 }  // namespace mbpls
+
+// one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)
+namespace mbpls {
+const void* anchor_step_reg() { return (const void*)&k_step_reg<512, 8, 4, 1, true>; }
+}  // namespace mbpls

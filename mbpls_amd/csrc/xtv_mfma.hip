@@ -279,3 +279,8 @@ int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv,
 }
 
 }  // namespace mbpls
+
+// one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)
+namespace mbpls {
+const void* anchor_xtv_mfma() { return (const void*)&k_pack_v; }
+}  // namespace mbpls

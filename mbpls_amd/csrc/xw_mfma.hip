@@ -179,3 +179,8 @@ int xw_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_W, int64_t ldw, 
 }
 
 }  // namespace mbpls
+
+// one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)
+namespace mbpls {
+const void* anchor_xw_mfma() { return (const void*)&k_pack_w; }
+}  // namespace mbpls

@@ -746,7 +746,8 @@ class HipEngine(EngineBase):
         Finished columns of W~, W and P are copied to the host by a helper thread behind events.  The queue is
         speculative (two iterations per component, which is what one response takes); returns the results of the
         components that converged that way (``k_done`` of them -- the caller resumes from there when k_done < K)."""
-        first_pass()          # statistics + first sweep: running while the queue's device state is built and uploaded
+        if first_pass is not None:
+            first_pass()      # statistics + first sweep: running while the queue's device state is built and uploaded
         with _ResidentQueue(self, Y, K, norm_kind, tol, mode=0) as rq:
             Wn, Pm = self.slots[wslot], self.slots[self._lazy_pslot]
             p8, B = 8 * self.p, self.nblocks

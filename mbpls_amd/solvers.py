@@ -593,11 +593,22 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     u0 = resp.start()
     alpha0 = 1.0 / u0.T.dot(u0).item()
     eng.slot("Wn", K)
-    eng.slot("P", K)
     # One response converges in two passes per component: lazy deflation (no rewrite of X) wins.  Several
     # responses iterate 50-500 times per component (paper protocol, q = 10): every sweep then pays the lazy
     # correction (~6 %), far more than one rewrite of X per component (measured 7.05 s -> 6.72 s).
     eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
+    # norm of the n x 1 difference as numpy's MATRIX norm (:887), see _fit_nipals_grams
+    _norm(np.zeros((2, 1)), norm)
+    kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
+    # One response: the whole fit is queued on the device.  Its first pass (statistics + first sweep) needs nothing but
+    # the matrix, the start vector and the W~ slot: launched NOW, so the GPU is at work while the host allocates the
+    # other slots and the host copies of the attributes (0.2-0.3 ms of every fit; ~10 ms of allocations of the first)
+    go_resident = not resp.sparse and max_iter >= 2 and eng.resident_supported(q, K, kind)
+    first = None
+    if go_resident:
+        first = eng.deferred_first_pass(standardize, u0, alpha0, ("Wn", 0))
+        first()
+    eng.slot("P", K)
     Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
     T = [np.empty((n, K)) for _ in range(B)]
     nu_all = np.empty((B, K))
@@ -610,15 +621,11 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     # host copies of the p x K attributes, filled column by column while later passes run on the GPU
     Wn_h, W_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
     vary = resp.ssq
-    # norm of the n x 1 difference as numpy's MATRIX norm (:887), see _fit_nipals_grams
-    _norm(np.zeros((2, 1)), norm)
-    kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
     k_start = 0
-    if not resp.sparse and max_iter >= 2 and eng.resident_supported(q, K, kind):
-        # One response: the whole fit is queued on the device (two iterations per component -- what one response takes),
-        # the host reads the results once.  Components the speculation did not hold for are resumed below.
-        first = eng.deferred_first_pass(standardize, u0, alpha0, ("Wn", 0))
-        out = eng.nipals_resident(Y, K, kind, max_tol, "Wn", Wn_h, W_h, P_h, first)
+    if go_resident:
+        # (two iterations per component -- what one response takes; the host reads the results once.  Components the
+        # speculation did not hold for are resumed below.)
+        out = eng.nipals_resident(Y, K, kind, max_tol, "Wn", Wn_h, W_h, P_h, None)      # first pass already queued
         if out.get("reason") == "offset":
             # badly offset columns: the same queue again with the passes that centre in registers (the first pass is
             # repeated because a sharded run has already summed its exchange buffer once more)

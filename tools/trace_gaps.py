@@ -2,7 +2,7 @@
 launch order with its duration and the idle gap in front of it, summed per kernel name.
 
     cd /tmp && rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 $REPO/tools/gap_fit.py 125000
-    python tools/trace_gaps.py OUT [--list]
+    python tools/trace_gaps.py OUT [--list] [--split-ms 100] [--pick last|slowest]
 """
 import csv
 import glob
@@ -28,15 +28,23 @@ def short(name):
     return name if not m else f"{m.group(1)}<{m.group(2)[:40]}>"
 
 
+def opt(name, default):
+    return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
+
+
 # fits are separated by >= 100 ms of idle (gap_fit.py sleeps 0.2 s between them)
+split_ns = float(opt("--split-ms", "100")) * 1e6
 fits, cur = [], [rows[0]]
 for a, b in zip(rows, rows[1:]):
-    if b[0] - a[1] > 100e6:
+    if b[0] - a[1] > split_ns:
         fits.append(cur)
         cur = []
     cur.append(b)
 fits.append(cur)
 fit = fits[-1]
+if opt("--pick", "last") == "slowest":
+    fit = max((f for f in fits if len(f) > 8), key=lambda f: f[-1][1] - f[0][0])
+    print("spans of all bursts (ms):", [round((f[-1][1] - f[0][0]) / 1e6, 2) for f in fits if len(f) > 8])
 span = (fit[-1][1] - fit[0][0]) / 1e6
 busy = sum(e - s for s, e, _ in fit) / 1e6
 print(f"{len(fits)} bursts; last: {len(fit)} kernels, first start -> last end {span:.3f} ms, busy {busy:.3f} ms, idle {span - busy:.3f} ms")
