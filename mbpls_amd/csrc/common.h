@@ -54,6 +54,8 @@ struct ChunkTable {
 }  // namespace mbpls
 
 constexpr int PIN_SLOTS = 4;
+constexpr int SMALL_PIN_SLOTS = 256;
+constexpr size_t SMALL_PIN_BYTES = 64u << 10;
 
 struct mbpls_ctx {
   int device = 0;
@@ -106,6 +108,10 @@ struct mbpls_ctx {
   size_t pin_half = 0;     // bytes per slot
   hipEvent_t pin_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned pin_next = 0;
+  void* pin_small = nullptr;           // ... and of the small ones (vectors, parameter blocks): SMALL_PIN_SLOTS x 64 KB
+  hipEvent_t pin_small_ev[SMALL_PIN_SLOTS];
+  unsigned pin_small_next = 0;
+  void* pin_copier = nullptr;          // pinned bounce buffer of the copier thread's device-to-host copies (<= 4 MB)
   std::mutex pin_mutex;
   int step_reg = 1;          // device-resident step: the register-resident kernel where it applies (step_reg.hip); 0 = general kernel
   unsigned step_spin_limit = 1u << 28;   // polls before a grid barrier of the multi-workgroup step gives up (tests lower it)

@@ -240,6 +240,12 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->pin_d2h) (void)hipHostFree(ctx->pin_d2h);
+  if (ctx->pin_copier) (void)hipHostFree(ctx->pin_copier);
+  if (ctx->pin_small) {
+    for (hipEvent_t e : ctx->pin_small_ev)
+      if (e) (void)hipEventDestroy(e);
+    (void)hipHostFree(ctx->pin_small);
+  }
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (auto& pd : ctx->pending) {
@@ -363,9 +369,23 @@ int mbpls_hip_host_free(mbpls_ctx* ctx, void* h_ptr) {
 int mbpls_hip_memcpy_h2d(mbpls_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   MB_ARG(ctx && (bytes == 0 || (d_dst && h_src)), "NULL argument");
   if (bytes == 0) return MBPLS_OK;
-  // pageable source: hipMemcpyAsync stages it before returning, so the host buffer is reusable
-  if (bytes < (256u << 10)) {
-    MB_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // Small copies (n-vectors, parameter blocks) bounce through a ring of pinned 64 KB slots of our own.  Handing the
+  // pageable source to hipMemcpyAsync was correct (the runtime stages it before returning) but every third fit of a
+  // shape with 48-56 KB vectors (n = 6000, 7000) the copy then EXECUTED 26-36 ms late on an idle GPU (rocprofv3
+  // memory-copy trace, profiles/r04_stall_n6000.txt): a 10 ms fit took 40.
+  if (bytes <= SMALL_PIN_BYTES) {
+    std::lock_guard<std::mutex> lock(ctx->pin_mutex);
+    if (!ctx->pin_small) {
+      MB_HIP(hipHostMalloc(&ctx->pin_small, (size_t)SMALL_PIN_SLOTS * SMALL_PIN_BYTES, hipHostMallocDefault));
+      for (int i = 0; i < SMALL_PIN_SLOTS; ++i) ctx->pin_small_ev[i] = nullptr;
+    }
+    const unsigned h = ctx->pin_small_next++ % SMALL_PIN_SLOTS;
+    if (!ctx->pin_small_ev[h]) MB_HIP(hipEventCreateWithFlags(&ctx->pin_small_ev[h], hipEventDisableTiming));
+    else MB_HIP(hipEventSynchronize(ctx->pin_small_ev[h]));      // 256 copies ago: done long since
+    char* buf = (char*)ctx->pin_small + (size_t)h * SMALL_PIN_BYTES;
+    memcpy(buf, h_src, bytes);
+    MB_HIP(hipMemcpyAsync(d_dst, buf, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MB_HIP(hipEventRecord(ctx->pin_small_ev[h], ctx->stream));
     return MBPLS_OK;
   }
   // larger copies bounce through our own ring of pinned slots (8 MB each): the host memcpy of a chunk overlaps the DMA of
@@ -652,6 +672,10 @@ extern "C" int mbpls_hip_warmup(mbpls_ctx* ctx) {
         MB_HIP(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
         MB_HIP(hipEventRecord(ctx->pin_ev[i], ctx->stream));
       }
+    }
+    if (!ctx->pin_small) {
+      MB_HIP(hipHostMalloc(&ctx->pin_small, (size_t)SMALL_PIN_SLOTS * SMALL_PIN_BYTES, hipHostMallocDefault));
+      for (int i = 0; i < SMALL_PIN_SLOTS; ++i) ctx->pin_small_ev[i] = nullptr;
     }
   }
   hipEvent_t e = nullptr;

@@ -618,6 +618,19 @@ int mbpls_hip_memcpy_d2h_after(mbpls_ctx* ctx, void* event, void* h_dst, const v
   MB_HIP(hipEventSynchronize((hipEvent_t)event));
   if (bytes == 0) return MBPLS_OK;
   MB_ARG(h_dst && d_src && ctx->copy_stream, "NULL argument");
+  // Copies of a few MB bounce through a pinned buffer of the copier thread: for a pageable destination the runtime
+  // pins the caller's pages for the transfer, and with 1.3 MB columns (n = 6000, p = 166 666: the scaler statistics
+  // sent out behind the first pass) every later fit's first host-to-device copy then EXECUTED 26-36 ms late on an idle
+  // GPU -- a 10 ms fit took 40 (rocprofv3 copy trace; gone with MBPLS_STREAM_STATS=0, profiles/r04_stall_n6000.txt).
+  // Large columns (8 MB at BASELINE config[1]) keep the direct path: 55 GB/s into pages the helper thread has mapped.
+  constexpr size_t COPIER_BOUNCE = (size_t)4 << 20;
+  if (bytes <= COPIER_BOUNCE) {
+    if (!ctx->pin_copier) MB_HIP(hipHostMalloc(&ctx->pin_copier, COPIER_BOUNCE, hipHostMallocDefault));
+    MB_HIP(hipMemcpyAsync(ctx->pin_copier, d_src, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    MB_HIP(hipStreamSynchronize(ctx->copy_stream));
+    memcpy(h_dst, ctx->pin_copier, bytes);
+    return MBPLS_OK;
+  }
   MB_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
   MB_HIP(hipStreamSynchronize(ctx->copy_stream));
   return MBPLS_OK;

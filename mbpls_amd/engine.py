@@ -1069,6 +1069,12 @@ def _prefault(arr, min_bytes=1 << 20):
     faults the pages in itself)."""
     if arr.nbytes < min_bytes or _PREFAULT.get("off"):
         return
+    if "env" not in _PREFAULT:
+        import os
+        _PREFAULT["env"] = True
+        if os.environ.get("MBPLS_NO_PREFAULT") == "1":
+            _PREFAULT["off"] = True
+            return
     import ctypes
     import queue
     import threading

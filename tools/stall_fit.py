@@ -18,9 +18,23 @@ X = DeviceMatrix(ctx, n, p, offs)
 X.fill_latent(ctx.from_host(Ts), 32, 0.5, 1234, 0)
 ctx.sync()
 keep = []
+
+
+def throttled():
+    """(periods throttled, microseconds throttled) of this cgroup's CPU quota so far"""
+    try:
+        d = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+    except Exception:
+        return (0, 0)
+
+
 for i in range(fits):
     m = MBPLS(n_components=K, method=method)
     keep.append(m)
+    th0 = throttled()
     t0 = time.perf_counter(); m.fit(X, Y); ctx.sync()
-    print(f"fit {i}: {1e3 * (time.perf_counter() - t0):.1f} ms  {({k: round(1e3 * v, 1) for k, v in m.fit_timings_.items()})}", flush=True)
+    th1 = throttled()
+    print(f"fit {i}: {1e3 * (time.perf_counter() - t0):.1f} ms  throttled +{th1[0] - th0[0]} periods +{(th1[1] - th0[1]) / 1e3:.1f} ms  "
+          f"{({k: round(1e3 * v, 1) for k, v in m.fit_timings_.items()})}", flush=True)
     time.sleep(0.15)
