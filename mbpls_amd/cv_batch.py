@@ -42,6 +42,10 @@ import numpy as np
 from . import _capi, solvers
 from .engine import HipEngine
 
+class DegenerateFold(Exception):
+    """a fold's iteration broke down (zero covariance): model_selection falls back to the fold-by-fold loop"""
+
+
 _EPS = np.finfo(np.float64).eps
 MAX_FOLDS = 256                   # folds per batch (the matrix-core products read X once per 64 right-hand sides)
 MIN_FOLDS = 8                     # fewer folds per read of X than this: fold-by-fold fits
@@ -53,35 +57,53 @@ def _folds_per_batch(ctx, p, K, n_folds):
     return int(max(0, min(MAX_FOLDS, n_folds, (free // 4) // (8 * p * (2 * K + 6)))))
 
 
+MAX_RESPONSES = 16
+
+
 def eligible(estimator, q, n, p, n_folds, ctx=None):
+    """One response: EVERY method -- with a single response NIPALS, UNIPALS, KERNEL and SIMPLS fit the same model
+    (ordinary PLS1 on the concatenated blocks: identical ``beta_`` and predictions to 1e-14), so
+    their folds take the batched NIPALS passes, without the confirming second iteration.  Several responses: NIPALS
+    (the inner loop of every fold advances together, a fold leaves it when its own stop rule is met)."""
     K = int(estimator.n_components)
-    ok = (estimator.method == "NIPALS" and estimator.sparse_data is not True and q == 1 and n_folds >= 2 and K <= 32
-          and estimator.nipals_convergence_norm in (2, -2, "fro", "nuc"))
+    if estimator.sparse_data is True or n_folds < 2 or K > 32:
+        return False
+    if q == 1:
+        ok = estimator.method in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS")
+        if estimator.method == "NIPALS":
+            ok = estimator.nipals_convergence_norm in (2, -2, "fro", "nuc")
+    else:
+        ok = (estimator.method == "NIPALS" and q <= MAX_RESPONSES
+              and estimator.nipals_convergence_norm in (2, -2, "fro", "nuc"))
     if ok and ctx is not None:
-        ok = _folds_per_batch(ctx, p, K, n_folds) >= min(MIN_FOLDS, n_folds)
+        ok = _folds_per_batch(ctx, p, K + (q + 1) // 2, n_folds) >= min(MIN_FOLDS, n_folds)
     return ok
 
 
 def predict_folds(estimator, Xdev, ctx, comm, y, splits, batch=None):
-    """out-of-fold predictions (n x 1) of a one-response NIPALS model for every (train, test) pair of ``splits``;
-    Xdev: the raw matrix resident in HBM (blocks side by side); it is only ever read"""
+    """out-of-fold predictions (n x q) for every (train, test) pair of ``splits`` (see ``eligible`` for the models
+    covered); Xdev: the raw matrix resident in HBM (blocks side by side); it is only ever read"""
     n, p = Xdev.n, Xdev.p
     K = int(estimator.n_components)
+    y = np.asarray(y, dtype=np.float64).reshape(n, -1)
+    q = y.shape[1]
     if batch is None:
-        batch = max(1, _folds_per_batch(ctx, p, K, len(splits)))
+        batch = max(1, _folds_per_batch(ctx, p, K + (q + 1) // 2, len(splits)))
     std = bool(estimator.standardize)
-    y = np.asarray(y, dtype=np.float64).reshape(n)
-    out = np.full((n, 1), np.nan)
+    out = np.full((n, q), np.nan)
+    # one response, a method without iteration (or NIPALS, whose second iteration only confirms the first): one sweep
+    one_pass = q == 1 and estimator.method != "NIPALS"
     eng = HipEngine(ctx=ctx, comm=comm)
     eng.load_device(Xdev, copy=False)
     from . import runtime
     try:
         with runtime.host_threads():                 # BLAS pools sized to the CPU quota, not to the visible CPUs
-            if std:
-                eng.prepare_stats(True)              # full-data mean / variance: one read, nothing written
-                eng._kscale = False                  # (the products below take the RAW matrix)
+            # statistics pass: full-data mean / variance in one read, nothing written -- and (ADVICE r3) the same
+            # validation as the fold-by-fold loop: a NaN / inf anywhere poisons a column's sum of squares -> ValueError
+            eng.prepare_stats(std)
+            eng._kscale = False                      # (the products below take the RAW matrix)
             for s0 in range(0, len(splits), batch):
-                _one_batch(eng, Xdev, y, splits[s0:s0 + batch], out, K, std, float(estimator.max_tol))
+                _one_batch(eng, Xdev, y, splits[s0:s0 + batch], out, K, std, float(estimator.max_tol), one_pass)
     finally:
         eng.X = None                                 # the caller owns the matrix
         eng.close()
@@ -105,8 +127,9 @@ def _fix_risky(Xdev, M, n_f, dmu, drs, p, F):
         ctx.sync()
 
 
-def _one_batch(eng, Xdev, y, part, out, K, std, tol):
+def _one_batch(eng, Xdev, y, part, out, K, std, tol, one_pass=False):
     n, p = Xdev.n, Xdev.p
+    q = y.shape[1]
     offs = list(Xdev.block_offsets)
     F, B = len(part), len(offs) - 1
     ctx, lib = eng.ctx, eng.ctx.lib
@@ -114,14 +137,15 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol):
     for f, (tr, te) in enumerate(part):
         M[np.asarray(tr), f] = 1.0
     n_f = M.sum(axis=0)
+    nf1 = n_f[:, None]
     if std:                                          # ColumnScaler.fit on the training responses of every fold
-        ymu = (y[:, None] * M).sum(axis=0) / n_f
-        d = (y[:, None] - ymu) * M
-        var = ((d * d).sum(axis=0) - d.sum(axis=0) ** 2 / n_f) / n_f
-        ysig = np.where(var <= n_f * _EPS * var + (n_f * ymu * _EPS) ** 2, 1.0, np.sqrt(var))
+        ymu = np.einsum("nq,nf->fq", y, M) / nf1                             # F x q
+        d = (y[:, None, :] - ymu[None]) * M[:, :, None]                      # n x F x q
+        var = ((d * d).sum(axis=0) - d.sum(axis=0) ** 2 / nf1) / nf1
+        ysig = np.where(var <= nf1 * _EPS * var + (nf1 * ymu * _EPS) ** 2, 1.0, np.sqrt(var))
     else:
-        ymu, ysig = np.zeros(F), np.ones(F)
-    Ys = (y[:, None] - ymu) / ysig * M               # n x F, zero on the held-out rows
+        ymu, ysig = np.zeros((F, q)), np.ones((F, q))
+    Ys = (y[:, None, :] - ymu[None]) / ysig[None] * M[:, :, None]            # n x F x q, zero on the held-out rows
     pf8 = 8 * p * F
     G, Cs = eng.slot("cvG", F, zero=False), eng.slot("cvC", F, zero=False)
     Wst, Pst = eng.slot("cvW", F * K, zero=False), eng.slot("cvP", F * K, zero=False)
@@ -160,7 +184,7 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol):
                                                          dg.ptr + 8 * p * int(f), 8 * p))
 
         Ts = np.zeros((F, n, K))                                             # fold-major: the deflation is n x K algebra
-        nu_all = np.ones((B, F, K)); V = np.zeros((F, K))
+        nu_all = np.ones((B, F, K)); V = np.zeros((F, q, K))
 
         def deflate(A, k):
             """(I - Ts_f Ts_f^T) a_f for every fold (columns of the n x F array A): n x k algebra per fold"""
@@ -181,10 +205,10 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol):
             return sums[:, :, 0], t
 
         for k in range(K):
-            u = Ys.copy()
+            u = Ys[:, :, 0].copy()                                           # the first response starts every component (:838)
             active = np.ones(F, dtype=bool)
             ts_old = np.zeros((n, F))
-            nu_fin = np.ones((B, F)); ts_fin = np.zeros((n, F)); v_fin = np.zeros(F)
+            nu_fin = np.ones((B, F)); ts_fin = np.zeros((n, F)); v_fin = np.zeros((F, q))
             run = 1
             prev_diff, stalls = None, np.zeros(F, dtype=np.int64)
             while active.any():
@@ -197,16 +221,26 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol):
                 ts = (Tm * sw[:, None, :]).sum(axis=0)                       # (:882)
                 ts /= np.sqrt((ts * ts).sum(axis=0))
                 diff = np.sqrt(((ts_old - ts) ** 2).sum(axis=0)) if run > 1 else np.full(F, np.inf)   # (:887)
-                v = (Ys * ts).sum(axis=0) / (ts * ts).sum(axis=0)            # (:899)
-                un = Ys * (v / (v * v))                                      # (:911)
+                v = np.einsum("nfq,nf->fq", Ys, ts) / (ts * ts).sum(axis=0)[:, None]     # F x q (:899)
+                un = np.einsum("nfq,fq->nf", Ys, v) / (v * v).sum(axis=1)    # (:911)
                 un /= np.sqrt((un * un).sum(axis=0))
-                # stagnation rule of the fold-by-fold loop (solvers.q1_noise_floor), per fold
+                if not (np.isfinite(un[:, active]).all() and np.isfinite(ts[:, active]).all()):
+                    # a fold without any covariance left (v = Y^T ts = 0) or with a degenerate score: the fold-by-fold
+                    # loop reports that fold the way a single fit does
+                    raise DegenerateFold(f"component {k}")
+                if one_pass:
+                    diff = np.zeros(F)                                       # no iteration: the first sweep is the model
+                # stagnation rule of the fold-by-fold loop (solvers.q1_noise_floor), per fold (one response only)
                 floor_hit = np.zeros(F, dtype=bool)
-                if run >= 2:
+                if run >= 2 and q == 1:
                     floor_hit, stalls = solvers.q1_noise_floor(run, diff, prev_diff, stalls)
                     prev_diff = diff
                 floor_hit = floor_hit & active & (diff > tol)
-                done = active & ((diff <= tol) | floor_hit)
+                capped = run >= solvers.NIPALS_MAX_ITER
+                if capped and (active & (diff > tol)).any():
+                    warnings.warn(f"NIPALS component {k}: no convergence to max_tol={tol} after {run} iterations in "
+                                  f"{int((active & (diff > tol)).sum())} fold(s); the reference would loop forever here.")
+                done = active & ((diff <= tol) | floor_hit | capped)
                 if floor_hit.any():
                     warnings.warn(f"NIPALS component {k}: ||ts_old - ts|| stays above max_tol={tol} in "
                                   f"{int(floor_hit.sum())} fold(s) (rounding noise of an exhausted "
@@ -221,33 +255,38 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol):
             # loadings p = X_k^T ts (:928; ts is unit length and orthogonal to the earlier scores up to rounding)
             weights(deflate(ts_fin, k), np.ones(F))
             keep(Pst, k, None)
-            Ts[:, :, k] = ts_fin.T; nu_all[:, :, k] = nu_fin; V[:, k] = v_fin
+            Ts[:, :, k] = ts_fin.T; nu_all[:, :, k] = nu_fin; V[:, :, k] = v_fin
 
         # ---- every fold: C_f = P_f^T W_f on the device (column k of fold f is column k F + f of the stacks: a p x K
         # matrix with leading dimension p F), the K x K pseudo-inverses stacked on the host, beta_f = W_f M_f V_f^T on the
         # device (:986-989)
         dC = ctx.empty(F * K * K)
         tmp.append(dC)
+        Bq = G if q == 1 else eng.slot("cvB", F * q, zero=False)             # beta of response j, fold f: column j F + f
         for f in range(F):
             _capi.check(lib.mbpls_hip_cross_product_dev(ctx.handle, p, Pst.ptr + 8 * p * f, p * F, K, Wst.ptr + 8 * p * f,
                                                         p * F, K, dC.ptr + 8 * K * K * f))
         Cm = dC.get().reshape(F, K, K)
         D = 1.0 / np.sqrt((nu_all ** 2).sum(axis=0))                         # F x K: 1 / ||W~[:, k]||
-        Mv = np.matmul(D[:, :, None] * np.linalg.pinv(Cm * D[:, None, :]), V[:, :, None])[:, :, 0]   # F x K
-        dMv = ctx.from_host(np.ascontiguousarray(Mv).ravel())
+        Mv = np.matmul(D[:, :, None] * np.linalg.pinv(Cm * D[:, None, :]), V.transpose(0, 2, 1))     # F x K x q
+        dMv = ctx.from_host(np.ascontiguousarray(Mv.transpose(0, 2, 1)).ravel())                     # [f][j][k]
         tmp.append(dMv)
-        for f in range(F):                                                   # beta_f -> column f of cvG
-            _capi.check(lib.mbpls_hip_right_multiply_dev(ctx.handle, p, Wst.ptr + 8 * p * f, p * F, K, dMv.ptr + 8 * K * f, 1,
-                                                         G.ptr + 8 * p * f, p))
-        # ---- predictions of all rows for all folds: one more product (:1369-1408); a fold keeps its held-out rows
-        _capi.check(lib.mbpls_hip_cv_weights(Xdev.handle, F, 1, G.ptr, dmu.ptr, drs.ptr, None, None, dg.ptr, Cs.ptr,
-                                             dsums.ptr))
-        XC = eng.x_w_slot("cvC", 0, F, per_block=True)
-        sums = dsums.get().reshape(B, F, 2)
-        yhat = sum(XC[b] - sums[b, :, 1] for b in range(B)) * ysig + ymu     # n x F
-        for f, (tr, te) in enumerate(part):
-            te = np.asarray(te)
-            out[te, 0] = yhat[te, f]
+        for f in range(F):                                                   # beta_f[:, j] -> column j F + f
+            for j in range(q):
+                _capi.check(lib.mbpls_hip_right_multiply_dev(ctx.handle, p, Wst.ptr + 8 * p * f, p * F, K,
+                                                             dMv.ptr + 8 * K * (f * q + j), 1,
+                                                             Bq.ptr + 8 * p * (j * F + f), p))
+        # ---- predictions of all rows for all folds: one more product per response (:1369-1408); a fold keeps its
+        # held-out rows
+        for j in range(q):
+            _capi.check(lib.mbpls_hip_cv_weights(Xdev.handle, F, 1, Bq.ptr + 8 * p * F * j, dmu.ptr, drs.ptr, None, None,
+                                                 dg.ptr, Cs.ptr, dsums.ptr))
+            XC = eng.x_w_slot("cvC", 0, F, per_block=True)
+            sums = dsums.get().reshape(B, F, 2)
+            yhat = sum(XC[b] - sums[b, :, 1] for b in range(B)) * ysig[:, j] + ymu[:, j]          # n x F
+            for f, (tr, te) in enumerate(part):
+                te = np.asarray(te)
+                out[te, j] = yhat[te, f]
     finally:
         for a_ in [dg, dmu, drs, dsu, dal, dsums] + tmp:
             a_.free()

@@ -2,10 +2,15 @@
 
 The reference's users call ``sklearn.model_selection.cross_val_predict(MBPLS(k), X, y, cv=len(X))``
 (examples/real_world_applications/*.ipynb): leave-one-out = n complete refits, each on a fresh row
-slice of X.  Here X is uploaded once; a fold is a *row mask* handed to the standardise pass, which
-writes zero rows for the held-out samples into the working copy (every later pass then ignores them
-for free) and takes the column statistics over the training samples only.  Predictions for the held-out
-rows come from one ``x_w`` pass over the same resident matrix.  No re-upload, no host slicing.
+slice of X.  Here X is uploaded once and only ever read:
+
+* batched folds (``cv_batch``): up to 256 folds are fitted per pass over X -- every read of the raw matrix serves all
+  of them through many-right-hand-side products, the folds' column statistics and deflations are applied
+  algebraically.  Covers one response with every method (they fit the same model then) and several-response NIPALS;
+* fold by fold (everything else: several-response UNIPALS / KERNEL / SIMPLS, missing values, column shards): a fold is a
+  *row mask* handed to the standardise pass, which writes zero rows for the held-out samples into the working copy and
+  takes the column statistics over the training samples only; predictions for the held-out rows come from one ``x_w``
+  pass over the same resident matrix.  No re-upload, no host slicing.
 """
 from __future__ import annotations
 
@@ -37,9 +42,9 @@ def cross_val_predict(estimator, X, y, cv=5, groups=None, batch_folds=True):
     cv: int (KFold without shuffling, as sklearn does for regressors), a CV splitter, or an iterable of
     (train, test) index pairs.  Returns an (n, q) array (``predict``'s shape).
 
-    One-response NIPALS models are fitted up to 256 folds at a time (as many as device memory holds), every pass over X
-    serving all of them
-    (``cv_batch``; ``batch_folds=False`` forces the fold-by-fold loop, which everything else takes)."""
+    One-response models of every method and several-response NIPALS models are fitted up to 256 folds at a time (as
+    many as device memory holds), every pass over X serving all of them (``cv_batch``; ``batch_folds=False`` forces
+    the fold-by-fold loop, which everything else takes)."""
     if not isinstance(estimator, MBPLS):
         raise TypeError("cross_val_predict of mbpls_amd works on mbpls_amd.MBPLS estimators")
     y = np.asarray(y, dtype=np.float64)
@@ -57,7 +62,10 @@ def cross_val_predict(estimator, X, y, cv=5, groups=None, batch_folds=True):
         from . import cv_batch
         if (batch_folds and not runtime.get_comm().is_distributed
                 and cv_batch.eligible(estimator, y2.shape[1], n, Xdev.p, len(splits), runtime.get_context())):
-            return cv_batch.predict_folds(estimator, Xdev, runtime.get_context(), runtime.get_comm(), y2, splits)
+            try:
+                return cv_batch.predict_folds(estimator, Xdev, runtime.get_context(), runtime.get_comm(), y2, splits)
+            except cv_batch.DegenerateFold:
+                pass                     # a fold broke down: the loop below treats every fold like a single fit
         out = np.full((n, y2.shape[1]), np.nan)
         for train, test in splits:
             est = MBPLS(**{**estimator.get_params(), "copy": True})

@@ -85,7 +85,7 @@ def test_fixture_matrix_with_streamed_columns(forced_long, fixture):
     ("SIMPLS", 1203, 700, 1, 3, [700], "cluster"),
     ("NIPALS", 100_000, 300, 1, 3, [100, 200], None),       # genuinely long columns (n > 65536), n >= p
     ("NIPALS", 100_000, 300, 1, 3, [100, 200], "two_phase"),
-    ("NIPALS", 30_000, 260, 3, 2, [100, 160], None),         # several responses: the inner loop in q x q algebra
+    ("NIPALS", 12_000, 260, 3, 2, [100, 160], None),         # several responses: the inner loop in q x q algebra
     ("UNIPALS", 100_000, 240, 2, 3, [240], None),
     ("KERNEL", 70_001, 200, 1, 3, [80, 120], None),
     ("SIMPLS", 90_000, 150, 2, 3, [150], None),

@@ -12,6 +12,15 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-6          # BASELINE.json north_star: 1e-6 relative float64, sign-aligned
+
+_ORACLE_CACHE = {}
+
+
+def _cached_oracle(key, make):
+    """several-response oracle fits take seconds of CPU: parametrisations that differ only in the GPU route share one"""
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = make()
+    return _ORACLE_CACHE[key]
 TIGHT = 1e-11       # what we actually expect (summation-order differences only)
 
 
@@ -334,7 +343,7 @@ def test_sklearn_plumbing(gpu_required):
 # ------------------------------------------------------------------ medium size vs the oracle
 @pytest.mark.parametrize("method,n,p,q,K,blocks", [
     ("NIPALS", 4096, 20000, 1, 5, [20000]),
-    ("NIPALS", 1024, 30000, 3, 3, [10000, 8000, 12000]),
+    ("NIPALS", 1024, 9000, 3, 3, [3000, 2500, 3500]),
     ("UNIPALS", 4096, 18000, 1, 4, [5000, 6000, 7000]),
     ("UNIPALS", 512, 12000, 4, 3, [12000]),
     ("KERNEL", 2048, 16000, 1, 5, [6000, 10000]),
@@ -498,6 +507,57 @@ def test_cross_val_predict_batched_folds(gpu_required, blocks, std, cv):
     assert util.relerr(got, loop) < 1e-9
 
 
+@pytest.mark.parametrize("method,q,blocks,cv", [("UNIPALS", 1, 2, "loo"), ("KERNEL", 1, 1, 6), ("SIMPLS", 1, 3, 5),
+                                                ("NIPALS", 3, 2, "loo"), ("NIPALS", 2, 1, 4)])
+def test_cross_val_predict_batched_folds_other_routes(gpu_required, method, q, blocks, cv):
+    """Round 4: one response with EVERY method (one model, the batched passes without the confirming iteration) and
+    several-response NIPALS (every fold's inner loop advances together) == a loop of oracle fits of that method."""
+    from mbpls_amd import MBPLS, cv_batch
+    from mbpls_amd.model_selection import cross_val_predict
+    n, p, K = 48, 500, 3
+    X, Y = orc.make_latent(n, p, q, r=6, seed=33 + q)
+    X[:, 7] = -2.0                                   # a constant column
+    cuts = np.linspace(0, p, blocks + 1).astype(int)
+    Xs = X if blocks == 1 else [np.ascontiguousarray(X[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    if cv == "loo":
+        cv_arg, splits = n, [(np.delete(np.arange(n), i), np.array([i])) for i in range(n)]
+    else:
+        from sklearn.model_selection import KFold
+        cv_arg, splits = cv, list(KFold(cv).split(X))
+    est = MBPLS(n_components=K, method=method, full_svd=True)
+    assert cv_batch.eligible(est, q, n, p, len(splits))
+    calls = []
+    real = cv_batch.predict_folds
+    cv_batch.predict_folds = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = cross_val_predict(est, Xs, Y, cv=cv_arg)
+    finally:
+        cv_batch.predict_folds = real
+    assert calls == [1] and got.shape == Y.shape
+    sp = (lambda A, idx: A[idx]) if blocks == 1 else (lambda A, idx: [b[idx] for b in A])
+    want = np.empty_like(Y)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tr, te in splits:
+            r = orc.fit(sp(Xs, tr), Y[tr], n_components=K, method=method, full_svd=True)
+            want[te] = orc.predict(r, sp(Xs, te))
+    assert util.relerr(got, want) < 1e-9, util.relerr(got, want)
+
+
+def test_cross_val_predict_batched_folds_validate_like_fit(gpu_required):
+    """advisor (round 3): the batched route skipped the validation of fit() when standardize=False -- a NaN in X gave
+    NaN predictions instead of fit()'s ValueError.  The statistics pass now always runs."""
+    from mbpls_amd import MBPLS
+    from mbpls_amd.model_selection import cross_val_predict
+    X, Y = orc.make_latent(40, 300, 1, r=4, seed=2)
+    X[3, 17] = np.nan
+    for std in (True, False):
+        with pytest.raises(ValueError):
+            cross_val_predict(MBPLS(n_components=2, standardize=std), X, Y, cv=8)
+
+
 @pytest.mark.parametrize("n,p,q,K", [(5, 1, 1, 1), (3, 2, 1, 1), (7, 3, 2, 2), (64, 1, 1, 1), (2, 5, 1, 1), (6, 4, 1, 3),
                                      (9, 300, 3, 3), (513, 2, 1, 2)])
 def test_tiny_and_ragged_shapes(gpu_required, n, p, q, K):
@@ -524,7 +584,7 @@ def test_both_deflation_modes(gpu_required, monkeypatch, mode, method, q):
     monkeypatch.setenv("MBPLS_DEFLATION", mode)
     X, Y = orc.make_latent(700, 5000, q, seed=21 + q)
     Xs = [np.ascontiguousarray(X[:, :2000]), np.ascontiguousarray(X[:, 2000:])]
-    ref = orc.fit(Xs, Y, n_components=5, method=method)
+    ref = _cached_oracle(("deflation modes", method, q), lambda: orc.fit(Xs, Y, n_components=5, method=method))
     mdl = MBPLS(n_components=5, method=method).fit(Xs, Y)
     w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} q={q} {mode}")
     assert w < 1e-8, w
@@ -588,7 +648,7 @@ def test_implicit_standardisation_of_offset_data(gpu_required, monkeypatch, offs
 
 
 @pytest.mark.parametrize("method", ["NIPALS", "UNIPALS", "KERNEL", "SIMPLS"])
-@pytest.mark.parametrize("q,blocks", [(1, [9000]), (3, [2500, 3000, 3500])])
+@pytest.mark.parametrize("q,blocks", [(1, [9000]), (3, [800, 1000, 1200])])
 def test_medium_vs_faithful_oracle(gpu_required, method, q, blocks):
     """The HIP path against the oracle's FAITHFUL mode -- the reference's own numpy op sequence (n x p outer products for
     the explained variance :933/:946, n x n SVDs :489-493 / :712-715, D A D deflation :722-725, per-iteration sweeps),
@@ -610,7 +670,7 @@ def test_medium_vs_faithful_oracle(gpu_required, method, q, blocks):
 
 
 @pytest.mark.parametrize("method,K,q,n,p", [("NIPALS", 40, 1, 1200, 900), ("NIPALS", 38, 1, 1200, 900),
-                                            ("NIPALS", 33, 2, 1200, 900), ("UNIPALS", 40, 1, 300, 2400),
+                                            ("NIPALS", 33, 2, 600, 500), ("UNIPALS", 40, 1, 300, 2400),
                                             ("UNIPALS", 35, 3, 300, 2400), ("KERNEL", 40, 2, 300, 2400),
                                             ("SIMPLS", 40, 1, 300, 2400)])
 def test_many_components(gpu_required, method, K, q, n, p):
@@ -822,7 +882,7 @@ def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, meth
     preparation, products with the operand standardised in registers.  Earlier form of this test: ONE raw-space
     pass for the loadings, the weights of the last sweep vector and their block scores (mbpls_hip_loadings_sweep_raw:
     no deflation) -- against the oracle and the stored path, with the caller's matrix bit-identical afterwards.
-    n = 9000: the two-phase long-column form of the same pass."""
+    n = 9000: the long-column form of the same pass (clusters of workgroups sharing a column)."""
     import mbpls_amd
     from mbpls_amd import MBPLS, DeviceMatrix
     from mbpls_amd.engine import HipEngine
@@ -845,8 +905,9 @@ def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, meth
     Xd = DeviceMatrix(ctx, n, p, offs)
     Xd.upload(X)
     mdl = MBPLS(n_components=3, method=method, standardize=standardize, full_svd=True).fit(Xd, Y)
-    if method != "KERNEL" and not (method == "SIMPLS" and n > 8192):
-        # one fused sweep pass per component (p = X^T t and X p), standardising in registers (tall SIMPLS keeps the products)
+    if method != "KERNEL":
+        # one fused sweep pass per component (p = X^T t and X p), standardising in registers -- on tall data too since the
+        # long-column passes read X once (clusters of workgroups, round 4; tall SIMPLS kept the products before)
         assert used == [] and "never written" in mdl.fit_plan_["standardisation"], mdl.fit_plan_
     else:
         assert used == [True]
@@ -906,7 +967,7 @@ def test_multi_response_nipals_on_association_matrices(gpu_required, monkeypatch
     Xn, Yn = orc.make_latent(40, 4000, 4, seed=91)
     Xns = [np.ascontiguousarray(Xn[:, :1500]), np.ascontiguousarray(Xn[:, 1500:2501]), np.ascontiguousarray(Xn[:, 2501:])]
     for std in (True, False):
-        ref = orc.fit(Xs, Y, n_components=4, standardize=std)
+        ref = _cached_oracle(("association", std), lambda: orc.fit(Xs, Y, n_components=4, standardize=std))
         mdl = MBPLS(n_components=4, standardize=std).fit(Xs, Y)
         got = _fit_flat(mdl, Xns, Yn)
         rflat = util.model_to_flat(ref)

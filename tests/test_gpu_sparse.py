@@ -67,9 +67,9 @@ def test_reference_fixture(gpu_required):
 
 
 @pytest.mark.parametrize("n,p,q,K,blocks,frac", [
-    (501, 3000, 2, 3, [1000, 800, 1200], 0.03),     # odd n: padded columns, several blocks
+    (501, 1500, 2, 3, [500, 400, 600], 0.03),     # odd n: padded columns, several blocks
     (4096, 6000, 1, 3, [6000], 0.01),               # the n = 4096 configuration of the dense hot path
-    (1200, 2500, 3, 4, [2500], 0.10),
+    (800, 1600, 3, 3, [1600], 0.10),
     (9000, 700, 1, 2, [300, 400], 0.02),            # n > 8192: long-column kernels
 ])
 def test_medium_vs_oracle(gpu_required, n, p, q, K, blocks, frac):
@@ -118,7 +118,7 @@ def test_missing_responses_reference_fixture(gpu_required):
     assert worst < 1e-8, worst
 
 
-@pytest.mark.parametrize("n,p,q,K,blocks", [(700, 2600, 3, 3, [1200, 1400]), (2048, 3000, 2, 2, [3000])])
+@pytest.mark.parametrize("n,p,q,K,blocks", [(500, 1500, 3, 3, [700, 800]), (1024, 2000, 2, 2, [2000])])
 def test_missing_responses_medium_vs_oracle(gpu_required, n, p, q, K, blocks):
     """missing responses at medium size: missing values in X (masked column passes on the GPU) and in Y (host, n x q)
     -- in rows the reference patches, so the oracle can follow.  One more case puts a missing response into a row
