@@ -76,7 +76,7 @@ def eligible(estimator, q, n, p, n_folds, ctx=None):
         ok = (estimator.method == "NIPALS" and q <= MAX_RESPONSES
               and estimator.nipals_convergence_norm in (2, -2, "fro", "nuc"))
     if ok and ctx is not None:
-        ok = _folds_per_batch(ctx, p, K + (q + 1) // 2, n_folds) >= min(MIN_FOLDS, n_folds)
+        ok = _folds_per_batch(ctx, p, K + (q if q > 1 else 0), n_folds) >= min(MIN_FOLDS, n_folds)
     return ok
 
 
@@ -88,7 +88,7 @@ def predict_folds(estimator, Xdev, ctx, comm, y, splits, batch=None):
     y = np.asarray(y, dtype=np.float64).reshape(n, -1)
     q = y.shape[1]
     if batch is None:
-        batch = max(1, _folds_per_batch(ctx, p, K + (q + 1) // 2, len(splits)))
+        batch = max(1, _folds_per_batch(ctx, p, K + (q if q > 1 else 0), len(splits)))
     std = bool(estimator.standardize)
     out = np.full((n, q), np.nan)
     # one response, a method without iteration (or NIPALS, whose second iteration only confirms the first): one sweep
@@ -125,6 +125,50 @@ def _fix_risky(Xdev, M, n_f, dmu, drs, p, F):
         _capi.check(lib.mbpls_hip_memcpy_h2d(ctx.handle, dmu.ptr + off, fix[0:1].ctypes.data, 8))
         _capi.check(lib.mbpls_hip_memcpy_h2d(ctx.handle, drs.ptr + off, fix[1:2].ctypes.data, 8))
         ctx.sync()
+
+
+def _qspace_loops(G, Ys, tol, max_iter, k):
+    """The NIPALS inner loop (mbpls.py:841-913) of EVERY fold in the q-dimensional space of its iterates -- the batched
+    form of solvers._subspace_loop_qspace: with M1 = G^T G, M2 = Y^T G, M3 = Y^T Y per fold, an iteration is O(q^2) per
+    fold and all folds advance together (a fold leaves when ||ts_old - ts|| <= tol from the second iteration on).
+    G, Ys: n x F x q.  Returns (iterations F, c of the last sweep vector F x q, ts n x F, v F x q)."""
+    F, q = G.shape[1], G.shape[2]
+    M1 = np.einsum("nfa,nfb->fab", G, G)
+    M2 = np.einsum("nfa,nfb->fab", Ys, G)
+    M3 = np.einsum("nfa,nfb->fab", Ys, Ys)
+    c = np.zeros((F, q)); c[:, 0] = 1.0                                      # the start vector Y[:, 0] (:838)
+    active = np.ones(F, dtype=bool)
+    ct_old = None
+    c_fin, ct_fin, n_it = np.zeros((F, q)), np.zeros((F, q)), np.zeros(F, dtype=np.int64)
+    run = 0
+    while active.any():
+        run += 1
+        ct = c / np.sqrt(np.einsum("fa,fab,fb->f", c, M1, c))[:, None]       # ts = G c~, unit length (:882-883)
+        if run > 1:
+            d = ct_old - ct
+            diff = np.sqrt(np.maximum(np.einsum("fa,fab,fb->f", d, M1, d), 0.0))            # (:887)
+        else:
+            diff = np.full(F, np.inf)
+        v = np.einsum("fab,fb->fa", M2, ct)                                  # (:899)
+        vv = (v * v).sum(axis=1)
+        un = np.sqrt(np.einsum("fa,fab,fb->f", v, M3, v)) / vv               # ||Y v / v^T v|| (:911-913)
+        done = active & (((run >= 2) & (diff <= tol)) | (run >= max_iter))
+        if run >= max_iter and (active & (diff > tol)).any():
+            warnings.warn(f"NIPALS component {k}: no convergence to max_tol={tol} after {max_iter} iterations in "
+                          f"{int((active & (diff > tol)).sum())} fold(s); the reference would loop forever here.")
+        c_fin[done] = c[done]; ct_fin[done] = ct[done]; n_it[done] = run
+        ct_old = ct
+        nxt = active & ~done
+        c[nxt] = (v / vv[:, None] / un[:, None])[nxt]
+        active = nxt
+        if not np.isfinite(c[active]).all():
+            raise DegenerateFold(f"component {k}")
+    ts = np.einsum("nfq,fq->nf", G, ct_fin)
+    ts /= np.sqrt((ts * ts).sum(axis=0))
+    v = np.einsum("nfq,nf->fq", Ys, ts) / (ts * ts).sum(axis=0)[:, None]
+    if not (np.isfinite(ts).all() and np.isfinite(v).all()):
+        raise DegenerateFold(f"component {k}")
+    return n_it, c_fin, ts, v
 
 
 def _one_batch(eng, Xdev, y, part, out, K, std, tol, one_pass=False):
@@ -204,7 +248,34 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol, one_pass=False):
                 t[b] = deflate((XC[b] - sums[b, :, 1]) * M, k)
             return sums[:, :, 0], t
 
+        Sst = eng.slot("cvS", F * q, zero=False) if q > 1 else None          # X_k^T (P y_j) of fold f: column j F + f
         for k in range(K):
+            if q > 1:
+                # Several responses: every sweep vector of the inner loop is u = Y c and the super score it yields is
+                # ts ~ G c with G = P X (X^T (P Y)) (solvers._fit_nipals_subspace), so q sweeps per COMPONENT -- all folds
+                # at once -- give every fold its n x q matrix G_f and the whole loop is q x q algebra, advanced for all
+                # folds together on the host; weights and block scores of the last sweep vector are combinations of
+                # the same products.
+                Bk = np.empty((B, n, F, q))
+                for j in range(q):
+                    _, tb = sweep(Ys[:, :, j], np.ones(F), k)                # g_j = X_k^T (P y_j) in dg, t~_b = P X_b g_j,b
+                    _capi.check(lib.mbpls_hip_memcpy_d2d(ctx.handle, Sst.ptr + j * pf8, dg.ptr, pf8))
+                    Bk[:, :, :, j] = tb
+                n_it, c_used, ts_fin, v_fin = _qspace_loops(Bk.sum(axis=0), Ys, tol, solvers.NIPALS_MAX_ITER, k)
+                u_used = np.einsum("nfq,fq->nf", Ys, c_used)                 # sweep vector of the last iteration
+                uu = (u_used * u_used).sum(axis=0)
+                coef = c_used / uu[:, None]                                  # w~ = S c / u^T u (:856)
+                dco = ctx.from_host(np.ascontiguousarray(coef).ravel())
+                for f in range(F):
+                    _capi.check(lib.mbpls_hip_right_multiply_dev(ctx.handle, p, Sst.ptr + 8 * p * f, p * F, q,
+                                                                 dco.ptr + 8 * q * f, 1, Wst.ptr + k * pf8 + 8 * p * f, p))
+                dco.free()
+                Bc = np.einsum("bnfq,fq->bnf", Bk, c_used)                   # P X_b X_b^T P u
+                nu_fin = np.sqrt(np.einsum("nf,bnf->bf", u_used, Bc)) / uu   # ||w~_b|| (:860)
+                weights(deflate(ts_fin, k), np.ones(F))                      # loadings p = X_k^T ts (:928)
+                keep(Pst, k, None)
+                Ts[:, :, k] = ts_fin.T; nu_all[:, :, k] = nu_fin; V[:, :, k] = v_fin
+                continue
             u = Ys[:, :, 0].copy()                                           # the first response starts every component (:838)
             active = np.ones(F, dtype=bool)
             ts_old = np.zeros((n, F))

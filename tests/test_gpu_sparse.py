@@ -69,7 +69,7 @@ def test_reference_fixture(gpu_required):
 @pytest.mark.parametrize("n,p,q,K,blocks,frac", [
     (501, 1500, 2, 3, [500, 400, 600], 0.03),     # odd n: padded columns, several blocks
     (4096, 6000, 1, 3, [6000], 0.01),               # the n = 4096 configuration of the dense hot path
-    (800, 1600, 3, 3, [1600], 0.10),
+    (1000, 2000, 3, 3, [2000], 0.10),
     (9000, 700, 1, 2, [300, 400], 0.02),            # n > 8192: long-column kernels
 ])
 def test_medium_vs_oracle(gpu_required, n, p, q, K, blocks, frac):
