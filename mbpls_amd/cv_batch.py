@@ -141,17 +141,19 @@ def _qspace_loops(G, Ys, tol, max_iter, k):
     ct_old = None
     c_fin, ct_fin, n_it = np.zeros((F, q)), np.zeros((F, q)), np.zeros(F, dtype=np.int64)
     run = 0
+    def quad(M, a):                                                          # a_f^T M_f a_f (matmul: the fast path)
+        return (a * np.matmul(M, a[:, :, None])[:, :, 0]).sum(axis=1)
+
     while active.any():
         run += 1
-        ct = c / np.sqrt(np.einsum("fa,fab,fb->f", c, M1, c))[:, None]       # ts = G c~, unit length (:882-883)
+        ct = c / np.sqrt(quad(M1, c))[:, None]                               # ts = G c~, unit length (:882-883)
         if run > 1:
-            d = ct_old - ct
-            diff = np.sqrt(np.maximum(np.einsum("fa,fab,fb->f", d, M1, d), 0.0))            # (:887)
+            diff = np.sqrt(np.maximum(quad(M1, ct_old - ct), 0.0))           # (:887)
         else:
             diff = np.full(F, np.inf)
-        v = np.einsum("fab,fb->fa", M2, ct)                                  # (:899)
+        v = np.matmul(M2, ct[:, :, None])[:, :, 0]                           # (:899)
         vv = (v * v).sum(axis=1)
-        un = np.sqrt(np.einsum("fa,fab,fb->f", v, M3, v)) / vv               # ||Y v / v^T v|| (:911-913)
+        un = np.sqrt(quad(M3, v)) / vv                                       # ||Y v / v^T v|| (:911-913)
         done = active & (((run >= 2) & (diff <= tol)) | (run >= max_iter))
         if run >= max_iter and (active & (diff > tol)).any():
             warnings.warn(f"NIPALS component {k}: no convergence to max_tol={tol} after {max_iter} iterations in "

@@ -118,7 +118,7 @@ def test_missing_responses_reference_fixture(gpu_required):
     assert worst < 1e-8, worst
 
 
-@pytest.mark.parametrize("n,p,q,K,blocks", [(500, 1500, 3, 3, [700, 800]), (1024, 2000, 2, 2, [2000])])
+@pytest.mark.parametrize("n,p,q,K,blocks", [(500, 1500, 3, 3, [700, 800]), (2048, 3000, 2, 2, [3000])])
 def test_missing_responses_medium_vs_oracle(gpu_required, n, p, q, K, blocks):
     """missing responses at medium size: missing values in X (masked column passes on the GPU) and in Y (host, n x q)
     -- in rows the reference patches, so the oracle can follow.  One more case puts a missing response into a row
