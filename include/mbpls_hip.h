@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 5   /* 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
+#define MBPLS_HIP_ABI_VERSION 5   /* 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
 
 enum {
   MBPLS_OK = 0,
@@ -512,6 +512,11 @@ int mbpls_hip_finalise_small(mbpls_ctx* ctx, int K, int nblocks, int q, const do
 /* mbpls_hip_right_multiply with the c1 x c2 matrix (row-major, c1, c2 <= 32) already on the device.                  */
 int mbpls_hip_right_multiply_dev(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_t lda, int c1, const double* d_M,
                                  int c2, double* d_C, int64_t ldc);
+/* The same for `folds` matrices in one launch (cross-validation folds batched per read of X, mbpls_amd/cv_batch.py):
+ * fold f works on d_A + f a_stride, the c1 x c2 row-major matrix d_M + f c1 c2, and writes d_C + f c_stride.  Replaces
+ * the per-fold R_ = W (P^T W)^+ / beta_ = R_ V_^T products (mbpls.py:988-989) of a loop of fits. */
+int mbpls_hip_right_multiply_folds(mbpls_ctx* ctx, int64_t p, int folds, const double* d_A, int64_t lda, int64_t a_stride,
+                                   int c1, const double* d_M, int c2, double* d_C, int64_t ldc, int64_t c_stride);
 /* d_C (p x c2, ldc) = d_A (p x c1, lda) @ h_M (c1 x c2 row-major HOST matrix):
  * R_ = W (P^T W)^+ and beta_ = R_ V^T (mbpls.py:988-989), column scalings W_b = W~_b diag(1/||w~_b||)
  * (:860) with a diagonal M on the row range of block b. */

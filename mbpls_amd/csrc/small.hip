@@ -95,6 +95,34 @@ __global__ __launch_bounds__(256) void k_right_multiply(int64_t p, const double*
   }
 }
 
+
+// the same for F matrices at once (cross-validation folds): fold f = blockIdx.y works on A + f a_stride, M + f c1 c2,
+// C + f c_stride
+__global__ __launch_bounds__(256) void k_right_multiply_folds(int64_t p, const double* __restrict__ A, int64_t lda,
+                                                              int64_t a_stride, int c1, const double* __restrict__ M,
+                                                              int c2, double* __restrict__ Cm, int64_t ldc,
+                                                              int64_t c_stride) {
+  __shared__ double sM[CMAX * CMAX];
+  const int f = blockIdx.y;
+  A += (int64_t)f * a_stride;
+  Cm += (int64_t)f * c_stride;
+  M += (int64_t)f * c1 * c2;
+  for (int e = threadIdx.x; e < c1 * c2; e += blockDim.x) sM[e] = M[e];
+  __syncthreads();
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < p; r += (int64_t)gridDim.x * blockDim.x) {
+    double a[CMAX];
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) a[i] = (i < c1) ? A[(int64_t)i * lda + r] : 0.0;
+    for (int j = 0; j < c2; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < CMAX; ++i)
+        if (i < c1) s = fma(a[i], sM[i * c2 + j], s);
+      Cm[(int64_t)j * ldc + r] = s;
+    }
+  }
+}
+
 }  // namespace mbpls
 
 namespace mbpls {
@@ -370,6 +398,18 @@ int mbpls_hip_right_multiply_dev(mbpls_ctx* ctx, int64_t p, const double* d_A, i
   MB_ARG(lda >= p && ldc >= p, "leading dimension < p");
   const int nwg = (int)std::min<int64_t>((p + 255) / 256, (int64_t)ctx->cus * 8);
   hipLaunchKernelGGL(k_right_multiply, dim3(nwg), dim3(256), 0, ctx->stream, p, d_A, lda, c1, d_M, c2, d_C, ldc, 0);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+int mbpls_hip_right_multiply_folds(mbpls_ctx* ctx, int64_t p, int folds, const double* d_A, int64_t lda, int64_t a_stride,
+                                   int c1, const double* d_M, int c2, double* d_C, int64_t ldc, int64_t c_stride) {
+  MB_ARG(ctx && d_A && d_M && d_C, "NULL argument");
+  MB_ARG(p >= 1 && folds >= 1 && folds <= 65535 && c1 >= 1 && c2 >= 1 && c1 <= CMAX && c2 <= CMAX,
+         "need 1 <= c1, c2 <= %d, 1 <= folds <= 65535", CMAX);
+  const int nwg = (int)std::min<int64_t>((p + 255) / 256, (int64_t)ctx->cus * 2);
+  hipLaunchKernelGGL(k_right_multiply_folds, dim3(nwg, (unsigned)folds), dim3(256), 0, ctx->stream, p, d_A, lda, a_stride,
+                     c1, d_M, c2, d_C, ldc, c_stride);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }

@@ -268,9 +268,8 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol, one_pass=False):
                 uu = (u_used * u_used).sum(axis=0)
                 coef = c_used / uu[:, None]                                  # w~ = S c / u^T u (:856)
                 dco = ctx.from_host(np.ascontiguousarray(coef).ravel())
-                for f in range(F):
-                    _capi.check(lib.mbpls_hip_right_multiply_dev(ctx.handle, p, Sst.ptr + 8 * p * f, p * F, q,
-                                                                 dco.ptr + 8 * q * f, 1, Wst.ptr + k * pf8 + 8 * p * f, p))
+                _capi.check(lib.mbpls_hip_right_multiply_folds(ctx.handle, p, F, Sst.ptr, p * F, p, q, dco.ptr, 1,
+                                                               Wst.ptr + k * pf8, p, p))
                 dco.free()
                 Bc = np.einsum("bnfq,fq->bnf", Bk, c_used)                   # P X_b X_b^T P u
                 nu_fin = np.sqrt(np.einsum("nf,bnf->bf", u_used, Bc)) / uu   # ||w~_b|| (:860)
@@ -342,13 +341,10 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol, one_pass=False):
         Cm = dC.get().reshape(F, K, K)
         D = 1.0 / np.sqrt((nu_all ** 2).sum(axis=0))                         # F x K: 1 / ||W~[:, k]||
         Mv = np.matmul(D[:, :, None] * np.linalg.pinv(Cm * D[:, None, :]), V.transpose(0, 2, 1))     # F x K x q
-        dMv = ctx.from_host(np.ascontiguousarray(Mv.transpose(0, 2, 1)).ravel())                     # [f][j][k]
+        dMv = ctx.from_host(np.ascontiguousarray(Mv).ravel())                # per fold a K x q row-major matrix
         tmp.append(dMv)
-        for f in range(F):                                                   # beta_f[:, j] -> column j F + f
-            for j in range(q):
-                _capi.check(lib.mbpls_hip_right_multiply_dev(ctx.handle, p, Wst.ptr + 8 * p * f, p * F, K,
-                                                             dMv.ptr + 8 * K * (f * q + j), 1,
-                                                             Bq.ptr + 8 * p * (j * F + f), p))
+        # beta_f = W_f M_f V_f^T for every fold in one launch: beta_f[:, j] -> column j F + f
+        _capi.check(lib.mbpls_hip_right_multiply_folds(ctx.handle, p, F, Wst.ptr, p * F, p, K, dMv.ptr, q, Bq.ptr, p * F, p))
         # ---- predictions of all rows for all folds: one more product per response (:1369-1408); a fold keeps its
         # held-out rows
         for j in range(q):
