@@ -65,8 +65,9 @@ int mbpls_hip_device_count(int* count);
 int mbpls_hip_create(int device, void* stream, mbpls_ctx** out);
 int mbpls_hip_destroy(mbpls_ctx* ctx);
 /* Optional: pay the process-wide first-use costs now instead of inside the first fit -- the code objects of the kernel
- * translation units (loaded lazily otherwise), the pinned bounce buffers, the first event.  Thread-safe; the Python
- * package calls it from a helper thread right after creating a context, so it overlaps with the caller's upload. */
+ * translation units (loaded lazily otherwise), the pinned bounce buffers, the first event.  The Python package calls it
+ * right after creating a context (on the calling thread: from a helper thread the code-object loads deadlocked against
+ * a dlopen of the main thread under rocprofv3). */
 int mbpls_hip_warmup(mbpls_ctx* ctx);
 int mbpls_hip_sync(mbpls_ctx* ctx);
 int mbpls_hip_device_info(mbpls_ctx* ctx, char* name, size_t name_len, int* compute_units,

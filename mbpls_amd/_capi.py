@@ -239,9 +239,6 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
-            th = getattr(self, "_warmup_thread", None)
-            if th is not None and th.is_alive():
-                th.join()
             if getattr(self, "_mapped", None) is not None:
                 self.lib.mbpls_hip_host_free(self.handle, self._mapped[2])
                 self._mapped = None

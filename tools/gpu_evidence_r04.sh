@@ -12,7 +12,7 @@ timeout 600 python3 bench.py --dist --p 250000 --steps 5 --warmup 3 --cpu-cols 0
 timeout 900 python tools/time_cv.py > $O/r04_time_cv.txt 2>&1
 for c in c3 c4 simpls nipals_q10 unipals_q10 nipals_mb; do timeout 600 python tools/bench_configs.py $c 2>/dev/null | tail -1 >> $O/r04_other_configs_lines.jsonl; done
 ( timeout 900 python tools/time_shapes.py 8 NIPALS 1 2>/dev/null | grep '^n='; timeout 600 python tools/time_shapes.py 8 UNIPALS 1 1200,2500,3000,5000,6000,7000,8192,12000,16384 2>/dev/null | grep '^n=' ) > $O/r04_shapes.txt
-( timeout 900 python tools/paper_protocol.py --shape a --data both 2>/dev/null; timeout 1500 python tools/paper_protocol.py --shape b --data both 2>/dev/null ) | grep '^{' > $O/r04_paper_protocol.jsonl
+( timeout 900 python tools/paper_protocol.py a --data both 2>/dev/null; timeout 1500 python tools/paper_protocol.py b --data both 2>/dev/null ) | grep '^{' > $O/r04_paper_protocol.jsonl
 ( echo "== after the fix (this build): UNIPALS n=6000 p=166666 3 blocks K=5, fresh estimators"; timeout 300 python tools/stall_fit.py 6000 166666 3 5 UNIPALS 12 2>&1 | cut -c1-70; echo "== MBPLS_STREAM_STATS=0"; MBPLS_STREAM_STATS=0 timeout 300 python tools/stall_fit.py 6000 166666 3 5 UNIPALS 6 2>&1 | cut -c1-70 ) > $O/r04_stall_n6000_after.txt
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 6 --cpu-cols 0 --e2e-cols 0 --no-extras > $O/bench_under_rocprof.log 2>&1; echo stats rc=$?
