@@ -775,7 +775,7 @@ def pmc_traffic(kernel, n, p):
     """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate
     runs, gfx950 x2 read correction) -- taken on the builder's lease, not in this run -- and only when they were taken
     on this exact shape, else None."""
-    for name in ("r03_pmc_traffic_c2.json", "r02_pmc_traffic_c2.json", "r01_pmc_traffic_c2.json"):
+    for name in ("r04_pmc_traffic_c2.json", "r03_pmc_traffic_c2.json", "r02_pmc_traffic_c2.json", "r01_pmc_traffic_c2.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)

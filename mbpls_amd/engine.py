@@ -778,7 +778,7 @@ class HipEngine(EngineBase):
                 rq.cross(self._lazy_pslot, wslot)
         return rq.result
 
-    def unipals_resident(self, Y, K, wslot, gslot, W_h, P_h, first_pass):
+    def unipals_resident(self, Y, K, wslot, gslot, W_h, P_h, first_pass, Wraw_h=None):
         """The p > n branch of UNIPALS with one response (mbpls.py:481-572) as one device queue: a component costs ONE
         pass (loadings + lazy deflation + the products X^T y, X_b (X^T y)_b of the next component, see
         solvers.fit_unipals); the step kernel forms ts = X (X^T y) / ||.||, v, u, the scalar c with w = c X^T y, the block
@@ -794,8 +794,10 @@ class HipEngine(EngineBase):
                     last = k == K - 1
                     # w_raw = X^T u = c X^T y (:503): the column the pass left in S times the scalar the step recorded
                     rq.scale_col(S.ptr, Wc.ptr + p8 * k, k)
-                    nu_copy, unit = rq.unit_blocks_on_host(W_h, W_h, k)              # w_b / ||w_b|| (:510-512)
-                    rq.stream_out([(rq.col(W_h, k), Wc.ptr + p8 * k)] + nu_copy
+                    # (Wraw_h: the caller also wants the raw weight columns -- they are what arrives; W_h is formed from them)
+                    src_h = W_h if Wraw_h is None else Wraw_h
+                    nu_copy, unit = rq.unit_blocks_on_host(src_h, W_h, k)            # w_b / ||w_b|| (:510-512)
+                    rq.stream_out([(rq.col(src_h, k), Wc.ptr + p8 * k)] + nu_copy
                                   + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []), post=unit)
                     self._res_loadings(k, last, None if last else (gslot, 0))        # p (:520), deflation (:535)
                     if not last:

@@ -559,9 +559,12 @@ def _fit_nipals_q1_fixed_point(eng, Y, K, standardize, calc_all):
     ||w~_b||, so ts = T sw is X w / ||X w||): the same model, fitted by the one-pass-per-component queue of fit_unipals.
     NIPALS' own attributes on top: W_non_normal_ (the raw weights of the last sweep vector, :975) and the iteration count,
     reported as 1 per component."""
-    res = fit_unipals(eng, Y, K, standardize)
+    res = fit_unipals(eng, Y, K, standardize, keep_raw_weights=True)
     _plan(eng, solver="nipals, one response, fixed point after one pass: " + str(eng.plan.get("solver", "")).replace("unipals: ", ""))
-    res.W_non_normal_ = _split(eng.fetch("Wc"), eng.block_offsets)
+    raw = res.pop("_W_raw_host", None)                     # (FitResult is a dict)
+    # the raw weight columns came with the streamed copies of the queue; a late fetch of the 8 p K-byte slot into
+    # unmapped pages cost 15-20 ms at p = 10^6
+    res.W_non_normal_ = _split(raw if raw is not None else eng.fetch("Wc"), eng.block_offsets)
     res.nipals_iterations_ = [1] * K
     res.nipals_converged_ = [True] * K
     if not calc_all:                                        # (:932-964 are skipped by the reference then)
@@ -823,9 +826,11 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
     return res
 
 
-def fit_unipals(eng, Y, K, standardize):
+def fit_unipals(eng, Y, K, standardize, keep_raw_weights=False):
     """mbpls.py:384-574 (calc_all is ignored by the reference here).
-    p>n (:481-572): ts = tlsv((X (X^T Y)) F(Y^T Y));  n>=p (:388-479): w = tlsv(X^T Y)."""
+    p>n (:481-572): ts = tlsv((X (X^T Y)) F(Y^T Y));  n>=p (:388-479): w = tlsv(X^T Y).
+    keep_raw_weights (device-resident one-response queue only): the un-normalised weight columns are streamed to the
+    host as well and returned as ``_W_raw_host`` (the NIPALS fixed-point route hands them out as W_non_normal_)."""
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
@@ -861,8 +866,9 @@ def fit_unipals(eng, Y, K, standardize):
         first = eng.deferred_first_pass(standardize, y0, 1.0, ("S", 0))
         eng.host_array((eng.p, K), reserve="R")
         eng.host_array((eng.p, q), reserve="beta")
+        Wraw_h = _host_array(eng, (eng.p, K)) if keep_raw_weights else None
         for attempt in range(2):
-            out = eng.unipals_resident(Y, K, "Wc", "S", W_h, P_h, first)
+            out = eng.unipals_resident(Y, K, "Wc", "S", W_h, P_h, first, Wraw_h)
             if out.get("reason") != "offset":
                 break                                       # (offset data: queued again with centring passes)
         resident = out.get("reason") != "barrier"
@@ -896,6 +902,8 @@ def fit_unipals(eng, Y, K, standardize):
         else:
             _finalise_device(eng, res, "Wc", K, tot_nrm, blk_nrm, V, W_host=W_h, P_host=P_h, C=out.get("PtW"))
         out["wait_copies"]()                                # streamed columns of W, P complete
+        if keep_raw_weights:
+            res._W_raw_host = Wraw_h
         return res
     varxb, m_raw, g_ssq = eng.prepare(standardize, v=y0 if fuse else None, alpha=1.0, g_slot=("S", 0) if fuse else None)
     yy = y0.T.dot(y0).item()
