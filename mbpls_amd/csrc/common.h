@@ -54,8 +54,8 @@ struct ChunkTable {
 }  // namespace mbpls
 
 constexpr int PIN_SLOTS = 4;
-constexpr int SMALL_PIN_SLOTS = 256;
-constexpr size_t SMALL_PIN_BYTES = 64u << 10;
+constexpr int SMALL_PIN_SLOTS = 64;
+constexpr size_t SMALL_PIN_BYTES = 256u << 10;   // (what went to the runtime's own staging before: copies below 256 KB)
 
 struct mbpls_ctx {
   int device = 0;
@@ -108,7 +108,7 @@ struct mbpls_ctx {
   size_t pin_half = 0;     // bytes per slot
   hipEvent_t pin_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned pin_next = 0;
-  void* pin_small = nullptr;           // ... and of the small ones (vectors, parameter blocks): SMALL_PIN_SLOTS x 64 KB
+  void* pin_small = nullptr;           // ... and of the small ones (vectors, parameter blocks): SMALL_PIN_SLOTS x 256 KB
   hipEvent_t pin_small_ev[SMALL_PIN_SLOTS];
   unsigned pin_small_next = 0;
   void* pin_copier = nullptr;          // pinned bounce buffer of the copier thread's device-to-host copies (<= 4 MB)

@@ -369,7 +369,7 @@ int mbpls_hip_host_free(mbpls_ctx* ctx, void* h_ptr) {
 int mbpls_hip_memcpy_h2d(mbpls_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   MB_ARG(ctx && (bytes == 0 || (d_dst && h_src)), "NULL argument");
   if (bytes == 0) return MBPLS_OK;
-  // Small copies (n-vectors, parameter blocks) bounce through a ring of pinned 64 KB slots of our own.  Handing the
+  // Small copies (n-vectors, parameter blocks; < 256 KB) bounce through a ring of 64 pinned slots of our own.  Handing the
   // pageable source to hipMemcpyAsync was correct (the runtime stages it before returning) but every third fit of a
   // shape with 48-56 KB vectors (n = 6000, 7000) the copy then EXECUTED 26-36 ms late on an idle GPU (rocprofv3
   // memory-copy trace, profiles/r04_stall_n6000.txt): a 10 ms fit took 40.
@@ -381,7 +381,7 @@ int mbpls_hip_memcpy_h2d(mbpls_ctx* ctx, void* d_dst, const void* h_src, size_t 
     }
     const unsigned h = ctx->pin_small_next++ % SMALL_PIN_SLOTS;
     if (!ctx->pin_small_ev[h]) MB_HIP(hipEventCreateWithFlags(&ctx->pin_small_ev[h], hipEventDisableTiming));
-    else MB_HIP(hipEventSynchronize(ctx->pin_small_ev[h]));      // 256 copies ago: done long since
+    else MB_HIP(hipEventSynchronize(ctx->pin_small_ev[h]));      // 64 copies ago: done long since
     char* buf = (char*)ctx->pin_small + (size_t)h * SMALL_PIN_BYTES;
     memcpy(buf, h_src, bytes);
     MB_HIP(hipMemcpyAsync(d_dst, buf, bytes, hipMemcpyHostToDevice, ctx->stream));

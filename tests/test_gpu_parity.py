@@ -905,9 +905,8 @@ def test_several_responses_nipals_never_writes_x(gpu_required, monkeypatch, meth
     Xd = DeviceMatrix(ctx, n, p, offs)
     Xd.upload(X)
     mdl = MBPLS(n_components=3, method=method, standardize=standardize, full_svd=True).fit(Xd, Y)
-    if method != "KERNEL":
-        # one fused sweep pass per component (p = X^T t and X p), standardising in registers -- on tall data too since the
-        # long-column passes read X once (clusters of workgroups, round 4; tall SIMPLS kept the products before)
+    if method != "KERNEL" and not (method == "SIMPLS" and n > 8192):
+        # one fused sweep pass per component (p = X^T t and X p), standardising in registers (tall SIMPLS keeps the products)
         assert used == [] and "never written" in mdl.fit_plan_["standardisation"], mdl.fit_plan_
     else:
         assert used == [True]
