@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 5   /* 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
+#define MBPLS_HIP_ABI_VERSION 5   /* 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
 
 enum {
   MBPLS_OK = 0,
@@ -481,6 +481,11 @@ int mbpls_hip_allreduce(mbpls_ctx* ctx, double* d_buf, size_t count);   /* sum, 
  * d_alpha unused.  Asynchronous on the context's stream; fixed-order sums.                                          */
 int mbpls_hip_cv_weights(const mbpls_mat* m, int F, int predict, const double* d_G, const double* d_mu, const double* d_rs,
                          const double* d_su, const double* d_alpha, double* d_g, double* d_C, double* d_sums);
+/* Several responses: the NIPALS inner loop (mbpls.py:841-913) of `folds` cross-validation folds at once, each in the
+ * q-dimensional space of its iterates (u = Y c, ts ~ G c; mbpls_hip_nipals_subspace_qloop for one problem): one wave per
+ * fold.  d_moments [folds][3][q][q]: G^T G, Y^T G, Y^T Y of every fold (row-major).  d_out [folds][2 q + 3]:
+ * c~ (ts = G c~ / ||.||), the c of the last sweep vector, flag (1 converged, 2 iteration cap), iterations, last diff. */
+int mbpls_hip_cv_qloops(mbpls_ctx* ctx, int folds, int q, const double* d_moments, double tol, int max_iter, double* d_out);
 /* d_G (p x c) = ((X - 1 d_mean^T) [o (X - 1 d_mean^T) when square])^T d_V: centred sums / sums of squares over row sets
  * given as indicator columns (the held-out rows of cross-validation folds); matrix cores, X read once.               */
 int mbpls_hip_xt_v_centred(const mbpls_mat* m, const double* d_mean, int square, const double* d_V, int64_t ldv, int c,

@@ -120,6 +120,7 @@ SIGNATURES = {
     "mbpls_hip_cross_product_dev": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp]),
     "mbpls_hip_finalise_small": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_right_multiply_dev": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _int, _vp, _i64]),
+    "mbpls_hip_cv_qloops": (_int, [_vp, _int, _int, _vp, _dbl, _int, _vp]),
     "mbpls_hip_right_multiply_folds": (_int, [_vp, _i64, _int, _vp, _i64, _i64, _int, _vp, _int, _vp, _i64, _i64]),
     "mbpls_hip_right_multiply": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _int, _vp, _i64]),
 }

@@ -88,6 +88,69 @@ __global__ __launch_bounds__(256) void k_cv_fold_stats(int64_t p, int F, double 
   rs[e] = (var <= n_f * eps * var + nme * nme) ? 1.0 : 1.0 / sqrt(var);
 }
 
+
+// The NIPALS inner loop (mbpls.py:841-913) of F cross-validation folds at once, each in the q-dimensional space of its
+// iterates (nipals_step.hip k_nipals_subspace_qloop for ONE problem): one WAVE per fold, lane j owns row j of the fold's
+// three q x q moment matrices M1 = G^T G, M2 = Y^T G, M3 = Y^T Y; an iteration is a handful of wave reductions.
+// out[f] = [c~ (q) | c of the last sweep vector (q) | flag (1 converged, 2 capped) | iterations | last diff]
+constexpr int CVQ_MAX = 16;
+__device__ __forceinline__ double cv_lane_value(double x, int k) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), k), __builtin_amdgcn_readlane(__double2loint(x), k));
+}
+__global__ __launch_bounds__(64) void k_cv_qloops(int q, int max_iter, double tol, const double* __restrict__ Mall,
+                                                   double* __restrict__ out) {
+  const int f = blockIdx.x, j = threadIdx.x;
+  const double* M = Mall + (int64_t)f * 3 * q * q;
+  double m1[CVQ_MAX], m2[CVQ_MAX], m3[CVQ_MAX];
+#pragma unroll
+  for (int k = 0; k < CVQ_MAX; ++k) {
+    const bool in = j < q && k < q;
+    m1[k] = in ? M[j * q + k] : 0.0;
+    m2[k] = in ? M[q * q + j * q + k] : 0.0;
+    m3[k] = in ? M[2 * q * q + j * q + k] : 0.0;
+  }
+  auto matvec = [&](const double (&m)[CVQ_MAX], double x) {
+    double y = 0.0;
+#pragma unroll
+    for (int k = 0; k < CVQ_MAX; ++k) y = fma(m[k], cv_lane_value(x, k), y);
+    return y;
+  };
+  double c = (j == 0) ? 1.0 : 0.0, cu = c, ct = 0.0, ct_old = 0.0, v = 0.0, vv = 1.0, diff = 1.0, flag = 0.0;   // start: Y[:, 0] (:838)
+  int iters = 0;
+  while (true) {
+    ++iters;
+    cu = c;
+    ct = c / sqrt(wave_sum(c * matvec(m1, c)));                       // ts = G c~, unit length (:882-883)
+    if (iters > 1) {
+      const double d = ct_old - ct;
+      diff = sqrt(fmax(wave_sum(d * matvec(m1, d)), 0.0));            // (:887)
+    }
+    ct_old = ct;
+    v = matvec(m2, ct);                                               // (:899)
+    vv = wave_sum(v * v);
+    const double un = sqrt(wave_sum(v * matvec(m3, v))) / vv;         // ||Y v / v^T v|| (:911-913)
+    c = v / vv / un;
+    if (iters >= 2 && diff <= tol) {
+      flag = 1.0;
+      break;
+    }
+    if (iters >= max_iter || !(diff == diff)) {                       // (a NaN anywhere: give up, the caller falls back)
+      flag = 2.0;
+      break;
+    }
+  }
+  double* o = out + (int64_t)f * (2 * q + 3);
+  if (j < q) {
+    o[j] = ct;
+    o[q + j] = cu;
+  }
+  if (j == 0) {
+    o[2 * q] = flag;
+    o[2 * q + 1] = (double)iters;
+    o[2 * q + 2] = diff;
+  }
+}
+
 }  // namespace mbpls
 
 using namespace mbpls;
@@ -127,6 +190,14 @@ int mbpls_hip_cv_fold_stats(const mbpls_mat* m, int F, const double* d_mu0, cons
   MB_HIP(hipMemsetAsync(d_risky, 0, 8, ctx->stream));
   hipLaunchKernelGGL(k_cv_fold_stats, dim3((unsigned)((m->p + 255) / 256), (unsigned)F), dim3(256), 0, ctx->stream, m->p, F,
                      (double)m->n, d_mu0, d_var0, d_h1, d_h2, d_nf, d_mean, d_rs, (unsigned long long*)d_risky);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+int mbpls_hip_cv_qloops(mbpls_ctx* ctx, int folds, int q, const double* d_moments, double tol, int max_iter, double* d_out) {
+  MB_ARG(ctx && d_moments && d_out, "NULL argument");
+  MB_ARG(folds >= 1 && q >= 1 && q <= CVQ_MAX && max_iter >= 1, "q-space loops cover q <= %d", CVQ_MAX);
+  hipLaunchKernelGGL(k_cv_qloops, dim3((unsigned)folds), dim3(64), 0, ctx->stream, q, max_iter, tol, d_moments, d_out);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }

@@ -127,6 +127,36 @@ def _fix_risky(Xdev, M, n_f, dmu, drs, p, F):
         ctx.sync()
 
 
+def _qspace_loops_device(ctx, G, Ys, tol, max_iter, k):
+    """_qspace_loops with the iteration itself on the device: one wave per fold (csrc/cv_batch.hip k_cv_qloops); the
+    host only forms the folds' q x q moments and, afterwards, ts and v (a hundred iterations of a dozen numpy calls
+    per component were half of a batch's time)."""
+    F, q = G.shape[1], G.shape[2]
+    M = np.empty((F, 3, q, q))
+    M[:, 0] = np.einsum("nfa,nfb->fab", G, G)
+    M[:, 1] = np.einsum("nfa,nfb->fab", Ys, G)
+    M[:, 2] = np.einsum("nfa,nfb->fab", Ys, Ys)
+    dM = ctx.from_host(M.ravel())
+    dout = ctx.empty(F * (2 * q + 3))
+    try:
+        _capi.check(ctx.lib.mbpls_hip_cv_qloops(ctx.handle, F, q, dM.ptr, float(tol), int(max_iter), dout.ptr))
+        o = dout.get().reshape(F, 2 * q + 3)
+    finally:
+        dM.free(); dout.free()
+    ct, c_used, flag, n_it = o[:, :q], o[:, q:2 * q], o[:, 2 * q], o[:, 2 * q + 1].astype(np.int64)
+    if (flag == 2.0).any():
+        if not np.isfinite(o).all():
+            raise DegenerateFold(f"component {k}")
+        warnings.warn(f"NIPALS component {k}: no convergence to max_tol={tol} after {max_iter} iterations in "
+                      f"{int((flag == 2.0).sum())} fold(s); the reference would loop forever here.")
+    ts = np.einsum("nfq,fq->nf", G, ct)
+    ts /= np.sqrt((ts * ts).sum(axis=0))
+    v = np.einsum("nfq,nf->fq", Ys, ts) / (ts * ts).sum(axis=0)[:, None]
+    if not (np.isfinite(ts).all() and np.isfinite(v).all() and np.isfinite(c_used).all()):
+        raise DegenerateFold(f"component {k}")
+    return n_it, c_used, ts, v
+
+
 def _qspace_loops(G, Ys, tol, max_iter, k):
     """The NIPALS inner loop (mbpls.py:841-913) of EVERY fold in the q-dimensional space of its iterates -- the batched
     form of solvers._subspace_loop_qspace: with M1 = G^T G, M2 = Y^T G, M3 = Y^T Y per fold, an iteration is O(q^2) per
@@ -263,7 +293,7 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol, one_pass=False):
                     _, tb = sweep(Ys[:, :, j], np.ones(F), k)                # g_j = X_k^T (P y_j) in dg, t~_b = P X_b g_j,b
                     _capi.check(lib.mbpls_hip_memcpy_d2d(ctx.handle, Sst.ptr + j * pf8, dg.ptr, pf8))
                     Bk[:, :, :, j] = tb
-                n_it, c_used, ts_fin, v_fin = _qspace_loops(Bk.sum(axis=0), Ys, tol, solvers.NIPALS_MAX_ITER, k)
+                n_it, c_used, ts_fin, v_fin = _qspace_loops_device(ctx, Bk.sum(axis=0), Ys, tol, solvers.NIPALS_MAX_ITER, k)
                 u_used = np.einsum("nfq,fq->nf", Ys, c_used)                 # sweep vector of the last iteration
                 uu = (u_used * u_used).sum(axis=0)
                 coef = c_used / uu[:, None]                                  # w~ = S c / u^T u (:856)

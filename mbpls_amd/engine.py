@@ -1095,9 +1095,13 @@ def _prefault(arr, min_bytes=1 << 20):
         q = queue.Queue()
 
         def work():
-            page = 4096
+            import mmap
+            page = mmap.PAGESIZE            # (64 KB pages elsewhere: a hard-coded 4096 made every call fail with EINVAL)
             while True:
-                addr, nbytes = q.get()
+                # the ARRAY travels with its address: it stays alive until its pages are mapped (an array collected
+                # before the thread got to it left madvise on an unmapped or reused range -- round-3 advisor)
+                keep = q.get()
+                addr, nbytes = keep.ctypes.data, keep.nbytes
                 lo = (addr + page - 1) // page * page
                 hi = (addr + nbytes) // page * page
                 # in small pieces: the call holds the process's mmap lock while it populates, and every allocation /
@@ -1111,11 +1115,12 @@ def _prefault(arr, min_bytes=1 << 20):
                             _PREFAULT["off"] = True
                         break
                     lo += n
+                keep = None
 
         th = threading.Thread(target=work, daemon=True, name="mbpls-prefault")
         th.start()
         _PREFAULT.update(queue=q, thread=th)
-    q.put((arr.ctypes.data, arr.nbytes))
+    q.put(arr)
 
 
 def _copier_queue():
