@@ -29,9 +29,11 @@ cheaper than through the loadings -- stays on the host like the n x B algebra of
 A batch of F folds costs 5 K + 3 products instead of F complete fits: leave-one-out on a small data set (n = 150,
 p = 3000, K = 5: all launches) and k-fold on a matrix that fills the GPU (every read of X serves all folds) alike.
 
-Used by ``model_selection.cross_val_predict`` for method='NIPALS', one response, the 2-norm stop rule, complete data,
-K <= 32 and at least 8 folds' worth of device memory; anything else takes the fold-by-fold loop.  Same numbers as that
-loop and as a loop of fits of the CPU oracle (tests/test_gpu_parity.py) to ~1e-12.
+Used by ``model_selection.cross_val_predict`` for complete data, K <= 32, at least 8 folds' worth of device memory and
+(round 4, ``eligible``) one response with EVERY method -- they fit the same model then --, several-response NIPALS
+(2-norm stop rule; the folds' inner loops in q-space, ``_qspace_loops_device``) and the p > n branches of several-response
+UNIPALS / KERNEL (stacked thin SVDs); anything else takes the fold-by-fold loop.  Same numbers as that loop and as a
+loop of fits of the CPU oracle (tests/test_gpu_parity.py) to ~1e-12.
 """
 from __future__ import annotations
 
@@ -72,9 +74,14 @@ def eligible(estimator, q, n, p, n_folds, ctx=None):
         ok = estimator.method in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS")
         if estimator.method == "NIPALS":
             ok = estimator.nipals_convergence_norm in (2, -2, "fro", "nuc")
+    elif estimator.method == "NIPALS":
+        ok = q <= MAX_RESPONSES and estimator.nipals_convergence_norm in (2, -2, "fro", "nuc")
     else:
-        ok = (estimator.method == "NIPALS" and q <= MAX_RESPONSES
-              and estimator.nipals_convergence_norm in (2, -2, "fro", "nuc"))
+        # UNIPALS / KERNEL with several responses: their p > n branches (mbpls.py:481-572, :694-805) take the top left
+        # singular vector of the same n x q matrix G the NIPALS loop iterates on (times a q x q factor of Y^T Y), so a
+        # component is the same q sweeps per batch plus F thin SVDs; the n >= p branches are a different model (an
+        # eigenvector of a non-symmetric matrix is not its singular vector) and stay with the fold-by-fold loop
+        ok = estimator.method in ("UNIPALS", "KERNEL") and q <= MAX_RESPONSES and p > n
     if ok and ctx is not None:
         ok = _folds_per_batch(ctx, p, K + (q if q > 1 else 0), n_folds) >= min(MIN_FOLDS, n_folds)
     return ok
@@ -93,6 +100,7 @@ def predict_folds(estimator, Xdev, ctx, comm, y, splits, batch=None):
     out = np.full((n, q), np.nan)
     # one response, a method without iteration (or NIPALS, whose second iteration only confirms the first): one sweep
     one_pass = q == 1 and estimator.method != "NIPALS"
+    method = estimator.method if q > 1 else "NIPALS"
     eng = HipEngine(ctx=ctx, comm=comm)
     eng.load_device(Xdev, copy=False)
     from . import runtime
@@ -103,7 +111,7 @@ def predict_folds(estimator, Xdev, ctx, comm, y, splits, batch=None):
             eng.prepare_stats(std)
             eng._kscale = False                      # (the products below take the RAW matrix)
             for s0 in range(0, len(splits), batch):
-                _one_batch(eng, Xdev, y, splits[s0:s0 + batch], out, K, std, float(estimator.max_tol), one_pass)
+                _one_batch(eng, Xdev, y, splits[s0:s0 + batch], out, K, std, float(estimator.max_tol), one_pass, method)
     finally:
         eng.X = None                                 # the caller owns the matrix
         eng.close()
@@ -203,7 +211,7 @@ def _qspace_loops(G, Ys, tol, max_iter, k):
     return n_it, c_fin, ts, v
 
 
-def _one_batch(eng, Xdev, y, part, out, K, std, tol, one_pass=False):
+def _one_batch(eng, Xdev, y, part, out, K, std, tol, one_pass=False, method="NIPALS"):
     n, p = Xdev.n, Xdev.p
     q = y.shape[1]
     offs = list(Xdev.block_offsets)
@@ -293,10 +301,28 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol, one_pass=False):
                     _, tb = sweep(Ys[:, :, j], np.ones(F), k)                # g_j = X_k^T (P y_j) in dg, t~_b = P X_b g_j,b
                     _capi.check(lib.mbpls_hip_memcpy_d2d(ctx.handle, Sst.ptr + j * pf8, dg.ptr, pf8))
                     Bk[:, :, :, j] = tb
-                n_it, c_used, ts_fin, v_fin = _qspace_loops_device(ctx, Bk.sum(axis=0), Ys, tol, solvers.NIPALS_MAX_ITER, k)
-                u_used = np.einsum("nfq,fq->nf", Ys, c_used)                 # sweep vector of the last iteration
-                uu = (u_used * u_used).sum(axis=0)
-                coef = c_used / uu[:, None]                                  # w~ = S c / u^T u (:856)
+                Gk = Bk.sum(axis=0)                                          # n x F x q: P X X^T P Y of every fold
+                if method == "NIPALS":
+                    n_it, c_used, ts_fin, v_fin = _qspace_loops_device(ctx, Gk, Ys, tol, solvers.NIPALS_MAX_ITER, k)
+                    u_used = np.einsum("nfq,fq->nf", Ys, c_used)             # sweep vector of the last iteration
+                    uu = (u_used * u_used).sum(axis=0)
+                    coef = c_used / uu[:, None]                              # w~ = S c / u^T u (:856)
+                else:
+                    # UNIPALS (:489-504): ts = tlsv(G F(Y^T Y)), w = X^T (Y v);  KERNEL (:712-731): the same with the
+                    # deflated responses Y_d = P Y in the factor and w = X^T (Y_d (Y_d^T ts)) -- all folds in stacked
+                    # LAPACK calls (F thin SVDs of n x q, F symmetric q x q eigen-decompositions)
+                    Yf = Ys if method == "UNIPALS" else np.stack([deflate(Ys[:, :, j], k) for j in range(q)], axis=2)
+                    lam, Q = np.linalg.eigh(np.einsum("nfa,nfb->fab", Yf, Yf))
+                    Fm = Q * np.sqrt(np.clip(lam, 0.0, None))[:, None, :]    # F(Y^T Y) per fold (solvers._psd_factor)
+                    thin = np.matmul(Gk.transpose(1, 0, 2), Fm)              # F x n x q
+                    ts_fin = np.linalg.svd(thin, full_matrices=False)[0][:, :, 0].T.copy()   # n x F, unit length
+                    v_fin = np.einsum("nfq,nf->fq", Ys, ts_fin) / (ts_fin * ts_fin).sum(axis=0)[:, None]
+                    c_used = v_fin if method == "UNIPALS" else np.einsum("nfq,nf->fq", Yf, ts_fin)
+                    u_used = np.einsum("nfq,fq->nf", Yf, c_used)
+                    uu = np.ones(F)
+                    coef = c_used
+                    if not (np.isfinite(ts_fin).all() and np.isfinite(coef).all()):
+                        raise DegenerateFold(f"component {k}")
                 dco = ctx.from_host(np.ascontiguousarray(coef).ravel())
                 _capi.check(lib.mbpls_hip_right_multiply_folds(ctx.handle, p, F, Sst.ptr, p * F, p, q, dco.ptr, 1,
                                                                Wst.ptr + k * pf8, p, p))

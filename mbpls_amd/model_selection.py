@@ -6,8 +6,9 @@ slice of X.  Here X is uploaded once and only ever read:
 
 * batched folds (``cv_batch``): up to 256 folds are fitted per pass over X -- every read of the raw matrix serves all
   of them through many-right-hand-side products, the folds' column statistics and deflations are applied
-  algebraically.  Covers one response with every method (they fit the same model then) and several-response NIPALS;
-* fold by fold (everything else: several-response UNIPALS / KERNEL / SIMPLS, missing values, column shards): a fold is a
+  algebraically.  Covers one response with every method (they fit the same model then) and several responses with
+  NIPALS and with the p > n branches of UNIPALS / KERNEL;
+* fold by fold (everything else: several-response SIMPLS, the n >= p branches, missing values, column shards): a fold is a
   *row mask* handed to the standardise pass, which writes zero rows for the held-out samples into the working copy and
   takes the column statistics over the training samples only; predictions for the held-out rows come from one ``x_w``
   pass over the same resident matrix.  No re-upload, no host slicing.
@@ -42,9 +43,9 @@ def cross_val_predict(estimator, X, y, cv=5, groups=None, batch_folds=True):
     cv: int (KFold without shuffling, as sklearn does for regressors), a CV splitter, or an iterable of
     (train, test) index pairs.  Returns an (n, q) array (``predict``'s shape).
 
-    One-response models of every method and several-response NIPALS models are fitted up to 256 folds at a time (as
-    many as device memory holds), every pass over X serving all of them (``cv_batch``; ``batch_folds=False`` forces
-    the fold-by-fold loop, which everything else takes)."""
+    One-response models of every method and several-response NIPALS / UNIPALS / KERNEL (p > n) models are fitted up to
+    256 folds at a time (as many as device memory holds), every pass over X serving all of them (``cv_batch``;
+    ``batch_folds=False`` forces the fold-by-fold loop, which everything else takes)."""
     if not isinstance(estimator, MBPLS):
         raise TypeError("cross_val_predict of mbpls_amd works on mbpls_amd.MBPLS estimators")
     y = np.asarray(y, dtype=np.float64)

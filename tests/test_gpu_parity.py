@@ -508,7 +508,8 @@ def test_cross_val_predict_batched_folds(gpu_required, blocks, std, cv):
 
 
 @pytest.mark.parametrize("method,q,blocks,cv", [("UNIPALS", 1, 2, "loo"), ("KERNEL", 1, 1, 6), ("SIMPLS", 1, 3, 5),
-                                                ("NIPALS", 3, 2, "loo"), ("NIPALS", 2, 1, 4)])
+                                                ("NIPALS", 3, 2, "loo"), ("NIPALS", 2, 1, 4),
+                                                ("UNIPALS", 3, 2, "loo"), ("KERNEL", 2, 3, 6)])
 def test_cross_val_predict_batched_folds_other_routes(gpu_required, method, q, blocks, cv):
     """Round 4: one response with EVERY method (one model, the batched passes without the confirming iteration) and
     several-response NIPALS (every fold's inner loop advances together) == a loop of oracle fits of that method."""

