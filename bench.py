@@ -40,6 +40,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E (MI355X_MICROARCH.md); the guide's measured copy ceiling is ~6290 GB/s
 
 
+def note(msg):
+    """progress on stderr (stdout carries the ONE JSON line): which leg a failure or a slow run belongs to"""
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def planted(n, q, r, seed, decay=0.85, noise_y=0.5):
     rng = np.random.RandomState(seed)
     T = rng.standard_normal((n, r))
@@ -197,6 +203,7 @@ def main():
     # every step is the fit of a FRESH estimator in a warm process -- what cross-validation and every real caller do
     # (a refit of the same estimator is timed beside it, outside the timed region).  The fitted models stay alive until
     # the timed region ends: releasing the previous result (0.35 GB of attributes at p = 1e6) is not part of fit().
+    note(f"timed region: {a.warmup} warm-up + {a.steps} timed fits")
     for _ in range(a.warmup):
         new_model().fit(X, Y)
     ctx.profile(True)
@@ -231,10 +238,13 @@ def main():
 
     extras = {}
     if not a.no_extras and a.method == "NIPALS" and q == 1:
+        note("extras: explicit deflation, fixed-point route")
         extras = nipals_extras(ctx, mdl, X, Y, n, p, barrier_sync)
     if not a.no_extras and dist is None and a.method == "NIPALS" and q == 1 and p >= 8 * 1024:
+        note("extras: shard proxy")
         extras["shard_proxy"] = shard_proxy(ctx, mbpls_amd, dT, Y, r, n, p // 8, K, dt / a.steps)
     if not a.no_extras and dist is None and a.method == "NIPALS" and q == 1 and len(offs) == 2:
+        note("extras: other solvers on the same matrix")
         extras["other_solvers_same_matrix"] = other_solvers(ctx, X, n, K, r)
     if dist is not None and not a.no_extras:
         extras["allreduce"] = time_allreduce(ctx, mbpls_amd.get_comm(), n * B + 3 * B + B * 40)
@@ -295,10 +305,13 @@ def main():
         }
         out.update(extras)
     if dist is None and a.e2e_cols != 0:
+        note("end-to-end leg (host numpy in)")
         e2e = end_to_end(ctx, X, Y, n, p if a.e2e_cols < 0 else min(a.e2e_cols, p), K, a.method)
         if rank == 0:
             out["end_to_end_host_numpy"] = e2e
     if rank == 0:
+        if a.cpu_cols > 0:
+            note("CPU baseline (oracle on the host cores)")
         if a.cpu_cols > 0 and dist is None:
             out["cpu_baseline"] = cpu_baseline(ctx, X, Y, n, p, min(a.cpu_cols, p), K, a.method, per_step)
         elif a.cpu_cols > 0:
@@ -618,6 +631,7 @@ def other_solvers(ctx, X, n, K, r):
     out = {}
     for name, method, q in (("nipals_q10", "NIPALS", 10), ("unipals_q10", "UNIPALS", 10), ("simpls_q1", "SIMPLS", 1),
                             ("unipals_q1", "UNIPALS", 1)):
+        note(f"  {name}")
         Yq = planted(n, q, r, 0)[1]                      # the same latent scores as X (seed 0), q response columns
         try:
             MBPLS(n_components=K, method=method).fit(X, Yq)
