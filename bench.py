@@ -88,9 +88,15 @@ def main():
     ap.add_argument("--first-fit-child", action="store_true",
                     help="(internal) fresh process: generate X, time the FIRST fit of the process and the second, print JSON")
     ap.add_argument("--no-first-fit", action="store_true", help="skip the cold-start leg (a child process run first)")
+    ap.add_argument("--extras-child", action="store_true",
+                    help="(internal) the side legs of the N = 1 line in a process of their own; prints one JSON object")
+    ap.add_argument("--full-fit-s", type=float, default=0.0, help="(internal) the parent's timed fit, for the shard proxy")
+    ap.add_argument("--extras-in-process", action="store_true", help="run the side legs in the timing process itself")
     a = ap.parse_args()
     if a.first_fit_child:
         return first_fit_child(a)
+    if a.extras_child:
+        return extras_child(a)
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process only starts the N ranks (fresh processes,
@@ -237,15 +243,18 @@ def main():
     phases = {k: round(1e3 * v, 2) for k, v in getattr(mdl, "fit_timings_", {}).items()}
 
     extras = {}
-    if not a.no_extras and a.method == "NIPALS" and q == 1:
-        note("extras: explicit deflation, fixed-point route")
+    e2e_from_child = None
+    if dist is None and not a.no_extras and not a.extras_in_process:
+        # The side legs (explicit deflation, fixed-point route, shard proxy, the other solvers, end to end from host
+        # memory) run in a CHILD process: nothing they do -- a fault in a secondary kernel included -- can cost the line
+        # its headline numbers, which are complete at this point.
+        note("side legs in a child process")
+        extras = run_extras_child(a, dt / a.steps)
+        e2e_from_child = extras.pop("end_to_end_host_numpy", None)
+    elif dist is None and not a.no_extras:
+        extras = side_legs(ctx, mbpls_amd, a, mdl, X, Y, dT, r, n, p, K, q, len(offs) == 2, barrier_sync, dt / a.steps)
+    elif not a.no_extras and a.method == "NIPALS" and q == 1:
         extras = nipals_extras(ctx, mdl, X, Y, n, p, barrier_sync)
-    if not a.no_extras and dist is None and a.method == "NIPALS" and q == 1 and p >= 8 * 1024:
-        note("extras: shard proxy")
-        extras["shard_proxy"] = shard_proxy(ctx, mbpls_amd, dT, Y, r, n, p // 8, K, dt / a.steps)
-    if not a.no_extras and dist is None and a.method == "NIPALS" and q == 1 and len(offs) == 2:
-        note("extras: other solvers on the same matrix")
-        extras["other_solvers_same_matrix"] = other_solvers(ctx, X, n, K, r)
     if dist is not None and not a.no_extras:
         extras["allreduce"] = time_allreduce(ctx, mbpls_amd.get_comm(), n * B + 3 * B + B * 40)
         extras["strong_scaling_c2"] = strong_scaling(ctx, mbpls_amd, dT, Y, r, rank, world, n, a.p, K, a.method,
@@ -304,7 +313,10 @@ def main():
             "comm": comm_info, "sharded_self_check": check,
         }
         out.update(extras)
-    if dist is None and a.e2e_cols != 0:
+    if e2e_from_child is not None:
+        if rank == 0:
+            out["end_to_end_host_numpy"] = e2e_from_child
+    elif dist is None and a.e2e_cols != 0 and (a.no_extras or a.extras_in_process):
         note("end-to-end leg (host numpy in)")
         e2e = end_to_end(ctx, X, Y, n, p if a.e2e_cols < 0 else min(a.e2e_cols, p), K, a.method)
         if rank == 0:
@@ -798,6 +810,64 @@ def pmc_traffic(kernel, n, p):
         except Exception:
             continue
     return None, None
+
+
+def side_legs(ctx, mbpls_amd, a, mdl, X, Y, dT, r, n, p, K, q, single_block, barrier_sync, full_fit_s):
+    """the side legs of the N = 1 line (never `value`): explicit deflation + fixed-point route, shard proxy, the other
+    solvers on the same matrix"""
+    extras = {}
+    if a.method == "NIPALS" and q == 1:
+        note("extras: explicit deflation, fixed-point route")
+        extras = nipals_extras(ctx, mdl, X, Y, n, p, barrier_sync)
+        if p >= 8 * 1024:
+            note("extras: shard proxy")
+            extras["shard_proxy"] = shard_proxy(ctx, mbpls_amd, dT, Y, r, n, p // 8, K, full_fit_s)
+        if single_block:
+            note("extras: other solvers on the same matrix")
+            extras["other_solvers_same_matrix"] = other_solvers(ctx, X, n, K, r)
+    return extras
+
+
+def extras_child(a):
+    """bench.py --extras-child: the side legs in a process of their own (same matrix, generated again in HBM)"""
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix
+    ctx = mbpls_amd.get_context()
+    n, p, K, q = a.n, a.p, a.K, a.q
+    Ts, Y = planted(n, q, 32, seed=0)
+    dT = ctx.from_host(Ts)
+    X = DeviceMatrix(ctx, n, p, [0, p])
+    X.fill_latent(dT, 32, 0.5, 1234, 0)
+    ctx.sync()
+
+    def sync():
+        ctx.sync()
+
+    mdl = MBPLS(n_components=K, method=a.method, standardize=True, calc_all=True, copy=True)
+    for _ in range(2):
+        mdl.fit(X, Y)
+    out = side_legs(ctx, mbpls_amd, a, mdl, X, Y, dT, 32, n, p, K, q, True, sync, a.full_fit_s)
+    if a.e2e_cols != 0:
+        note("end-to-end leg (host numpy in)")
+        out["end_to_end_host_numpy"] = end_to_end(ctx, X, Y, n, p if a.e2e_cols < 0 else min(a.e2e_cols, p), K, a.method)
+    out["side_legs_process"] = "child process of the timing run (same matrix generated again; a failure here cannot cost the line)"
+    print(json.dumps(out), flush=True)
+    X.close()
+    return 0
+
+
+def run_extras_child(a, full_fit_s):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--extras-child", "--n", str(a.n), "--p", str(a.p), "--K", str(a.K),
+           "--q", str(a.q), "--method", a.method, "--e2e-cols", str(a.e2e_cols), "--full-fit-s", repr(float(full_fit_s))]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=None, text=True, timeout=1200)
+        for line in reversed(r.stdout.splitlines()):
+            if line.lstrip().startswith("{"):
+                return json.loads(line)
+        return {"side_legs_error": f"child exited with {r.returncode} and printed no JSON"}
+    except Exception as e:                               # noqa: BLE001 -- reported in the line, never fatal
+        return {"side_legs_error": f"{type(e).__name__}: {e}"}
 
 
 def first_fit_child(a):

@@ -1,6 +1,9 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04j; mkdir -p $O
-for i in 1 2; do timeout 900 python3 bench.py > $O/bench_$i.log 2> $O/bench_$i.err; echo "bench $i rc=$?"; grep "bench \|Exception\|rror" $O/bench_$i.err | tail -12; done
-tail -1 $O/bench_2.log > $O/r04_bench_c2_line.json
-( timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "cross_val" ) 2>&1 | tail -2
-timeout 900 python tools/time_cv.py > $O/r04_time_cv.txt 2>&1; cat $O/r04_time_cv.txt
+( time timeout 900 python3 bench.py > $O/bench_1.log 2> $O/bench_1.err ) 2>&1 | grep real; echo "bench rc=$?"; grep "bench \|Exception\|rror" $O/bench_1.err | tail -14
+tail -1 $O/bench_1.log > $O/r04_bench_c2_line.json
+python3 -c "
+import json; d=json.load(open('$O/r04_bench_c2_line.json'))
+print(sorted(d.keys()))
+print(d['value'], d['fit_wall_s'], d['first_fit_wall_s'], d['explicit_deflation']['deflate_sweep_read_write'], d['shard_proxy']['fixed_ms_per_fit'], d['end_to_end_host_numpy'])
+print(d.get('side_legs_process'), d['optional_q1_fixed_point'])"
