@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 5   /* 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
+#define MBPLS_HIP_ABI_VERSION 6   /* 6: mbpls_nipals_step.C / ldc, mbpls_hip_queue_r_update, mbpls_hip_flush_r_update (R_ / beta_ column by column during the fit), mbpls_hip_copier_submit / _wait (native copier thread); 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
 
 enum {
   MBPLS_OK = 0,
@@ -418,8 +418,28 @@ typedef struct mbpls_nipals_step {
   double* nu2_host;        /* optional (NULL: unused): K x nblocks doubles in HOST-MAPPED memory (mbpls_hip_host_alloc):
                               the step that records component kc also stores scal[kc][0][:] there, so a host thread
                               waiting on an event behind the step can read the block norms without a copy            */
+  double* C;               /* optional (NULL: unused): K x K, column-major, leading dimension ldc.  The step that records
+                              component kc (nd == kc) writes column kc of C = P^T W~ (mbpls.py:988) above and on the
+                              diagonal: C[i][kc] = p_i^T w~_kc = sum_b d[b][i] for i < kc -- the lazy-deflation sums the
+                              pass has just delivered ARE these dot products -- and C[kc][kc] = p_kc^T w~_kc =
+                              ts^T (X_kc w~_kc) from the score vectors in hand.  Below the diagonal P^T W~ vanishes
+                              (X_(i) w~_k = 0 for i > k), so R_ = W~ C^-1 can be built column by column while the fit
+                              runs: mbpls_hip_queue_r_update                                                        */
+  int64_t ldc;
 } mbpls_nipals_step;
 int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s);
+/* R_ = W (P^T W)^+ (mbpls.py:988 / :569) one column per component, while the fit is still running.  P^T W~ is upper
+ * triangular (see mbpls_nipals_step.C) and the column scaling of W cancels, so R C = W~ gives
+ *   R[:, k] = (W~[:, k] - sum_{i<k} R[:, i] C[i][k]) / C[k][k],      beta += R[:, k] v_k  (one response, :989 / :570)
+ * with d_Ccol = column k of C (k + 1 doubles) and d_vk = V[0][k], both written by the step that recorded component k.
+ * The update is QUEUED: it rides as extra workgroups on the next chunk reduction of a column pass on this context (no
+ * launch of its own between two passes); mbpls_hip_flush_r_update launches it by itself if no pass has taken it.
+ * d_beta: p doubles, set (not accumulated) at k = 0; may be NULL.  A no-op when the device skip flag is raised.
+ * The caller checks the conditioning of C afterwards (a vanishing diagonal entry = an exhausted matrix, where the
+ * reference's pinv truncates) and falls back to mbpls_hip_finalise_small + mbpls_hip_right_multiply_dev.             */
+int mbpls_hip_queue_r_update(mbpls_ctx* ctx, int64_t p, const double* d_w, double* d_R, int64_t ldr, int k,
+                             const double* d_Ccol, const double* d_vk, double* d_beta);
+int mbpls_hip_flush_r_update(mbpls_ctx* ctx);
 /* d_par != NULL: every column pass on this context reads alpha = d_par[0], inv_tt = d_par[1] from the device and
  * does nothing when d_par[2] != 0.  NULL restores the host-scalar behaviour.                                        */
 int mbpls_hip_set_pass_params(mbpls_ctx* ctx, const double* d_par);
@@ -446,6 +466,28 @@ int mbpls_hip_host_alloc(mbpls_ctx* ctx, size_t bytes, void** h_ptr, void** d_pt
 int mbpls_hip_host_free(mbpls_ctx* ctx, void* h_ptr);
 int mbpls_hip_memcpy_d2h_after(mbpls_ctx* ctx, void* event, void* h_dst, const void* d_src, size_t bytes);
 int mbpls_hip_event_destroy(mbpls_ctx* ctx, void* event);
+/* The copier: one native thread per context that carries finished results to the host while the compute stream keeps
+ * running (csrc/copier.hip).  A job = an event recorded on the compute stream NOW + device-to-host copies that run once
+ * it has completed + optionally the block normalisation of a column that has just arrived,
+ *   h_dst[j] = h_src[j] / sqrt(h_nu2[b])  for offsets[b] <= j < offsets[b + 1]      (w_b = w~_b / ||w~_b||, mbpls.py:860)
+ * with h_nu2 in host(-mapped) memory that is read when the job runs (mbpls_nipals_step.nu2_host).  Jobs run in submission
+ * order.  *ticket identifies the job; mbpls_hip_copier_wait returns when that job and all earlier ones are complete (and
+ * reports the first failure of any of them).  The host arrays must stay alive until then.                             */
+typedef struct mbpls_copy {
+  void* h_dst;
+  const void* d_src;
+  size_t bytes;
+} mbpls_copy;
+typedef struct mbpls_unit_scale {
+  const double* h_src;
+  double* h_dst;               /* may be h_src */
+  int nblocks;
+  const int64_t* offsets;      /* nblocks + 1 (copied at submission) */
+  const double* h_nu2;         /* nblocks squared norms */
+} mbpls_unit_scale;
+int mbpls_hip_copier_submit(mbpls_ctx* ctx, int ncopies, const mbpls_copy* copies, const mbpls_unit_scale* scale,
+                            uint64_t* ticket);
+int mbpls_hip_copier_wait(mbpls_ctx* ctx, uint64_t ticket);
 
 /* ---- exchange step of the column-sharded fit: RCCL over xGMI, inside the C ABI ---------------------
  * Feature columns are split over one process per GPU; every per-iteration quantity that is a sum over features (the

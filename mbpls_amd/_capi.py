@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmbpls_hip.so")
 ROW_MAJOR, COL_MAJOR = 0, 1
 COMM_ID_BYTES = 128
 SCALE_FIT, SCALE_APPLY, SCALE_NONE = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i64, _dbl, _int, _sz = C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
@@ -30,7 +30,17 @@ class NipalsStep(C.Structure):
                 ("centre", _int), ("norm_kind", _int), ("mode", _int), ("tol", _dbl), ("amp2_max", _dbl),
                 ("xchg", _vp), ("Y", _vp), ("Ts", _vp), ("Tsc", _vp), ("U", _vp), ("V", _vp), ("Tb", _vp),
                 ("scal", _vp), ("ssq_x", _vp), ("iters", _vp), ("u_cur", _vp), ("ts_old", _vp), ("vpass", _vp),
-                ("tspass", _vp), ("cu", _vp), ("ce", _vp), ("par", _vp), ("nu2_host", _vp)]
+                ("tspass", _vp), ("cu", _vp), ("ce", _vp), ("par", _vp), ("nu2_host", _vp), ("C", _vp), ("ldc", _i64)]
+
+
+class Copy(C.Structure):
+    """``mbpls_copy``: one device-to-host copy of a copier job"""
+    _fields_ = [("h_dst", _vp), ("d_src", _vp), ("bytes", _sz)]
+
+
+class UnitScale(C.Structure):
+    """``mbpls_unit_scale``: h_dst[j] = h_src[j] / sqrt(h_nu2[block of j]) once the job's copies have landed"""
+    _fields_ = [("h_src", _vp), ("h_dst", _vp), ("nblocks", _int), ("offsets", _vp), ("h_nu2", _vp)]
 
 
 STEP_MAX_BLOCKS = 16
@@ -108,6 +118,10 @@ SIGNATURES = {
     "mbpls_hip_block_unit_col": (_int, [_vp, _vp, _vp, _vp]),
     "mbpls_hip_set_true_space_outputs": (_int, [_vp, _vp, _vp]),
     "mbpls_hip_scale_col_by": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "mbpls_hip_copier_submit": (_int, [_vp, _int, C.POINTER(Copy), C.POINTER(UnitScale), C.POINTER(C.c_uint64)]),
+    "mbpls_hip_copier_wait": (_int, [_vp, C.c_uint64]),
+    "mbpls_hip_queue_r_update": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _vp]),
+    "mbpls_hip_flush_r_update": (_int, [_vp]),
     "mbpls_hip_event_record": (_int, [_vp, _pp]),
     "mbpls_hip_host_alloc": (_int, [_vp, _sz, _pp, _pp]),
     "mbpls_hip_host_free": (_int, [_vp, _vp]),
@@ -269,6 +283,37 @@ class Context:
             arr = np.ctypeslib.as_array((C.c_double * size).from_address(h.value))
             cur = self._mapped = (arr, d.value, h.value)
         return cur[0], cur[1]
+
+    def copier_submit(self, copies, scale=None):
+        """Hand a job to the context's copier thread (``mbpls_hip_copier_submit``): ``copies`` = [(contiguous host
+        array, device address)], carried out once everything queued on the compute stream so far has run;
+        ``scale`` = (src column, dst column, int64 block offsets, address of the squared block norms in host-mapped
+        memory): dst = src / sqrt(norm of its block) afterwards.  Returns the ticket for ``copier_wait``.  The host
+        arrays are kept alive here until a wait has covered them."""
+        n = len(copies)
+        arr = (Copy * max(n, 1))()
+        for i, (dst, src) in enumerate(copies):
+            arr[i].h_dst, arr[i].d_src, arr[i].bytes = dst.ctypes.data, int(src), dst.nbytes
+        sc = None
+        if scale is not None:
+            src_h, dst_h, offs, nu2_addr = scale
+            sc = C.byref(UnitScale(src_h.ctypes.data, dst_h.ctypes.data, len(offs) - 1, offs.ctypes.data, int(nu2_addr)))
+        t = C.c_uint64()
+        check(self.lib.mbpls_hip_copier_submit(self.handle, n, arr, sc, C.byref(t)))
+        keep = self.__dict__.setdefault("_copier_keep", [])
+        keep.append((t.value, [c[0] for c in copies], scale))
+        return t.value
+
+    def copier_wait(self, ticket):
+        """every job up to ``ticket`` has landed (raises the first failure of any of them)"""
+        if not ticket:
+            return
+        try:
+            check(self.lib.mbpls_hip_copier_wait(self.handle, C.c_uint64(int(ticket))))
+        finally:
+            keep = self.__dict__.get("_copier_keep")
+            if keep:
+                keep[:] = [e for e in keep if e[0] > ticket]
 
     def info(self):
         name = C.create_string_buffer(256)

@@ -431,6 +431,33 @@ __global__ __launch_bounds__(256) void k_finish_stats(int64_t p, double* __restr
 //   per-chunk scalars.
 constexpr int RC_W = 16;
 constexpr int RC_ROWS = 16;
+
+// One column of R_ = W~ C^-1 and its share of beta_ (mbpls_hip_queue_r_update): thread `tid` of `nthreads` walks the
+// features.  C is upper triangular, so column k only needs the k columns before it; fixed order of the terms.
+__device__ __forceinline__ void r_update_cols(const RUpdate& ru, int64_t tid, int64_t nthreads) {
+  const int k = ru.k;
+  const double ckk = ru.Ccol[k];
+  const double vk = ru.vk ? ru.vk[0] : 0.0;
+  double* __restrict__ rk = ru.R + (int64_t)k * ru.ldr;
+  for (int64_t j = tid; j < ru.p; j += nthreads) {
+    double acc = ru.w[j];
+#pragma unroll 4
+    for (int i = 0; i < k; ++i) acc = fma(-ru.R[j + (int64_t)i * ru.ldr], ru.Ccol[i], acc);
+    const double r = acc / ckk;
+    rk[j] = r;
+    if (ru.beta) ru.beta[j] = (k == 0 ? 0.0 : ru.beta[j]) + r * vk;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_r_update(RUpdate ru, const double* __restrict__ dpar) {
+  if (dpar && dpar[2] != 0.0) return;
+  r_update_cols(ru, (int64_t)blockIdx.x * 1024 + threadIdx.x, (int64_t)gridDim.x * 1024);
+}
+
+static unsigned r_update_blocks(const mbpls_ctx* ctx, const RUpdate& ru) {
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ctx->cus, (ru.p + 2047) / 2048));
+}
+
 __global__ __launch_bounds__(64 * RC_W) void k_reduce_chunks(const double* __restrict__ part_t,
                                                              const double* __restrict__ part_s,
                                                              const int* __restrict__ blk_start, int64_t n,
@@ -439,9 +466,16 @@ __global__ __launch_bounds__(64 * RC_W) void k_reduce_chunks(const double* __res
                                                              const double* __restrict__ part_d, int nd,
                                                              double* __restrict__ out_d /* [nblocks][nd] */,
                                                              double* __restrict__ out_amp /* [nblocks] max of slot 3 */,
-                                                             const double* __restrict__ dpar) {
+                                                             const double* __restrict__ dpar,
+                                                             RUpdate ru, unsigned nrb /* workgroups of the reduction in x */) {
   __shared__ double comb[RC_W][RC_ROWS];
   if (dpar && dpar[2] != 0.0) return;
+  if (blockIdx.x >= nrb) {
+    // a queued column of R_ rides along: the workgroups behind the reduction's own (block row 0 only)
+    if (blockIdx.y == 0)
+      r_update_cols(ru, (int64_t)(blockIdx.x - nrb) * (64 * RC_W) + threadIdx.x, (int64_t)(gridDim.x - nrb) * (64 * RC_W));
+    return;
+  }
   const int b = blockIdx.y;
   const int cs = blk_start[b], ce = blk_start[b + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -613,10 +647,26 @@ int reduce_chunks(mbpls_ctx* ctx, const mbpls_mat* m, const double* part_t, cons
                   double* d_t, double* d_ssq_g, double* d_ssq_p, double* d_ssq_x,
                   const double* part_d, int nd, double* d_d, double* d_amp, const ChunkTable* table) {
   const ChunkTable& ct = table ? *table : m->fine;
-  dim3 grid(d_t ? (unsigned)((m->n + RC_ROWS - 1) / RC_ROWS) : 1u, (unsigned)m->nblocks);
+  const unsigned nrb = d_t ? (unsigned)((m->n + RC_ROWS - 1) / RC_ROWS) : 1u;
+  RUpdate ru = ctx->r_update;
+  unsigned extra = 0;
+  if (ru.k >= 0) {
+    extra = r_update_blocks(ctx, ru);
+    ctx->r_update.k = -1;
+  }
+  dim3 grid(nrb + extra, (unsigned)m->nblocks);
   hipLaunchKernelGGL(k_reduce_chunks, grid, dim3(64 * RC_W), 0, ctx->stream, part_t, part_s,
                      (const int*)ct.d_blk_start, m->n, d_t, d_ssq_g, d_ssq_p, d_ssq_x, part_d, nd, d_d, d_amp,
-                     ctx->dpar);
+                     ctx->dpar, ru, nrb);
+  MB_HIP(hipGetLastError());
+  return MBPLS_OK;
+}
+
+int flush_r_update(mbpls_ctx* ctx) {
+  RUpdate ru = ctx->r_update;
+  if (ru.k < 0) return MBPLS_OK;
+  ctx->r_update.k = -1;
+  hipLaunchKernelGGL(k_r_update, dim3(r_update_blocks(ctx, ru)), dim3(1024), 0, ctx->stream, ru, ctx->dpar);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }
@@ -637,6 +687,22 @@ static int partial_buffers(mbpls_ctx* ctx, const mbpls_mat* m, double** part_t, 
 using namespace mbpls;
 
 extern "C" {
+
+int mbpls_hip_queue_r_update(mbpls_ctx* ctx, int64_t p, const double* d_w, double* d_R, int64_t ldr, int k,
+                             const double* d_Ccol, const double* d_vk, double* d_beta) {
+  MB_ARG(ctx && d_w && d_R && d_Ccol, "NULL argument");
+  MB_ARG(p >= 1 && ldr >= p && k >= 0, "bad shape (p=%lld ldr=%lld k=%d)", (long long)p, (long long)ldr, k);
+  MB_ARG(!d_beta || d_vk, "d_beta needs d_vk");
+  MB_TRY(flush_r_update(ctx));            // (an update nobody took: it must not be lost)
+  RUpdate& ru = ctx->r_update;
+  ru.p = p; ru.ldr = ldr; ru.w = d_w; ru.R = d_R; ru.Ccol = d_Ccol; ru.vk = d_vk; ru.beta = d_beta; ru.k = k;
+  return MBPLS_OK;
+}
+
+int mbpls_hip_flush_r_update(mbpls_ctx* ctx) {
+  MB_ARG(ctx, "ctx is NULL");
+  return flush_r_update(ctx);
+}
 
 int mbpls_hip_sweep(const mbpls_mat* m, const double* d_v, double alpha, double* d_g, double* d_t,
                     double* d_ssq_g) {

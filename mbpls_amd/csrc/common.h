@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -56,6 +57,17 @@ struct ChunkTable {
 constexpr int PIN_SLOTS = 4;
 constexpr int SMALL_PIN_SLOTS = 64;
 constexpr size_t SMALL_PIN_BYTES = 256u << 10;   // (what went to the runtime's own staging before: copies below 256 KB)
+
+// A queued column of R_ = W~ C^-1 (mbpls_hip_queue_r_update): taken along by the next chunk reduction as extra workgroups
+struct RUpdate {
+  int64_t p = 0, ldr = 0;
+  const double* w = nullptr;
+  double* R = nullptr;
+  const double* Ccol = nullptr;
+  const double* vk = nullptr;
+  double* beta = nullptr;
+  int k = -1;              // -1: nothing queued
+};
 
 struct mbpls_ctx {
   int device = 0;
@@ -113,6 +125,8 @@ struct mbpls_ctx {
   unsigned pin_small_next = 0;
   void* pin_copier = nullptr;          // pinned bounce buffer of the copier thread's device-to-host copies (<= 4 MB)
   std::mutex pin_mutex;
+  void* copier = nullptr;    // CopierState* (copier.hip): the thread that carries finished columns to the host
+  RUpdate r_update;          // queued by mbpls_hip_queue_r_update, consumed by reduce_chunks / mbpls_hip_flush_r_update
   int step_reg = 1;          // device-resident step: the register-resident kernel where it applies (step_reg.hip); 0 = general kernel
   unsigned step_spin_limit = 1u << 28;   // polls before a grid barrier of the multi-workgroup step gives up (tests lower it)
   void* step_ws = nullptr;   // grid barrier + per-workgroup totals of the multi-workgroup step kernel (resident.hip)
@@ -129,6 +143,11 @@ struct mbpls_ctx {
   double prof_ms[MBPLS_K_COUNT] = {0};
   double prof_bytes[MBPLS_K_COUNT] = {0};
 };
+
+namespace mbpls {
+void copier_shutdown(mbpls_ctx* ctx);   // copier.hip
+int copier_warmup(mbpls_ctx* ctx);
+}  // namespace mbpls
 
 struct mbpls_mat {
   mbpls_ctx* ctx = nullptr;

@@ -229,6 +229,7 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
   if (!ctx) return MBPLS_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  mbpls::copier_shutdown(ctx);
   if (ctx->rccl) (void)mbpls_hip_comm_destroy(ctx);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->stage) (void)hipFree(ctx->stage);
@@ -678,6 +679,7 @@ extern "C" int mbpls_hip_warmup(mbpls_ctx* ctx) {
       for (int i = 0; i < SMALL_PIN_SLOTS; ++i) ctx->pin_small_ev[i] = nullptr;
     }
   }
+  MB_TRY(mbpls::copier_warmup(ctx));          // the copier thread, its stream and bounce buffers
   hipEvent_t e = nullptr;
   if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) (void)hipEventDestroy(e);
   return MBPLS_OK;

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
 
   // ---- diff = ||ts_old - ts|| (:887), Y^T ts, ts^T ts
   double d4[4] = {0.0, 0.0, 0.0, 0.0};
+  double x4[4] = {0.0, 0.0, 0.0, 0.0};     // [0]: ts^T (X_k w~), the diagonal entry of column kc of P^T W~ (s.C)
   double dmax = 0.0, dmin = 1.0e300;
   double yv[QM];
 #pragma unroll
@@ -257,6 +258,16 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
     const double t = r_vp[i] / tsn;
     const double d = r_to[i] - t;
     r_to[i] = t;
+    if (s.C) {
+      double xw = 0.0;                       // row i of X_k w~ = sum_b ||w~_b|| t_b  (UNIPALS: the unnormalised ts)
+      if (uni) xw = r_vp[i];
+      else {
+#pragma unroll
+        for (int b = 0; b < BM; ++b)
+          if (b < B) xw = fma(nu[b], tb[(int64_t)b * n + i], xw);
+      }
+      x4[0] = fma(t, xw, x4[0]);
+    }
     d4[0] = fma(d, d, d4[0]);
     d4[1] += fabs(d);
     d4[2] = fma(t, t, d4[2]);
@@ -267,20 +278,23 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
     for (int j = 0; j < QM; ++j)
       if (j < q) yv[j] = fma(r_Y[(int64_t)j * n + i], t, yv[j]);
   }
-  if constexpr (QM + 4 <= 16) {
-    double c2[QM + 4];
+  if constexpr (QM + 5 <= 16) {
+    double c2[QM + 5];
 #pragma unroll
     for (int j = 0; j < 4; ++j) c2[j] = d4[j];
 #pragma unroll
     for (int j = 0; j < QM; ++j) c2[4 + j] = yv[j];
-    grid_sum<QM + 4>(c2, QM + 4, part, tot, sg, epoch);
+    c2[QM + 4] = x4[0];
+    grid_sum<QM + 5>(c2, QM + 5, part, tot, sg, epoch);
 #pragma unroll
     for (int j = 0; j < 4; ++j) d4[j] = c2[j];
 #pragma unroll
     for (int j = 0; j < QM; ++j) yv[j] = c2[4 + j];
+    x4[0] = c2[QM + 4];
   } else {
     grid_sum<4>(d4, 4, part, tot, sg, epoch);
     grid_sum<QM>(yv, q, part, tot, sg, epoch);
+    if (s.C) grid_sum<4>(x4, 1, part, tot, sg, epoch);
   }
   double diff;
   if (s.norm_kind == 0) diff = sqrt(d4[0]);
@@ -446,6 +460,17 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   project(kc + 1);         // ... against the score being deflated as well (Tsc[:, kc], just written by this thread)
   dots(s.vpass, s.cu);     // j < kc only: the component being deflated is handled inside the pass (its <ts, v>)
   dots(s.tspass, s.ce);
+  if (s.C && blockIdx.x == 0) {
+    // column kc of C = P^T W~ (see step_reg.hip / mbpls_nipals_step.C)
+    const double f = uni ? c_uni : 1.0;
+    double* cc = s.C + (int64_t)kc * s.ldc;
+    if (tid < nd && nd == kc) {
+      double a = 0.0;
+      for (int b = 0; b < B; ++b) a += dd[b * nd + tid];
+      cc[tid] = f * a;
+    }
+    if (tid == 0) cc[kc] = (nd == kc) ? f * (uni ? x4[0] / d4[2] : x4[0]) : 0.0;
+  }
 #pragma unroll
   for (int j = 0; j < QM; ++j)
     if (j < q && lead) s.V[(int64_t)kc * q + j] = yv[j];

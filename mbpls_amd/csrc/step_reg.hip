@@ -69,10 +69,16 @@ __device__ __forceinline__ void sr_sum(double (&v)[M], double* part, int& buf) {
   buf ^= 1;
 }
 
-template <int SR_T, int RPT, int SR_JC, int BM, bool FULL>
+// NL: earlier scores SR_JC .. SR_JC + NL - 1 are parked in LDS (dynamic, NL * SR_T * RPT doubles): requested with the other
+// loads at the top, used by the lazy-deflation fix from the registers they arrive in, then written to the thread's OWN
+// slots (a thread only ever touches its rows: no barrier) and re-read from there by the re-orthogonalisation and the
+// coefficient dots.  Walking them through L2 once per phase made the step grow with the component index (13 us at
+// component 0, 28 us at component 9: the fixed cost of a fit that does not shrink with the column shard).
+template <int SR_T, int RPT, int SR_JC, int BM, bool FULL, int NL>
 __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
   constexpr int SR_W = SR_T / 64;
   constexpr int NJ = SR_JC < 7 ? SR_JC : 7;       // scores per re-orthogonalisation round
+  extern __shared__ double s_sc[];                // [NL][RPT][SR_T]
   __shared__ double part[2 * 8 * 16];
   __shared__ double s_mx[SR_W], s_mn[SR_W];
   int buf = 0;
@@ -145,6 +151,18 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
 #pragma unroll
     for (int i = 0; i < RPT; ++i) tc[j][i] = (j < kc) ? ld(tcj, i) : 0.0;
   }
+  double tl[NL > 0 ? NL : 1][RPT];                // the scores that go to LDS
+  if constexpr (NL > 0) {
+    if (kc > SR_JC) {
+#pragma unroll
+      for (int jl = 0; jl < NL; ++jl) {
+        const double* tcj = s.Tsc + (int64_t)(SR_JC + jl < kc ? SR_JC + jl : 0) * n;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) tl[jl][i] = (SR_JC + jl < kc) ? ld(tcj, i) : 0.0;
+      }
+    }
+  }
+  auto lds_at = [&](int jl, int i) -> double& { return s_sc[(jl * RPT + i) * SR_T + tid]; };
   // t~_b = A_b - Ts d_b (lazy deflation): nd is 0 or kc
 #pragma unroll
   for (int j = 0; j < SR_JC; ++j)
@@ -157,7 +175,25 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
           for (int i = 0; i < RPT; ++i) t[b][i] = fma(-tc[j][i], dbj, t[b][i]);
         }
     }
-  for (int j = SR_JC; j < nd; ++j) {
+  if constexpr (NL > 0) {
+    if (kc > SR_JC) {
+#pragma unroll
+      for (int jl = 0; jl < NL; ++jl) {
+        if (SR_JC + jl < nd) {
+#pragma unroll
+          for (int b = 0; b < BM; ++b)
+            if (b < B) {
+              const double dbj = dd[b * nd + SR_JC + jl];
+#pragma unroll
+              for (int i = 0; i < RPT; ++i) t[b][i] = fma(-tl[jl][i], dbj, t[b][i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) lds_at(jl, i) = tl[jl][i];
+      }
+    }
+  }
+  for (int j = SR_JC + NL; j < nd; ++j) {
     double tj[RPT];
     const double* tcj = s.Tsc + (int64_t)j * n;
 #pragma unroll
@@ -233,12 +269,20 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
   const double tsn = sqrt(m2[0]);
 
   // ---- diff = ||ts_old - ts|| (:887), Y^T ts, ts^T ts, sum ts
-  double c2[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  // (c2[5] = ts^T (X_k w~): the diagonal entry of column kc of P^T W~, see mbpls_nipals_step.C)
+  double c2[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double dmax = 0.0, dmin = 1.0e300;
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const double tt = ts[i] / tsn;
     ts[i] = tt;
+    {
+      double xw = 0.0;                       // row i of X_k w~ = sum_b ||w~_b|| t_b  (UNIPALS: sum_b X_b (X_b^T y))
+#pragma unroll
+      for (int b = 0; b < BM; ++b)
+        if (b < B) xw = uni ? xw + t[b][i] : fma(nu[b], t[b][i], xw);
+      c2[5] = fma(tt, xw, c2[5]);
+    }
     if (ok[i]) {
       const double d = to[i] - tt;
       c2[0] = fma(d, d, c2[0]);
@@ -251,7 +295,7 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
     c2[3] += tt;
     c2[4] = fma(y[i], tt, c2[4]);
   }
-  sr_sum<5, SR_W>(c2, part, buf);
+  sr_sum<6, SR_W>(c2, part, buf);
   double diff;
   if (s.norm_kind == 0) diff = sqrt(c2[0]);
   else if (s.norm_kind == 1) diff = c2[1];
@@ -314,6 +358,18 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
         for (int i = 0; i < RPT; ++i)
           if (ok[i]) tbo[ro[i]] = uni ? f * t[b][i] : t[b][i];
       }
+    if (s.C) {
+      // column kc of C = P^T W~: the lazy-deflation sums of the pass above the diagonal, ts^T (X_k w~) / ts^T ts on it
+      // (UNIPALS: w = c X^T y).  Without the sums (nd != kc) the diagonal is zeroed: the caller then takes the other route
+      const double f = uni ? c_uni : 1.0;
+      double* cc = s.C + (int64_t)kc * s.ldc;
+      if (tid < nd && nd == kc) {
+        double a = 0.0;
+        for (int b = 0; b < B; ++b) a += dd[b * nd + tid];
+        cc[tid] = f * a;
+      }
+      if (lead) cc[kc] = (nd == kc) ? f * (uni ? c2[5] / tt_ : c2[5]) : 0.0;
+    }
     if (lead) {
       s.V[kc] = yv;
       double tot_w = 0.0;
@@ -399,9 +455,11 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
       const bool cached = j0 == 0;                   // (j0 + jj < SR_JC whenever j0 == 0)
+      const int jl = j0 + jj - SR_JC;                // its LDS slot, if it has one
       const double* tcj = s.Tsc + (int64_t)(jj < m ? j0 + jj : 0) * n;
 #pragma unroll
-      for (int i = 0; i < RPT; ++i) tj[jj][i] = cached ? tc[jj][i] : ((jj < m) ? ld(tcj, i) : 0.0);
+      for (int i = 0; i < RPT; ++i)
+        tj[jj][i] = cached ? tc[jj][i] : (jj >= m ? 0.0 : ((NL > 0 && jl < NL) ? lds_at(jl, i) : ld(tcj, i)));
     }
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj)
@@ -444,9 +502,15 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) c[jj] = fma(tc[jj][i], vq[i], c[jj]);      // (tc = 0 beyond kc)
       } else if (jj < m) {
-        const double* tcj = s.Tsc + (int64_t)(j0 + jj) * n;
+        const int jl = j0 + jj - SR_JC;
+        if (NL > 0 && jl < NL) {
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) c[jj] = fma(ld(tcj, i), vq[i], c[jj]);
+          for (int i = 0; i < RPT; ++i) c[jj] = fma(lds_at(jl, i), vq[i], c[jj]);
+        } else {
+          const double* tcj = s.Tsc + (int64_t)(j0 + jj) * n;
+#pragma unroll
+          for (int i = 0; i < RPT; ++i) c[jj] = fma(ld(tcj, i), vq[i], c[jj]);
+        }
       }
     }
     sr_sum<16, SR_W>(c, part, buf);
@@ -461,21 +525,35 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
 // MBPLS_ERR_UNSUPPORTED: shape outside this kernel (the caller uses the general one)
 int launch_step_reg(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
   if (s->q != 1 || s->nblocks > 4 || s->n > 4096) return MBPLS_ERR_UNSUPPORTED;
-#define MB_STEP(T_, R_, J_)                                                                                  \
+#define MB_STEP_K(T_, R_, J_, B_, F_, L_)                                                                      \
+  do {                                                                                                       \
+    auto fn = k_step_reg<T_, R_, J_, B_, F_, L_>;                                                            \
+    constexpr size_t lds = sizeof(double) * (size_t)(L_) * (T_) * (R_);                                      \
+    static bool attr_set = false;                                                                            \
+    if (lds > 0 && !attr_set) {                                                                              \
+      MB_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+      attr_set = true;                                                                                       \
+    }                                                                                                        \
+    hipLaunchKernelGGL(fn, dim3(1), dim3(T_), lds, ctx->stream, *s);                                         \
+  } while (0)
+#define MB_STEP(T_, R_, J_, L_)                                                                              \
   do {                                                                                                       \
     const bool full = s->n == (int64_t)(R_) * (T_);                                                          \
-    if (s->nblocks == 1 && full) hipLaunchKernelGGL((k_step_reg<T_, R_, J_, 1, true>), dim3(1), dim3(T_), 0, ctx->stream, *s);   \
-    else if (s->nblocks == 1) hipLaunchKernelGGL((k_step_reg<T_, R_, J_, 1, false>), dim3(1), dim3(T_), 0, ctx->stream, *s);     \
-    else if (full) hipLaunchKernelGGL((k_step_reg<T_, R_, J_, 4, true>), dim3(1), dim3(T_), 0, ctx->stream, *s);                 \
-    else hipLaunchKernelGGL((k_step_reg<T_, R_, J_, 4, false>), dim3(1), dim3(T_), 0, ctx->stream, *s);      \
+    if (s->nblocks == 1 && full) MB_STEP_K(T_, R_, J_, 1, true, L_);                                         \
+    else if (s->nblocks == 1) MB_STEP_K(T_, R_, J_, 1, false, L_);                                           \
+    else if (full) MB_STEP_K(T_, R_, J_, 4, true, 0);                                                        \
+    else MB_STEP_K(T_, R_, J_, 4, false, 0);                                                                 \
   } while (0)
   const int64_t n = s->n;
-  if (n <= 256) MB_STEP(256, 1, 8);
-  else if (n <= 512) MB_STEP(256, 2, 8);
-  else if (n <= 1024) MB_STEP(256, 4, 8);
-  else if (n <= 2048) MB_STEP(256, 8, 8);
-  else MB_STEP(512, 8, 4);
+  // (LDS slots: 256 threads x RPT rows = 2-16 KB per score -> 8 of them; 512 x 8 rows = 32 KB -> 4.  The four-block
+  // instantiations have no registers to receive them in.)
+  if (n <= 256) MB_STEP(256, 1, 8, 8);
+  else if (n <= 512) MB_STEP(256, 2, 8, 8);
+  else if (n <= 1024) MB_STEP(256, 4, 8, 8);
+  else if (n <= 2048) MB_STEP(256, 8, 8, 8);
+  else MB_STEP(512, 8, 4, 4);
 #undef MB_STEP
+#undef MB_STEP_K
   MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }
@@ -484,5 +562,5 @@ int launch_step_reg(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
 
 // one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)
 namespace mbpls {
-const void* anchor_step_reg() { return (const void*)&k_step_reg<512, 8, 4, 1, true>; }
+const void* anchor_step_reg() { return (const void*)&k_step_reg<512, 8, 4, 1, true, 4>; }
 }  // namespace mbpls

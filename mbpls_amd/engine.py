@@ -201,22 +201,14 @@ class HipEngine(EngineBase):
         return out
 
     def fetch_async(self, name):
-        """D2H of a whole slot by the helper thread, behind everything queued on the compute stream so far; returns
+        """D2H of a whole slot by the copier thread, behind everything queued on the compute stream so far; returns
         (host array, wait) -- wait() blocks until the array is complete (and re-raises a copy error)."""
-        import threading
         S = self.slots[name]
         out = self._host_for_slot(name, S.shape)
-        ev = _capi._vp()
-        _capi.check(self.ctx.lib.mbpls_hip_event_record(self.ctx.handle, _capi.C.byref(ev)))
-        errors, done = [], threading.Event()
-        q = _copier_queue()
-        q.put((self.ctx, ev, [(out, S.ptr)], errors))
-        q.put(done)
+        ticket = self.ctx.copier_submit([(out, S.ptr)])
 
         def wait():
-            done.wait()
-            if errors:
-                raise errors[0]
+            self.ctx.copier_wait(ticket)
             return out
 
         return out, wait
@@ -386,28 +378,19 @@ class HipEngine(EngineBase):
         """mean / scale / var are final once the standardise pass has run: send them to the host through the copier
         thread now (behind an event), so the three p-length copies -- page faults of fresh arrays included -- overlap
         with the rest of the fit instead of sitting at its end.  ``host_stats`` / ``wait_stats`` hand them over."""
-        import threading
         if self.mean is None or self.scale is None or not self.opts.stream_stats:
             return
         arrs = [self.mean, self.scale] + ([self.var] if getattr(self, "var", None) is not None else [])
         S = self.host_array((self.p, 3), prefault=False)   # one F-ordered p x 3 array (copied right after the first pass)
         host = [S[:, i] for i in range(len(arrs))]
-        ev = _capi._vp()
-        _capi.check(self.ctx.lib.mbpls_hip_event_record(self.ctx.handle, _capi.C.byref(ev)))
-        q = _copier_queue()
-        self._stats_errors = []
-        q.put((self.ctx, ev, [(h, d.ptr) for h, d in zip(host, arrs)], self._stats_errors))
-        self._stats_done = threading.Event()
-        q.put(self._stats_done)
+        self._stats_ticket = self.ctx.copier_submit([(h, d.ptr) for h, d in zip(host, arrs)])
         self.host_stats = tuple(host) if len(host) == 3 else (host[0], host[1], None)
 
     def wait_stats(self):
         """(mean, scale, var) on the host, or None when they were not streamed"""
         if self.host_stats is None:
             return None
-        self._stats_done.wait()
-        if self._stats_errors:
-            raise self._stats_errors[0]
+        self.ctx.copier_wait(self._stats_ticket)
         return self.host_stats
 
     def _prepare_passes(self, src, standardize, mode, v, alpha, g_slot, mean, defer):
@@ -754,6 +737,7 @@ class HipEngine(EngineBase):
             Wn, Pm = self.slots[wslot], self.slots[self._lazy_pslot]
             p8, B = 8 * self.p, self.nblocks
             with self._timed("queue_passes"):
+                rq.incremental(wslot)
                 rq.step(0, 1, 0)
                 for k in range(K):
                     last = k == K - 1
@@ -767,17 +751,20 @@ class HipEngine(EngineBase):
                     cols = ([(rq.col(Wn_h, k), Wn.ptr + p8 * k)] + nu_copy
                             + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []))
                     if last:
-                        rq.stream_out(cols, post=unit)
+                        rq.stream_out(cols, post=unit, k=k)
+                    rq.r_update(k)        # R_[:, k], beta_: extra workgroups of the chunk reduction behind the next pass
                     self._res_loadings(k, last, None if last else (wslot, k + 1))   # (:928, :969) + next first sweep
+                    rq.r_flush()
                     if not last:
-                        rq.stream_out(cols, post=unit)
+                        rq.stream_out(cols + rq.r_cols(k), post=unit, k=k)
                     if not last:
                         rq.step(k + 1, 1, k + 1)
                     else:
                         rq.allreduce()
                 rq.last_loadings_norms()
-                rq.stream_out([(rq.col(P_h, K - 1), Pm.ptr + p8 * (K - 1))])
-                rq.cross(self._lazy_pslot, wslot)
+                rq.stream_out([(rq.col(P_h, K - 1), Pm.ptr + p8 * (K - 1))] + rq.r_cols(K - 1, beta=True))
+                if not rq.incr:
+                    rq.cross(self._lazy_pslot, wslot)
         return rq.result
 
     def unipals_resident(self, Y, K, wslot, gslot, W_h, P_h, first_pass, Wraw_h=None):
@@ -791,6 +778,7 @@ class HipEngine(EngineBase):
             S, Wc, Pm = self.slots[gslot], self.slots[wslot], self.slots[self._lazy_pslot]
             p8 = 8 * self.p
             with self._timed("queue_passes"):
+                rq.incremental(wslot)
                 rq.step(0, 1, 0)
                 for k in range(K):
                     last = k == K - 1
@@ -800,15 +788,19 @@ class HipEngine(EngineBase):
                     src_h = W_h if Wraw_h is None else Wraw_h
                     nu_copy, unit = rq.unit_blocks_on_host(src_h, W_h, k)            # w_b / ||w_b|| (:510-512)
                     rq.stream_out([(rq.col(src_h, k), Wc.ptr + p8 * k)] + nu_copy
-                                  + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []), post=unit)
+                                  + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else [])
+                                  + (rq.r_cols(k - 1) if k else []), post=unit, k=k)
+                    rq.r_update(k)
                     self._res_loadings(k, last, None if last else (gslot, 0))        # p (:520), deflation (:535)
+                    rq.r_flush()
                     if not last:
                         rq.step(k + 1, 1, k + 1)
                     else:
                         rq.allreduce()
                 rq.last_loadings_norms()
-                rq.stream_out([(rq.col(P_h, K - 1), Pm.ptr + p8 * (K - 1))])
-                rq.cross(self._lazy_pslot, wslot)
+                rq.stream_out([(rq.col(P_h, K - 1), Pm.ptr + p8 * (K - 1))] + rq.r_cols(K - 1, beta=True))
+                if not rq.incr:
+                    rq.cross(self._lazy_pslot, wslot)
         return rq.result
 
     def xt_v(self, V, alpha, slot, k0=0, want_ssq=False):
@@ -1062,7 +1054,6 @@ class HipEngine(EngineBase):
         return np.asarray(self.G[1].get()).reshape(n, ldg).T[:n, :n]
 
 
-_COPIER = {}
 _PREFAULT = {}
 
 
@@ -1123,43 +1114,6 @@ def _prefault(arr, min_bytes=1 << 20):
     q.put(arr)
 
 
-def _copier_queue():
-    """The job queue of the process-wide helper thread that copies finished columns to the host behind events.  ONE
-    thread for the life of the process: a fresh thread per fit makes the HIP runtime set up (and at some point tear
-    down, with a device-wide synchronisation) per-thread copy resources -- measured as one 23 ms stall in every sixth
-    fit."""
-    import queue
-    import threading
-    q = _COPIER.get("queue")
-    if q is None or not _COPIER["thread"].is_alive():
-        q = queue.Queue()
-
-        def work():
-            while True:
-                job = q.get()
-                if isinstance(job, threading.Event):
-                    job.set()
-                    continue
-                ctx, ev, copies, errors = job[:4]
-                post = job[4] if len(job) > 4 else None
-                try:
-                    for dst, src in copies:
-                        _capi.check(ctx.lib.mbpls_hip_memcpy_d2h_after(ctx.handle, ev, dst.ctypes.data, src, dst.nbytes))
-                    if post is not None:
-                        post()                  # host arithmetic on what just arrived (numpy releases the GIL)
-                except BaseException as e:      # re-raised on the thread that owns the fit
-                    errors.append(e)
-                finally:
-                    ctx.lib.mbpls_hip_event_destroy(ctx.handle, ev)
-                    # drop every reference to the host arrays before blocking on the queue again
-                    job = ctx = ev = copies = errors = dst = src = post = None
-
-        th = threading.Thread(target=work, daemon=True, name="mbpls-copier")
-        th.start()
-        _COPIER.update(queue=q, thread=th)
-    return q
-
-
 class _ResidentQueue:
     """State of one device-resident fit (csrc/resident.hip): the device buffers the step kernel works on, the helper
     thread that copies finished columns to the host behind events, and the read-back of the results.  Used as a context
@@ -1178,6 +1132,7 @@ class _ResidentQueue:
             + ([("Tsc", n * K)] if self.istd else []) + [("M", K * K), ("MV", K * q)]
         self.crossed = False
         self.finalised = None
+        self.incr = False
         self.off, o = {}, 0
         for key, sz in sizes:
             self.off[key] = (o, sz)
@@ -1206,8 +1161,10 @@ class _ResidentQueue:
         # kernel that waits behind -- and slows -- the running pass: 180 us each)
         self.nu2_h, nu2_d = ctx.mapped_scalars(K * B)
         self.st.nu2_host = nu2_d
-        self.errors = []
-        self.jobs = _copier_queue()
+        self.ticket = 0                             # of the last job handed to the copier thread
+        self.scores_ticket = 0                      # of the job that carries the last component's n-vectors
+        # host image of [par .. Tb]: the n-vectors arrive per component through the copier, the scalars at the end
+        self.h = np.empty(self.off["Tb"][0] + self.off["Tb"][1] - self.off["par"][0])
         self.result = None
 
     @staticmethod
@@ -1216,30 +1173,72 @@ class _ResidentQueue:
         assert c.flags.c_contiguous
         return c
 
-    def stream_out(self, copies, post=None):
-        """copy finished device columns to the host (helper thread) behind everything queued on the compute stream so
-        far; ``post``: host arithmetic the helper thread does on them afterwards"""
-        ev = _capi._vp()
-        _capi.check(self.lib.mbpls_hip_event_record(self.ctx.handle, _capi.C.byref(ev)))
-        self.jobs.put((self.ctx, ev, copies, self.errors, post))
+    def stream_out(self, copies, post=None, k=None):
+        """copy finished device columns to the host (the context's copier thread, csrc/copier.hip) behind everything
+        queued on the compute stream so far; ``post``: the block normalisation the thread does on what arrived
+        (``unit_blocks_on_host``); ``k``: the n-vectors the step recorded for component k (super score, u, block
+        scores) leave with this job as well -- the read-back behind the last pass is then a few hundred bytes instead
+        of n (2 + B) K doubles (1 MB at n = 4096, K = 10: 90 us of every fit)"""
+        if k is not None:
+            n, B, o0 = self.eng.n, self.eng.nblocks, self.off["par"][0]
+            for key, width in (("Ts", 1), ("U", 1), ("Tb", B)):
+                a = self.off[key][0] - o0 + n * width * k
+                copies = copies + [(self.h[a:a + n * width], self.ptr[key] + 8 * n * width * k)]
+        self.ticket = self.ctx.copier_submit(copies, scale=post)
+        if k is not None and k == self.K - 1:
+            self.scores_ticket = self.ticket
 
     def unit_blocks_on_host(self, src_h, dst_h, k):
         """(copies, post) for stream_out: w_b = w~_b / ||w~_b|| (mbpls.py:860 / :510-512) for column k, formed by the
-        helper thread from the column it has just copied (``src_h[:, k]``, may be ``dst_h`` itself) and the block norms
-        the step of component k left on the device -- a p-sized kernel between two passes costs the queue more than
-        the division costs a thread that is waiting anyway (on a side stream it ran 60x slower and slowed the pass:
-        the fat pass workgroups leave no registers for a second kernel's waves)."""
+        copier thread from the column it has just copied (``src_h[:, k]``, may be ``dst_h`` itself) and the block norms
+        the step of component k left in host-mapped memory -- a p-sized kernel between two passes costs the queue more
+        than the division costs a thread that is waiting anyway (on a side stream it ran 60x slower and slowed the
+        pass: the fat pass workgroups leave no registers for a second kernel's waves)."""
         B = self.eng.nblocks
-        offs = self.eng.block_offsets
-        nu2 = self.nu2_h
+        offs = getattr(self, "_offs64", None)
+        if offs is None:
+            offs = self._offs64 = np.ascontiguousarray(self.eng.block_offsets, dtype=np.int64)
+        return [], (self.col(src_h, k), self.col(dst_h, k), offs, self.nu2_h.ctypes.data + 8 * k * B)
 
-        def post():
-            with np.errstate(divide="ignore", invalid="ignore"):       # (a block without weight: as on the device)
-                for b in range(B):
-                    r0, r1 = offs[b], offs[b + 1]
-                    np.divide(src_h[r0:r1, k], np.sqrt(nu2[k * B + b]), out=dst_h[r0:r1, k])
+    # ---- R_ / beta_ column by column while the fit runs
+    def incremental(self, wslot):
+        """R_ = W (P^T W)^+ and beta_ = R_ V^T (mbpls.py:988-989 / :569-570) without a p x K product and a p x K copy
+        BEHIND the last pass (at p = 10^6, K = 10: 88 MB over PCIe, 2.8 ms of a 106 ms fit; 0.35 of the 1.5 ms a
+        shard-sized fit spends outside its passes).  C = P^T W~ is upper triangular -- X_i w~_k = 0 for i > k: every
+        deflation removes the score direction X_k w~_k -- and the column scaling of W cancels, so R C = W~ yields
+        column k from the columns before it as soon as column k of C is known.  That column costs nothing: above the
+        diagonal it is the lazy-deflation sums p_i^T w~_k the sweep pass delivers anyway, on the diagonal
+        ts^T (X_k w~_k), a dot product of vectors the step has in registers (``mbpls_nipals_step.C``).  The p-sized
+        update rides as extra workgroups on the chunk reduction of the next pass (``mbpls_hip_queue_r_update``: no
+        launch of its own), and the finished column leaves with W~'s and P's.  The conditioning of C is checked when
+        the queue returns; an exhausted matrix (where the reference's pinv truncates) takes the product route."""
+        eng, K = self.eng, self.K
+        if not eng.opts.r_incremental or self.st.q != 1:
+            return
+        self.st.C, self.st.ldc = self.ptr["C"], K
+        self.Rd, self.Bd = eng.slot("R", K, zero=False), eng.slot("beta", 1, zero=False)
+        self.R_h = eng._host_for_slot("R", (eng.p, K))
+        self.beta_h = eng._host_for_slot("beta", (eng.p, 1))
+        self.wslot = wslot
+        self.incr = True
 
-        return [], post
+    def r_update(self, k):
+        if self.incr:
+            eng, K, p = self.eng, self.K, self.eng.p
+            W = eng.slots[self.wslot]
+            _capi.check(self.lib.mbpls_hip_queue_r_update(self.ctx.handle, p, W.ptr + 8 * p * k, self.Rd.ptr, p, k,
+                                                          self.ptr["C"] + 8 * K * k, self.ptr["V"] + 8 * k, self.Bd.ptr))
+
+    def r_flush(self):
+        """the queued update goes by itself if the pass had no chunk reduction to carry it"""
+        if self.incr:
+            _capi.check(self.lib.mbpls_hip_flush_r_update(self.ctx.handle))
+
+    def r_cols(self, k, beta=False):
+        if not self.incr:
+            return []
+        return ([(self.col(self.R_h, k), self.Rd.ptr + 8 * self.eng.p * k)]
+                + ([(self.col(self.beta_h, 0), self.Bd.ptr)] if beta else []))
 
     # ---- launches
     def allreduce(self):
@@ -1308,25 +1307,28 @@ class _ResidentQueue:
             if et is None:
                 eng.run_deferred(all_of_it=True)          # host chores while the GPU works through the queue
                 with eng._timed("wait_kernel+d2h_small"):
-                    # par .. Tb in ONE copy (waits for the queue)
-                    o0, o1 = self.off["par"][0], self.off["Tb"][0] + self.off["Tb"][1]
-                    h = np.empty(o1 - o0)
+                    # par .. V in ONE copy (waits for the queue); Ts, U, Tb have left column by column (stream_out)
+                    o0, o1 = self.off["par"][0], self.off["V"][0] + self.off["V"][1]
+                    h = self.h
                     _capi.check(self.lib.mbpls_hip_memcpy_d2h(self.ctx.handle, h.ctypes.data, self.state.ptr + 8 * o0,
-                                                              h.nbytes))
+                                                              8 * (o1 - o0)))
         finally:
             self.lib.mbpls_hip_set_pass_params(self.ctx.handle, None)
-            import threading
-            done = threading.Event()
-            self.jobs.put(done)             # every copy queued before this one has landed when it is set
-            errors = self.errors
+            ctx, ticket = self.ctx, self.ticket
 
-            def wait_copies():
-                done.wait()
-                if errors:
-                    raise errors[0]
+            def wait_copies():              # every column handed to the copier thread by this queue has landed
+                ctx.copier_wait(ticket)
+
+            scores_ticket = self.scores_ticket or ticket
+
+            def wait_scores():              # ... the n-vectors of every component (on their way before the last pass)
+                ctx.copier_wait(scores_ticket)
 
         if et is not None or h is None:
-            done.wait()
+            try:
+                wait_copies()
+            except _capi.HipError:
+                pass                        # (the error that brought us here is the one to report)
             self.state.free()
             return False
         par = self._view(h, "par")
@@ -1346,6 +1348,18 @@ class _ResidentQueue:
             return False
         k_done = K if par[2] == 0.0 else int(par[3])
         scal = self._view(h, "scal").reshape(K, 4, B)
+        if self.incr and k_done == K:
+            # R_ / beta_ came column by column from R C = W~ with the triangular C the steps recorded: good as long as
+            # C diag(1 / ||w~_k||) is comfortably invertible (numpy's pinv of :988 only departs from the inverse when
+            # singular values fall below 1e-15 of the largest: an exhausted matrix); otherwise the product route
+            Cm = self._view(h, "C").reshape((K, K), order="F")
+            try:
+                sv = np.linalg.svd(Cm / np.sqrt(scal[:, 0, :].sum(axis=1)), compute_uv=False)
+            except np.linalg.LinAlgError:                 # (not finite)
+                sv = np.zeros(2)
+            if sv[-1] > 1e-10 * sv[0]:                    # (False for NaN as well)
+                R_h, beta_h = self.R_h, self.beta_h
+                self.finalised = (lambda: (wait_copies(), R_h)[1], lambda: beta_h)
         # the attribute columns the helper thread is still copying / scaling must have landed before they are used:
         # the caller waits right before it hands them out (wait_copies), not here
         # (R_ / beta_ were computed and sent on their way by the queue itself: cross())
@@ -1353,7 +1367,7 @@ class _ResidentQueue:
         if self.finalised and finalised is None:
             for w in self.finalised:                  # a failed speculation: let the (meaningless) copies land, drop them
                 w()
-        self.result = dict(k_done=k_done, wait_copies=wait_copies, finalised=finalised, Ts=self._view(h, "Ts", (n, K)), U=self._view(h, "U", (n, K)),
+        self.result = dict(k_done=k_done, wait_copies=wait_copies, wait_scores=wait_scores, finalised=finalised, Ts=self._view(h, "Ts", (n, K)), U=self._view(h, "U", (n, K)),
                            V=self._view(h, "V", (q, K)), Tb=self._view(h, "Tb").reshape(K, B, n), scal=scal,
                            ssq_x=self._view(h, "ssqx").copy(), iters=self._view(h, "iters"), last_diff=float(par[4]),
                            PtW=self._view(h, "C").reshape(K, K).copy() if (self.crossed and k_done == K) else None)

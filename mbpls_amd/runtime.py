@@ -29,7 +29,7 @@ def _warm_up(ctx):
     """First-use costs of a process, paid when the context is created -- while the caller has not yet uploaded or
     generated its data -- instead of inside its first fit (measured at BASELINE config[1]: first fit 0.137 s against
     0.105 s warm before, 0.115 s with this): the kernels' code objects (loaded lazily, one per translation unit), the
-    pinned bounce buffers, the BLAS thread-pool scan of threadpoolctl, the copier thread.  Synchronous on purpose: from
+    pinned bounce buffers, the copier thread (csrc/copier.hip), the BLAS thread-pool scan of threadpoolctl.  Synchronous on purpose: from
     a helper thread the code-object loads deadlocked against a dlopen of the main thread under rocprofv3 (the profiler
     hooks both).  Everything here is also done on demand; MBPLS_NO_WARMUP=1 switches it off."""
     import os
@@ -38,8 +38,6 @@ def _warm_up(ctx):
     try:
         ctx.lib.mbpls_hip_warmup(ctx.handle)
         _thread_limits()
-        from . import engine
-        engine._copier_queue()
     except Exception:          # a warm-up, never an error
         pass
 

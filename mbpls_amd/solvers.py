@@ -74,6 +74,15 @@ def _bip_corrected(a, sizes):
     return f / f.sum()
 
 
+def _bip_corrected_all(A, sizes):
+    """_bip_corrected for every column of A (B x K) at once"""
+    if A.shape[0] == 1:
+        return np.ones_like(A)
+    sizes = np.asarray(sizes, dtype=np.float64)
+    f = A * (1.0 - sizes / sizes.sum())[:, None]
+    return f / f.sum(axis=0)
+
+
 def _split(arr, offsets):
     return [arr[offsets[b]:offsets[b + 1]] for b in range(len(offsets) - 1)]
 
@@ -663,7 +672,20 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
                                           P_host=P_h, fetch="async", C=out.get("PtW"))
         if not whole:
             out["wait_copies"]()                            # the host loop below writes the same host columns
-        for k in range(k_start):
+        else:
+            # every component came from the device: the recorded scalars are the attributes, for all components at once
+            A[:] = out["scal"][:, 1, :].T
+            iters = [int(i) for i in out["iters"]]
+            converged = [True] * K                          # (the device step records a component only when it converged)
+            if calc_all:                                    # (:932-964), analytic (ts^T ts)(p^T p)
+                out["wait_scores"]()                        # (the n-vectors arrive through the copier thread)
+                ssq_p = out["scal"][:, 2, :]                # K x B
+                tt = np.einsum("ik,ik->k", Ts, Ts)
+                evx = list(tt * ssq_p.sum(axis=1) / varx)
+                evy = list(tt * np.einsum("jk,jk->k", V, V) / vary)
+                evxb[:] = (tt[:, None] * ssq_p / varxb).T
+                Acorr[:] = _bip_corrected_all(A, sizes)
+        for k in range(k_start if not whole else 0):
             ts, v = out["Ts"][:, k:k + 1], out["V"][:, k:k + 1]
             V[:, k:k + 1] = v
             if not whole:
@@ -883,18 +905,18 @@ def fit_unipals(eng, Y, K, standardize, keep_raw_weights=False):
         varx = varxb.sum()
         Ts, U = out["Ts"], out["U"]                         # the downloaded arrays are the attributes
         T = [out["Tb"][:, b, :].T for b in range(B)]
-        for k in range(K):
-            ts, v = out["Ts"][:, k:k + 1], out["V"][:, k:k + 1]
-            V[:, k:k + 1] = v
-            ssq = out["scal"][k, 0]
-            A[:, k] = out["scal"][k, 1]
-            blk_nrm[:, k] = np.sqrt(ssq); tot_nrm[k] = np.sqrt(ssq.sum())
-            ssq_p = out["scal"][k, 2]
-            tt = ts.T.dot(ts).item()
-            evx.append(tt * ssq_p.sum() / varx)             # (:521-533)
-            evxb[:, k] = tt * ssq_p / varxb
-            evy.append(tt * v.T.dot(v).item() / vary)       # (:538-540)
-            Acorr[:, k] = _bip_corrected(A[:, k], sizes)    # (:542-553)
+        out["wait_scores"]()                                # (they arrive through the copier thread, before the last pass)
+        # the recorded scalars are the attributes, for all components at once
+        V[:] = out["V"]
+        ssq, ssq_p = out["scal"][:, 0, :], out["scal"][:, 2, :]      # K x B each
+        A[:] = out["scal"][:, 1, :].T
+        blk_nrm[:] = np.sqrt(ssq).T
+        tot_nrm[:] = np.sqrt(ssq.sum(axis=1))
+        tt = np.einsum("ik,ik->k", Ts, Ts)
+        evx = list(tt * ssq_p.sum(axis=1) / varx)           # (:521-533)
+        evxb[:] = (tt[:, None] * ssq_p / varxb).T
+        evy = list(tt * np.einsum("jk,jk->k", V, V) / vary)  # (:538-540)
+        Acorr[:] = _bip_corrected_all(A, sizes)             # (:542-553)
         res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, explained_var_x_=evx, explained_var_y_=evy,
                         explained_var_xblocks_=evxb, A_corrected_=Acorr)
         if out.get("finalised"):

@@ -1,0 +1,71 @@
+"""The copier thread of the C ABI (csrc/copier.hip, mbpls_hip_copier_submit / _wait): finished device columns are carried
+to host arrays behind an event, small ones through pinned bounce buffers and out of them piece by piece on several
+threads, with the block normalisation w_b = w~_b / ||w~_b|| (mbpls.py:860) done on the way."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx():
+    import mbpls_amd
+    return mbpls_amd.get_context()
+
+
+@pytest.mark.parametrize("p", [1, 7, 8191, 8192, 8193, 125_000, 600_001])
+def test_copies_arrive_bit_exact_in_submission_order(p):
+    ctx = _ctx()
+    rng = np.random.default_rng(p)
+    K = 5
+    src = np.asfortranarray(rng.standard_normal((p, K)))
+    dev = ctx.from_host(src.ravel(order="F"))
+    tickets, outs = [], []
+    for rep in range(3):
+        out = np.full((p, K), np.nan, order="F")
+        # column copies (every offset: columns of an F-ordered array are only 8-byte aligned) ...
+        t = ctx.copier_submit([(out[:, k], dev.ptr + 8 * p * k) for k in range(K - 1)])
+        # ... and a second job for the last column
+        t2 = ctx.copier_submit([(out[:, K - 1], dev.ptr + 8 * p * (K - 1))])
+        assert t2 == t + 1
+        tickets.append(t2)
+        outs.append(out)
+    ctx.copier_wait(tickets[-1])
+    for out in outs:
+        assert np.array_equal(out, src)
+
+
+@pytest.mark.parametrize("in_place", [False, True])
+@pytest.mark.parametrize("p,offs", [(1000, [0, 1000]), (125_000, [0, 40_000, 40_001, 125_000]), (70_000, [0, 8192, 65536, 70_000])])
+def test_block_normalisation_rides_on_the_copy(p, offs, in_place):
+    ctx = _ctx()
+    rng = np.random.default_rng(p + in_place)
+    B = len(offs) - 1
+    w = rng.standard_normal(p)
+    dev = ctx.from_host(w)
+    nu2_h, _ = ctx.mapped_scalars(64)
+    nu2 = rng.uniform(0.5, 4.0, B)
+    nu2_h[8:8 + B] = nu2
+    raw = np.full((p, 2), np.nan, order="F")
+    unit = raw if in_place else np.full((p, 2), np.nan, order="F")
+    offs64 = np.asarray(offs, dtype=np.int64)
+    t = ctx.copier_submit([(raw[:, 1], dev.ptr)], scale=(raw[:, 1], unit[:, 1], offs64, nu2_h.ctypes.data + 8 * 8))
+    ctx.copier_wait(t)
+    want = w.copy()
+    for b in range(B):
+        want[offs[b]:offs[b + 1]] = w[offs[b]:offs[b + 1]] / np.sqrt(nu2[b])
+    assert np.array_equal(unit[:, 1], want)               # the same IEEE division
+    if not in_place:
+        assert np.array_equal(raw[:, 1], w)
+    assert np.isnan(raw[:, 0]).all()
+
+
+def test_large_copies_take_the_direct_path():
+    ctx = _ctx()
+    p = 700_000                                            # 5.6 MB: above the bounce size
+    src = np.arange(p, dtype=np.float64)
+    dev = ctx.from_host(src)
+    out = np.empty(p)
+    small = np.empty(10)
+    t = ctx.copier_submit([(small, dev.ptr + 8 * 5), (out, dev.ptr), (small, dev.ptr + 8 * 100)])
+    ctx.copier_wait(t)
+    assert np.array_equal(out, src) and np.array_equal(small, src[100:110])

@@ -18,6 +18,8 @@ ap.add_argument("--blocks", type=int, default=1)
 ap.add_argument("--fits", type=int, default=4)
 ap.add_argument("--show", default="last")
 ap.add_argument("--fresh", action="store_true")
+ap.add_argument("--tail-profile", action="store_true", help="sys.setprofile from the end of the queue's read-back to the end of fit")
+ap.add_argument("--rccl", action="store_true", help="the sharded code path with ONE rank (RCCL communicator)")
 ap.add_argument("--min-us", type=float, default=0.0)
 a = ap.parse_args()
 
@@ -28,6 +30,8 @@ from mbpls_amd import MBPLS, DeviceMatrix, _capi, engine, solvers, mbpls as mb
 
 n, p, K = a.n, a.p, a.K
 ctx = mbpls_amd.get_context()
+if a.rccl:
+    mbpls_amd.set_comm(mbpls_amd.RcclComm(ctx, 0, 1, lambda payload: payload))
 Ts, Y = planted(n, 1, 32, 0)
 offs = [int(round(b * p / a.blocks)) for b in range(a.blocks + 1)]
 X = DeviceMatrix(ctx, n, p, offs)
@@ -64,7 +68,9 @@ wrap(mb.MBPLS, "_engine")
 wrap(_capi.DeviceArray, "set", "DeviceArray.set")
 wrap(_capi.DeviceArray, "get", "DeviceArray.get")
 wrap(_capi.Context, "sync", "ctx.sync")
+wrap(_capi.Context, "copier_wait", "copier_wait")
 wrap(np.linalg, "pinv")
+wrap(np.linalg, "svd")
 # device allocations that miss the pool / frees that leave it (the runtime calls behind them may wait for the device)
 real_malloc, real_free = ctx.lib.mbpls_hip_malloc, ctx.lib.mbpls_hip_free
 
@@ -86,6 +92,47 @@ def t_free(*aa):
 
 
 ctx.lib.mbpls_hip_malloc, ctx.lib.mbpls_hip_free = t_malloc, t_free
+
+# the device-to-host copies: of the copier thread (behind events) and the blocking ones of the fitting thread
+import threading
+
+
+def t_copy(name, real, size_arg):
+    def f(*aa):
+        t0 = time.perf_counter()
+        try:
+            return real(*aa)
+        finally:
+            who = "copier" if threading.current_thread().name == "mbpls-copier" else "main"
+            log.append((t0, time.perf_counter(), 6 if who == "copier" else depth[0],
+                        f"[{who}] {name} {int(aa[size_arg]) / 1e6:.3f} MB"))
+    return f
+
+
+ctx.lib.mbpls_hip_memcpy_d2h_after = t_copy("d2h_after", ctx.lib.mbpls_hip_memcpy_d2h_after, 4)
+ctx.lib.mbpls_hip_memcpy_d2h = t_copy("d2h", ctx.lib.mbpls_hip_memcpy_d2h, 3)
+
+tail_events = []
+if a.tail_profile:
+    real_d2h = ctx.lib.mbpls_hip_memcpy_d2h
+
+    def tracer(frame, event, arg):
+        t = time.perf_counter()
+        if event in ("call", "return"):
+            co = frame.f_code
+            tail_events.append((t, event, f"{os.path.basename(co.co_filename)}:{co.co_firstlineno} {co.co_name}"))
+        elif event in ("c_call", "c_return"):
+            tail_events.append((t, "call" if event == "c_call" else "return", f"<C> {getattr(arg, '__qualname__', getattr(arg, '__name__', str(arg)))}"))
+
+    def d2h_then_trace(*aa):
+        r = real_d2h(*aa)
+        if int(aa[3]) < 100_000 and sys._getframe(1).f_code.co_name == "__exit__":
+            tail_events.clear()
+            tail_events.append((time.perf_counter(), "mark", "read-back done"))
+            sys.setprofile(tracer)
+        return r
+
+    ctx.lib.mbpls_hip_memcpy_d2h = d2h_then_trace
 runs, keep = [], []
 m = MBPLS(n_components=K, method=a.method)
 for i in range(a.fits):
@@ -94,15 +141,30 @@ for i in range(a.fits):
         m = MBPLS(n_components=K, method=a.method)
         keep.append(m)
     t0 = time.perf_counter(); m.fit(X, Y); t1 = time.perf_counter()
-    runs.append((t1 - t0, t0, list(log), dict(m.fit_timings_)))
+    sys.setprofile(None)
+    tail = list(tail_events)
+    runs.append((t1 - t0, t0, list(log), dict(m.fit_timings_), tail))
 print("fits (ms):", [round(1e3 * r[0], 2) for r in runs])
 pick = {"first": 0, "last": len(runs) - 1, "slowest": int(np.argmax([r[0] for r in runs]))}[a.show]
-dt, t0, lg, phases = runs[pick]
+dt, t0, lg, phases, tail = runs[pick]
 print(f"fit #{pick}: {1e6 * dt:.0f} us   phases (ms): " + str({k: round(1e3 * v, 2) for k, v in phases.items()}))
 skip = {"_res_sweep", "_res_loadings", "rq.step", "rq.stream_out"}
 for s0, s1, d, nm in sorted(lg):
-    if nm in skip and not (s0 - t0 < 700e-6):
+    if (nm in skip or nm.startswith("[copier]")) and not (s0 - t0 < 700e-6 or s1 - t0 > dt - 1500e-6):
         continue
     if 1e6 * (s1 - s0) < a.min_us:
         continue
     print(f"{1e6 * (s0 - t0):9.0f} {1e6 * (s1 - s0):8.0f} us  {'  ' * d}{nm}")
+
+if a.tail_profile and tail:
+    print("---- tail (profiled: every call costs ~1 us extra) ----")
+    base = tail[0][0]
+    stack = []
+    for t, ev, name in tail[1:]:
+        if ev == "call":
+            stack.append((t, name))
+        elif stack:
+            t_in, nm = stack.pop()
+            if 1e6 * (t - t_in) >= max(a.min_us, 3.0):
+                print(f"{1e6 * (t_in - base):8.0f} {1e6 * (t - t_in):7.0f} us  {'  ' * len(stack)}{nm}")
+    print(f"{1e6 * (tail[-1][0] - base):8.0f} end of the profiled region")
