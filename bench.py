@@ -692,18 +692,29 @@ def shard_proxy(ctx, mbpls_amd, dT, Y, r, n, p_shard, K, full_fit_s):
         mbpls_amd.set_comm(comm)
         for _ in range(3):
             MBPLS(n_components=K).fit(Xs, Y)
+        # the fit as it runs in production first (no events in the stream), then the same fits with HIP events around
+        # every pass for their durations: the events themselves cost a shard-sized fit 0.1-0.2 ms (42 records, each a
+        # barrier packet between two launches), which is the measurement's cost, not the fit's
+        steps, keep = 10, []
+
+        def timed_fits():
+            walls = []
+            for _ in range(steps):
+                ctx.sync()
+                t1 = time.perf_counter()
+                keep.append(MBPLS(n_components=K).fit(Xs, Y))
+                walls.append(time.perf_counter() - t1)
+            return float(np.median(walls))
+
+        wall = timed_fits()
         ctx.profile(True); ctx.profile_reset()
-        steps, walls, keep = 10, [], []
-        for _ in range(steps):
-            ctx.sync()
-            t1 = time.perf_counter()
-            keep.append(MBPLS(n_components=K).fit(Xs, Y))
-            walls.append(time.perf_counter() - t1)
+        wall_prof = timed_fits()
         pr = ctx.profile_get(); ctx.profile(False)
-        wall = float(np.median(walls))
         passes = sum(v["total_ms"] for v in pr.values()) / steps
-        out.update({"fit_wall_s": round(wall, 5), "sum_of_passes_ms": round(passes, 3),
+        out.update({"fit_wall_s": round(wall, 5), "fit_wall_with_events_s": round(wall_prof, 5),
+                    "sum_of_passes_ms": round(passes, 3),
                     "fixed_ms_per_fit": round(1e3 * wall - passes, 3),
+                    "fixed_ms_per_fit_with_events": round(1e3 * wall_prof - passes, 3),
                     "passes": {k: {"launches": v["launches"] // steps, "avg_ms": round(v["avg_ms"], 4)} for k, v in pr.items()},
                     "nipals_iterations": list(keep[-1].nipals_iterations_),
                     "ratio_full_fit_over_shard_fit": round(full_fit_s / wall, 2),

@@ -75,6 +75,7 @@ struct mbpls_ctx {
   int cus = 256;
   // tunables
   int chunks_per_cu = 4;
+  int chunks_adaptive = 1;   // (cleared when chunks_per_cu is set by hand) narrow matrices get half as many chunks, see mat_create
   int rows_per_thread = 0;   // 0 = auto
   int prefetch = 2;          // columns in flight per workgroup (register slots)
   int xw_chunks_per_cu = 1;

@@ -210,7 +210,10 @@ int mbpls_hip_create(int device, void* stream, mbpls_ctx** out) {
   ctx->device = device;
   ctx->stream = (hipStream_t)stream;
   ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char* e = getenv("MBPLS_HIP_CHUNKS_PER_CU")) ctx->chunks_per_cu = std::max(1, atoi(e));
+  if (const char* e = getenv("MBPLS_HIP_CHUNKS_PER_CU")) {
+    ctx->chunks_per_cu = std::max(1, atoi(e));
+    ctx->chunks_adaptive = 0;
+  }
   if (const char* e = getenv("MBPLS_HIP_ROWS_PER_THREAD")) ctx->rows_per_thread = atoi(e);
   if (const char* e = getenv("MBPLS_HIP_PREFETCH")) ctx->prefetch = atoi(e);
   if (const char* e = getenv("MBPLS_HIP_XW_CHUNKS_PER_CU")) ctx->xw_chunks_per_cu = std::max(1, atoi(e));
@@ -286,7 +289,10 @@ int mbpls_hip_device_info(mbpls_ctx* ctx, char* name, size_t name_len, int* comp
 
 int mbpls_hip_set_tunable(mbpls_ctx* ctx, const char* key, int value) {
   MB_ARG(ctx && key, "NULL argument");
-  if (!strcmp(key, "chunks_per_cu")) ctx->chunks_per_cu = std::max(1, value);
+  if (!strcmp(key, "chunks_per_cu")) {
+    ctx->chunks_per_cu = std::max(1, value);
+    ctx->chunks_adaptive = 0;
+  }
   else if (!strcmp(key, "rows_per_thread")) ctx->rows_per_thread = value;
   else if (!strcmp(key, "xw_chunks_per_cu")) ctx->xw_chunks_per_cu = std::max(1, value);
   else if (!strcmp(key, "prefetch")) ctx->prefetch = value;
@@ -514,7 +520,14 @@ int mbpls_hip_mat_create(mbpls_ctx* ctx, int64_t n, int64_t p, int nblocks, cons
       return MBPLS_ERR_HIP;
     }
   }
-  int rc = build_chunks(ctx, m->block_offsets, ctx->cus * ctx->chunks_per_cu, &m->fine);
+  // One workgroup per chunk, one partial n-vector per workgroup.  Four chunks per CU let fast and slow CUs even out on a
+  // wide matrix; on a narrow one (a column shard: 125 000 columns = 122 per chunk) the per-chunk costs -- prologue, the
+  // 32 KB partial, its share of the chunk reduction -- outweigh that: with two per CU (one round of equal workgroups at
+  // two resident per CU) the passes of a shard-sized fit run 3 % faster and the reduction 13 -> 9 us; at 10^6 columns
+  // (976 per chunk) four stay 0.3-0.7 % ahead (rocprofv3, round 4).
+  int cpc = ctx->chunks_per_cu;
+  if (ctx->chunks_adaptive && cpc >= 4 && p / ((int64_t)ctx->cus * cpc) < 512) cpc /= 2;
+  int rc = build_chunks(ctx, m->block_offsets, ctx->cus * cpc, &m->fine);
   if (rc == MBPLS_OK) {
     // row-slab kernels: slabs of 512 rows already multiply the workgroup count
     const int slabs = (int)((n + 511) / 512);

@@ -455,11 +455,11 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
       const bool cached = j0 == 0;                   // (j0 + jj < SR_JC whenever j0 == 0)
-      const int jl = j0 + jj - SR_JC;                // its LDS slot, if it has one
+      const int jl = j0 + jj - SR_JC;                // its LDS slot, if it has one (NJ < SR_JC: a round can start in the registers' range)
       const double* tcj = s.Tsc + (int64_t)(jj < m ? j0 + jj : 0) * n;
 #pragma unroll
       for (int i = 0; i < RPT; ++i)
-        tj[jj][i] = cached ? tc[jj][i] : (jj >= m ? 0.0 : ((NL > 0 && jl < NL) ? lds_at(jl, i) : ld(tcj, i)));
+        tj[jj][i] = cached ? tc[jj][i] : (jj >= m ? 0.0 : ((NL > 0 && jl >= 0 && jl < NL) ? lds_at(jl, i) : ld(tcj, i)));
     }
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj)

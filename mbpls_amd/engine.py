@@ -1367,7 +1367,9 @@ class _ResidentQueue:
         if self.finalised and finalised is None:
             for w in self.finalised:                  # a failed speculation: let the (meaningless) copies land, drop them
                 w()
-        self.result = dict(k_done=k_done, wait_copies=wait_copies, wait_scores=wait_scores, finalised=finalised, Ts=self._view(h, "Ts", (n, K)), U=self._view(h, "U", (n, K)),
+        self.result = dict(k_done=k_done, wait_copies=wait_copies, wait_scores=wait_scores, finalised=finalised,
+                           r_route=("column by column during the fit" if (self.incr and finalised) else
+                                    "one product behind the last pass"), Ts=self._view(h, "Ts", (n, K)), U=self._view(h, "U", (n, K)),
                            V=self._view(h, "V", (q, K)), Tb=self._view(h, "Tb").reshape(K, B, n), scal=scal,
                            ssq_x=self._view(h, "ssqx").copy(), iters=self._view(h, "iters"), last_diff=float(par[4]),
                            PtW=self._view(h, "C").reshape(K, K).copy() if (self.crossed and k_done == K) else None)

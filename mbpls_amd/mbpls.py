@@ -177,7 +177,7 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
                 raise ValueError("row-subset fits need a DeviceMatrix and copy=True (the resident matrix is kept)")
         if self.standardize:
             self.y_scaler_ = ColumnScaler().fit(Y if row_mask is None else Y[row_mask])   # :325-326
-            Ys = self.y_scaler_.transform(Y)
+            Ys = self.y_scaler_._standardised(Y)
         else:
             Ys = Y
         if row_mask is not None:

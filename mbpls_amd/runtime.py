@@ -110,12 +110,36 @@ def _thread_limits():
                 _state["tp"] = None
 
 
-@contextlib.contextmanager
+class _HostThreads:
+    """Limit BLAS/OpenMP pools to the CPU quota for the host-side K x K / p x K algebra, restore on exit.  What
+    ``threadpoolctl``'s ``limit()`` does, without its per-call inventory of every library (25 us at the head of every
+    fit): the pools that are larger than the limit are set through their controllers and put back afterwards."""
+
+    def __enter__(self):
+        self.changed = []
+        _thread_limits()
+        tp = _state["tp"]
+        if tp is None:
+            return self
+        limit = _state["tp_limit"]
+        try:
+            for lc in tp.lib_controllers:
+                cur = lc.num_threads
+                if cur is not None and cur > limit:
+                    lc.set_num_threads(limit)
+                    self.changed.append((lc, cur))
+        except Exception:  # pragma: no cover -- an unusual pool: leave it alone
+            pass
+        return self
+
+    def __exit__(self, *exc):
+        for lc, cur in self.changed:
+            try:
+                lc.set_num_threads(cur)
+            except Exception:  # pragma: no cover
+                pass
+        return False
+
+
 def host_threads():
-    """Limit BLAS/OpenMP pools to the CPU quota for the host-side K x K / p x K algebra."""
-    _thread_limits()
-    if _state["tp"] is None:
-        yield
-        return
-    with _state["tp"].limit(limits=_state["tp_limit"]):
-        yield
+    return _HostThreads()

@@ -63,6 +63,10 @@ class ColumnScaler(_Base):
         return self
 
     def transform(self, X, copy=True):
+        return self._standardised(X)
+
+    def _standardised(self, X):
+        """``transform`` without sklearn's ``set_output`` wrapper around it (12 us per call; MBPLS.fit's own use)"""
         Z = np.array(X, dtype=np.float64, copy=True)
         Z -= self.mean_
         Z /= self.scale_

@@ -52,6 +52,18 @@ def _norm(x, order):
     return np.linalg.norm(np.asarray(x).reshape(-1, 1), ord=order)
 
 
+_NORM_ORDERS_OK = set()
+
+
+def _check_norm_order(order):
+    """raises for an invalid ``nipals_convergence_norm`` exactly as the reference does at :887 (numpy's own errors);
+    an order that passed once is not tried again (for order 2 the trial is an SVD: 35 us at the head of every fit)"""
+    key = (type(order).__name__, order if isinstance(order, (int, float, str)) else repr(order))
+    if key not in _NORM_ORDERS_OK:
+        _norm(np.zeros((2, 1)), order)
+        _NORM_ORDERS_OK.add(key)
+
+
 def _psd_factor(G):
     lam, Q = np.linalg.eigh((G + G.T) * 0.5)
     return Q * np.sqrt(np.clip(lam, 0.0, None))
@@ -401,7 +413,7 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     nu_all = np.empty((B, K))
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
     converged = []
-    _norm(np.zeros((2, 1)), norm)                           # raises for invalid orders exactly as the reference (:887)
+    _check_norm_order(norm)                           # raises for invalid orders exactly as the reference (:887)
     kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
     c0 = np.zeros((q, 1)); c0[0, 0] = 1.0                   # the start vector Y[:, 0] (:838)
     for k in range(K):
@@ -483,7 +495,7 @@ def _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     converged = []
     # norm of the n x 1 difference as numpy's MATRIX norm (:887): 2, 'fro', 'nuc', -2 -> ||d||_2; 1, -1 -> sum |d|;
     # inf -> max |d|; -inf -> min |d|; anything else raises exactly as in the reference
-    _norm(np.zeros((2, 1)), norm)
+    _check_norm_order(norm)
     kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
     on_device = kind is not None and K <= 16 and q <= 16
     Yc = np.asfortranarray(Y)
@@ -600,7 +612,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     resp = _Responses(Y)
     Y = resp.Y                                              # missing responses (sparse_data=True) as zeros + masks
     if q == 1 and eng.opts.q1_fixed_point and not eng.sparse and not resp.sparse and max_iter >= 1:
-        _norm(np.zeros((2, 1)), norm)                       # raises for invalid orders exactly as the reference (:887)
+        _check_norm_order(norm)                       # raises for invalid orders exactly as the reference (:887)
         return _fit_nipals_q1_fixed_point(eng, Y, K, standardize, calc_all)
     u0 = resp.start()
     alpha0 = 1.0 / u0.T.dot(u0).item()
@@ -610,7 +622,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     # correction (~6 %), far more than one rewrite of X per component (measured 7.05 s -> 6.72 s).
     eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
     # norm of the n x 1 difference as numpy's MATRIX norm (:887), see _fit_nipals_grams
-    _norm(np.zeros((2, 1)), norm)
+    _check_norm_order(norm)
     kind = {2: 0, -2: 0, "fro": 0, "nuc": 0, 1: 1, -1: 1, np.inf: 2, -np.inf: 3}.get(norm)
     # One response: the whole fit is queued on the device.  Its first pass (statistics + first sweep) needs nothing but
     # the matrix, the start vector and the W~ slot: launched NOW, so the GPU is at work while the host allocates the
@@ -648,6 +660,7 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     _plan(eng, solver="nipals: device-resident queue" if resident else "nipals: host-driven loop")
     if resident:
         _plan(eng, resumed_on_host_at=None if out["k_done"] == K else int(out["k_done"]))
+        _plan(eng, r_and_beta=out.get("r_route") if out["k_done"] == K else "one product behind the last pass")
         varxb = out["ssq_x"]                                # summed over the column shards on the device already
         if not np.all(np.isfinite(varxb)):
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
@@ -899,6 +912,7 @@ def fit_unipals(eng, Y, K, standardize, keep_raw_weights=False):
     _plan(eng, solver=("unipals: device-resident queue, one pass per component" if resident else
                        "unipals: host-driven loop" + (", one pass per component" if fuse else "")))
     if resident:
+        _plan(eng, r_and_beta=out.get("r_route"))
         varxb = out["ssq_x"]
         if not np.all(np.isfinite(varxb)):
             raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")

@@ -421,6 +421,40 @@ def test_q1_fixed_point_option(gpu_required, monkeypatch):
     assert w < 1e-9
 
 
+@pytest.mark.parametrize("method,nblocks,K", [("NIPALS", 1, 6), ("NIPALS", 3, 7), ("UNIPALS", 2, 12)])
+def test_r_and_beta_column_by_column(gpu_required, monkeypatch, method, nblocks, K):
+    """A device-resident fit builds R_ = W (P^T W)^+ and beta_ = R_ V^T (mbpls.py:988-989 / :569-570) one column per
+    component while it runs (P^T W~ is upper triangular; its columns come with the lazy-deflation sums): same
+    attributes as the product behind the last pass (MBPLS_R_INCREMENTAL=0) and as the oracle, including the deep
+    components of a long fit; a rank-deficient matrix -- where the reference's pinv truncates -- takes the product."""
+    from mbpls_amd import MBPLS
+    n, p = 1024, 6000
+    X, Y = orc.make_latent(n, p, 1, r=20, seed=33)
+    cuts = [0] + [p * (b + 1) // nblocks for b in range(nblocks)]
+    blocks = [np.ascontiguousarray(X[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    ref = orc.fit(blocks, Y, n_components=K, method=method)
+    mdl = MBPLS(n_components=K, method=method).fit(blocks, Y)
+    assert mdl.fit_plan_["r_and_beta"] == "column by column during the fit"
+    monkeypatch.setenv("MBPLS_R_INCREMENTAL", "0")
+    old = MBPLS(n_components=K, method=method).fit(blocks, Y)
+    monkeypatch.delenv("MBPLS_R_INCREMENTAL")
+    assert old.fit_plan_["r_and_beta"] == "one product behind the last pass"
+    for got in (mdl, old):
+        assert util.compare(util.model_to_flat(got), util.model_to_flat(ref), TOL, what=f"{method} R/beta") < 1e-9
+    assert util.relerr(mdl.R_, old.R_) < 1e-11 and util.relerr(mdl.beta_, old.beta_) < 1e-11
+    # Ts = X R with the fitted scalers: the defining property of R_
+    Z = np.hstack([(b - sc.mean_) / sc.scale_ for b, sc in zip(blocks, mdl.x_scalers_)])
+    assert util.relerr(Z.dot(mdl.R_), mdl.Ts_) < 1e-9
+    # rank 3 < K = 5: the columns recorded for the exhausted components are not trusted
+    rng = np.random.RandomState(5)
+    Xr = rng.randn(256, 3).dot(rng.randn(3, 2000))
+    yr = Xr[:, :1] + 0.1 * rng.randn(256, 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        low = MBPLS(n_components=5, method=method, standardize=False).fit([Xr], yr)
+    assert low.fit_plan_["r_and_beta"] == "one product behind the last pass"
+
+
 @pytest.mark.parametrize("q", [2, 4])
 def test_row_subset_fit_and_cross_val_predict(gpu_required, q):
     """Fits on a ROW SUBSET of a resident matrix == the oracle on the sliced arrays; cross_val_predict on the

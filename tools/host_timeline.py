@@ -19,6 +19,7 @@ ap.add_argument("--fits", type=int, default=4)
 ap.add_argument("--show", default="last")
 ap.add_argument("--fresh", action="store_true")
 ap.add_argument("--tail-profile", action="store_true", help="sys.setprofile from the end of the queue's read-back to the end of fit")
+ap.add_argument("--head-profile", action="store_true", help="sys.setprofile from the start of fit to the start of the queue")
 ap.add_argument("--rccl", action="store_true", help="the sharded code path with ONE rank (RCCL communicator)")
 ap.add_argument("--min-us", type=float, default=0.0)
 a = ap.parse_args()
@@ -113,6 +114,22 @@ ctx.lib.mbpls_hip_memcpy_d2h_after = t_copy("d2h_after", ctx.lib.mbpls_hip_memcp
 ctx.lib.mbpls_hip_memcpy_d2h = t_copy("d2h", ctx.lib.mbpls_hip_memcpy_d2h, 3)
 
 tail_events = []
+if a.head_profile:
+    def tracer(frame, event, arg):
+        t = time.perf_counter()
+        if event in ("call", "return"):
+            co = frame.f_code
+            tail_events.append((t, event, f"{os.path.basename(co.co_filename)}:{co.co_firstlineno} {co.co_name}"))
+        elif event in ("c_call", "c_return"):
+            tail_events.append((t, "call" if event == "c_call" else "return", f"<C> {getattr(arg, '__qualname__', getattr(arg, '__name__', str(arg)))}"))
+
+    real_res = engine.HipEngine.nipals_resident
+
+    def res_stop(self, *aa, **kk):
+        sys.setprofile(None)
+        return real_res(self, *aa, **kk)
+
+    engine.HipEngine.nipals_resident = res_stop
 if a.tail_profile:
     real_d2h = ctx.lib.mbpls_hip_memcpy_d2h
 
@@ -140,6 +157,10 @@ for i in range(a.fits):
     if a.fresh:
         m = MBPLS(n_components=K, method=a.method)
         keep.append(m)
+    if a.head_profile:
+        tail_events.clear()
+        tail_events.append((time.perf_counter(), 'mark', 'fit starts'))
+        sys.setprofile(tracer)
     t0 = time.perf_counter(); m.fit(X, Y); t1 = time.perf_counter()
     sys.setprofile(None)
     tail = list(tail_events)
@@ -156,7 +177,7 @@ for s0, s1, d, nm in sorted(lg):
         continue
     print(f"{1e6 * (s0 - t0):9.0f} {1e6 * (s1 - s0):8.0f} us  {'  ' * d}{nm}")
 
-if a.tail_profile and tail:
+if (a.tail_profile or a.head_profile) and tail:
     print("---- tail (profiled: every call costs ~1 us extra) ----")
     base = tail[0][0]
     stack = []
