@@ -421,14 +421,16 @@ def test_q1_fixed_point_option(gpu_required, monkeypatch):
     assert w < 1e-9
 
 
-@pytest.mark.parametrize("method,nblocks,K", [("NIPALS", 1, 6), ("NIPALS", 3, 7), ("UNIPALS", 2, 12)])
-def test_r_and_beta_column_by_column(gpu_required, monkeypatch, method, nblocks, K):
+@pytest.mark.parametrize("method,nblocks,K,n", [("NIPALS", 1, 6, 1024), ("NIPALS", 3, 7, 1024), ("UNIPALS", 2, 12, 1024),
+                                                ("NIPALS", 6, 5, 300), ("UNIPALS", 6, 6, 5000), ("NIPALS", 2, 5, 5000)])
+def test_r_and_beta_column_by_column(gpu_required, monkeypatch, method, nblocks, K, n):
     """A device-resident fit builds R_ = W (P^T W)^+ and beta_ = R_ V^T (mbpls.py:988-989 / :569-570) one column per
     component while it runs (P^T W~ is upper triangular; its columns come with the lazy-deflation sums): same
     attributes as the product behind the last pass (MBPLS_R_INCREMENTAL=0) and as the oracle, including the deep
-    components of a long fit; a rank-deficient matrix -- where the reference's pinv truncates -- takes the product."""
+    components of a long fit; a rank-deficient matrix -- where the reference's pinv truncates -- takes the product.
+    (n = 300 / 1024: the register-resident step kernels; six blocks and n = 5000: the general one.)"""
     from mbpls_amd import MBPLS
-    n, p = 1024, 6000
+    p = 6000
     X, Y = orc.make_latent(n, p, 1, r=20, seed=33)
     cuts = [0] + [p * (b + 1) // nblocks for b in range(nblocks)]
     blocks = [np.ascontiguousarray(X[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
