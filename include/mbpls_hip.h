@@ -426,6 +426,11 @@ typedef struct mbpls_nipals_step {
                               (X_(i) w~_k = 0 for i > k), so R_ = W~ C^-1 can be built column by column while the fit
                               runs: mbpls_hip_queue_r_update                                                        */
   int64_t ldc;
+  double* host_seq;        /* optional (NULL: unused): one double in HOST-MAPPED memory.  Every launch stores seq_value there
+                              FIRST (before the skip test), so a host thread can learn that everything queued on the stream
+                              before this step has completed without an event in the stream (an event record between two
+                              launches idles the queue for ~6 us): mbpls_hip_copier_submit with h_flag                  */
+  double seq_value;
 } mbpls_nipals_step;
 int mbpls_hip_nipals_step(mbpls_ctx* ctx, const mbpls_nipals_step* s);
 /* R_ = W (P^T W)^+ (mbpls.py:988 / :569) one column per component, while the fit is still running.  P^T W~ is upper
@@ -486,7 +491,10 @@ typedef struct mbpls_unit_scale {
   const double* h_nu2;         /* nblocks squared norms */
 } mbpls_unit_scale;
 int mbpls_hip_copier_submit(mbpls_ctx* ctx, int ncopies, const mbpls_copy* copies, const mbpls_unit_scale* scale,
-                            uint64_t* ticket);
+                            const double* h_flag, double flag_at_least, uint64_t* ticket);
+/* h_flag != NULL: no event is recorded; the job starts once *h_flag >= flag_at_least instead (h_flag: host-mapped memory
+ * that a kernel queued BEHIND the producers of the copied data writes, mbpls_nipals_step.host_seq).  The caller must make
+ * sure that kernel is launched -- or store the value itself when it gives up.                                          */
 int mbpls_hip_copier_wait(mbpls_ctx* ctx, uint64_t ticket);
 
 /* ---- exchange step of the column-sharded fit: RCCL over xGMI, inside the C ABI ---------------------

@@ -30,7 +30,7 @@ class NipalsStep(C.Structure):
                 ("centre", _int), ("norm_kind", _int), ("mode", _int), ("tol", _dbl), ("amp2_max", _dbl),
                 ("xchg", _vp), ("Y", _vp), ("Ts", _vp), ("Tsc", _vp), ("U", _vp), ("V", _vp), ("Tb", _vp),
                 ("scal", _vp), ("ssq_x", _vp), ("iters", _vp), ("u_cur", _vp), ("ts_old", _vp), ("vpass", _vp),
-                ("tspass", _vp), ("cu", _vp), ("ce", _vp), ("par", _vp), ("nu2_host", _vp), ("C", _vp), ("ldc", _i64)]
+                ("tspass", _vp), ("cu", _vp), ("ce", _vp), ("par", _vp), ("nu2_host", _vp), ("C", _vp), ("ldc", _i64), ("host_seq", _vp), ("seq_value", _dbl)]
 
 
 class Copy(C.Structure):
@@ -118,7 +118,7 @@ SIGNATURES = {
     "mbpls_hip_block_unit_col": (_int, [_vp, _vp, _vp, _vp]),
     "mbpls_hip_set_true_space_outputs": (_int, [_vp, _vp, _vp]),
     "mbpls_hip_scale_col_by": (_int, [_vp, _i64, _vp, _vp, _vp]),
-    "mbpls_hip_copier_submit": (_int, [_vp, _int, C.POINTER(Copy), C.POINTER(UnitScale), C.POINTER(C.c_uint64)]),
+    "mbpls_hip_copier_submit": (_int, [_vp, _int, C.POINTER(Copy), C.POINTER(UnitScale), _vp, _dbl, C.POINTER(C.c_uint64)]),
     "mbpls_hip_copier_wait": (_int, [_vp, C.c_uint64]),
     "mbpls_hip_queue_r_update": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _vp]),
     "mbpls_hip_flush_r_update": (_int, [_vp]),
@@ -284,11 +284,13 @@ class Context:
             cur = self._mapped = (arr, d.value, h.value)
         return cur[0], cur[1]
 
-    def copier_submit(self, copies, scale=None):
+    def copier_submit(self, copies, scale=None, flag=None):
         """Hand a job to the context's copier thread (``mbpls_hip_copier_submit``): ``copies`` = [(contiguous host
         array, device address)], carried out once everything queued on the compute stream so far has run;
         ``scale`` = (src column, dst column, int64 block offsets, address of the squared block norms in host-mapped
-        memory): dst = src / sqrt(norm of its block) afterwards.  Returns the ticket for ``copier_wait``.  The host
+        memory): dst = src / sqrt(norm of its block) afterwards.  ``flag`` = (host address, value): no event is
+        recorded on the stream; the job starts once the double at that address is >= value (written by a kernel queued
+        behind the producers, ``mbpls_nipals_step.host_seq``).  Returns the ticket for ``copier_wait``.  The host
         arrays are kept alive here until a wait has covered them."""
         n = len(copies)
         arr = (Copy * max(n, 1))()
@@ -299,7 +301,8 @@ class Context:
             src_h, dst_h, offs, nu2_addr = scale
             sc = C.byref(UnitScale(src_h.ctypes.data, dst_h.ctypes.data, len(offs) - 1, offs.ctypes.data, int(nu2_addr)))
         t = C.c_uint64()
-        check(self.lib.mbpls_hip_copier_submit(self.handle, n, arr, sc, C.byref(t)))
+        faddr, fval = (None, 0.0) if flag is None else (int(flag[0]), float(flag[1]))
+        check(self.lib.mbpls_hip_copier_submit(self.handle, n, arr, sc, faddr, fval, C.byref(t)))
         keep = self.__dict__.setdefault("_copier_keep", [])
         keep.append((t.value, [c[0] for c in copies], scale))
         return t.value

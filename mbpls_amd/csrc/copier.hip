@@ -37,7 +37,9 @@ namespace mbpls {
 
 struct CopierJob {
   uint64_t id = 0;
-  hipEvent_t ev = nullptr;
+  hipEvent_t ev = nullptr;           // NULL: wait for *flag >= flag_min instead
+  const volatile double* flag = nullptr;
+  double flag_min = 0.0;
   std::vector<mbpls_copy> copies;
   bool has_scale = false;
   const double* s_src = nullptr;
@@ -170,7 +172,16 @@ static int copier_run(CopierState* cs, CopierJob& job) {
   } while (0)
   const bool trace = copier_trace();
   const double t_in = trace ? now_us() : 0.0;
-  CP_HIP(hipEventSynchronize(job.ev));
+  if (job.ev) {
+    CP_HIP(hipEventSynchronize(job.ev));
+  } else {
+    // a kernel behind the producers of this job's data stores the value (host-mapped memory): poll, politely after a while
+    for (unsigned spins = 0; !(*job.flag >= job.flag_min); ++spins) {
+      if (spins < 4000) __builtin_ia32_pause();
+      else std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
   const double t_ev = trace ? now_us() : 0.0;
   cs->cv_help.notify_all();          // the helpers wake up while the first DMA is in flight
   double t_dma = 0.0, t_cpy = 0.0, t_scale = 0.0;
@@ -270,7 +281,7 @@ static void copier_main(CopierState* cs) {
       cs->jobs.pop_front();
     }
     const int rc = copier_run(cs, job);
-    {
+    if (job.ev) {
       std::lock_guard<std::mutex> lock(cs->ctx->user_event_mutex);
       cs->ctx->user_event_pool.push_back(job.ev);
     }
@@ -337,7 +348,7 @@ using namespace mbpls;
 extern "C" {
 
 int mbpls_hip_copier_submit(mbpls_ctx* ctx, int ncopies, const mbpls_copy* copies, const mbpls_unit_scale* scale,
-                            uint64_t* ticket) {
+                            const double* h_flag, double flag_at_least, uint64_t* ticket) {
   MB_ARG(ctx && ticket && ncopies >= 0 && (ncopies == 0 || copies), "bad argument");
   for (int i = 0; i < ncopies; ++i)
     MB_ARG(copies[i].bytes == 0 || (copies[i].h_dst && copies[i].d_src), "copy %d: NULL pointer", i);
@@ -346,15 +357,20 @@ int mbpls_hip_copier_submit(mbpls_ctx* ctx, int ncopies, const mbpls_copy* copie
   CopierState* cs = nullptr;
   MB_TRY(copier_get(ctx, &cs));
   CopierJob job;
-  {
-    std::lock_guard<std::mutex> lock(ctx->user_event_mutex);
-    if (!ctx->user_event_pool.empty()) {
-      job.ev = ctx->user_event_pool.back();
-      ctx->user_event_pool.pop_back();
+  if (h_flag) {
+    job.flag = h_flag;
+    job.flag_min = flag_at_least;
+  } else {
+    {
+      std::lock_guard<std::mutex> lock(ctx->user_event_mutex);
+      if (!ctx->user_event_pool.empty()) {
+        job.ev = ctx->user_event_pool.back();
+        ctx->user_event_pool.pop_back();
+      }
     }
+    if (!job.ev) MB_HIP(hipEventCreateWithFlags(&job.ev, hipEventDisableTiming));
+    MB_HIP(hipEventRecord(job.ev, ctx->stream));
   }
-  if (!job.ev) MB_HIP(hipEventCreateWithFlags(&job.ev, hipEventDisableTiming));
-  MB_HIP(hipEventRecord(job.ev, ctx->stream));
   job.copies.assign(copies, copies + ncopies);
   if (scale) {
     job.has_scale = true;

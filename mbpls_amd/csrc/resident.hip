@@ -107,6 +107,8 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   __shared__ double s_mx[WG1024 / 64], s_mn[WG1024 / 64];
   __shared__ unsigned s_dead;
   double* par = s.par;
+  if (s.host_seq && threadIdx.x == 0 && blockIdx.x == 0)
+    __hip_atomic_store(s.host_seq, s.seq_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (par[2] != 0.0) return;             // an earlier component needed more iterations than were queued
   const int tid = threadIdx.x;
   if (tid == 0) s_dead = 0u;

@@ -83,6 +83,8 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
   __shared__ double s_mx[SR_W], s_mn[SR_W];
   int buf = 0;
   double* par = s.par;
+  // (first of all: a host thread may be waiting to learn that the kernels queued before this one are done)
+  if (s.host_seq && threadIdx.x == 0) __hip_atomic_store(s.host_seq, s.seq_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (par[2] != 0.0) return;             // an earlier component needed more iterations than were queued
   const int tid = threadIdx.x;
   const bool lead = tid == 0;

@@ -744,9 +744,10 @@ class HipEngine(EngineBase):
                     self._res_sweep(k, (wslot, k))                   # second iteration (:856, :875)
                     rq.step(k, 2, k)
                     # w~ column k is final; w_b = w~_b / ||w~_b|| (:860) is formed on the host from it and the norms the
-                    # step just recorded.  The event the copies wait for is recorded BEHIND the loadings pass (an event
-                    # between the step and the pass cost the queue 6 us of idle each) -- except for the last component,
-                    # whose columns would otherwise leave after the fit's last kernel
+                    # step just recorded.  The copies start when the step BEHIND the loadings pass has begun (it says
+                    # so in host-mapped memory: no event in the stream -- an event record between two launches idles
+                    # the queue for 6 us) -- except for the last component, whose columns leave behind an event
+                    # recorded before its loadings pass (they would otherwise wait for the fit's last kernel)
                     nu_copy, unit = rq.unit_blocks_on_host(Wn_h, W_h, k)
                     cols = ([(rq.col(Wn_h, k), Wn.ptr + p8 * k)] + nu_copy
                             + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else []))
@@ -756,8 +757,7 @@ class HipEngine(EngineBase):
                     self._res_loadings(k, last, None if last else (wslot, k + 1))   # (:928, :969) + next first sweep
                     rq.r_flush()
                     if not last:
-                        rq.stream_out(cols + rq.r_cols(k), post=unit, k=k)
-                    if not last:
+                        rq.stream_out(cols + rq.r_cols(k), post=unit, k=k, after_next_step=True)
                         rq.step(k + 1, 1, k + 1)
                     else:
                         rq.allreduce()
@@ -789,7 +789,7 @@ class HipEngine(EngineBase):
                     nu_copy, unit = rq.unit_blocks_on_host(src_h, W_h, k)            # w_b / ||w_b|| (:510-512)
                     rq.stream_out([(rq.col(src_h, k), Wc.ptr + p8 * k)] + nu_copy
                                   + ([(rq.col(P_h, k - 1), Pm.ptr + p8 * (k - 1))] if k else [])
-                                  + (rq.r_cols(k - 1) if k else []), post=unit, k=k)
+                                  + (rq.r_cols(k - 1) if k else []), post=unit, k=k, after_next_step=not last)
                     rq.r_update(k)
                     self._res_loadings(k, last, None if last else (gslot, 0))        # p (:520), deflation (:535)
                     rq.r_flush()
@@ -1159,8 +1159,15 @@ class _ResidentQueue:
         # block norms of every recorded component, written by the step straight into pinned host memory: the helper
         # thread that forms w_b = w~_b / ||w~_b|| reads them there (a copy of B doubles into pageable memory is a blit
         # kernel that waits behind -- and slows -- the running pass: 180 us each)
-        self.nu2_h, nu2_d = ctx.mapped_scalars(K * B)
+        self.nu2_h, nu2_d = ctx.mapped_scalars(K * B + 8)
         self.st.nu2_host = nu2_d
+        # ... and the number of the step launch that has started, stored there by every step first of all: the copier
+        # thread starts a job when the step queued BEHIND the job's data has begun, instead of waiting for an event
+        # recorded on the stream (an event record between two launches idles the queue for ~6 us: 60 us of a fit)
+        self.seq_h = self.nu2_h[K * B:K * B + 1]
+        self.seq_h[0] = 0.0
+        self.st.host_seq = nu2_d + 8 * K * B
+        self.nsteps = 0
         self.ticket = 0                             # of the last job handed to the copier thread
         self.scores_ticket = 0                      # of the job that carries the last component's n-vectors
         # host image of [par .. Tb]: the n-vectors arrive per component through the copier, the scalars at the end
@@ -1173,18 +1180,20 @@ class _ResidentQueue:
         assert c.flags.c_contiguous
         return c
 
-    def stream_out(self, copies, post=None, k=None):
+    def stream_out(self, copies, post=None, k=None, after_next_step=False):
         """copy finished device columns to the host (the context's copier thread, csrc/copier.hip) behind everything
         queued on the compute stream so far; ``post``: the block normalisation the thread does on what arrived
         (``unit_blocks_on_host``); ``k``: the n-vectors the step recorded for component k (super score, u, block
         scores) leave with this job as well -- the read-back behind the last pass is then a few hundred bytes instead
-        of n (2 + B) K doubles (1 MB at n = 4096, K = 10: 90 us of every fit)"""
+        of n (2 + B) K doubles (1 MB at n = 4096, K = 10: 90 us of every fit); ``after_next_step``: the caller launches
+        a step right after this call -- the job waits for THAT step to start (``host_seq``) instead of an event"""
         if k is not None:
             n, B, o0 = self.eng.n, self.eng.nblocks, self.off["par"][0]
             for key, width in (("Ts", 1), ("U", 1), ("Tb", B)):
                 a = self.off[key][0] - o0 + n * width * k
                 copies = copies + [(self.h[a:a + n * width], self.ptr[key] + 8 * n * width * k)]
-        self.ticket = self.ctx.copier_submit(copies, scale=post)
+        flag = (self.seq_h.ctypes.data, self.nsteps + 1) if after_next_step else None
+        self.ticket = self.ctx.copier_submit(copies, scale=post, flag=flag)
         if k is not None and k == self.K - 1:
             self.scores_ticket = self.ticket
 
@@ -1247,7 +1256,8 @@ class _ResidentQueue:
 
     def step(self, kc, run, nd):
         self.allreduce()
-        self.st.kc, self.st.run, self.st.nd = kc, run, nd
+        self.nsteps += 1
+        self.st.kc, self.st.run, self.st.nd, self.st.seq_value = kc, run, nd, float(self.nsteps)
         _capi.check(self.lib.mbpls_hip_nipals_step(self.ctx.handle, self.st))
 
     def last_loadings_norms(self):
@@ -1325,6 +1335,7 @@ class _ResidentQueue:
                 ctx.copier_wait(scores_ticket)
 
         if et is not None or h is None:
+            self.seq_h[0] = np.inf          # (a job may be waiting for a step that was never launched)
             try:
                 wait_copies()
             except _capi.HipError:

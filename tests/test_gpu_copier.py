@@ -69,3 +69,28 @@ def test_large_copies_take_the_direct_path():
     t = ctx.copier_submit([(small, dev.ptr + 8 * 5), (out, dev.ptr), (small, dev.ptr + 8 * 100)])
     ctx.copier_wait(t)
     assert np.array_equal(out, src) and np.array_equal(small, src[100:110])
+
+
+def test_a_job_can_wait_for_a_value_in_host_mapped_memory_instead_of_an_event():
+    """``flag``: no event on the stream; the job starts once the double at the address reaches the value (in a fit a
+    step kernel queued behind the producers stores it, ``mbpls_nipals_step.host_seq``; here the host does)."""
+    import threading
+    import time
+    ctx = _ctx()
+    src = np.arange(1000.0)
+    dev = ctx.from_host(src)
+    ctx.sync()
+    flags, _ = ctx.mapped_scalars(64)
+    flags[40] = 0.0
+    out = np.full(1000, np.nan)
+    t = ctx.copier_submit([(out, dev.ptr)], flag=(flags.ctypes.data + 8 * 40, 3.0))
+    later = ctx.copier_submit([(np.empty(4), dev.ptr)])          # queued behind it (jobs run in order)
+    time.sleep(0.05)
+    assert np.isnan(out).all()                                     # still waiting
+    flags[40] = 2.0
+    time.sleep(0.02)
+    assert np.isnan(out).all()
+    threading.Timer(0.02, lambda: flags.__setitem__(40, 3.0)).start()
+    ctx.copier_wait(later)
+    assert np.array_equal(out, src)
+    assert t < later

@@ -15,6 +15,7 @@ ap.add_argument("--p", type=int, default=125_000)
 ap.add_argument("--K", type=int, default=10)
 ap.add_argument("--method", default="NIPALS")
 ap.add_argument("--blocks", type=int, default=1)
+ap.add_argument("--q", type=int, default=1)
 ap.add_argument("--fits", type=int, default=4)
 ap.add_argument("--show", default="last")
 ap.add_argument("--fresh", action="store_true")
@@ -33,7 +34,7 @@ n, p, K = a.n, a.p, a.K
 ctx = mbpls_amd.get_context()
 if a.rccl:
     mbpls_amd.set_comm(mbpls_amd.RcclComm(ctx, 0, 1, lambda payload: payload))
-Ts, Y = planted(n, 1, 32, 0)
+Ts, Y = planted(n, a.q, 32, 0)
 offs = [int(round(b * p / a.blocks)) for b in range(a.blocks + 1)]
 X = DeviceMatrix(ctx, n, p, offs)
 X.fill_latent(ctx.from_host(Ts), 32, 0.5, 1234, 0)
@@ -61,6 +62,9 @@ for nm in ("load_device", "_set_matrix", "slot", "prepare", "_prepare_implicit",
     wrap(engine.HipEngine, nm)
 for nm in ("__init__", "__exit__", "step", "stream_out"):
     wrap(engine._ResidentQueue, nm, "rq." + nm)
+for nm in ("sweep", "deflate_sweep", "xt_v", "x_w_slot", "nipals_subspace_loop", "fetch_col", "prepare_stats", "put", "_xw", "x_w_host"):
+    if hasattr(engine.HipEngine, nm):
+        wrap(engine.HipEngine, nm)
 wrap(solvers, "_finalise_device")
 wrap(solvers, "_global_sizes")
 wrap(mb, "check_array")
