@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 6   /* 6: mbpls_nipals_step.C / ldc, mbpls_hip_queue_r_update, mbpls_hip_flush_r_update (R_ / beta_ column by column during the fit), mbpls_hip_copier_submit / _wait (native copier thread); 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
+#define MBPLS_HIP_ABI_VERSION 6   /* 6: mbpls_hip_mat_transpose; mbpls_nipals_step.C / ldc / host_seq, mbpls_hip_queue_r_update, mbpls_hip_flush_r_update (R_ / beta_ column by column during the fit), mbpls_hip_copier_submit / _wait (native copier thread); 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
 
 enum {
   MBPLS_OK = 0,
@@ -123,6 +123,11 @@ int mbpls_hip_profile_get(mbpls_ctx* ctx, int kind, int64_t* launches, double* t
  * d_storage: NULL (library allocates p*ld doubles) or caller-owned device memory of that size. */
 int mbpls_hip_mat_create(mbpls_ctx* ctx, int64_t n, int64_t p, int nblocks,
                          const int64_t* block_offsets, void* d_storage, mbpls_mat** out);
+/* dst = src^T on the device: src is n x p (feature-major: p columns of n samples), dst must have been created as p x n
+ * (n columns of p "samples": the row-major image of src).  With it the p x p product X^T X of the n >= p branches
+ * (mbpls.py:586, VAR = X^T X) is the association matrix of the transposed matrix -- mbpls_hip_gram(dst) -- on the
+ * symmetric matrix-core kernel, instead of p/48 many-right-hand-side products that each read all of X.              */
+int mbpls_hip_mat_transpose(const mbpls_mat* src, mbpls_mat* dst);
 int mbpls_hip_mat_destroy(mbpls_mat* m);
 int mbpls_hip_mat_info(const mbpls_mat* m, int64_t* n, int64_t* p, int64_t* ld, void** d_data,
                        int* nblocks, int* nchunks);

@@ -120,6 +120,7 @@ SIGNATURES = {
     "mbpls_hip_scale_col_by": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "mbpls_hip_copier_submit": (_int, [_vp, _int, C.POINTER(Copy), C.POINTER(UnitScale), _vp, _dbl, C.POINTER(C.c_uint64)]),
     "mbpls_hip_copier_wait": (_int, [_vp, C.c_uint64]),
+    "mbpls_hip_mat_transpose": (_int, [_vp, _vp]),
     "mbpls_hip_queue_r_update": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _vp]),
     "mbpls_hip_flush_r_update": (_int, [_vp]),
     "mbpls_hip_event_record": (_int, [_vp, _pp]),
@@ -482,6 +483,13 @@ class DeviceMatrix:
             self.close()
         except Exception:
             pass
+
+    def transposed(self):
+        """A new p x n DeviceMatrix holding this matrix's transpose (one block): the Gram kernel applied to it yields
+        X^T X (``mbpls_hip_mat_transpose``).  The caller closes it."""
+        T = DeviceMatrix(self.ctx, self.p, self.n)
+        check(self.ctx.lib.mbpls_hip_mat_transpose(self.handle, T.handle))
+        return T
 
     def upload(self, host, col0=0):
         """Copy a host n x w array into columns [col0, col0+w)."""

@@ -149,6 +149,26 @@ __global__ __launch_bounds__(256) void k_transpose_in(const double* __restrict__
   }
 }
 
+
+// dst[i*ldd + j] = src[j*lds + i] (i < n, j < p): the feature-major matrix as its own transpose (rows beyond p up to ldd: 0)
+__global__ __launch_bounds__(256) void k_transpose_mat(const double* __restrict__ src, int64_t lds, int64_t n, int64_t p,
+                                                       double* __restrict__ dst, int64_t ldd) {
+  __shared__ double tile[TT][TT + 1];
+  const int64_t i0 = (int64_t)blockIdx.x * TT, j0 = (int64_t)blockIdx.y * TT;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = ty; r < TT; r += 8) {
+    const int64_t j = j0 + r, i = i0 + tx;
+    tile[r][tx] = (i < n && j < p) ? src[j * lds + i] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < TT; r += 8) {
+    const int64_t i = i0 + r, j = j0 + tx;
+    if (i < n && j < ldd) dst[i * ldd + j] = (j < p) ? tile[tx][r] : 0.0;
+  }
+}
+
 // src[j*ld + i]  ->  stage[i*w + j]
 __global__ __launch_bounds__(256) void k_transpose_out(const double* __restrict__ src, int64_t ld, int64_t n,
                                                        int64_t w, double* __restrict__ stage) {
@@ -539,6 +559,19 @@ int mbpls_hip_mat_create(mbpls_ctx* ctx, int64_t n, int64_t p, int nblocks, cons
     return rc;
   }
   *out = m;
+  return MBPLS_OK;
+}
+
+
+int mbpls_hip_mat_transpose(const mbpls_mat* src, mbpls_mat* dst) {
+  MB_ARG(src && dst && src != dst, "NULL argument");
+  MB_ARG(dst->n == src->p && dst->p == src->n, "dst must be %lld x %lld (got %lld x %lld)", (long long)src->p,
+         (long long)src->n, (long long)dst->n, (long long)dst->p);
+  mbpls_ctx* ctx = src->ctx;
+  dim3 grid((unsigned)((src->n + TT - 1) / TT), (unsigned)((std::max(src->p, dst->ld) + TT - 1) / TT));
+  hipLaunchKernelGGL(k_transpose_mat, grid, dim3(256), 0, ctx->stream, (const double*)src->data, src->ld, src->n, src->p,
+                     dst->data, dst->ld);
+  MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }
 

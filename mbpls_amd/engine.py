@@ -837,7 +837,18 @@ class HipEngine(EngineBase):
         p = self.p
         ldg = p + (p & 1)
         store = self.ctx.empty(ldg * p, zero=True)
-        self.X.xt_v(self.X.data_ptr, p, 1.0, store, None, ldv=self.X.ld, ldg=ldg)
+        free = self.ctx.info()["free_bytes"] + self.ctx._pool_bytes
+        if p >= 2048 and 8 * self.n * (p + 1) + 3 * 8 * ldg * p < free:
+            # X^T X is the association matrix of X^T: the symmetric matrix-core kernel (half the flops, operands reused
+            # in 128 x 128 tiles) on a transposed copy, instead of p / 48 many-right-hand-side products that each read
+            # all of X (n = p = 20 000: 0.39 s at 41 TFLOP/s of the full product -> 0.12 s)
+            Xt = self.X.transposed()
+            try:
+                Xt.gram(store, ldg)
+            finally:
+                Xt.close()
+        else:
+            self.X.xt_v(self.X.data_ptr, p, 1.0, store, None, ldv=self.X.ld, ldg=ldg)
         Vm = _capi.DeviceMatrix(self.ctx, p, p, [0, p], storage=store.ptr)
         self._xtx = (Vm, store)
 

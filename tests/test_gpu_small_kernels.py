@@ -125,3 +125,28 @@ def test_fold_statistics_and_fold_algebra(ctx, n, p, blocks):
     sums = dsums.get().reshape(len(offs) - 1, F, 2)
     np.testing.assert_allclose(sums[:, :, 1].sum(axis=0), (mean * G * rs).sum(axis=0), rtol=1e-9, atol=1e-9)
     Xd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,p", [(1, 1), (33, 7), (64, 96), (257, 1000), (1000, 257)])
+def test_device_transpose_and_xtx_through_the_gram_kernel(n, p):
+    """mbpls_hip_mat_transpose: the p x n image of an n x p matrix, bit for bit; the Gram kernel applied to it is
+    X^T X (the n >= p branches, mbpls.py:586)."""
+    import mbpls_amd
+    from mbpls_amd import DeviceMatrix
+    ctx = mbpls_amd.get_context()
+    rng = np.random.default_rng(n * 131 + p)
+    X = rng.standard_normal((n, p))
+    Xd = DeviceMatrix(ctx, n, p)
+    Xd.upload(X)
+    Xt = Xd.transposed()
+    assert (Xt.n, Xt.p) == (p, n)
+    assert np.array_equal(Xt.download(), X.T)
+    ldg = p + (p & 1)
+    G = ctx.empty(ldg * p, zero=True)
+    Xt.gram(G, ldg)
+    got = G.get().reshape(p, ldg)[:, :p]
+    want = X.T.dot(X)
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    assert np.array_equal(got, got.T)
+    G.free(); Xt.close(); Xd.close()
