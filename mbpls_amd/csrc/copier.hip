@@ -72,10 +72,12 @@ struct CopierState {
     const int64_t* offs = nullptr;
     int nblocks = 0;
   } land;
-  // (epoch << 32) | next piece.  `land` belongs to the epoch in the upper half and is only rewritten once every piece of
-  // it is finished and the lower half has been parked at LAND_CLOSED, so a piece can only be claimed (compare-and-swap on
-  // an unchanged epoch) while the description a thread copied for that epoch is the valid one
+  // (epoch << 32) | next piece.  `land` belongs to the epoch in the upper half.  The copier thread rewrites it only after
+  // every piece is finished, the lower half has been parked at LAND_CLOSED and no helper is copying it (land_readers);
+  // a helper copies it only while it is registered as a reader AND the ticket shows an open epoch, and claims pieces by
+  // compare-and-swap on that unchanged epoch.
   std::atomic<uint64_t> land_ticket{0xFFFFFFFFull};
+  std::atomic<int> land_readers{0};        // helper threads copying `land` right now: it is not rewritten meanwhile
   std::atomic<int64_t> land_left{0};       // pieces not finished yet
   uint64_t land_epoch = 0;                 // (copier thread only)
   std::vector<std::thread> helpers;
@@ -106,9 +108,9 @@ static void land_piece(const CopierState::Land& L, size_t a, size_t b) {
 
 constexpr uint64_t LAND_CLOSED = 0xFFFFFFFFull;
 
-// take pieces of epoch `epoch` until none are left (others may still be working on theirs when this returns)
-static void land_work(CopierState* cs, uint64_t epoch) {
-  const CopierState::Land L = cs->land;          // (only used for pieces claimed under `epoch`, see land_ticket)
+// take pieces of epoch `epoch` (whose description is L) until none are left (others may still be working on theirs
+// when this returns)
+static void land_work(CopierState* cs, uint64_t epoch, const CopierState::Land& L) {
   const uint64_t npieces = (L.bytes + COPIER_PIECE - 1) / COPIER_PIECE;
   for (;;) {
     uint64_t t = cs->land_ticket.load(std::memory_order_acquire);
@@ -142,8 +144,15 @@ static void helper_main(CopierState* cs) {
       if (cs->hstop.load(std::memory_order_relaxed)) return;
       continue;
     }
-    seen = cs->land_ticket.load(std::memory_order_acquire) >> 32;
-    land_work(cs, seen);
+    // register as a reader, then look again: an open epoch cannot be rewritten while we are registered
+    cs->land_readers.fetch_add(1, std::memory_order_acq_rel);
+    const uint64_t t = cs->land_ticket.load(std::memory_order_acquire);
+    const bool open = (t & 0xFFFFFFFFull) != LAND_CLOSED;
+    CopierState::Land L;
+    if (open) L = cs->land;
+    cs->land_readers.fetch_sub(1, std::memory_order_acq_rel);
+    seen = t >> 32;
+    if (open) land_work(cs, seen, L);             // (parked: the pieces of that epoch are done; wait for the next one)
   }
 }
 
@@ -193,6 +202,7 @@ static int copier_run(CopierState* cs, CopierJob& job) {
     CP_HIP(hipEventSynchronize(cs->bev[prev_slot]));
     const double b = trace ? now_us() : 0.0;
     const mbpls_copy& c = job.copies[prev];
+    while (cs->land_readers.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();   // (ticket is parked: no new readers copy)
     CopierState::Land& L = cs->land;
     L = CopierState::Land{};
     L.src = (const char*)cs->bounce[prev_slot];
@@ -211,7 +221,7 @@ static int copier_run(CopierState* cs, CopierJob& job) {
     cs->land_left.store(npieces, std::memory_order_relaxed);
     const uint64_t epoch = ++cs->land_epoch;
     cs->land_ticket.store(epoch << 32, std::memory_order_release);       // open: pieces 0 .. npieces - 1
-    land_work(cs, epoch);
+    land_work(cs, epoch, L);
     while (cs->land_left.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
     cs->land_ticket.store((epoch << 32) | LAND_CLOSED, std::memory_order_release);
     if (trace) {
