@@ -1,4 +1,2 @@
 #!/bin/bash
-for i in 1 2 3; do timeout 600 python3 -m pytest tests/test_gpu_copier.py -m gpu -x -q 2>&1 | tail -1; done
-timeout 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "golden or c2 or column_by_column or unipals" 2>&1 | tail -2
-timeout 300 python3 tools/shard_fixed.py --local 2>&1 | tail -1 | cut -c1-250
+timeout 300 python3 tools/profile_fit.py --n 20000 --p 1000 --q 10 --K 20 --blocks 2 2>&1 | grep -v "^$" | head -60
