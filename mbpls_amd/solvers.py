@@ -70,9 +70,19 @@ def _psd_factor(G):
 
 
 def _tlsv(thin):
-    """first left singular vector of a thin matrix (host LAPACK), n x 1"""
-    if thin.shape[1] == 1:
+    """first left singular vector of a thin matrix (host LAPACK), n x 1.  Tall and thin (m >= 8 q): from the leading
+    eigenvector v1 of the q x q Gram matrix, u1 = A v1 / ||A v1|| -- for the LEADING pair the squared spectrum costs at
+    most a factor (s1 + s2)/s1 in the perturbation bound, and one q x q eigenproblem + two products replace LAPACK's
+    QR-then-SVD of all q vectors (20 000 x 10: 1.3 -> 0.1 ms per component on the GPU box's host, 39 -> 1.8 ms here);
+    a nearly double leading singular value (where the vector is ill-determined either way) takes the SVD."""
+    m, q = thin.shape
+    if q == 1:
         return thin / np.linalg.norm(thin)
+    if m >= 8 * q:
+        lam, vec = np.linalg.eigh(thin.T.dot(thin))
+        if lam[-1] > 0.0 and lam[-1] - lam[-2] > 1e-4 * lam[-1]:
+            u = thin.dot(vec[:, -1:])
+            return u / np.linalg.norm(u)
     return np.linalg.svd(thin, full_matrices=False)[0][:, 0:1]
 
 
