@@ -897,8 +897,12 @@ def fit_unipals(eng, Y, K, standardize, keep_raw_weights=False):
         # (the n >= p branch mixes in xt_v / x_w on the deflated X as well: explicit)
         eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
     fuse = wide and q == 1
+    # n >= p: the stored matrix is only read (deflation applied to the small operands, below) once a rewrite of it costs
+    # more than the n x q projections on the host: from about half a gigabyte (a 160 MB matrix -- the paper's shape (a)
+    # -- is deflated in 50 us, the projections cost 0.2 ms)
+    nodeflate_tall = (not wide) and eng.opts.unipals_nodeflate and 8.0 * n * p_total >= 5e8
     vary = (Y ** 2).sum()
-    Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
+    Ts = np.empty((n, K), order="F"); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
     T = [np.empty((n, K)) for _ in range(B)]
     blk_nrm = np.empty((B, K)); tot_nrm = np.empty(K)
     evx, evy, evxb, Acorr = [], [], np.empty((B, K)), np.empty((B, K))
@@ -981,12 +985,19 @@ def fit_unipals(eng, Y, K, standardize, keep_raw_weights=False):
             else:
                 t_raw, ssq = eng.sweep(u, 1.0, ("Wc", k))   # w_raw = X^T u (:503), t~_b = X_b w_raw_b
         else:
-            eng.xt_v(Y, 1.0, "S", 0)
+            # n >= p (:388-479).  The deflation :470 is X_k = P X_0 with P = I - Ts Ts^T (unit, mutually orthogonal
+            # scores), so X_k^T Y = X_0^T (P Y), X_k,b w_b = P X_0,b w_b and p = X_k^T ts = X_0^T ts: three READS of the
+            # stored matrix per component and no rewrite (MBPLS_UNIPALS_NODEFLATE=0: deflate in place as the reference)
+            Tp = Ts[:, :k]
+            lazy = nodeflate_tall
+            eng.xt_v(Y - Tp.dot(Tp.T.dot(Y)) if (lazy and k) else Y, 1.0, "S", 0)
             C = eng.fetch("S")[:, :q]
             w = _tlsv(C)                                    # (:396-400): S = C C^T is symmetric
             eng.put_col("Wc", k, w)
             tb = eng.x_w_slot("Wc", k, 1, per_block=True)
             t_raw = np.hstack(tb)
+            if lazy and k:
+                t_raw = t_raw - Tp.dot(Tp.T.dot(t_raw))
             ssq = eng.comm.allreduce_host(np.array([float((w[eng.block_offsets[b]:eng.block_offsets[b + 1]] ** 2).sum())
                                                     for b in range(B)]))
             ts = t_raw.sum(axis=1, keepdims=True)           # X w (:416)
@@ -1010,7 +1021,8 @@ def fit_unipals(eng, Y, K, standardize, keep_raw_weights=False):
             if k > 0:
                 eng.fetch_col("P", k - 1, P_h)
 
-        ssq_p, m_raw, g_ssq = eng.deflate_sweep(ts, 1.0 / tt, not last, ("P", k), y0 if nxt else None, 1.0,
+        ssq_p, m_raw, g_ssq = eng.deflate_sweep(ts, 1.0 / tt, (not last) and (wide or not nodeflate_tall),
+                                            ("P", k), y0 if nxt else None, 1.0,
                                             ("S", 0) if nxt else None,   # p (:520), X - ts p^T (:535)
                                             overlap=stream_out if wide else None)
         Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u; V[:, k:k + 1] = v; A[:, k] = a
