@@ -1,4 +1,6 @@
 #!/bin/bash
-timeout 1500 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q -k "UNIPALS or unipals or ngtp or golden or random" 2>&1 | tail -3
-timeout 600 python3 tools/paper_protocol.py a --data planted --methods UNIPALS 2>/dev/null | grep '^{' | cut -c1-260
-timeout 600 python3 tools/paper_protocol.py b --data planted --methods UNIPALS 2>/dev/null | grep '^{' | cut -c1-260
+O=$GRAFT_REPO_ROOT/gpurun_out/r04ev
+mkdir -p $O
+( timeout 900 python3 tools/paper_protocol.py a --data both 2>/dev/null; timeout 1500 python3 tools/paper_protocol.py b --data both 2>/dev/null ) | grep '^{' > $O/r04_paper_protocol.jsonl
+wc -l $O/r04_paper_protocol.jsonl
+bash tools/gpu_suite.sh 2>&1 | tail -5
