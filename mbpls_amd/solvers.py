@@ -418,7 +418,8 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     varxb = prod.varxb
     varx = varxb.sum()
     vary = (Y ** 2).sum()
-    Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
+    Ts = np.empty((n, K), order="F")        # (its leading columns are contiguous operands of the projections)
+    U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
     T = [np.empty((n, K)) for _ in range(B)]
     nu_all = np.empty((B, K))
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
@@ -498,7 +499,8 @@ def _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
     varx = varxb.sum()
     vary = (Y ** 2).sum()
     eng.slot("Wn", K); eng.slot("P", K); eng.slot("WP", 2)
-    Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
+    Ts = np.empty((n, K), order="F")        # (its leading columns are contiguous operands of the projections)
+    U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
     T = [np.empty((n, K)) for _ in range(B)]
     nu_all = np.empty((B, K))
     evx, evy, evxb, Acorr, iters = [], [], np.empty((B, K)), np.empty((B, K)), []
@@ -835,7 +837,8 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
     varx = varxb.sum()
     vary = (Y ** 2).sum()
     F = _psd_factor(Y.T.dot(Y))
-    Ts = np.empty((n, K)); U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
+    Ts = np.empty((n, K), order="F")        # (its leading columns are contiguous operands of the projections)
+    U = np.empty((n, K)); V = np.empty((q, K)); A = np.empty((B, K))
     T = [np.empty((n, K)) for _ in range(B)]
     blk_nrm = np.empty((B, K)); tot_nrm = np.empty(K)
     evx, evy, evxb, Acorr = [], [], np.empty((B, K)), np.empty((B, K))
@@ -1246,7 +1249,7 @@ def fit_simpls(eng, Y, K, standardize):
     cS = K + 1                                              # first S column inside Z
     eng.slot("Z", nz); eng.slot("R", K); eng.slot("W", K); eng.slot("P", K)
     eng.use_lazy_deflation(K, "P", prefer="lazy")           # (never deflates: the never-writes-X passes when they apply)
-    XS = np.empty((n, q)); XV = np.empty((n, K))
+    XS = np.empty((n, q)); XV = np.empty((n, K), order="F")
     _, tb, _ = eng.prepare(standardize, v=Y[:, 0:1], alpha=1.0, g_slot=("Z", cS))       # S[:, 0] = X^T y_0 (:998), X S[:, 0]
     XS[:, 0] = tb.sum(axis=1)
     if q == 2:
@@ -1258,7 +1261,7 @@ def fit_simpls(eng, Y, K, standardize):
         XS[:, 1:] = eng.x_w_slot("Z", cS + 1, q - 1)
     rm = getattr(eng, "rowmask", None)
     inc = None if rm is None else (np.asarray(rm).ravel() != 0)
-    Ts = np.empty((n, K)); U = np.empty((n, K)); Q = np.empty((q, K))
+    Ts = np.empty((n, K), order="F"); U = np.empty((n, K)); Q = np.empty((q, K))   # (F: contiguous leading columns)
     W_h, R_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
 
     def fetch_cols(c):          # columns of a finished component leave on the copy stream, beside a pass over X
@@ -1328,7 +1331,7 @@ def _fit_simpls_products(eng, Y, K, standardize):
     eng.xt_v(Y, 1.0, "Z", cS)                               # S = X^T Y (:998)
     rm = getattr(eng, "rowmask", None)
     inc = None if rm is None else (np.asarray(rm).ravel() != 0)
-    Ts = np.empty((n, K)); U = np.empty((n, K)); Q = np.empty((q, K))
+    Ts = np.empty((n, K), order="F"); U = np.empty((n, K)); Q = np.empty((q, K))   # (F: contiguous leading columns)
     W_h, R_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
 
     def fetch_cols(c):          # columns of a finished component leave on the copy stream, beside a pass over X
