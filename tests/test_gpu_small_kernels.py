@@ -150,3 +150,32 @@ def test_device_transpose_and_xtx_through_the_gram_kernel(n, p):
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
     assert np.array_equal(got, got.T)
     G.free(); Xt.close(); Xd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,K", [(1, 1), (1000, 5), (70_001, 12), (600_000, 3)])
+def test_r_update_builds_w_times_inverse_of_a_triangular_matrix(p, K):
+    """mbpls_hip_queue_r_update / mbpls_hip_flush_r_update: R[:, k] = (W[:, k] - sum_{i<k} R[:, i] C[i, k]) / C[k, k] and
+    beta += R[:, k] v_k -- R_ = W (P^T W)^+ (mbpls.py:988) for the upper-triangular P^T W of a PLS fit, one column per
+    call.  Here each update goes by itself (no column pass to carry it)."""
+    import mbpls_amd
+    from mbpls_amd import _capi
+    ctx = mbpls_amd.get_context()
+    lib = ctx.lib
+    rng = np.random.default_rng(p + K)
+    W = np.asfortranarray(rng.standard_normal((p, K)))
+    Cm = np.triu(rng.standard_normal((K, K))) + 3.0 * np.eye(K)
+    v = rng.standard_normal(K)
+    dW, dC, dv = ctx.from_host(W.ravel(order="F")), ctx.from_host(np.asfortranarray(Cm).ravel(order="F")), ctx.from_host(v)
+    dR, dbeta = ctx.empty(p * K), ctx.empty(p)
+    for k in range(K):
+        _capi.check(lib.mbpls_hip_queue_r_update(ctx.handle, p, dW.ptr + 8 * p * k, dR.ptr, p, k, dC.ptr + 8 * K * k,
+                                                 dv.ptr + 8 * k, dbeta.ptr))
+        _capi.check(lib.mbpls_hip_flush_r_update(ctx.handle))
+        _capi.check(lib.mbpls_hip_flush_r_update(ctx.handle))          # nothing queued: a no-op
+    R = dR.get().reshape(K, p).T
+    want = W.dot(np.linalg.inv(Cm))
+    assert np.abs(R - want).max() <= 1e-12 * np.abs(want).max()
+    assert np.abs(dbeta.get() - want.dot(v)).max() <= 1e-12 * max(1.0, np.abs(want.dot(v)).max())
+    for a in (dW, dC, dv, dR, dbeta):
+        a.free()
