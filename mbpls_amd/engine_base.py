@@ -26,7 +26,7 @@ class EngineBase:
         self.timings = {}
 
     # ---- host buffers
-    def host_array(self, shape, reserve=None, prefault=True):
+    def host_array(self, shape, reserve=None, prefault=True, prefault_tail_only=False):
         return np.empty(shape, order="F")
 
     def fetch_async(self, name):

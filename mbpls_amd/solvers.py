@@ -170,8 +170,9 @@ class FitResult(dict):
 
 def _host_array(eng, shape):
     """F-ordered host array for a p x K attribute that is filled column by column DURING the fit (the copies' own page
-    faults hide behind the passes: no helper-thread mapping for these)"""
-    return eng.host_array(shape, prefault=False)
+    faults hide behind the passes: no helper-thread mapping for these -- except for the LAST column, which arrives behind
+    the last pass)"""
+    return eng.host_array(shape, prefault=False, prefault_tail_only=True)
 
 
 class _ResponseProducts:
