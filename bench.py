@@ -828,11 +828,16 @@ def side_legs(ctx, mbpls_amd, a, mdl, X, Y, dT, r, n, p, K, q, single_block, bar
     solvers on the same matrix"""
     extras = {}
     if a.method == "NIPALS" and q == 1:
+        proxy = None
+        if p >= 8 * 1024:
+            # (first: a millisecond-scale host measurement is best taken before the legs that leave tens of thousands
+            # of Python objects and 32 GB of freed pool memory behind)
+            note("extras: shard proxy")
+            proxy = shard_proxy(ctx, mbpls_amd, dT, Y, r, n, p // 8, K, full_fit_s)
         note("extras: explicit deflation, fixed-point route")
         extras = nipals_extras(ctx, mdl, X, Y, n, p, barrier_sync)
-        if p >= 8 * 1024:
-            note("extras: shard proxy")
-            extras["shard_proxy"] = shard_proxy(ctx, mbpls_amd, dT, Y, r, n, p // 8, K, full_fit_s)
+        if proxy is not None:
+            extras["shard_proxy"] = proxy
         if single_block:
             note("extras: other solvers on the same matrix")
             extras["other_solvers_same_matrix"] = other_solvers(ctx, X, n, K, r)
