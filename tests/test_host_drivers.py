@@ -176,3 +176,45 @@ def test_one_response_noise_floor_is_a_stagnation_rule():
             assert it == it_ref and conv
         else:
             assert not conv and it <= solvers.NIPALS_Q1_NOISE_FLOOR_MAX
+
+
+def test_leading_singular_vector_of_a_tall_thin_matrix():
+    """solvers._tlsv: the leading left singular vector through the q x q Gram matrix (tall thin operands of the n >= p
+    branches, mbpls.py:396-400 / :590) equals LAPACK's to rounding -- also with a wide spread of singular values -- and a
+    nearly double leading singular value takes the SVD itself."""
+    from mbpls_amd import solvers
+    rng = np.random.RandomState(3)
+    for m, q, spread in ((500, 3, 1.0), (20000, 10, 1e-6), (4096, 16, 1e-10)):
+        A = rng.standard_normal((m, q)) * np.logspace(0, np.log10(spread), q)
+        want = np.linalg.svd(A, full_matrices=False)[0][:, 0:1]
+        got = solvers._tlsv(A)
+        s = np.sign((want * got).sum())
+        assert np.abs(got * s - want).max() < 1e-13
+        assert abs(np.linalg.norm(got) - 1.0) < 1e-14
+    # two equal leading singular values: the Gram route is not taken (whatever LAPACK returns is returned)
+    Q = np.linalg.qr(rng.standard_normal((300, 4)))[0]
+    A = Q * np.array([2.0, 2.0, 1.0, 0.5])
+    assert np.array_equal(solvers._tlsv(A), np.linalg.svd(A, full_matrices=False)[0][:, 0:1])
+    # one column: just normalised
+    a = rng.standard_normal((50, 1))
+    assert np.allclose(solvers._tlsv(a), a / np.linalg.norm(a))
+
+
+def test_host_thread_limits_are_set_and_put_back():
+    """runtime.host_threads: BLAS / OpenMP pools larger than the CPU quota are limited for the duration of a fit and
+    restored afterwards (what threadpoolctl.limit does, without its per-call inventory)."""
+    from mbpls_amd import runtime
+    runtime._thread_limits()
+    tp = runtime._state.get("tp")
+    if tp is None or not tp.lib_controllers:
+        pytest.skip("no thread pools to control here")
+    before = [lc.num_threads for lc in tp.lib_controllers]
+    old = runtime._state["tp_limit"]
+    runtime._state["tp_limit"] = 1
+    try:
+        with runtime.host_threads() as h:
+            assert all(lc.num_threads == 1 for lc in tp.lib_controllers if (lc.num_threads is not None))
+            assert len(h.changed) == sum(1 for b in before if b is not None and b > 1)
+    finally:
+        runtime._state["tp_limit"] = old
+    assert [lc.num_threads for lc in tp.lib_controllers] == before
