@@ -473,7 +473,7 @@ int mbpls_hip_event_record(mbpls_ctx* ctx, void** event);
  * scalars a kernel hands to a waiting host thread -- a blocking copy of 8 bytes into pageable memory is a blit kernel
  * that queues up behind (and slows) whatever is running.                                                           */
 int mbpls_hip_host_alloc(mbpls_ctx* ctx, size_t bytes, void** h_ptr, void** d_ptr);
-int mbpls_hip_host_free(mbpls_ctx* ctx, void* h_ptr);
+int mbpls_hip_host_free(mbpls_ctx* ctx, void* h_ptr);   /* (blocks still allocated are released by mbpls_hip_destroy) */
 int mbpls_hip_memcpy_d2h_after(mbpls_ctx* ctx, void* event, void* h_dst, const void* d_src, size_t bytes);
 int mbpls_hip_event_destroy(mbpls_ctx* ctx, void* event);
 /* The copier: one native thread per context that carries finished results to the host while the compute stream keeps

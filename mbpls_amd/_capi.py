@@ -255,9 +255,7 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
-            if getattr(self, "_mapped", None) is not None:
-                self.lib.mbpls_hip_host_free(self.handle, self._mapped[2])
-                self._mapped = None
+            self._mapped = None     # (released by mbpls_hip_destroy, once the copier thread -- which may poll a flag in it -- has stopped)
             self.trim_pool()
             self.lib.mbpls_hip_destroy(self.handle)
             self.handle = None

@@ -126,6 +126,7 @@ struct mbpls_ctx {
   unsigned pin_small_next = 0;
   void* pin_copier = nullptr;          // pinned bounce buffer of the copier thread's device-to-host copies (<= 4 MB)
   std::mutex pin_mutex;
+  std::vector<void*> host_blocks;      // mbpls_hip_host_alloc'd memory not yet freed (released by mbpls_hip_destroy AFTER the copier thread, which may be polling a flag in it, has stopped)
   void* copier = nullptr;    // CopierState* (copier.hip): the thread that carries finished columns to the host
   RUpdate r_update;          // queued by mbpls_hip_queue_r_update, consumed by reduce_chunks / mbpls_hip_flush_r_update
   int step_reg = 1;          // device-resident step: the register-resident kernel where it applies (step_reg.hip); 0 = general kernel

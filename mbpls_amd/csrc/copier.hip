@@ -84,6 +84,7 @@ struct CopierState {
   std::mutex hmu;
   std::condition_variable cv_help;
   std::atomic<bool> hstop{false};
+  std::atomic<bool> stopping{false};       // the context is being destroyed: a job still waiting for its flag gives up
 };
 
 constexpr int COPIER_HELPERS = 3;
@@ -188,6 +189,10 @@ static int copier_run(CopierState* cs, CopierJob& job) {
     for (unsigned spins = 0; !(*job.flag >= job.flag_min); ++spins) {
       if (spins < 4000) __builtin_ia32_pause();
       else std::this_thread::sleep_for(std::chrono::microseconds(20));
+      if (cs->stopping.load(std::memory_order_relaxed)) {
+        cs->error_text = "the context was destroyed while a copy job was waiting for its flag";
+        return MBPLS_ERR_HIP;
+      }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
   }
@@ -324,6 +329,7 @@ static int copier_get(mbpls_ctx* ctx, CopierState** out) {
 void copier_shutdown(mbpls_ctx* ctx) {
   auto* cs = (CopierState*)ctx->copier;
   if (!cs) return;
+  cs->stopping.store(true);
   {
     std::lock_guard<std::mutex> lock(cs->mu);
     cs->stop = true;

@@ -253,6 +253,8 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   mbpls::copier_shutdown(ctx);
+  for (void* hb : ctx->host_blocks) (void)hipHostFree(hb);
+  ctx->host_blocks.clear();
   if (ctx->rccl) (void)mbpls_hip_comm_destroy(ctx);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->stage) (void)hipFree(ctx->stage);
@@ -382,6 +384,10 @@ int mbpls_hip_host_alloc(mbpls_ctx* ctx, size_t bytes, void** h_ptr, void** d_pt
   MB_HIP(hipHostMalloc(h_ptr, bytes, hipHostMallocMapped | hipHostMallocCoherent));
   memset(*h_ptr, 0, bytes);
   MB_HIP(hipHostGetDevicePointer(d_ptr, *h_ptr, 0));
+  {
+    std::lock_guard<std::mutex> lock(ctx->pin_mutex);
+    ctx->host_blocks.push_back(*h_ptr);
+  }
   return MBPLS_OK;
 }
 
@@ -389,6 +395,11 @@ int mbpls_hip_host_free(mbpls_ctx* ctx, void* h_ptr) {
   MB_ARG(ctx, "ctx is NULL");
   if (!h_ptr) return MBPLS_OK;
   MB_HIP(hipStreamSynchronize(ctx->stream));
+  {
+    std::lock_guard<std::mutex> lock(ctx->pin_mutex);
+    auto it = std::find(ctx->host_blocks.begin(), ctx->host_blocks.end(), h_ptr);
+    if (it != ctx->host_blocks.end()) ctx->host_blocks.erase(it);
+  }
   MB_HIP(hipHostFree(h_ptr));
   return MBPLS_OK;
 }

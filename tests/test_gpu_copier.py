@@ -94,3 +94,23 @@ def test_a_job_can_wait_for_a_value_in_host_mapped_memory_instead_of_an_event():
     ctx.copier_wait(later)
     assert np.array_equal(out, src)
     assert t < later
+
+
+def test_destroying_the_context_releases_a_job_that_waits_for_its_flag():
+    """a job whose flag is never stored must not keep mbpls_hip_destroy from returning"""
+    import time
+    from mbpls_amd import _capi
+    ctx = _capi.Context(0)
+    src = np.arange(64.0)
+    dev = ctx.from_host(src)
+    ctx.sync()
+    flags, _ = ctx.mapped_scalars(16)
+    flags[3] = 0.0
+    out = np.full(64, np.nan)
+    ctx.copier_submit([(out, dev.ptr)], flag=(flags.ctypes.data + 8 * 3, 1.0))
+    time.sleep(0.02)
+    t = time.perf_counter()
+    dev.free()
+    ctx.close()
+    assert time.perf_counter() - t < 2.0
+    assert np.isnan(out).all()
