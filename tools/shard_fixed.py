@@ -18,6 +18,13 @@ if "--cpc" in sys.argv:
     ctx.set_tunable("chunks_per_cu", int(sys.argv[sys.argv.index("--cpc") + 1]))
 Ts, Y = planted(n, 1, 32, 0)
 dT = ctx.from_host(Ts)
+if "--with-big" in sys.argv:          # as in bench.py's side-leg process: the full matrix resident, two fits of it first
+    Xbig = DeviceMatrix(ctx, n, 1_000_000, [0, 1_000_000])
+    Xbig.fill_latent(dT, 32, 0.5, 1234, 0)
+    ctx.sync()
+    big = MBPLS(n_components=K)
+    for _ in range(2):
+        big.fit(Xbig, Y)
 if "--local" in sys.argv:
     X = DeviceMatrix(ctx, n, p, [0, p])
     X.fill_latent(dT, 32, 0.5, 1234, 0)
