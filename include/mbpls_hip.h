@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 6   /* 6: mbpls_hip_mat_transpose; mbpls_nipals_step.C / ldc / host_seq, mbpls_hip_queue_r_update, mbpls_hip_flush_r_update (R_ / beta_ column by column during the fit), mbpls_hip_copier_submit / _wait (native copier thread); 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
+#define MBPLS_HIP_ABI_VERSION 6   /* 6: mbpls_hip_mat_transpose; mbpls_nipals_step.C / ldc / host_seq, mbpls_hip_queue_r_update, mbpls_hip_flush_r_update (R_ / beta_ column by column during the fit), mbpls_hip_copier_submit / _wait (native copier thread; replaces mbpls_hip_event_record / _memcpy_d2h_after / _event_destroy); 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
 
 enum {
   MBPLS_OK = 0,
@@ -465,17 +465,11 @@ int mbpls_hip_block_unit_col(const mbpls_mat* m, const double* d_src, double* d_
 int mbpls_hip_set_true_space_outputs(mbpls_ctx* ctx, const double* d_rscale, double* d_p_true);
 /* d_dst[j] = d_src[j] * d_scalar[0] for a p-length column (UNIPALS: w = X^T u = c X^T y, mbpls.py:503).              */
 int mbpls_hip_scale_col_by(mbpls_ctx* ctx, int64_t p, const double* d_src, double* d_dst, const double* d_scalar);
-/* Ordered device-to-host copies for finished columns: record an event behind the kernels queued so far; a HELPER
- * thread then waits for that event only (not for the stream) and copies on the copy stream, so the queueing thread
- * never blocks.                                                                                                   */
-int mbpls_hip_event_record(mbpls_ctx* ctx, void** event);
 /* Pinned host memory the device can write directly (zero copy): *h_ptr for the host, *d_ptr for kernels.  For a few
  * scalars a kernel hands to a waiting host thread -- a blocking copy of 8 bytes into pageable memory is a blit kernel
  * that queues up behind (and slows) whatever is running.                                                           */
 int mbpls_hip_host_alloc(mbpls_ctx* ctx, size_t bytes, void** h_ptr, void** d_ptr);
 int mbpls_hip_host_free(mbpls_ctx* ctx, void* h_ptr);   /* (blocks still allocated are released by mbpls_hip_destroy) */
-int mbpls_hip_memcpy_d2h_after(mbpls_ctx* ctx, void* event, void* h_dst, const void* d_src, size_t bytes);
-int mbpls_hip_event_destroy(mbpls_ctx* ctx, void* event);
 /* The copier: one native thread per context that carries finished results to the host while the compute stream keeps
  * running (csrc/copier.hip).  A job = an event recorded on the compute stream NOW + device-to-host copies that run once
  * it has completed + optionally the block normalisation of a column that has just arrived,

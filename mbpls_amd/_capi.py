@@ -123,11 +123,8 @@ SIGNATURES = {
     "mbpls_hip_mat_transpose": (_int, [_vp, _vp]),
     "mbpls_hip_queue_r_update": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _vp]),
     "mbpls_hip_flush_r_update": (_int, [_vp]),
-    "mbpls_hip_event_record": (_int, [_vp, _pp]),
     "mbpls_hip_host_alloc": (_int, [_vp, _sz, _pp, _pp]),
     "mbpls_hip_host_free": (_int, [_vp, _vp]),
-    "mbpls_hip_memcpy_d2h_after": (_int, [_vp, _vp, _vp, _vp, _sz]),
-    "mbpls_hip_event_destroy": (_int, [_vp, _vp]),
     "mbpls_hip_cross_product": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp]),
     "mbpls_hip_cv_weights": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbpls_hip_xt_v_centred": (_int, [_vp, _vp, _int, _vp, _i64, _int, _vp, _i64]),

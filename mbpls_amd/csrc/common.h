@@ -124,7 +124,6 @@ struct mbpls_ctx {
   void* pin_small = nullptr;           // ... and of the small ones (vectors, parameter blocks): SMALL_PIN_SLOTS x 256 KB
   hipEvent_t pin_small_ev[SMALL_PIN_SLOTS];
   unsigned pin_small_next = 0;
-  void* pin_copier = nullptr;          // pinned bounce buffer of the copier thread's device-to-host copies (<= 4 MB)
   std::mutex pin_mutex;
   std::vector<void*> host_blocks;      // mbpls_hip_host_alloc'd memory not yet freed (released by mbpls_hip_destroy AFTER the copier thread, which may be polling a flag in it, has stopped)
   void* copier = nullptr;    // CopierState* (copier.hip): the thread that carries finished columns to the host

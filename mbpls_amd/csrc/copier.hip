@@ -12,8 +12,13 @@
 // between any two copies and took 200-320 us per 1 MB column that costs 60 us by itself (tools/host_timeline.py, shard
 // sized fit: 0.45 of the 1.5 ms it spent outside its passes).  Here nothing takes a lock the fitting thread holds, copies
 // of up to 4 MB are double-buffered through two pinned bounce buffers (the DMA of copy i+1 runs while copy i is moved to
-// its destination; why small copies bounce at all: resident.hip, mbpls_hip_memcpy_d2h_after), and the waiter spins
-// briefly before it sleeps.
+// its destination), and the waiter spins briefly before it sleeps.
+//
+// Why small copies bounce at all: for a pageable destination the runtime pins the caller's pages for the transfer, and with
+// 1.3 MB columns (n = 6000, p = 166 666: the scaler statistics sent out behind the first pass) every later fit's first
+// host-to-device copy then EXECUTED 26-36 ms late on an idle GPU -- a 10 ms fit took 40 (rocprofv3 copy trace; gone with
+// MBPLS_STREAM_STATS=0, profiles/r04_stall_n6000.txt).  Large columns (8 MB at BASELINE config[1]) keep the direct path:
+// 55 GB/s into pages the host side has mapped.
 //
 // The move out of the bounce buffer is what a small copy costs: one core moves ~7 GB/s into fresh pages (MBPLS_COPIER_TRACE=1:
 // 3 MB behind the last pass = 25 us of waiting for the DMA and 410 us of memcpy; the block normalisation as a second sweep

@@ -266,7 +266,6 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->pin_d2h) (void)hipHostFree(ctx->pin_d2h);
-  if (ctx->pin_copier) (void)hipHostFree(ctx->pin_copier);
   if (ctx->pin_small) {
     for (hipEvent_t e : ctx->pin_small_ev)
       if (e) (void)hipEventDestroy(e);

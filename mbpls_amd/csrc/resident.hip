@@ -619,59 +619,6 @@ int mbpls_hip_scale_col_by(mbpls_ctx* ctx, int64_t p, const double* d_src, doubl
   return MBPLS_OK;
 }
 
-/* ---- ordered device-to-host copies: the copy waits (on the copy stream / in the calling thread) for an event
- * recorded on the compute stream, not for the whole stream -- finished columns leave while later passes run, and
- * the thread that queues the passes never blocks. */
-int mbpls_hip_event_record(mbpls_ctx* ctx, void** event) {
-  MB_ARG(ctx && event, "NULL argument");
-  hipEvent_t e = nullptr;
-  if (!ctx->copy_stream) MB_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-  {
-    std::lock_guard<std::mutex> lock(ctx->user_event_mutex);
-    if (!ctx->user_event_pool.empty()) {
-      e = ctx->user_event_pool.back();
-      ctx->user_event_pool.pop_back();
-    }
-  }
-  if (!e) MB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  MB_HIP(hipEventRecord(e, ctx->stream));
-  *event = (void*)e;
-  return MBPLS_OK;
-}
-
-int mbpls_hip_memcpy_d2h_after(mbpls_ctx* ctx, void* event, void* h_dst, const void* d_src, size_t bytes) {
-  MB_ARG(ctx && event, "NULL argument");
-  MB_HIP(hipSetDevice(ctx->device));   // called from a helper thread (the current device is per thread)
-  MB_HIP(hipEventSynchronize((hipEvent_t)event));
-  if (bytes == 0) return MBPLS_OK;
-  MB_ARG(h_dst && d_src && ctx->copy_stream, "NULL argument");
-  // Copies of a few MB bounce through a pinned buffer of the copier thread: for a pageable destination the runtime
-  // pins the caller's pages for the transfer, and with 1.3 MB columns (n = 6000, p = 166 666: the scaler statistics
-  // sent out behind the first pass) every later fit's first host-to-device copy then EXECUTED 26-36 ms late on an idle
-  // GPU -- a 10 ms fit took 40 (rocprofv3 copy trace; gone with MBPLS_STREAM_STATS=0, profiles/r04_stall_n6000.txt).
-  // Large columns (8 MB at BASELINE config[1]) keep the direct path: 55 GB/s into pages the helper thread has mapped.
-  constexpr size_t COPIER_BOUNCE = (size_t)4 << 20;
-  if (bytes <= COPIER_BOUNCE) {
-    if (!ctx->pin_copier) MB_HIP(hipHostMalloc(&ctx->pin_copier, COPIER_BOUNCE, hipHostMallocDefault));
-    MB_HIP(hipMemcpyAsync(ctx->pin_copier, d_src, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
-    MB_HIP(hipStreamSynchronize(ctx->copy_stream));
-    memcpy(h_dst, ctx->pin_copier, bytes);
-    return MBPLS_OK;
-  }
-  MB_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
-  MB_HIP(hipStreamSynchronize(ctx->copy_stream));
-  return MBPLS_OK;
-}
-
-int mbpls_hip_event_destroy(mbpls_ctx* ctx, void* event) {
-  MB_ARG(ctx, "ctx is NULL");
-  if (event) {      // back to the pool (destroyed with the context)
-    std::lock_guard<std::mutex> lock(ctx->user_event_mutex);
-    ctx->user_event_pool.push_back((hipEvent_t)event);
-  }
-  return MBPLS_OK;
-}
-
 }  // extern "C"
 
 // one kernel of this translation unit, for mbpls_hip_warmup (its code object is loaded on first use otherwise)

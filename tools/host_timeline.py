@@ -114,7 +114,6 @@ def t_copy(name, real, size_arg):
     return f
 
 
-ctx.lib.mbpls_hip_memcpy_d2h_after = t_copy("d2h_after", ctx.lib.mbpls_hip_memcpy_d2h_after, 4)
 ctx.lib.mbpls_hip_memcpy_d2h = t_copy("d2h", ctx.lib.mbpls_hip_memcpy_d2h, 3)
 
 tail_events = []
