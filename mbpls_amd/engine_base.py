@@ -59,7 +59,17 @@ class EngineBase:
         pass
 
     def xtx_operator(self):
-        """callable w (p x c host) -> (X^T X) w: here through a host copy of the p x p matrix"""
+        """callable w (p x c host) -> (X^T X) w: here through a host copy of the p x p matrix.  Column shards: the
+        rows of X^T X that belong to this rank's features need every rank's columns, so (X^T X) w is taken as
+        X_r^T (sum over ranks of X_s w_s) -- two products per call, the first one summed over the shards."""
+        if getattr(self.comm, "is_distributed", False):
+            def apply(w):
+                w = np.asarray(w, dtype=np.float64).reshape(self.p, -1)
+                t = self.x_w_host(w)                        # n x c, summed over the shards
+                self.slot("XtXw", w.shape[1])
+                self.xt_v(t, 1.0, "XtXw", 0)
+                return self.fetch("XtXw")[:, :w.shape[1]].copy()
+            return apply
         self.slot("XtX", self.p)
         self.xt_self("XtX")
         VAR = self.fetch("XtX")

@@ -69,13 +69,22 @@ def _psd_factor(G):
     return Q * np.sqrt(np.clip(lam, 0.0, None))
 
 
-def _tlsv(thin):
-    """first left singular vector of a thin matrix (host LAPACK), n x 1.  Tall and thin (m >= 8 q): from the leading
+def _tlsv(thin, reduce=None):
+    """first left singular vector of a thin matrix (host LAPACK), n x 1.  ``reduce`` (column shards: the ROWS of a p x q
+    operand are split over the ranks): the sum over ranks of a small host array -- the Gram route below is then the
+    only one (its q x q matrix and the norm of the vector are sums over the row shards).
+    Tall and thin (m >= 8 q): from the leading
     eigenvector v1 of the q x q Gram matrix, u1 = A v1 / ||A v1|| -- for the LEADING pair the squared spectrum costs at
     most a factor (s1 + s2)/s1 in the perturbation bound, and one q x q eigenproblem + two products replace LAPACK's
     QR-then-SVD of all q vectors (20 000 x 10: 1.3 -> 0.1 ms per component on the GPU box's host, 39 -> 1.8 ms here);
     a nearly double leading singular value (where the vector is ill-determined either way) takes the SVD."""
     m, q = thin.shape
+    if reduce is not None:
+        if q == 1:
+            return thin / np.sqrt(reduce(thin.T.dot(thin)).item())
+        lam, vec = np.linalg.eigh(reduce(thin.T.dot(thin)))
+        u = thin.dot(vec[:, -1:])
+        return u / np.sqrt(reduce(u.T.dot(u)).item())
     if q == 1:
         return thin / np.linalg.norm(thin)
     if m >= 8 * q:
@@ -996,7 +1005,7 @@ def fit_unipals(eng, Y, K, standardize, keep_raw_weights=False):
             lazy = nodeflate_tall
             eng.xt_v(Y - Tp.dot(Tp.T.dot(Y)) if (lazy and k) else Y, 1.0, "S", 0)
             C = eng.fetch("S")[:, :q]
-            w = _tlsv(C)                                    # (:396-400): S = C C^T is symmetric
+            w = _tlsv(C, eng.comm.allreduce_host if eng.comm.is_distributed else None)   # (:396-400): S = C C^T is symmetric
             eng.put_col("Wc", k, w)
             tb = eng.x_w_slot("Wc", k, 1, per_block=True)
             t_raw = np.hstack(tb)
@@ -1193,21 +1202,24 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
     Wc = np.empty((p, 0)); P = np.empty((p, 0)); V = np.empty((q, 0)); U = np.empty((n, 0))
     Gd = np.empty((p, 0)); dens = np.empty(0)
     _plan(eng, solver="kernel n >= p: rank-1 deflation of X^T X, one p x p product per component")
+    # (column shards: every p-length inner product below is a sum over the ranks' rows)
+    ar = eng.comm.allreduce_host
     for k in range(K):
-        w = _tlsv(COV)                                      # S = COV COV^T stays true under :631,:633
+        w = _tlsv(COV, ar if eng.comm.is_distributed else None)    # S = COV COV^T stays true under :631,:633
         g = var0(w)                                         # VAR_0 w
         if k:
-            g = g - Gd.dot(Gd.T.dot(w) / dens[:, None])     # ... - sum_i g_i (g_i^T w) / den_i  =  VAR_k w
-        den = w.T.dot(g).item()                             # (:595)
-        v = w.T.dot(COV) / den                              # (:596)
+            g = g - Gd.dot(ar(Gd.T.dot(w)) / dens[:, None])   # ... - sum_i g_i (g_i^T w) / den_i  =  VAR_k w
+        den = ar(w.T.dot(g)).item()                         # (:595)
+        wC = ar(w.T.dot(COV))
+        v = wC / den                                        # (:596)
         pl = g.T / den                                      # (:599)  w^T VAR / den, VAR symmetric
         if calc_all:
             u = Y.dot(v.T) / v.dot(v.T)                     # (:624-625)
             U = np.hstack((U, u / np.linalg.norm(u)))
-        COV = COV - pl.T.dot(w.T.dot(COV))                  # (:633)
+        COV = COV - pl.T.dot(wC)                            # (:633)
         Gd = np.hstack((Gd, g)); dens = np.append(dens, den)
         V = np.hstack((V, v.T)); P = np.hstack((P, pl.T)); Wc = np.hstack((Wc, w))
-    R = Wc.dot(np.linalg.pinv(P.T.dot(Wc)))                 # (:642)
+    R = Wc.dot(np.linalg.pinv(ar(P.T.dot(Wc))))             # (:642)
     beta = R.dot(V.T)                                       # (:643)
     Ts = eng.x_w_host(R)                                    # (:644)
     nrm = np.linalg.norm(Ts, axis=0)
@@ -1217,7 +1229,7 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
     if calc_all:
         offs = eng.block_offsets
         eng.put("Wblk", Wc)
-        wnorm2 = np.array([(Wc[offs[b]:offs[b + 1]] ** 2).sum(axis=0) for b in range(B)])
+        wnorm2 = ar(np.array([(Wc[offs[b]:offs[b + 1]] ** 2).sum(axis=0) for b in range(B)]))
         _kernel_extras(eng, res, Y, P, V, Ts, varxb, "Wblk", wnorm2)
     res.R_ = R
     res.beta_ = beta

@@ -52,6 +52,23 @@ def main():
         assert util.relerr(yh, orc.predict(ref, full)) < 1e-8, method
         if method == "NIPALS" and q == 1:
             assert mdl.nipals_iterations_ == ref.nipals_iterations_
+    # n >= p (mbpls.py:388-479, :580-692): the leading singular vector of a p x q matrix whose rows are split over the
+    # ranks, (X^T X) w from every rank's columns
+    X, Y = orc.make_latent(700, 500, q, r=8, seed=6)
+    sizes = [200, 300]
+    full = list(np.split(X, np.cumsum(sizes)[:-1], axis=1))
+    ranges = shard_columns(sizes, rank, world)
+    local = [np.ascontiguousarray(b[:, lo:hi]) for b, (lo, hi) in zip(full, ranges)]
+    for method in ("UNIPALS", "KERNEL"):
+        ref = orc.fit(full, Y, n_components=3, method=method, full_svd=True)
+        with mbpls_amd.column_sharded(comm):
+            mdl = MBPLS(n_components=3, method=method).fit(local, Y)
+            yh = mdl.predict(local)
+        s = np.sign(np.sum(ref.Ts_ * mdl.Ts_, axis=0))
+        assert util.relerr(mdl.Ts_ * s, ref.Ts_) < 1e-8, ("n >= p", method)
+        for b, (lo, hi) in enumerate(ranges):
+            assert util.relerr(mdl.P_[b] * s, ref.P_[b][lo:hi]) < 1e-8, ("n >= p", method)
+        assert util.relerr(yh, orc.predict(ref, full)) < 1e-8, ("n >= p", method)
     print(f"rank {rank}/{world}: RCCL-sharded fit == oracle ({which}, q={q})", flush=True)
     dist.barrier()
     dist.destroy_process_group()

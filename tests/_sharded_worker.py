@@ -24,7 +24,18 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     comm = TorchDistComm(device=None)
-    g = util.load("matrix_pgtn")
+    worst = 0.0
+    # p > n and n >= p: the n >= p branches of UNIPALS / KERNEL (mbpls.py:388-479, :580-692) take their leading singular
+    # vector from a p x q matrix whose ROWS are split over the ranks, and X^T X w needs every rank's columns
+    for fixture in ("matrix_pgtn", "matrix_ngtp"):
+        worst = max(worst, one_fixture(util.load(fixture), rank, world, comm))
+    # all ranks must have taken identical decisions (iteration counts) and agree on the global scores
+    print(f"rank {rank}: sharded == unsharded reference, worst rel err {worst:.2e}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def one_fixture(g, rank, world, comm):
     splits = [int(s) for s in g["splits"]]
     cuts = np.cumsum(splits)[:-1]
     worst = 0.0
@@ -65,10 +76,7 @@ def main():
                     else:
                         sref[k] = v
                 worst = max(worst, util.compare(flat, sref, 1e-9, what=f"rank{rank}/q{q}/{blocks}/{m}"))
-    # all ranks must have taken identical decisions (iteration counts) and agree on the global scores
-    print(f"rank {rank}: sharded == unsharded reference, worst rel err {worst:.2e}", flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+    return worst
 
 
 if __name__ == "__main__":
