@@ -102,6 +102,23 @@ def main():
         ref = ors.fit(fulls, Y, n_components=3)
         mdl = MBPLS(n_components=3, sparse_data=True).fit(locals_, Y)
         check(mdl, ref, ranges, fulln, localn, Yn, "sparse", ors.predict, ors.transform)
+        # n >= p (mbpls.py:388-479, :580-692 and the NIPALS / SIMPLS paths on such data): row-sharded p x q operands
+        sizes2 = [201, 300]
+        X2, Y2 = orc.make_latent(700, sum(sizes2), q, r=8, seed=7)
+        Xn2, Yn2 = orc.make_latent(40, sum(sizes2), q, r=8, seed=8)
+        cuts2 = np.cumsum(sizes2)[:-1]
+        ranges2 = shard_columns(sizes2, rank, world)
+
+        def shard2(A):
+            full = list(np.split(A, cuts2, axis=1))
+            return full, [np.ascontiguousarray(b[:, lo:hi]) for b, (lo, hi) in zip(full, ranges2)]
+
+        full2, local2 = shard2(X2)
+        full_new2, local_new2 = shard2(Xn2)
+        for method in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+            ref = orc.fit(full2, Y2, n_components=3, method=method, full_svd=True)
+            mdl = MBPLS(n_components=3, method=method).fit(local2, Y2)
+            check(mdl, ref, ranges2, full_new2, local_new2, Yn2, method + " n>=p", orc.predict, orc.transform)
     print(f"rank {rank}/{world}: sharded fit on a shared GPU == oracle", flush=True)
     dist.barrier()
     dist.destroy_process_group()
