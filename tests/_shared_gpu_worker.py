@@ -92,6 +92,10 @@ def main():
         mbpls_amd.get_context().set_tunable("long_columns_from", 0)
         check(MBPLS(n_components=3).fit(local, Y), ref, ranges, full_new, local_new, Yn, "long", orc.predict,
               orc.transform)
+        for method in ("UNIPALS", "KERNEL", "SIMPLS"):         # ... and the other solvers' routes for long columns
+            ref_m = orc.fit(full, Y, n_components=3, method=method, full_svd=True)
+            check(MBPLS(n_components=3, method=method).fit(local, Y), ref_m, ranges, full_new, local_new, Yn,
+                  "long " + method, orc.predict, orc.transform)
         mbpls_amd.get_context().set_tunable("long_columns_from", 8192)
         # missing values
         rng = np.random.RandomState(3)
