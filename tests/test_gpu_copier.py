@@ -114,3 +114,32 @@ def test_destroying_the_context_releases_a_job_that_waits_for_its_flag():
     ctx.close()
     assert time.perf_counter() - t < 2.0
     assert np.isnan(out).all()
+
+
+@pytest.mark.parametrize("n,p,blocks,K,method", [(4096, 60000, 3, 6, "NIPALS"), (300, 5000, 2, 6, "NIPALS"),
+                                                 (1000, 40000, 4, 8, "UNIPALS")])
+def test_repeated_fits_are_bit_identical(n, p, blocks, K, method):
+    """Every attribute of a device-resident fit travels through the copier thread (pieces of a column moved by several
+    threads, the block normalisation fused, jobs started by events or by a step kernel's flag): forty fits of the same
+    data must agree bit for bit."""
+    import hashlib
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix
+    ctx = _ctx()
+    rng = np.random.default_rng(n)
+    T = rng.standard_normal((n, 8))
+    Y = T[:, :1] + 0.3 * rng.standard_normal((n, 1))
+    offs = [int(round(b * p / blocks)) for b in range(blocks + 1)]
+    X = DeviceMatrix(ctx, n, p, offs)
+    X.fill_latent(ctx.from_host(T), 8, 0.5, 99, 0)
+    ctx.sync()
+
+    def digest(m):
+        h = hashlib.sha1()
+        for a in [m.R_, m.beta_, m.Ts_, m.U_, m.V_] + list(m.W_) + list(m.P_) + list(m.T_):
+            h.update(np.ascontiguousarray(a).tobytes())
+        return h.hexdigest()
+
+    first = digest(MBPLS(n_components=K, method=method).fit(X, Y))
+    assert all(digest(MBPLS(n_components=K, method=method).fit(X, Y)) == first for _ in range(40))
+    X.close()
