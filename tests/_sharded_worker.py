@@ -39,9 +39,9 @@ def one_fixture(g, rank, world, comm):
     splits = [int(s) for s in g["splits"]]
     cuts = np.cumsum(splits)[:-1]
     worst = 0.0
-    for q in (1, 3):
+    for q, std, ca in ((1, 1, 1), (3, 1, 1), (1, 0, 0), (3, 0, 1), (3, 1, 0)):
         X, Y = g[f"in/q{q}/X"], g[f"in/q{q}/Y"]
-        Ys = ColumnScaler().fit(Y).transform(Y)
+        Ys = ColumnScaler().fit(Y).transform(Y) if std else Y
         for blocks in ("single", "multi"):
             full = [X] if blocks == "single" else list(np.split(X, cuts, axis=1))
             ranges = shard_columns([b.shape[1] for b in full], rank, world)
@@ -49,14 +49,14 @@ def one_fixture(g, rank, world, comm):
             for m in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
                 eng = NumpyEngine(comm).load_host_blocks(local)
                 if m == "NIPALS":
-                    res = solvers.fit_nipals(eng, Ys, 3, True)
+                    res = solvers.fit_nipals(eng, Ys, 3, bool(std), calc_all=bool(ca))
                 elif m == "UNIPALS":
-                    res = solvers.fit_unipals(eng, Ys, 3, True)
+                    res = solvers.fit_unipals(eng, Ys, 3, bool(std))
                 elif m == "KERNEL":
-                    res = solvers.fit_kernel(eng, Ys, 3, True, True)
+                    res = solvers.fit_kernel(eng, Ys, 3, bool(std), bool(ca))
                 else:
-                    res = solvers.fit_simpls(eng, Ys, 3, True)
-                ref = util.sub(g, f"ref/q{q}/{blocks}/{m}/std1/ca1")
+                    res = solvers.fit_simpls(eng, Ys, 3, bool(std))
+                ref = util.sub(g, f"ref/q{q}/{blocks}/{m}/std{std}/ca{ca}")
                 # feature-indexed attributes: compare this rank's rows with the same rows of the reference
                 flat = util.model_to_flat(res)
                 sref = {}
@@ -75,7 +75,7 @@ def one_fixture(g, rank, world, comm):
                         sref[k] = v[rows]
                     else:
                         sref[k] = v
-                worst = max(worst, util.compare(flat, sref, 1e-9, what=f"rank{rank}/q{q}/{blocks}/{m}"))
+                worst = max(worst, util.compare(flat, sref, 1e-9, what=f"rank{rank}/q{q}/{blocks}/{m}/std{std}/ca{ca}"))
     return worst
 
 
