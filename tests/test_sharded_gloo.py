@@ -4,6 +4,8 @@ import socket
 import subprocess
 import sys
 
+import pytest
+
 import numpy as np
 
 from mbpls_amd.comm import shard_columns
@@ -32,11 +34,14 @@ def test_shard_columns_partition():
             assert (w.max(axis=0) - w.min(axis=0) <= 1).all()      # balanced
 
 
-def test_sharded_fit_world2_gloo():
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_fit_gloo(world):
+    """p > n and n >= p fixtures, four methods, with / without standardisation and calc_all: every rank's shard of the
+    attributes equals the unsharded reference (three ranks: uneven shards)"""
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", PYTHONPATH=ROOT)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "_sharded_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("sharded == unsharded reference") == 2, r.stdout
+    assert r.stdout.count("sharded == unsharded reference") == world, r.stdout
