@@ -917,13 +917,15 @@ class HipEngine(EngineBase):
         n = self.n
         ldg = n + (n & 1)
         store = self._gram_store(ldg * n)
+        # (the wrapper first: creating a matrix object synchronises the stream -- behind the launch it made the host wait
+        # for the whole Gram, 1.9 s at BASELINE config[3], with nothing to do but wait)
+        Gm = _capi.DeviceMatrix(self.ctx, n, n, [0, n], storage=store.ptr)
         if self._kscale:
             # (the one-fma form, centre_first=False, measured no faster: the cost is the fifth load per k-step)
             self.X.gram(store.ptr, ldg, mean=self.mean, rscale=self.rs, centre_first=True)
         else:
             self.X.gram(store.ptr, ldg)
         self.comm.allreduce_device(store)        # partial Grams of the column shards (in place, RCCL when sharded)
-        Gm = _capi.DeviceMatrix(self.ctx, n, n, [0, n], storage=store.ptr)
         self.G = (Gm, store)
         return self
 

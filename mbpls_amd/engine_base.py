@@ -29,6 +29,9 @@ class EngineBase:
     def host_array(self, shape, reserve=None, prefault=True, prefault_tail_only=False):
         return np.empty(shape, order="F")
 
+    def run_deferred(self, count=1, all_of_it=False):
+        """host chores an estimator queued for the time the device is busy (HipEngine); nothing to do here"""
+
     def fetch_async(self, name):
         out = self.fetch(name)
         return out, (lambda: out)

@@ -1127,6 +1127,13 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
                         explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)))
     if p_total > n:
         eng.gram()                                          # AS_X (:704)
+        # the host is idle while the matrix cores build the association matrix: the p x K attributes' host arrays are
+        # allocated now (their pages mapped by the helper thread: the copies at the end then run at PCIe speed instead of
+        # page-fault speed, 4 x 320 MB at BASELINE config[3]: 80 -> 45 ms) and what a refit still owes the previous
+        # fit's attributes is released now (53 ms of page-table teardown at that size)
+        for name, cols in (("R", K), ("beta", q), ("Wblk", K), ("P", K), ("Wc", K)):
+            eng.host_array((eng.p, cols), reserve=name)
+        eng.run_deferred(all_of_it=True)
         Yd = Y.copy()
         Ts = np.empty((n, 0)); U = np.empty((n, 0))
         for k in range(K):
