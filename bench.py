@@ -387,15 +387,29 @@ def count_gpus_without_hip():
         return None
 
 
-def _die_with_parent():
-    """preexec of a rank: SIGTERM when the launcher dies (PR_SET_PDEATHSIG) -- a killed launcher leaves no rank behind
-    in a collective with the GPUs leased"""
+def _bind_prctl():
+    """libc's prctl, resolved ONCE in the launcher before any thread or rank exists: the preexec of a rank runs between
+    fork and exec, where an import or a dlopen can find a lock held by one of the launcher's pump threads"""
     try:
         import ctypes
-        import signal
-        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM, 0, 0, 0)
+        fn = ctypes.CDLL("libc.so.6", use_errno=True).prctl
+        fn.argtypes = [ctypes.c_int, ctypes.c_ulong, ctypes.c_ulong, ctypes.c_ulong, ctypes.c_ulong]
+        fn.restype = ctypes.c_int
+        return fn
     except Exception:
-        pass
+        return None
+
+
+def _die_with_parent(prctl, launcher_pid):
+    """preexec of a rank: SIGTERM when the launcher dies (PR_SET_PDEATHSIG) -- a killed launcher leaves no rank behind
+    in a collective with the GPUs leased.  Only calls what was bound before the fork; and if the launcher died between
+    the fork and the prctl (the signal would never come), the rank gives up at once."""
+    def preexec():
+        if prctl is not None:
+            prctl(1, 15, 0, 0, 0)                  # PR_SET_PDEATHSIG, SIGTERM
+            if os.getppid() != launcher_pid:
+                os._exit(1)
+    return preexec
 
 
 DEFAULT_LAUNCH_TIMEOUT_S = 3000.0
@@ -472,10 +486,11 @@ def launch_ranks(world, argv, timeout=DEFAULT_LAUNCH_TIMEOUT_S, python=None):
     failed = None
     timed_out = False
     try:
+        preexec = _die_with_parent(_bind_prctl(), os.getpid())
         for r in range(world):
             e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
             pr = subprocess.Popen([python] + list(argv), env=e, stdout=subprocess.PIPE, stderr=None,
-                                  start_new_session=True, preexec_fn=_die_with_parent)
+                                  start_new_session=True, preexec_fn=preexec)
             th = threading.Thread(target=pump, args=(pr.stdout, r, lines0 if r == 0 else None), daemon=True)
             th.start()
             procs.append(pr)

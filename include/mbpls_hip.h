@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 6   /* 6: mbpls_hip_mat_transpose; mbpls_nipals_step.C / ldc / host_seq, mbpls_hip_queue_r_update, mbpls_hip_flush_r_update (R_ / beta_ column by column during the fit), mbpls_hip_copier_submit / _wait (native copier thread; replaces mbpls_hip_event_record / _memcpy_d2h_after / _event_destroy); 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
+#define MBPLS_HIP_ABI_VERSION 7   /* 7: mbpls_hip_cluster_columns (cluster passes launched cooperatively, capacity from the occupancy query, time-outs flagged in host-mapped memory); 6: mbpls_hip_mat_transpose; mbpls_nipals_step.C / ldc / host_seq, mbpls_hip_queue_r_update, mbpls_hip_flush_r_update (R_ / beta_ column by column during the fit), mbpls_hip_copier_submit / _wait (native copier thread; replaces mbpls_hip_event_record / _memcpy_d2h_after / _event_destroy); 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
 
 enum {
   MBPLS_OK = 0,
@@ -82,14 +82,22 @@ int mbpls_hip_device_info(mbpls_ctx* ctx, char* name, size_t name_len, int* comp
  * "cluster_passes" (default 1: the never-writes-X passes of long columns -- statistics + sweep, sweep, loadings + sweep
  * on the raw matrix -- run on clusters of workgroups that share a column and read X ONCE, csrc/colpass_cluster.hip;
  * 0 = the two-phase passes, two reads), "cluster_slab_rows" (128..8192, default 8192: rows of a column held by one
- * workgroup of a cluster), "cluster_spin_limit" (polls before a hand-off between the workgroups of a cluster gives up).
+ * workgroup of a cluster), "cluster_spin_limit" (polls before a hand-off between the workgroups of a cluster gives up),
+ * "cluster_cap" (workgroups of a cluster pass the device holds at once; -1 = ask the runtime, the default; tests).
  * Returns MBPLS_ERR_ARG for unknown keys. */
 int mbpls_hip_set_tunable(mbpls_ctx* ctx, const char* key, int value);
 /* Cluster passes (long columns, one read of X; replaces the two visits numpy's X.T.dot(u) :856 and X.dot(w) :875 make):
  * the workgroups of a cluster hand partial column sums to each other inside the launch, every wait bounded by
  * "cluster_spin_limit".  Drains the stream and returns in *timeouts how many waits gave up since the last call
- * (0 on a healthy device; results of a pass that gave up are garbage and the caller must raise). */
+ * (0 on a healthy device; results of a pass that gave up are garbage: the caller switches "cluster_passes" off and runs
+ * the fit again -- these passes never write X).  Without a time-out the call is a stream synchronisation and a read
+ * of one host-mapped word. */
 int mbpls_hip_cluster_status(mbpls_ctx* ctx, int* timeouts);
+/* *yes = 1 when the never-writes-X passes of a matrix with n samples run on clusters of workgroups on this context:
+ * "cluster_passes" is on, n is above "long_columns_from", and the device holds a whole pass at once (asked from the
+ * runtime's occupancy query; the launches are cooperative, and a refused one switches the context to the two-phase
+ * passes for good). */
+int mbpls_hip_cluster_columns(mbpls_ctx* ctx, int64_t n, int* yes);
 
 /* ---- raw device memory (so a host needs nothing but this library) ------------------------- */
 int mbpls_hip_malloc(mbpls_ctx* ctx, size_t bytes, void** d_ptr);

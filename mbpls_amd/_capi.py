@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmbpls_hip.so")
 ROW_MAJOR, COL_MAJOR = 0, 1
 COMM_ID_BYTES = 128
 SCALE_FIT, SCALE_APPLY, SCALE_NONE = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp, _i64, _dbl, _int, _sz = C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
@@ -58,6 +58,7 @@ SIGNATURES = {
     "mbpls_hip_device_info": (_int, [_vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_sz), C.POINTER(_sz)]),
     "mbpls_hip_set_tunable": (_int, [_vp, C.c_char_p, _int]),
     "mbpls_hip_cluster_status": (_int, [_vp, C.POINTER(_int)]),
+    "mbpls_hip_cluster_columns": (_int, [_vp, _i64, C.POINTER(_int)]),
     "mbpls_hip_malloc": (_int, [_vp, _sz, _pp]),
     "mbpls_hip_free": (_int, [_vp, _vp]),
     "mbpls_hip_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
@@ -142,6 +143,12 @@ _lib = None
 
 class HipError(RuntimeError):
     pass
+
+
+class ClusterTimeout(HipError):
+    """A hand-off between the workgroups of a column cluster gave up (csrc/colpass_cluster.hip): the results of that
+    pass are garbage, nothing was written to X.  ``MBPLS._fit`` switches the context to the two-phase passes and runs
+    the fit again."""
 
 
 def load():
@@ -329,6 +336,12 @@ class Context:
             self.long_columns_from = max(0, min(int(value), 65536))
         if key == "cluster_passes":
             self.cluster_passes = 1 if value else 0
+
+    def cluster_columns(self, n):
+        """the never-writes-X passes of a matrix with n samples run on clusters of workgroups (one read of X)"""
+        v = _int(0)
+        check(self.lib.mbpls_hip_cluster_columns(self.handle, int(n), C.byref(v)))
+        return bool(v.value)
 
     def cluster_status(self):
         """hand-offs of the cluster passes (long columns) that gave up since the last call; drains the stream"""

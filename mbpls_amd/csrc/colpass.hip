@@ -708,8 +708,10 @@ int mbpls_hip_sweep(const mbpls_mat* m, const double* d_v, double alpha, double*
                     double* d_ssq_g) {
   MB_ARG(m && d_v, "NULL argument");
   mbpls_ctx* ctx = m->ctx;
-  if (cluster_columns(ctx, m->n) && d_t)
-    return cluster_sweep_lazy(m, d_v, alpha, d_g, d_t, d_ssq_g, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr);
+  if (cluster_columns(ctx, m->n) && d_t) {
+    const int rc = cluster_sweep_lazy(m, d_v, alpha, d_g, d_t, d_ssq_g, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr);
+    if (rc != MBPLS_ERR_UNSUPPORTED) return rc;      // (a refused cooperative launch: the two-phase pass below)
+  }
   if (long_columns(ctx, m->n)) return long_sweep(m, d_v, alpha, d_g, d_t, d_ssq_g);
   PassArgs a{};
   MB_TRY(partial_buffers(ctx, m, &a.part_t, &a.part_s));
@@ -755,8 +757,10 @@ int mbpls_hip_sweep_lazy_scaled(const mbpls_mat* m, const double* d_v, double al
   MB_ARG(!d_mean || d_r2, "d_mean needs d_r2");
   MB_ARG(kprev >= 0 && kprev < KD && (kprev == 0 || (d_P && d_cu && d_d)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   mbpls_ctx* ctx = m->ctx;
-  if (cluster_columns(ctx, m->n) && d_t)
-    return cluster_sweep_lazy(m, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu, d_d, d_r2, d_mean);
+  if (cluster_columns(ctx, m->n) && d_t) {
+    const int rc = cluster_sweep_lazy(m, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu, d_d, d_r2, d_mean);
+    if (rc != MBPLS_ERR_UNSUPPORTED) return rc;
+  }
   if (long_columns(ctx, m->n)) {
     MB_TRY(long_sweep_lazy(m, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu, d_d, d_r2, d_mean));
     return d_r2 ? true_space_cols(ctx, m->p, d_g, nullptr) : MBPLS_OK;
@@ -790,9 +794,11 @@ int mbpls_hip_loadings_sweep_lazy_scaled(const mbpls_mat* m, const double* d_ts,
   MB_ARG(kprev >= 0 && kprev < KD - 1 && (kprev == 0 || (d_P && d_ce)), "bad lazy-deflation arguments (kprev=%d)", kprev);
   MB_ARG(!d_v || (d_d && (kprev == 0 || d_cu)), "sweep part needs d_cu / d_d");
   mbpls_ctx* ctx = m->ctx;
-  if (cluster_columns(ctx, m->n) && (!d_v || d_t))
-    return cluster_loadings_sweep(m, d_ts, inv_tt, 1, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu,
-                                  d_ce, d_v ? d_d : nullptr, d_r2, d_mean);
+  if (cluster_columns(ctx, m->n) && (!d_v || d_t)) {
+    const int rc = cluster_loadings_sweep(m, d_ts, inv_tt, 1, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev,
+                                          d_cu, d_ce, d_v ? d_d : nullptr, d_r2, d_mean);
+    if (rc != MBPLS_ERR_UNSUPPORTED) return rc;
+  }
   if (long_columns(ctx, m->n)) {
     MB_TRY(long_loadings_sweep_lazy(m, d_ts, inv_tt, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g, d_P, ldp, kprev, d_cu,
                                     d_ce, d_d, d_r2, d_mean));
@@ -820,9 +826,11 @@ int mbpls_hip_loadings_sweep_raw(const mbpls_mat* m, const double* d_ts, double 
                                  const double* d_r2, const double* d_mean) {
   MB_ARG(m && d_ts && d_v && d_t && d_r2, "NULL argument");
   mbpls_ctx* ctx = m->ctx;
-  if (cluster_columns(ctx, m->n))
-    return cluster_loadings_sweep(m, d_ts, inv_tt, 0, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g, nullptr, 0, 0, nullptr,
-                                  nullptr, nullptr, d_r2, d_mean);
+  if (cluster_columns(ctx, m->n)) {
+    const int rc = cluster_loadings_sweep(m, d_ts, inv_tt, 0, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g, nullptr, 0, 0,
+                                          nullptr, nullptr, nullptr, d_r2, d_mean);
+    if (rc != MBPLS_ERR_UNSUPPORTED) return rc;
+  }
   if (long_columns(ctx, m->n)) {
     MB_TRY(long_loadings_sweep_raw(m, d_ts, inv_tt, d_p, d_ssq_p, d_v, alpha, d_g, d_t, d_ssq_g, d_r2, d_mean));
     return true_space_cols(ctx, m->p, d_g, d_p);
@@ -883,9 +891,12 @@ int mbpls_hip_standardize_stats_sweep(const mbpls_mat* src, int mode, double* d_
   MB_ARG(mode == MBPLS_SCALE_FIT || mode == MBPLS_SCALE_NONE, "bad mode %d", mode);
   MB_ARG(mode == MBPLS_SCALE_NONE || (d_mean && d_scale), "mean/scale buffers required");
   mbpls_ctx* ctx = src->ctx;
+  int cl_rc = MBPLS_ERR_UNSUPPORTED;
   if (cluster_columns(ctx, src->n)) {
-    MB_TRY(cluster_standardize_stats_sweep(src, mode, d_mean, d_scale, d_r2, d_ssq_x, d_amp, d_v, alpha, d_g, d_t,
-                                           d_ssq_g));
+    cl_rc = cluster_standardize_stats_sweep(src, mode, d_mean, d_scale, d_r2, d_ssq_x, d_amp, d_v, alpha, d_g, d_t, d_ssq_g);
+    if (cl_rc != MBPLS_OK && cl_rc != MBPLS_ERR_UNSUPPORTED) return cl_rc;
+  }
+  if (cl_rc == MBPLS_OK) {
     if (mode == MBPLS_SCALE_FIT) {
       hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)((src->p + 255) / 256)), dim3(256), 0, ctx->stream, src->p,
                          d_scale, (const double*)d_r2, d_rscale, d_g, ctx->var_out);

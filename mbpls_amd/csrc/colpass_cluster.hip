@@ -59,6 +59,7 @@ struct ClArgs {
   unsigned spin_limit;
   int prefetch;          // shared exchange wave: issue the loads of the next slot one iteration ahead
   unsigned* err;         // device word: polls that gave up
+  unsigned* flag;        // host-mapped word: set when a poll gave up (the host sees it without a copy)
   double* par;           // device-resident pass parameters (writable view of a.dpar) or NULL
 };
 
@@ -105,6 +106,7 @@ struct ClPoll {
     if (lane == 0) {
       *s_dead = 1u;
       atomicAdd(c.err, 1u);
+      __hip_atomic_store(c.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (c.par) {
         c.par[7] = 1.0;
         c.par[2] = 1.0;            // everything queued behind becomes a no-op
@@ -332,6 +334,7 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
     auto give_up = [&]() {
       *v_dead = 1u;
       atomicAdd(c.err, 1u);
+      __hip_atomic_store(c.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (c.par) {
         c.par[7] = 1.0;
         c.par[2] = 1.0;
@@ -649,10 +652,34 @@ struct ClPlan {
 
 constexpr int CL_R = 16;
 
+// How many workgroups of a cluster pass the device holds AT ONCE: the members of a cluster wait for each other inside
+// the launch, so a pass may never be larger than that.  Asked from the runtime for the fattest instantiation (512
+// threads, 128 KB of dynamic LDS) instead of assumed from the CU count; 0 when the device is partitioned by a CU mask
+// the occupancy query does not see (the passes then stay with the two-phase kernels of colpass_long.hip).  The launch
+// itself is cooperative (cl_launch): the runtime refuses a grid it cannot make co-resident, and on top of that every
+// wait inside the kernel is bounded -- a pass that shared the device with another tenant's resident workgroups gives
+// up, flags it in host-mapped memory, and the host re-runs the fit on the two-phase passes (MBPLS._fit).
+static int cl_capacity(mbpls_ctx* ctx) {
+  if (ctx->cluster_cap >= 0) return ctx->cluster_cap;
+  int cap = 0;
+  if (!getenv("HSA_CU_MASK") && !getenv("ROC_GLOBAL_CU_MASK")) {
+    auto fn = k_colpass_cl<16, CL_TMAX, 3, 2, false, false, true, true, false>;
+    const size_t lds = 2 * CL_TMAX * 8 * 16;
+    int per_cu = 0;
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, CL_TMAX, lds) == hipSuccess)
+      cap = std::max(0, std::min(per_cu, 1)) * ctx->cus;
+    else
+      (void)hipGetLastError();
+  }
+  ctx->cluster_cap = cap;
+  return cap;
+}
+
 static bool cl_plan_for(const mbpls_ctx* ctx, int64_t n, bool ded, ClPlan* pl) {
   const int tc = ded ? CL_TMAX - 64 : CL_TMAX;
   const int64_t slab = std::max<int64_t>(128, std::min<int64_t>(ctx->cluster_slab_rows, (int64_t)CL_R * tc)) / 128 * 128;
-  const int cap = ctx->cus;                                   // one workgroup per CU (the vectors fill the LDS)
+  const int cap = ctx->cluster_cap;                           // co-resident workgroups (one per CU: the vectors fill the LDS)
   const int64_t wmin = (n + slab - 1) / slab;
   if (wmin > cap || wmin > 256 || wmin < 1) return false;
   pl->ded = ded;
@@ -667,6 +694,7 @@ static bool cl_plan_for(const mbpls_ctx* ctx, int64_t n, bool ded, ClPlan* pl) {
 // Dedicated exchange wave unless giving its rows to an eighth compute wave saves a workgroup per column or lets
 // another cluster run beside the others (ctx->cluster_exchange: 0 = this rule, 1 = always dedicated, 2 = never).
 static bool cl_plan(const mbpls_ctx* ctx, int64_t n, ClPlan* pl) {
+  if (cl_capacity(const_cast<mbpls_ctx*>(ctx)) <= 0) return false;
   ClPlan d, s;
   const bool okd = cl_plan_for(ctx, n, true, &d), oks = cl_plan_for(ctx, n, false, &s);
   if (!okd && !oks) return false;
@@ -759,6 +787,10 @@ static int cl_exchange_buffer(mbpls_ctx* ctx, size_t doubles, double** xch, unsi
     ctx->cl_ws_bytes = grown;
     MB_HIP(hipMemsetAsync(ctx->cl_ws, 0, 256, ctx->stream));
   }
+  if (!ctx->cl_flag_h) {
+    MB_HIP(hipHostMalloc((void**)&ctx->cl_flag_h, 64, hipHostMallocMapped));
+    *ctx->cl_flag_h = 0u;
+  }
   *err = (unsigned*)ctx->cl_ws;
   *xch = (double*)((char*)ctx->cl_ws + 256);
   return MBPLS_OK;
@@ -799,6 +831,7 @@ static int cl_launch(mbpls_ctx* ctx, const mbpls_mat* mc, PassArgs a, bool cen) 
   const size_t slots = (size_t)m->p + (size_t)ct.nchunks;
   const size_t xd = slots * (size_t)CL_NV * (size_t)pl.W;
   MB_TRY(cl_exchange_buffer(ctx, xd, &c.xch, &c.err));
+  MB_HIP(hipHostGetDevicePointer((void**)&c.flag, ctx->cl_flag_h, 0));
   ProfScope prof(ctx, kind, 8.0 * (double)m->n * (double)m->p * (writes ? 2.0 : 1.0));
   hipLaunchKernelGGL(k_cl_fill, dim3((unsigned)((xd / 2 + 256) / 256)), dim3(256), 0, ctx->stream, (int64_t)xd,
                      (unsigned long long*)c.xch, ctx->dpar);
@@ -809,12 +842,9 @@ static int cl_launch(mbpls_ctx* ctx, const mbpls_mat* mc, PassArgs a, bool cen) 
 #define MB_CL(DED_, CEN_)                                                                                   \
   do {                                                                                                      \
     auto fn = k_colpass_cl<CL_R, CL_TMAX, 3, 2, DED_, STATS, DEFL, SWEEP, CEN_>;                            \
-    static bool attr_set = false;                                                                           \
-    if (!attr_set) {                                                                                        \
-      MB_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CL_TMAX * (CL_R / 2) * 16)); \
-      attr_set = true;                                                                                      \
-    }                                                                                                       \
-    hipLaunchKernelGGL(fn, grid, block, dyn, ctx->stream, c);                                               \
+    MB_ALLOW_LDS(ctx, fn, 2 * CL_TMAX * (CL_R / 2) * 16);                                                   \
+    void* args[] = {(void*)&c};                                                                             \
+    launched = hipLaunchCooperativeKernel((const void*)fn, grid, block, args, dyn, ctx->stream);            \
   } while (0)
 #define MB_CL_CEN(DED_)                           \
   do {                                            \
@@ -825,11 +855,19 @@ static int cl_launch(mbpls_ctx* ctx, const mbpls_mat* mc, PassArgs a, bool cen) 
       else MB_CL(DED_, false);                    \
     }                                             \
   } while (0)
+  hipError_t launched = hipSuccess;
   if (pl.ded) MB_CL_CEN(true);
   else MB_CL_CEN(false);
 #undef MB_CL_CEN
 #undef MB_CL
-  MB_HIP(hipGetLastError());
+  if (launched != hipSuccess) {
+    // (hipErrorCooperativeLaunchTooLarge: the device holds fewer workgroups than the plan assumed -- a partition or
+    // another limit the occupancy query did not see; the caller falls back to the two-phase passes)
+    (void)hipGetLastError();
+    set_error("cluster pass: cooperative launch of %u workgroups refused: %s", grid.x, hipGetErrorString(launched));
+    ctx->cluster_cap = 0;
+    return MBPLS_ERR_UNSUPPORTED;
+  }
   return MBPLS_OK;
 }
 
@@ -899,15 +937,24 @@ int cluster_stats_reduce(const mbpls_mat* src, double* d_t, double* d_ssq_g, dou
 
 using namespace mbpls;
 
+extern "C" int mbpls_hip_cluster_columns(mbpls_ctx* ctx, int64_t n, int* yes) {
+  MB_ARG(ctx && yes, "NULL argument");
+  *yes = cluster_columns(ctx, n) ? 1 : 0;
+  return MBPLS_OK;
+}
+
 extern "C" int mbpls_hip_cluster_status(mbpls_ctx* ctx, int* timeouts) {
   MB_ARG(ctx && timeouts, "NULL argument");
   *timeouts = 0;
-  if (!ctx->cl_ws) return MBPLS_OK;
+  if (!ctx->cl_ws || !ctx->cl_flag_h) return MBPLS_OK;
+  MB_HIP(hipStreamSynchronize(ctx->stream));
+  if (__atomic_load_n(ctx->cl_flag_h, __ATOMIC_ACQUIRE) == 0u) return MBPLS_OK;   // the everyday answer: no copy at all
   unsigned v = 0;
   MB_HIP(hipMemcpyAsync(&v, ctx->cl_ws, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   MB_HIP(hipStreamSynchronize(ctx->stream));
-  if (v) MB_HIP(hipMemsetAsync(ctx->cl_ws, 0, sizeof(unsigned), ctx->stream));
-  *timeouts = (int)v;
+  MB_HIP(hipMemsetAsync(ctx->cl_ws, 0, sizeof(unsigned), ctx->stream));
+  __atomic_store_n(ctx->cl_flag_h, 0u, __ATOMIC_RELEASE);
+  *timeouts = (int)std::max(1u, v);
   return MBPLS_OK;
 }
 

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <cmath>
 #include <mutex>
 #include <string>
@@ -33,6 +34,18 @@ void set_error(const char* fmt, ...);
       ::mbpls::set_error(__VA_ARGS__); \
       return MBPLS_ERR_ARG;            \
     }                                  \
+  } while (0)
+
+// More than 64 KB of dynamic LDS has to be allowed per kernel AND per device (hipFuncSetAttribute acts on the current
+// device's copy of the code object): one bit per device ordinal remembers where it has been done.
+#define MB_ALLOW_LDS(ctx_, fn_, bytes_)                                                                            \
+  do {                                                                                                             \
+    static std::atomic<uint64_t> done_{0};                                                                         \
+    const uint64_t bit_ = 1ull << ((unsigned)(ctx_)->device & 63u);                                                \
+    if (!(done_.load(std::memory_order_relaxed) & bit_) || (ctx_)->device >= 64) {                                 \
+      MB_HIP(hipFuncSetAttribute((const void*)(fn_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes_)));  \
+      done_.fetch_or(bit_, std::memory_order_relaxed);                                                             \
+    }                                                                                                              \
   } while (0)
 
 #define MB_TRY(expr)          \
@@ -90,7 +103,9 @@ struct mbpls_ctx {
   int cluster_prefetch = 0;            // shared exchange wave: loads of the next column's partial sums issued ahead
   int cluster_exchange = 0;            // 0: dedicated exchange wave unless sharing saves workgroups; 1: always; 2: never
   unsigned cluster_spin_limit = 1u << 22;   // polls before a cluster hand-off gives up
+  int cluster_cap = -1;                // workgroups of a cluster pass the device holds at once (-1: not asked yet; 0: none)
   void* cl_ws = nullptr;               // fine-grained: [error word | exchange slots] of the cluster passes
+  unsigned* cl_flag_h = nullptr;       // host-mapped word a pass sets when a hand-off gave up (read by the host without a copy)
   size_t cl_ws_bytes = 0;
   // workspace for chunk partials (grown on demand, never shrunk)
   void* ws = nullptr;

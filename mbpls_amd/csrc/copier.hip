@@ -151,8 +151,10 @@ static void helper_main(CopierState* cs) {
       continue;
     }
     // register as a reader, then look again: an open epoch cannot be rewritten while we are registered
-    cs->land_readers.fetch_add(1, std::memory_order_acq_rel);
-    const uint64_t t = cs->land_ticket.load(std::memory_order_acquire);
+    // (store-then-load on two variables against the writer's store-then-load below: both sides sequentially
+    // consistent, or the reader could see the old open ticket while the writer sees no reader)
+    cs->land_readers.fetch_add(1, std::memory_order_seq_cst);
+    const uint64_t t = cs->land_ticket.load(std::memory_order_seq_cst);
     const bool open = (t & 0xFFFFFFFFull) != LAND_CLOSED;
     CopierState::Land L;
     if (open) L = cs->land;
@@ -212,7 +214,7 @@ static int copier_run(CopierState* cs, CopierJob& job) {
     CP_HIP(hipEventSynchronize(cs->bev[prev_slot]));
     const double b = trace ? now_us() : 0.0;
     const mbpls_copy& c = job.copies[prev];
-    while (cs->land_readers.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();   // (ticket is parked: no new readers copy)
+    while (cs->land_readers.load(std::memory_order_seq_cst) > 0) __builtin_ia32_pause();   // (ticket is parked: no new readers copy)
     CopierState::Land& L = cs->land;
     L = CopierState::Land{};
     L.src = (const char*)cs->bounce[prev_slot];
@@ -233,7 +235,7 @@ static int copier_run(CopierState* cs, CopierJob& job) {
     cs->land_ticket.store(epoch << 32, std::memory_order_release);       // open: pieces 0 .. npieces - 1
     land_work(cs, epoch, L);
     while (cs->land_left.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
-    cs->land_ticket.store((epoch << 32) | LAND_CLOSED, std::memory_order_release);
+    cs->land_ticket.store((epoch << 32) | LAND_CLOSED, std::memory_order_seq_cst);
     if (trace) {
       t_dma += b - a;
       t_cpy += now_us() - b;

@@ -493,11 +493,7 @@ extern "C" int mbpls_hip_nipals_subspace_loop(mbpls_ctx* ctx, int64_t n, int q, 
   MB_ARG(n >= 1 && n <= 8192 && q >= 1 && q <= SS_QMAX, "subspace loop covers n <= 8192, q <= %d", SS_QMAX);
   MB_ARG(norm_kind >= 0 && norm_kind <= 3 && max_iter >= 1, "bad norm kind %d / max_iter %d", norm_kind, max_iter);
   SubspaceArgs s{n, q, norm_kind, max_iter, tol, d_G, d_Y, d_c0, d_ts, d_u, d_v, d_c_used, d_state};
-  static bool lds_attr_set = false;      // more than 64 KB of dynamic LDS needs to be allowed once per process
-  if (!lds_attr_set) {
-    MB_HIP(hipFuncSetAttribute((const void*)k_nipals_subspace_loop, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192));
-    lds_attr_set = true;
-  }
+  MB_ALLOW_LDS(ctx, k_nipals_subspace_loop, 16 * 8192);   // more than 64 KB of dynamic LDS: allowed once per device
   hipLaunchKernelGGL(k_nipals_subspace_loop, dim3(1), dim3(SS_T), (size_t)(16 * n), ctx->stream, s);
   MB_HIP(hipGetLastError());
   return MBPLS_OK;

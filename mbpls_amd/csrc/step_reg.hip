@@ -531,11 +531,7 @@ int launch_step_reg(mbpls_ctx* ctx, const mbpls_nipals_step* s) {
   do {                                                                                                       \
     auto fn = k_step_reg<T_, R_, J_, B_, F_, L_>;                                                            \
     constexpr size_t lds = sizeof(double) * (size_t)(L_) * (T_) * (R_);                                      \
-    static bool attr_set = false;                                                                            \
-    if (lds > 0 && !attr_set) {                                                                              \
-      MB_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
-      attr_set = true;                                                                                       \
-    }                                                                                                        \
+    if (lds > 0) MB_ALLOW_LDS(ctx, fn, lds);                                                                 \
     hipLaunchKernelGGL(fn, dim3(1), dim3(T_), lds, ctx->stream, *s);                                         \
   } while (0)
 #define MB_STEP(T_, R_, J_, L_)                                                                              \

@@ -328,6 +328,7 @@ class HipEngine(EngineBase):
                 self.comm.allreduce_device(self._xchg)
         with self._timed("wait_kernel+d2h_small"):
             h = self._xchg.get()
+        self.check_cluster_passes()
         t = h[: n * B].reshape(B, n).T.copy() if want_t else None   # n x B
         o = n * B
         if self.sparse and want_t:
@@ -446,16 +447,19 @@ class HipEngine(EngineBase):
     def cluster_passes(self):
         """the never-writes-X passes of this matrix run on clusters of workgroups (long columns, one read of X)"""
         return (not self.sparse and self.n > getattr(self.ctx, "long_columns_from", 8192)
-                and bool(getattr(self.ctx, "cluster_passes", 0)) and hasattr(self.ctx, "cluster_status"))
+                and bool(getattr(self.ctx, "cluster_passes", 0)) and hasattr(self.ctx, "cluster_status")
+                and self.ctx.cluster_columns(self.n))
 
     def check_cluster_passes(self):
         """Long columns: the workgroups of a cluster hand partial sums to each other inside a launch, every wait
-        bounded; a wait that gave up leaves garbage behind -- never hand that to the caller."""
-        if self.cluster_passes:
+        bounded; a wait that gave up leaves garbage behind -- never hand that to the caller, and never iterate on it:
+        called behind every pass of a host-driven loop (the exchange buffer has just been read, so the check is a
+        read of one host-mapped word), when a device-resident queue returns, and at the end of the fit."""
+        if getattr(self.ctx, "cluster_passes", 0) and not self.sparse and self.n > getattr(self.ctx, "long_columns_from", 8192):
             bad = self.ctx.cluster_status()
             if bad:
-                raise _capi.HipError(f"{bad} hand-off(s) between the workgroups of a column cluster timed out "
-                                     "(csrc/colpass_cluster.hip); set_tunable('cluster_passes', 0) selects the two-phase passes")
+                raise _capi.ClusterTimeout(f"{bad} hand-off(s) between the workgroups of a column cluster timed out "
+                                           "(csrc/colpass_cluster.hip)")
 
     def scaled_products(self):
         """after an implicit first pass (raw matrix, statistics known): the many-right-hand-side products X^T V / X W
@@ -1179,14 +1183,18 @@ class _ResidentQueue:
         # block norms of every recorded component, written by the step straight into pinned host memory: the helper
         # thread that forms w_b = w~_b / ||w~_b|| reads them there (a copy of B doubles into pageable memory is a blit
         # kernel that waits behind -- and slows -- the running pass: 180 us each)
-        self.nu2_h, nu2_d = ctx.mapped_scalars(K * B + 8)
+        blk_h, blk_d = ctx.mapped_scalars(K * B + 8)
+        self.nu2_h, nu2_d = blk_h[8:8 + K * B], blk_d + 64
         self.st.nu2_host = nu2_d
         # ... and the number of the step launch that has started, stored there by every step first of all: the copier
         # thread starts a job when the step queued BEHIND the job's data has begun, instead of waiting for an event
         # recorded on the stream (an event record between two launches idles the queue for ~6 us: 60 us of a fit)
-        self.seq_h = self.nu2_h[K * B:K * B + 1]
-        self.seq_h[0] = 0.0
-        self.st.host_seq = nu2_d + 8 * K * B
+        # The word has a FIXED place in the context's block and its values never decrease over the life of the context
+        # (``ctx._seq_base`` + step number): nothing a fit leaves behind can release a job of the next one early.
+        self.seq_h = blk_h[0:1]
+        self.seq0 = float(getattr(ctx, "_seq_base", 0.0))
+        self.seq_h[0] = self.seq0                   # (what the last step of the previous queue stored; new block: unset)
+        self.st.host_seq = blk_d
         self.nsteps = 0
         self.ticket = 0                             # of the last job handed to the copier thread
         self.scores_ticket = 0                      # of the job that carries the last component's n-vectors
@@ -1212,7 +1220,7 @@ class _ResidentQueue:
             for key, width in (("Ts", 1), ("U", 1), ("Tb", B)):
                 a = self.off[key][0] - o0 + n * width * k
                 copies = copies + [(self.h[a:a + n * width], self.ptr[key] + 8 * n * width * k)]
-        flag = (self.seq_h.ctypes.data, self.nsteps + 1) if after_next_step else None
+        flag = (self.seq_h.ctypes.data, self.seq0 + self.nsteps + 1) if after_next_step else None
         self.ticket = self.ctx.copier_submit(copies, scale=post, flag=flag)
         if k is not None and k == self.K - 1:
             self.scores_ticket = self.ticket
@@ -1277,7 +1285,7 @@ class _ResidentQueue:
     def step(self, kc, run, nd):
         self.allreduce()
         self.nsteps += 1
-        self.st.kc, self.st.run, self.st.nd, self.st.seq_value = kc, run, nd, float(self.nsteps)
+        self.st.kc, self.st.run, self.st.nd, self.st.seq_value = kc, run, nd, self.seq0 + self.nsteps
         _capi.check(self.lib.mbpls_hip_nipals_step(self.ctx.handle, self.st))
 
     def last_loadings_norms(self):
@@ -1345,6 +1353,7 @@ class _ResidentQueue:
         finally:
             self.lib.mbpls_hip_set_pass_params(self.ctx.handle, None)
             ctx, ticket = self.ctx, self.ticket
+            ctx._seq_base = self.seq0 + self.nsteps
 
             def wait_copies():              # every column handed to the copier thread by this queue has landed
                 ctx.copier_wait(ticket)
@@ -1355,19 +1364,27 @@ class _ResidentQueue:
                 ctx.copier_wait(scores_ticket)
 
         if et is not None or h is None:
+            # what was queued before the error may still be running: let it finish before the buffers it works on go
+            # back to the pool and before the flag is touched (a step of THIS queue storing its number later on would
+            # otherwise race with the release below)
+            self.lib.mbpls_hip_sync(self.ctx.handle)
             self.seq_h[0] = np.inf          # (a job may be waiting for a step that was never launched)
             try:
                 wait_copies()
             except _capi.HipError:
                 pass                        # (the error that brought us here is the one to report)
+            self.seq_h[0] = ctx._seq_base
             self.state.free()
             return False
         par = self._view(h, "par")
         if par[7] != 0.0:
             # a grid barrier of the multi-workgroup step gave up (cooperative launch: should never happen) -- nothing
-            # was written to X, so the caller simply runs the fit with its host-driven loop
+            # was written to X, so the caller simply runs the fit with its host-driven loop.  (A hand-off of a cluster
+            # pass that gave up sets the same flag: that one goes up to MBPLS._fit, which runs the fit again on the
+            # two-phase passes.)
             wait_copies()
             self.state.free()
+            eng.check_cluster_passes()
             self.result = dict(k_done=0, reason="barrier")
             return False
         if par[2] != 0.0 and par[5] == 1.0:
@@ -1408,5 +1425,9 @@ class _ResidentQueue:
             # hand the lazy-deflation state to the host-driven loop
             Tc = _capi.DeviceArray(self.ctx, (n, K), ptr=self.ptr["Tsc"]).get()
             eng._lazy_ts = [np.ascontiguousarray(Tc[:, i]) for i in range(k_done)]
+        # the copier reads Ts / U / Tb columns out of the state block: the last of those jobs must have run before the
+        # block goes back to the pool (the next allocation of that size may overwrite it).  The caller needs the scores
+        # at once anyway, so the wait is not an extra one.
+        wait_scores()
         self.state.free()
         return False

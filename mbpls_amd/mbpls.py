@@ -200,22 +200,44 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         threads = runtime.host_threads()
         threads.__enter__()
         try:
-            with eng._timed("load"):
-                if device_input:
-                    eng.load_device(X, copy=self.copy)
-                else:
-                    eng.load_host_blocks(blocks)
             K = self.n_components
-            if self.method == 'NIPALS':
-                res = solvers.fit_nipals(eng, Ys, K, self.standardize, self.max_tol,
-                                         self.nipals_convergence_norm, self.calc_all)
-            elif self.method == 'UNIPALS':
-                res = solvers.fit_unipals(eng, Ys, K, self.standardize)
-            elif self.method == 'KERNEL':
-                res = solvers.fit_kernel(eng, Ys, K, self.standardize, self.calc_all)
-            else:
-                res = solvers.fit_simpls(eng, Ys, K, self.standardize)
-            eng.check_cluster_passes()                      # long columns: a hand-off between workgroups gave up -> raise
+            for attempt in (0, 1):
+                try:
+                    with eng._timed("load"):
+                        if device_input:
+                            eng.load_device(X, copy=self.copy)
+                        else:
+                            eng.load_host_blocks(blocks)
+                    if self.method == 'NIPALS':
+                        res = solvers.fit_nipals(eng, Ys, K, self.standardize, self.max_tol,
+                                                 self.nipals_convergence_norm, self.calc_all)
+                    elif self.method == 'UNIPALS':
+                        res = solvers.fit_unipals(eng, Ys, K, self.standardize)
+                    elif self.method == 'KERNEL':
+                        res = solvers.fit_kernel(eng, Ys, K, self.standardize, self.calc_all)
+                    else:
+                        res = solvers.fit_simpls(eng, Ys, K, self.standardize)
+                    eng.check_cluster_passes()              # long columns: a hand-off between workgroups gave up -> raise
+                    break
+                except _capi.ClusterTimeout as err:
+                    # Long columns: the workgroups that share a column wait for each other inside the launch, which
+                    # needs all of them on the device at once.  The launch is cooperative and sized from the runtime's
+                    # occupancy figure, but a second tenant (another rank or process on this GPU, a CU mask) can still
+                    # keep partners off the device until the bounded waits give up.  Those passes never write X: the
+                    # context takes the two-phase passes from now on and the fit runs again -- unless this fit has
+                    # already overwritten the caller's own device matrix (copy=False with a storing pass).
+                    wrote_callers = (device_input and not self.copy and
+                                     (eng.plan.get("deflation") == "explicit"
+                                      or str(eng.plan.get("standardisation", "")).startswith("stored")))
+                    if attempt or wrote_callers:
+                        raise
+                    warnings.warn(f"{err}; this context now uses the two-phase long-column passes (two reads of X per "
+                                  "pass) and the fit is run again", RuntimeWarning)
+                    eng.ctx.set_tunable("cluster_passes", 0)
+                    pending = eng.deferred_host_work
+                    eng.close()
+                    eng = self._engine()
+                    eng.sparse, eng.rowmask, eng.deferred_host_work = sparse, None if row_mask is None else row_mask.astype(np.float64), pending
             if row_mask is not None:                        # n-row outputs: included samples only
                 for key in ("Ts_", "U_"):
                     if key in res:

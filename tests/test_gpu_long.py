@@ -214,3 +214,67 @@ def test_many_lazy_corrections_through_the_finishing_kernel(forced_long):
     ref = orc.fit(X, Y, n_components=K, method="UNIPALS")
     mdl = MBPLS(n_components=K, method="UNIPALS").fit(X, Y)
     assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"UNIPALS K={K}") < 1e-6
+
+
+@pytest.mark.parametrize("method,q,route", [
+    ("NIPALS", 1, "device-resident queue"),      # the time-out reaches the host when the queue returns
+    ("NIPALS", 2, "host-driven loop"),           # ... behind the first pass of the loop
+    ("UNIPALS", 1, "device-resident queue"),
+])
+def test_cluster_handoff_timeout_reruns_the_fit_on_two_phase_passes(gpu_required, method, q, route):
+    """A hand-off between the workgroups of a column cluster that gives up (another tenant keeps partners off the
+    device; forced here with a spin limit of one poll) must not reach the caller as garbage nor be iterated on: the
+    fit warns, switches the context to the two-phase passes and runs again -- same numbers as the oracle."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS
+    ctx = mbpls_amd.get_context()
+    n, p, K = 2100, 900, 3
+    X, Y = orc.make_latent(n, p, q, seed=21)
+    ref = orc.fit([X[:, :400], X[:, 400:]], Y, n_components=K, method=method, full_svd=(method == "SIMPLS"))
+    ctx.set_tunable("long_columns_from", 0)
+    _long_mode(ctx, "cluster")
+    ctx.set_tunable("cluster_spin_limit", 1)
+    try:
+        assert ctx.cluster_columns(n)
+        with pytest.warns(RuntimeWarning, match="two-phase long-column passes"):
+            mdl = MBPLS(n_components=K, method=method, full_svd=(method == "SIMPLS")).fit([X[:, :400], X[:, 400:]], Y)
+        assert ctx.cluster_passes == 0 and not ctx.cluster_columns(n)
+        assert "two streaming phases" in mdl.fit_plan_["kernels"], mdl.fit_plan_
+        assert ctx.cluster_status() == 0                       # the flag was consumed by the fit
+        w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} q={q} after a time-out")
+        assert w < 1e-8, w
+    finally:
+        ctx.set_tunable("cluster_spin_limit", 1 << 22)
+        ctx.set_tunable("long_columns_from", 8192)
+        _long_mode(ctx, None)
+        ctx.cluster_status()
+
+
+def test_refused_cooperative_launch_falls_through_to_two_phase_passes(gpu_required):
+    """The cluster passes are launched cooperatively with a grid sized from the runtime's occupancy figure.  A grid the
+    device cannot hold at once (forced: capacity set to 4096 workgroups) is refused by the runtime; the pass then runs
+    on the two-phase kernels in the same call and the context stays there."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS
+    ctx = mbpls_amd.get_context()
+    n, p, K = 1500, 5000, 3
+    X, Y = orc.make_latent(n, p, 1, seed=22)
+    ref = orc.fit(X, Y, n_components=K)
+    ctx.set_tunable("long_columns_from", 0)
+    _long_mode(ctx, "cluster")
+    ctx.set_tunable("cluster_cap", 4096)
+    try:
+        assert ctx.cluster_columns(n)
+        mdl = MBPLS(n_components=K).fit(X, Y)
+        assert not ctx.cluster_columns(n)                      # capacity 0 after the refusal
+        w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="refused cooperative launch")
+        assert w < 1e-8, w
+        ctx.set_tunable("cluster_cap", -1)                     # ask the runtime again
+        assert ctx.cluster_columns(n)
+        again = MBPLS(n_components=K).fit(X, Y)
+        assert "clusters of workgroups" in again.fit_plan_["kernels"]
+        assert util.compare(util.model_to_flat(again), util.model_to_flat(ref), TOL, what="cluster passes back") < 1e-8
+    finally:
+        ctx.set_tunable("cluster_cap", -1)
+        ctx.set_tunable("long_columns_from", 8192)
+        _long_mode(ctx, None)
