@@ -29,7 +29,7 @@ class FitOptions:
     nipals_qspace: bool = True          # MBPLS_NIPALS_QSPACE=0: that loop on n-vectors (the reference's own formulas) for the 2-norm too
     nipals_gram: bool = True            # MBPLS_NIPALS_GRAM=0: ... and without the association-matrix form either
     unipals_nodeflate: bool = True      # MBPLS_UNIPALS_NODEFLATE=0: UNIPALS, several responses, on the deflated X
-    q1_fixed_point: bool = False        # MBPLS_NIPALS_Q1_FIXED_POINT=1: opt-in, skip the redundant second iteration
+    q1_fixed_point: bool = True         # MBPLS_NIPALS_Q1_FIXED_POINT=0: one-response NIPALS with the reference's two passes per component (the second only re-derives the first)
     r_incremental: bool = True          # MBPLS_R_INCREMENTAL=0: R_ / beta_ of a device-resident fit from one product at its end
 
     @classmethod
@@ -44,5 +44,5 @@ class FitOptions:
                    nipals_qspace=_flag("MBPLS_NIPALS_QSPACE", True),
                    nipals_gram=_flag("MBPLS_NIPALS_GRAM", True),
                    unipals_nodeflate=_flag("MBPLS_UNIPALS_NODEFLATE", True),
-                   q1_fixed_point=os.environ.get("MBPLS_NIPALS_Q1_FIXED_POINT", "0") == "1",
+                   q1_fixed_point=_flag("MBPLS_NIPALS_Q1_FIXED_POINT", True),
                    r_incremental=_flag("MBPLS_R_INCREMENTAL", True))

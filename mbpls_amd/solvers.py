@@ -594,7 +594,8 @@ def _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
 
 
 def _fit_nipals_q1_fixed_point(eng, Y, K, standardize, calc_all):
-    """OPT-IN (MBPLS_NIPALS_Q1_FIXED_POINT=1, off by default).  One response: u after the first pass of a component is
+    """The default route of one-response NIPALS (MBPLS_NIPALS_Q1_FIXED_POINT=0 selects the reference's two passes per
+    component instead: same attributes, 2K + 1 reads of X instead of K + 1).  One response: u after the first pass of a component is
     sign(v) y/||y|| whatever ts was (v is 1 x 1, and v = y^T ts > 0: a sum of squares), so the second pass of the
     reference's loop (:841) computes w~_2 = ||y|| w~_1 and reproduces ts exactly -- the iteration is at its fixed point
     after ONE pass and the second only re-derives it.  Without it a component is: weights X_k^T u with u = y/||y||, block

@@ -40,18 +40,24 @@ def main():
     full = list(np.split(X, np.cumsum(sizes)[:-1], axis=1))
     ranges = shard_columns(sizes, rank, world)
     local = [np.ascontiguousarray(b[:, lo:hi]) for b, (lo, hi) in zip(full, ranges)]
-    for method in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+    # (one-response NIPALS: the default one-pass-per-component route, then the reference's two passes per component)
+    for method, q1_route in (("NIPALS", "1"), ("NIPALS", "0"), ("UNIPALS", "1"), ("KERNEL", "1"), ("SIMPLS", "1")):
+        if q1_route == "0" and q != 1:
+            continue
+        os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = q1_route
         ref = orc.fit(full, Y, n_components=3, method=method, full_svd=True)
         with mbpls_amd.column_sharded(comm):
             mdl = MBPLS(n_components=3, method=method).fit(local, Y)
             yh = mdl.predict(local)
+        os.environ.pop("MBPLS_NIPALS_Q1_FIXED_POINT")
         s = np.sign(np.sum(ref.Ts_ * mdl.Ts_, axis=0))
         assert util.relerr(mdl.Ts_ * s, ref.Ts_) < 1e-8, method
         for b, (lo, hi) in enumerate(ranges):
             assert util.relerr(mdl.P_[b] * s, ref.P_[b][lo:hi]) < 1e-8, method
         assert util.relerr(yh, orc.predict(ref, full)) < 1e-8, method
         if method == "NIPALS" and q == 1:
-            assert mdl.nipals_iterations_ == ref.nipals_iterations_
+            util.check_nipals_iterations(mdl, ref)
+            assert ("fixed point" in mdl.fit_plan_["solver"]) == (q1_route == "1"), mdl.fit_plan_
     # n >= p (mbpls.py:388-479, :580-692): the leading singular vector of a p x q matrix whose rows are split over the
     # ranks, (X^T X) w from every rank's columns
     X, Y = orc.make_latent(700, 500, q, r=8, seed=6)

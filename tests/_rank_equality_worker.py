@@ -47,7 +47,10 @@ def main():
     cuts = np.cumsum(sizes)[:-1]
     ranges = shard_columns(sizes, rank, world)
     offs = np.concatenate(([0], np.cumsum(sizes)))
-    for q, K in ((1, 6), (3, 3)):
+    # (one response twice: the default one-pass-per-component route, then the reference's two passes per component,
+    # whose stop decision is the one that must not differ between ranks)
+    for q, K, q1_route in ((1, 6, "1"), (1, 6, "0"), (3, 3, "1")):
+        os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = q1_route
         X, Y = orc.make_latent(n, sum(sizes), q, r=8, seed=11 + q)
         full = list(np.split(X, cuts, axis=1))
         local = [np.ascontiguousarray(b[:, lo:hi]) for b, (lo, hi) in zip(full, ranges)]
@@ -64,7 +67,8 @@ def main():
             for k, v in mine.items():
                 assert np.array_equal(v, other[k]), (k, q)
         if q == 1:
-            assert list(mdl.nipals_iterations_) == list(ref.nipals_iterations_) == [2] * K
+            util.check_nipals_iterations(mdl, ref, K)
+            assert ("fixed point" in mdl.fit_plan_["solver"]) == (q1_route == "1"), mdl.fit_plan_
         else:
             assert all(abs(a - b) <= 2 for a, b in zip(mdl.nipals_iterations_, ref.nipals_iterations_))
         # the sharded attributes, assembled over the ranks, against the oracle

@@ -77,12 +77,15 @@ def main():
                 assert all(abs(a - b) <= 2 for a, b in zip(mdl.nipals_iterations_, ref.nipals_iterations_))
         # one response: lazy deflation + implicit standardisation (X never written), sharded
         Y1, Yn1 = Y[:, :1], Yn[:, :1]
-        for method, K in (("NIPALS", 5), ("UNIPALS", 3)):
+        for method, K, q1_route in (("NIPALS", 5, "1"), ("NIPALS", 5, "0"), ("UNIPALS", 3, "1")):
+            os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = q1_route       # one pass per component (default) / the reference's two
             ref = orc.fit(full, Y1, n_components=K, method=method)
             mdl = MBPLS(n_components=K, method=method).fit(local, Y1)
+            os.environ.pop("MBPLS_NIPALS_Q1_FIXED_POINT")
             check(mdl, ref, ranges, full_new, local_new, Yn1, method + " q=1", orc.predict, orc.transform)
             if method == "NIPALS":
-                assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K
+                util.check_nipals_iterations(mdl, ref, K)
+                assert ("fixed point" in mdl.fit_plan_["solver"]) == (q1_route == "1"), mdl.fit_plan_
         # explicit deflation and the streamed-column passes through the same exchange
         os.environ["MBPLS_DEFLATION"] = "explicit"
         ref = orc.fit(full, Y, n_components=3, method="NIPALS")

@@ -28,3 +28,21 @@ def gpu_required():
     lib = _capi.load()  # raises loudly if the .so is missing
     assert _capi.device_count() > 0, "no HIP device visible"
     return lib
+
+
+@pytest.fixture
+def two_pass_nipals(monkeypatch):
+    """One-response NIPALS with the reference's iteration structure (two passes per component, mbpls.py:841-913) instead
+    of the default one-pass route (the second pass only re-derives the first): for the tests of that queue, its stop rule
+    and its iteration counts."""
+    monkeypatch.setenv("MBPLS_NIPALS_Q1_FIXED_POINT", "0")
+
+
+@pytest.fixture(params=["one_pass", "two_passes"])
+def q1_route(request, monkeypatch):
+    """both routes of one-response NIPALS: the default (one pass per component) and the reference's two passes"""
+    if request.param == "two_passes":
+        monkeypatch.setenv("MBPLS_NIPALS_Q1_FIXED_POINT", "0")
+    else:
+        monkeypatch.delenv("MBPLS_NIPALS_Q1_FIXED_POINT", raising=False)
+    return request.param

@@ -40,7 +40,9 @@ def test_world2_self_launched_line():
     assert d["sharded_self_check"] is not None
     assert d["allreduce"]["mean_us"] > 0 and d["allreduce"]["doubles"] > 0
     sc = d["strong_scaling_c2"]
-    assert sc["fit_wall_s"] > 0 and sc["nipals_iterations"] == [2] * len(sc["nipals_iterations"])
+    # (round 5 on: one pass per component for one response; before: the reference's two)
+    want = 1 if os.path.basename(path) >= "r05" else 2
+    assert sc["fit_wall_s"] > 0 and sc["nipals_iterations"] == [want] * len(sc["nipals_iterations"])
     assert d["comm"]["world_size"] == 2
     if os.path.basename(path) >= "r04":                     # from round 4 on the N > 1 line carries its own CPU baseline
         cb = d["cpu_baseline"]

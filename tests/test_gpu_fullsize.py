@@ -127,7 +127,7 @@ def test_c2_nipals_full_size(gpu_required, monkeypatch):
     X, Y = device_problem(ctx, n, p, [0, p])
     try:
         mdl = MBPLS(n_components=K, method="NIPALS").fit(X, Y)
-        assert mdl.nipals_iterations_ == [2] * K                          # (c)
+        assert mdl.nipals_iterations_ == [1] * K                          # (c) one response: one pass per component
         check_orthonormal(mdl.Ts_)
         yhat = check_generic_products(mdl, X, Y)                          # (a)
         assert 0.5 < 1.0 - np.sum((Y - yhat) ** 2) / np.sum((Y - Y.mean()) ** 2) < 1.0    # a sensible model
@@ -152,9 +152,20 @@ def test_c2_nipals_full_size(gpu_required, monkeypatch):
         monkeypatch.setenv("MBPLS_DEFLATION", "explicit")
         m2 = MBPLS(n_components=K, method="NIPALS").fit(X, Y)
         monkeypatch.delenv("MBPLS_DEFLATION")
-        assert m2.nipals_iterations_ == [2] * K
+        assert m2.nipals_iterations_ == [1] * K
         w = util.compare(util.model_to_flat(m2), util.model_to_flat(mdl), TOL, what="explicit vs lazy")
         assert w < TOL
+        del m2
+        # (e) the reference's iteration structure -- two passes per component, the second re-deriving the first until
+        # ||ts_old - ts|| <= 1e-14 (mbpls.py:841) -- gives the same model, and meets its stop rule on every component
+        monkeypatch.setenv("MBPLS_NIPALS_Q1_FIXED_POINT", "0")
+        m3 = MBPLS(n_components=K, method="NIPALS").fit(X, Y)
+        monkeypatch.delenv("MBPLS_NIPALS_Q1_FIXED_POINT")
+        assert m3.nipals_iterations_ == [2] * K and all(m3.nipals_converged_)
+        assert "fixed point" in mdl.fit_plan_["solver"] and "fixed point" not in m3.fit_plan_["solver"]
+        w = util.compare(util.model_to_flat(m3), util.model_to_flat(mdl), TOL, what="two passes vs one per component")
+        assert w < 1e-9, w
+        del m3
         cols2, data2 = download_sample(X, ranges[:3], width)
         assert np.array_equal(data2, data[:, :cols2.size])                # copy=True: the caller's matrix is intact
     finally:
@@ -200,7 +211,7 @@ def test_c3_unipals_multiblock_full_size(gpu_required, monkeypatch):
         assert util.compare(util.model_to_flat(m2), util.model_to_flat(mdl), TOL, what="explicit vs lazy") < TOL
         # multiblock NIPALS on the same matrix converges to the same subspace for one response
         m3 = MBPLS(n_components=K, method="NIPALS").fit(X, Y)
-        assert m3.nipals_iterations_ == [2] * K
+        assert m3.nipals_iterations_ == [1] * K
         assert util.relerr(np.abs(m3.Ts_), np.abs(mdl.Ts_)) < 1e-6
         assert util.relerr(m3.beta_, mdl.beta_) < 1e-6
     finally:

@@ -247,8 +247,8 @@ def test_reference_golden_csvs(gpu_required, fixture, methods):
         assert np.allclose(preds[0], p, atol=1e-3)
 
 
-def test_quickstart_config1(gpu_required):
-    """BASELINE.json configs[0]: README quick-start, n=40 p=200 K=2."""
+def test_quickstart_config1(gpu_required, q1_route):
+    """BASELINE.json configs[0]: README quick-start, n=40 p=200 K=2 (one-response NIPALS on both of its routes)."""
     from mbpls_amd import MBPLS
     g = util.load("quickstart_c1")
     for m in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
@@ -256,7 +256,7 @@ def test_quickstart_config1(gpu_required):
         w = util.compare(_fit_flat(mdl, g["x"], g["y"]), util.sub(g, f"ref/{m}"), TOL, what=m)
         assert w < 1e-9
         if m == "NIPALS":
-            assert mdl.nipals_iterations_ == [2, 2]
+            assert mdl.nipals_iterations_ == ([1, 1] if q1_route == "one_pass" else [2, 2])
 
 
 @pytest.mark.parametrize("fixture", ["matrix_pgtn", "matrix_ngtp"])
@@ -355,15 +355,13 @@ def test_sklearn_plumbing(gpu_required):
     ("KERNEL", 4096, 3000, 3, 6, [1000, 2000]),     # n >= p (mbpls.py:580-692): rank-1 deflation of X^T X on the device
     ("KERNEL", 2500, 2500, 1, 4, [2500]),           # n == p takes the same branch
 ])
-def test_medium_vs_oracle(gpu_required, method, n, p, q, K, blocks):
+def test_medium_vs_oracle(gpu_required, monkeypatch, method, n, p, q, K, blocks):
     from mbpls_amd import MBPLS
     X, Y = orc.make_latent(n, p, q, seed=n + p)
     Xn, Yn = orc.make_latent(64, p, q, seed=1)
     cuts = np.cumsum(blocks)[:-1]
     sp = (lambda A: A) if len(blocks) == 1 else (lambda A: [np.ascontiguousarray(b) for b in np.split(A, cuts, axis=1)])
     ref = orc.fit(sp(X), Y, n_components=K, method=method, full_svd=True)
-    mdl = MBPLS(n_components=K, method=method, full_svd=True).fit(sp(X), Y)
-    got = _fit_flat(mdl, sp(Xn), Yn)
     rflat = util.model_to_flat(ref)
     rflat["predict"] = orc.predict(ref, sp(Xn))
     if method != "SIMPLS":
@@ -373,13 +371,20 @@ def test_medium_vs_oracle(gpu_required, method, n, p, q, K, blocks):
     else:
         rTs, rU = orc.transform(ref, sp(Xn), Yn)
     rflat["Ts_new"], rflat["U_new"] = rTs, rU
-    w = util.compare(got, rflat, TOL, what=f"{method} n={n} p={p}")
-    assert w < 1e-8, w
-    if method == "NIPALS" and q == 1:
-        assert ref.nipals_iterations_ == [2] * K
-        # lazy deflation (K < 39) with re-orthogonalised sweep vectors reaches the stop rule ||ts_old - ts|| <= 1e-14
-        # (mbpls.py:841) on the second iteration of EVERY component, as the explicitly deflated reference does
-        assert list(mdl.nipals_iterations_) == list(ref.nipals_iterations_), mdl.nipals_iterations_
+    # one-response NIPALS: the default route (one pass per component), then the reference's two passes per component
+    for q1_route in (("1", "0") if (method == "NIPALS" and q == 1) else ("1",)):
+        monkeypatch.setenv("MBPLS_NIPALS_Q1_FIXED_POINT", q1_route)
+        mdl = MBPLS(n_components=K, method=method, full_svd=True).fit(sp(X), Y)
+        got = _fit_flat(mdl, sp(Xn), Yn)
+        w = util.compare(got, rflat, TOL, what=f"{method} n={n} p={p} route {q1_route}")
+        assert w < 1e-8, w
+        if method == "NIPALS" and q == 1:
+            assert ref.nipals_iterations_ == [2] * K
+            # two-pass route: lazy deflation (K < 39) with re-orthogonalised sweep vectors reaches the stop rule
+            # ||ts_old - ts|| <= 1e-14 (mbpls.py:841) on the second iteration of EVERY component, as the explicitly
+            # deflated reference does; the default route makes the one pass that matters
+            util.check_nipals_iterations(mdl, ref, K)
+            assert ("fixed point" in mdl.fit_plan_["solver"]) == (q1_route == "1"), mdl.fit_plan_
 
 
 @pytest.mark.parametrize("p,c1,c2", [(70, 2, 2), (1001, 3, 1), (50000, 10, 10), (300001, 20, 7), (4097, 32, 32)])
@@ -409,7 +414,8 @@ def test_small_dense_helpers(ctx, p, c1, c2):
 
 
 def test_q1_fixed_point_option(gpu_required, monkeypatch):
-    """Opt-in shortcut (MBPLS_NIPALS_Q1_FIXED_POINT=1): same attributes, one pass per component less."""
+    """One pass per component for one-response NIPALS (the default; MBPLS_NIPALS_Q1_FIXED_POINT=1 says so explicitly):
+    same attributes as the reference's two passes."""
     from mbpls_amd import MBPLS
     X, Y = orc.make_latent(4096, 12000, 1, seed=21)
     blocks = [np.ascontiguousarray(X[:, :5000]), np.ascontiguousarray(X[:, 5000:])]
@@ -630,7 +636,7 @@ def test_both_deflation_modes(gpu_required, monkeypatch, mode, method, q):
 @pytest.mark.parametrize("offset,n,p", [(0.0, 1000, 6000), (3.0, 1000, 6000), (50.0, 1000, 6000), (1.0e3, 1000, 6000),
                                         (1.0e3, 300, 40), (5.0e3, 64, 7), (1.0e6, 1000, 6000)])
 @pytest.mark.parametrize("resident", ["1", "0"])
-def test_implicit_standardisation_of_offset_data(gpu_required, monkeypatch, offset, n, p, resident):
+def test_implicit_standardisation_of_offset_data(gpu_required, monkeypatch, q1_route, offset, n, p, resident):
     """One response + lazy deflation: the fit never writes X (statistics-only first pass, raw-space passes after).
     The statistics pass shifts every element by the column's first sample and reports max |mean|/scale; above
     HipEngine.CENTRE_FROM_OFFSET the later passes subtract the column mean in registers before every dot product and
@@ -668,7 +674,7 @@ def test_implicit_standardisation_of_offset_data(gpu_required, monkeypatch, offs
     assert centred == (offset >= 50.0) or offset == 3.0      # both flavours of the passes are exercised
     assert cen == [centred]
     assert len(seen) == (2 if centred and resident == "1" else 1)      # queued twice when the device finds offset data
-    assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * K, (mdl.nipals_iterations_, ref.nipals_iterations_)
+    util.check_nipals_iterations(mdl, ref, K)
     w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"offset {offset}")
     # the input itself is only known to offset * eps scale units: that, not the arithmetic, bounds the agreement
     assert w < max(1e-9, 1e3 * offset * np.finfo(float).eps), w
@@ -679,7 +685,7 @@ def test_implicit_standardisation_of_offset_data(gpu_required, monkeypatch, offs
     seen.clear()
     m2 = MBPLS(n_components=K).fit(Xd, Y)
     assert seen == []
-    assert m2.nipals_iterations_ == [2] * K
+    util.check_nipals_iterations(m2, ref, K)
     assert util.compare(util.model_to_flat(m2), util.model_to_flat(ref), TOL, what="stored") < max(1e-8, 1e3 * offset * 2.3e-16)
     Xd.close()
 
@@ -710,7 +716,7 @@ def test_medium_vs_faithful_oracle(gpu_required, method, q, blocks):
                                             ("NIPALS", 33, 2, 600, 500), ("UNIPALS", 40, 1, 300, 2400),
                                             ("UNIPALS", 35, 3, 300, 2400), ("KERNEL", 40, 2, 300, 2400),
                                             ("SIMPLS", 40, 1, 300, 2400)])
-def test_many_components(gpu_required, method, K, q, n, p):
+def test_many_components(gpu_required, monkeypatch, method, K, q, n, p):
     """More components than one 32-column tile of the device helpers (cross products / right-multiplications are tiled)
     and than the lazy-deflation correction registers hold (K >= 39 takes the stored, explicitly deflated path): any K
     works, as in the reference.  (NIPALS on tall data: with p > n the response is fitted exactly after ~30 components
@@ -720,20 +726,24 @@ def test_many_components(gpu_required, method, K, q, n, p):
     h = p // 2 - 50
     Xs = [np.ascontiguousarray(X[:, :h]), np.ascontiguousarray(X[:, h:])]
     ref = orc.fit(Xs, Y, n_components=K, method=method)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        mdl = MBPLS(n_components=K, method=method).fit(Xs, Y)
-    w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} K={K} q={q}")
-    assert w < 1e-8, w
-    if method == "NIPALS" and q == 1:
-        assert ref.nipals_iterations_ == [2] * K
-        # lazy deflation (K < 39) with re-orthogonalised sweep vectors reaches the stop rule ||ts_old - ts|| <= 1e-14
-        # (mbpls.py:841) on the second iteration of EVERY component, as the explicitly deflated reference does
-        assert list(mdl.nipals_iterations_) == list(ref.nipals_iterations_), mdl.nipals_iterations_
+    # one-response NIPALS: the default route (one pass per component), then the reference's two passes per component
+    for q1_route in (("1", "0") if (method == "NIPALS" and q == 1) else ("1",)):
+        monkeypatch.setenv("MBPLS_NIPALS_Q1_FIXED_POINT", q1_route)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mdl = MBPLS(n_components=K, method=method).fit(Xs, Y)
+        w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"{method} K={K} q={q} route {q1_route}")
+        assert w < 1e-8, w
+        if method == "NIPALS" and q == 1:
+            assert ref.nipals_iterations_ == [2] * K
+            # two-pass route: lazy deflation (K < 39) with re-orthogonalised sweep vectors reaches the stop rule
+            # ||ts_old - ts|| <= 1e-14 (mbpls.py:841) on the second iteration of EVERY component, as the explicitly
+            # deflated reference does; the default route makes the one pass that matters
+            util.check_nipals_iterations(mdl, ref, K)
 
 
 @pytest.mark.parametrize("n,p,K", [(512, 8192, 30), (1024, 16384, 34)])
-def test_exhausted_response_iterations_follow_the_oracle(gpu_required, n, p, K):
+def test_exhausted_response_iterations_follow_the_oracle(gpu_required, two_pass_nipals, n, p, K):
     """Deep components of a response that p >> n columns fit exactly: the REFERENCE algorithm (oracle, explicit
     deflation) meets ||ts_old - ts|| <= 1e-14 on the second iteration for the first 24 / 27 components and then no
     longer terminates (iteration cap).  The lazily deflated fit -- sweep vectors re-orthogonalised against the earlier
@@ -766,7 +776,7 @@ def test_exhausted_response_iterations_follow_the_oracle(gpu_required, n, p, K):
 @pytest.mark.parametrize("blocks,standardize,norm,implicit", [(1, True, 2, "1"), (3, True, 2, "1"), (3, False, 1, "1"),
                                                               (2, True, np.inf, "0"), (1, True, -np.inf, "1"),
                                                               (16, True, "fro", "1")])
-def test_device_resident_nipals(gpu_required, monkeypatch, blocks, standardize, norm, implicit):
+def test_device_resident_nipals(gpu_required, two_pass_nipals, monkeypatch, blocks, standardize, norm, implicit):
     """One response: the whole NIPALS fit is queued on the device (csrc/resident.hip does the n x B algebra and the
     stop test between the passes; no host round trip per pass).  Same numbers as the host-driven loop
     (MBPLS_RESIDENT=0) and as the oracle, for every variant of the passes (implicit / stored standardisation, no
@@ -833,7 +843,7 @@ def test_device_resident_unipals(gpu_required, monkeypatch, blocks, standardize,
 
 
 @pytest.mark.parametrize("resume_at", [0, 3])
-def test_device_resident_nipals_resumes_on_the_host(gpu_required, monkeypatch, resume_at):
+def test_device_resident_nipals_resumes_on_the_host(gpu_required, two_pass_nipals, monkeypatch, resume_at):
     """The device queue is speculative (two iterations per component).  When a component does not meet the stop rule
     on its second iteration the queued launches behind it turn into no-ops and the host-driven loop resumes at that
     component: forced here at component 0 (impossible tolerance on the device) and emulated at component 3."""
@@ -1164,7 +1174,7 @@ def test_ragged_sample_counts_above_4096(gpu_required, monkeypatch, n):
     blocks = [np.ascontiguousarray(X[:, :700]), np.ascontiguousarray(X[:, 700:])]
     ref = orc.fit(blocks, Y, n_components=3, method="NIPALS")
     mdl = MBPLS(n_components=3).fit(blocks, Y)
-    assert mdl.nipals_iterations_ == ref.nipals_iterations_ == [2] * 3
+    util.check_nipals_iterations(mdl, ref, 3)
     assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"ragged n={n}") < 1e-9
     assert util.relerr(mdl.predict(blocks), orc.predict(ref, blocks)) < 1e-9
     monkeypatch.setenv("MBPLS_DEFLATION", "explicit")

@@ -58,17 +58,20 @@ def test_reference_csv_inputs():
             util.compare(util.model_to_flat(res), util.sub(g, f"ref/{m}/full1"), TOL, skip=FIT_ONLY_SKIP, what=m)
 
 
-def test_nipals_iterations_q1():
+def test_nipals_iterations_q1(monkeypatch):
+    """the reference's iteration structure (two passes per component for one response), selected by the switch"""
     g = util.load("quickstart_c1")
+    monkeypatch.setenv("MBPLS_NIPALS_Q1_FIXED_POINT", "0")
     res = run_driver(g["x"], g["y"], "NIPALS", 2)
     assert res.nipals_iterations_ == [2, 2]
     util.compare(util.model_to_flat(res), util.sub(g, "ref/NIPALS"), TOL, skip=FIT_ONLY_SKIP)
 
 
-def test_q1_fixed_point_option(monkeypatch):
-    """Opt-in: for one response the second NIPALS pass is skipped; every attribute must be unchanged."""
+def test_q1_fixed_point_is_the_default(monkeypatch):
+    """For one response the second NIPALS pass only re-derives the first (u is y / v whatever ts was): the default route
+    makes one pass per component; every attribute must be what the reference's two passes give."""
     g = util.load("quickstart_c1")
-    monkeypatch.setenv("MBPLS_NIPALS_Q1_FIXED_POINT", "1")
+    monkeypatch.delenv("MBPLS_NIPALS_Q1_FIXED_POINT", raising=False)
     res = run_driver(g["x"], g["y"], "NIPALS", 2)
     assert res.nipals_iterations_ == [1, 1]
     util.compare(util.model_to_flat(res), util.sub(g, "ref/NIPALS"), TOL, skip=FIT_ONLY_SKIP)
@@ -146,7 +149,7 @@ def test_scalers_are_sklearn_standard_scalers():
     assert isinstance(clone(carried), ColumnScaler)
 
 
-def test_one_response_noise_floor_is_a_stagnation_rule():
+def test_one_response_noise_floor_is_a_stagnation_rule(two_pass_nipals):
     """advisor finding (round 3): a fixed cut-off at four iterations also stopped components the reference finishes in
     five.  The one-response loop gives up only when ||ts_old - ts|| has STOPPED shrinking; iteration counts equal the
     oracle's wherever the oracle converges, and a difference that still shrinks is never cut."""

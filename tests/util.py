@@ -80,3 +80,20 @@ def compare(got, ref, tol, skip=(), only=None, what=""):
         assert e <= tol, f"{what}: {k} rel err {e:.3e} > {tol:.1e}"
         worst = max(worst, e)
     return worst
+
+
+def check_nipals_iterations(mdl, ref, K=None, two=True):
+    """Iteration counts of a NIPALS fit against the oracle's.  The default route of ONE-RESPONSE NIPALS makes one pass per
+    component (the reference's second pass only re-derives the first, solvers._fit_nipals_q1_fixed_point) and reports 1;
+    the premise -- the reference converges in two -- is checked on the oracle (``two``).  Every other route repeats the
+    reference's loop and must stop where the oracle stops."""
+    got, want = list(mdl.nipals_iterations_), list(ref.nipals_iterations_)
+    plan = getattr(mdl, "fit_plan_", None) or {}
+    if "fixed point after one pass" in str(plan.get("solver", "")):
+        assert got == [1] * len(want), got
+        if two:
+            assert want == [2] * len(want), want
+    else:
+        assert got == want, (got, want)
+    if K is not None:
+        assert len(got) == K
