@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--first-fit-child", action="store_true",
                     help="(internal) fresh process: generate X, time the FIRST fit of the process and the second, print JSON")
     ap.add_argument("--no-first-fit", action="store_true", help="skip the cold-start leg (a child process run first)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic "
+                         "live; the committed figure under profiles/ is reported instead, labelled so")
     ap.add_argument("--extras-child", action="store_true",
                     help="(internal) the side legs of the N = 1 line in a process of their own; prints one JSON object")
     ap.add_argument("--full-fit-s", type=float, default=0.0, help="(internal) the parent's timed fit, for the shard proxy")
@@ -116,6 +119,12 @@ def main():
     cold = None
     if world == 1 and not a.dist and not a.no_first_fit and not a.no_extras:
         cold = run_first_fit_child(a)
+    # roofline.traffic: HBM bytes per launch from the PMC counters of THIS machine -- one fit of the same workload in a
+    # child process under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate runs, with --kernel-trace only), also
+    # before this process touches the GPU
+    live_pmc = None
+    if world == 1 and not a.dist and not a.no_pmc and not a.no_extras:
+        live_pmc = run_pmc_children(a)
     import mbpls_amd
     from mbpls_amd import MBPLS, DeviceMatrix
 
@@ -280,7 +289,7 @@ def main():
         roof = None
         if dom[0]:
             k = dom[1]
-            traffic, src = pmc_traffic(dom[0], n, p)
+            traffic, src = pmc_traffic(dom[0], n, p, live_pmc)
             ceiling = X.probe_read_bandwidth(3)      # best pure-read kernel on this box, same buffer (after the timed region)
             roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(k["GBps"], 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(k["GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -313,6 +322,7 @@ def main():
             "effective_GBps_reference_algorithm_bytes": round(ref_units * unit_bytes / per_step / 1e9, 1),
             "ref_units_per_fit": ref_units,
             "roofline": roof,
+            "pmc_traffic_this_run": live_pmc,
             "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4), "GBps": round(v["GBps"], 1)}
                         for k, v in prof.items()},
             "host_phases_ms_last_fit": phases,
@@ -855,11 +865,103 @@ def end_to_end(ctx, X, Y, n, cols, K, method):
         return {"skipped": "not enough host memory"}
 
 
-def pmc_traffic(kernel, n, p):
-    """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate
-    runs, gfx950 x2 read correction) -- taken on the builder's lease, not in this run -- and only when they were taken
-    on this exact shape, else None."""
-    for name in ("r04_pmc_traffic_c2.json", "r03_pmc_traffic_c2.json", "r02_pmc_traffic_c2.json", "r01_pmc_traffic_c2.json"):
+PASS_NAMES = {("true", "false", "true"): "standardize_sweep", ("false", "false", "true"): "sweep",
+              ("false", "true", "true"): "deflate_sweep", ("false", "true", "false"): "deflate"}
+
+
+def parse_pmc_csv(path, counter):
+    """average `counter` value per launch of every register-resident column pass (k_colpass<R, TMAX, D, STD, DEFL,
+    SWEEP, ...>) in a rocprofv3 counter_collection.csv, keyed by the pass names of the HIP-event profile"""
+    import collections
+    import csv
+    agg = collections.defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            kn = r.get("Kernel_Name", "")
+            if "k_colpass<" not in kn or r.get("Counter_Name") != counter:
+                continue
+            args = [x.strip() for x in kn.split("<", 1)[1].split(">")[0].split(",")]
+            nm = PASS_NAMES.get(tuple(args[3:6]))
+            if nm:
+                agg[nm].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def run_pmc_children(a, timeout_s=240):
+    """Two child runs of ONE fit of this workload under `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace` (separate
+    passes; no other trace domain), from /tmp with TMPDIR=/tmp as the profiler wants.  Unit and correction exactly as
+    MI355X_MICROARCH.md section HBM prescribes: the derived counters are in KiB; on gfx950 FETCH_SIZE tallies the
+    128-byte requests of a wide coalesced (16 B/lane) stream as 64 bytes, so read bytes = 2 x FETCH_SIZE x 1024, and
+    WRITE_SIZE x 1024 is exact for 16 B/lane streaming stores.  Returns {kernel: {...}} or {"error": ...}; never fatal."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    out = {"method": "rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate child runs of one fit of this workload "
+                     "(--kernel-trace only); read bytes = 2 x FETCH_SIZE x 1024 (gfx950 correction for wide coalesced "
+                     "streams, MI355X_MICROARCH.md section HBM), write bytes = WRITE_SIZE x 1024", "kernels": {}}
+    tmp = tempfile.mkdtemp(prefix="mbpls_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.time()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            note(f"PMC pass {counter} (child process under rocprofv3)")
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--cpu-cols", "0",
+                   "--e2e-cols", "0", "--no-extras", "--no-first-fit", "--no-pmc", "--n", str(a.n), "--p", str(a.p),
+                   "--K", str(a.K), "--q", str(a.q), "--method", a.method]
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                                  start_new_session=True)
+            try:
+                _, err = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.wait()
+                return {"error": f"{counter} pass timed out after {timeout_s} s"}
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if pr.returncode != 0 or not files:
+                return {"error": f"{counter} pass: exit {pr.returncode}, {len(files)} counter files: {(err or '')[-300:]}"}
+            for nm, (avg, cnt) in parse_pmc_csv(files[0], counter).items():
+                k = out["kernels"].setdefault(nm, {})
+                k[counter + "_KiB_avg"] = avg
+                k["launches"] = cnt
+        unit = 8.0 * a.n * a.p
+        for nm, k in list(out["kernels"].items()):
+            if "FETCH_SIZE_KiB_avg" not in k or "WRITE_SIZE_KiB_avg" not in k:
+                del out["kernels"][nm]
+                continue
+            k["hbm_read_bytes"] = 2.0 * k["FETCH_SIZE_KiB_avg"] * 1024.0
+            k["hbm_write_bytes"] = k["WRITE_SIZE_KiB_avg"] * 1024.0
+            k["hbm_bytes_per_launch"] = k["hbm_read_bytes"] + k["hbm_write_bytes"]
+            k["over_algorithmic_8np"] = round(k["hbm_bytes_per_launch"] / unit, 4)
+        out["wall_s"] = round(time.time() - t0, 1)
+        if not out["kernels"]:
+            return {"error": "no column-pass kernels in the counter files"}
+        return out
+    except Exception as e:                               # noqa: BLE001 -- the committed figure is reported instead
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_traffic(kernel, n, p, live=None):
+    """HBM bytes per launch of `kernel`: from the PMC passes of THIS run (run_pmc_children) when they succeeded, else
+    from the COMMITTED rocprofv3 PMC passes (same command, taken on the builder's lease, labelled so) -- and those only
+    when they were taken on this exact shape, else None."""
+    if live and "kernels" in live and kernel in live["kernels"]:
+        return (live["kernels"][kernel]["hbm_bytes_per_launch"],
+                "measured in this run: two rocprofv3 --pmc child passes (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024, "
+                "MI355X_MICROARCH.md section HBM), per launch of this kernel")
+    for name in ("r05_pmc_traffic_c2.json", "r04_pmc_traffic_c2.json", "r03_pmc_traffic_c2.json", "r02_pmc_traffic_c2.json",
+                 "r01_pmc_traffic_c2.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)

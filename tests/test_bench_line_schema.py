@@ -56,3 +56,23 @@ def test_rccl_line_reports_what_rccl_reports():
     assert c["backend"].startswith("rccl") and c["rccl_ranks"] == d["n_gpus"] == c["world_size"]
     assert c["rccl_user_rank"] == 0 and c["rccl_version"] > 0
     assert d["allreduce"]["mean_us"] > 0
+
+
+def test_pmc_counter_files_are_parsed_as_the_committed_summary_says():
+    """bench.run_pmc_children measures roofline.traffic live (two rocprofv3 --pmc child passes); its parser, on the
+    committed counter files of round 4, must give the committed per-kernel figures (FETCH_SIZE in KiB, x 2 x 1024 on
+    gfx950 for the read bytes; WRITE_SIZE x 1024)."""
+    import bench
+    prof = os.path.join(ROOT, "profiles")
+    with open(os.path.join(prof, "r04_pmc_traffic_c2.json")) as f:
+        want = json.load(f)["kernels"]
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        got = bench.parse_pmc_csv(os.path.join(prof, f"r04_pmc_{counter}_bench_c2_counter_collection.csv"), counter)
+        assert set(got) == set(want)
+        for k, (avg, cnt) in got.items():
+            assert cnt == want[k]["launches"]
+            assert abs(avg - want[k][counter + "_KiB_avg"]) <= 1e-9 * avg
+    live = {"kernels": {"sweep": {"hbm_bytes_per_launch": 1.0}}}
+    assert bench.pmc_traffic("sweep", 4096, 1_000_000, live)[0] == 1.0
+    val, src = bench.pmc_traffic("sweep", 4096, 1_000_000, {"error": "x"})
+    assert val == want["sweep"]["hbm_bytes_per_launch"] and "not measured in this run" in src
