@@ -40,7 +40,7 @@ struct GramArgs {
 // SCALE 1: z = (x - mean) * rscale (two operations per value, safe for any column offset); SCALE 2: z = fma(x, rscale,
 // -mean * rscale) (one operation; its rounding is amplified by |mean_j|/scale_j, so callers use it when the
 // statistics pass reported a small offset measure).
-template <int SCALE, int PD>
+template <int SCALE>
 __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   // XCD-aware remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous run of work items
   const int nwg = gridDim.x;
@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   // group issue.  A load therefore has (PD-1) x 16 MFMAs (~3000 cycles) to land: HBM/L2 latency is
   // covered without relying on the second wave of the SIMD.  No select and no branch sits between a load
   // and its MFMA (prefetch index clamped, not guarded), sched_barrier pins the staggered order.
+  constexpr int PD = 4;
   const int64_t nsteps = (jend - jbeg) / 4;           // complete groups of 4 features
   const int64_t nmain = (nsteps / PD) * PD;
   const char* xb = (const char*)(a.X + jbeg * a.ld);
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
       }
       if constexpr (SCALE != 0) MB_GLD(msv[s], oms, msb + s * 64);
     }
-    static_assert(PD >= 4 && PD <= 6, "the step sequences below are written for rings of 4 to 6 slots");
+    static_assert(PD == 4, "the step macro below is written for a ring of 4 slots");
 #define MB_GRAM_STEP(S, SL)                                                                                 \
   {                                                                                                         \
     int64_t nx = it + (S) + PD - 1;               /* group to prefetch */                                   \
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
     }                                                                                                       \
     if constexpr (SCALE != 0) {                                                                             \
       MB_GLD(msv[SL], oms, msb + nx * 64);                                                                  \
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * PD - 5) : "memory");   /* PD groups x 5 loads in flight, oldest retired */ \
+      asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   /* 4 groups x 5 loads in flight, oldest retired */ \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
       /* z = (x - mean) * rscale on the 8 operand values, INTERLEAVED with the 16 MFMAs: an MFMA occupies the */ \
       /* matrix pipe for 16 cycles but the issue port for 4, so two VALU ops ride along with each one        */ \
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
       }                                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
     } else {                                                                                                \
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PD - 4) : "memory");   /* PD groups x 4 loads in flight, oldest retired */ \
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
       _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)     \
           acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[S][mi >> 1][mi & 1], bv[S][ni >> 1][ni & 1], \
@@ -153,12 +154,10 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
     }                                                                                                       \
   }
     for (int64_t it = 0; it < nmain; it += PD) {
-      MB_GRAM_STEP(0, PD - 1)
+      MB_GRAM_STEP(0, 3)
       MB_GRAM_STEP(1, 0)
       MB_GRAM_STEP(2, 1)
       MB_GRAM_STEP(3, 2)
-      if constexpr (PD >= 5) MB_GRAM_STEP(4, 3)
-      if constexpr (PD >= 6) MB_GRAM_STEP(5, 4)
     }
 #undef MB_GRAM_STEP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -303,17 +302,9 @@ extern "C" int mbpls_hip_gram_scaled(const mbpls_mat* m, const double* d_mean, c
   a.out = part; a.ldg = ldg;
   {
     ProfScope prof(ctx, MBPLS_K_GRAM, 8.0 * (double)n * (double)p);
-    const dim3 grid((unsigned)(ntiles * nslices));
-#define MB_GRAM_LAUNCH(PD_)                                                                            \
-  do {                                                                                                 \
-    if (ms && centre_first) hipLaunchKernelGGL((k_gram<1, PD_>), grid, dim3(256), 0, ctx->stream, a);  \
-    else if (ms) hipLaunchKernelGGL((k_gram<2, PD_>), grid, dim3(256), 0, ctx->stream, a);             \
-    else hipLaunchKernelGGL((k_gram<0, PD_>), grid, dim3(256), 0, ctx->stream, a);                     \
-  } while (0)
-    if (ctx->gram_ring >= 6 && !ms) MB_GRAM_LAUNCH(6);    // (with operand standardisation six slots spill: five)
-    else if (ctx->gram_ring >= 5) MB_GRAM_LAUNCH(5);
-    else MB_GRAM_LAUNCH(4);
-#undef MB_GRAM_LAUNCH
+    if (ms && centre_first) hipLaunchKernelGGL(k_gram<1>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
+    else if (ms) hipLaunchKernelGGL(k_gram<2>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_gram<0>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
   }
   MB_HIP(hipGetLastError());
   dim3 fgrid((unsigned)((n + 255) / 256), (unsigned)n);
