@@ -1,0 +1,49 @@
+#!/bin/bash
+# Evidence of one round (everything named profiles/<round>_*): run on the GPU box from the repo root,
+#   gpurun --timeout 3400 -- 'bash tools/gpu_evidence.sh r05 [part ...]'      parts: bench dist configs shapes cv paper sparse prof long gaps (default: all)
+# then, back on the build machine:  python tools/collect_evidence.py r05 [--table]
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+RND=${1:-r05}
+shift
+PARTS=${*:-bench dist configs shapes cv paper sparse prof long gaps}
+O=$R/gpurun_out/${RND}ev
+mkdir -p $O
+cd $R
+has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
+if has bench; then
+  ( time timeout 900 python3 bench.py > $O/bench_full.log 2> $O/bench_full.err ) 2> $O/bench_full.time; echo bench rc=$?; tail -1 $O/bench_full.log > $O/${RND}_bench_c2_line.json; tail -3 $O/bench_full.time
+fi
+if has dist; then
+  MBPLS_BENCH_SHARED_GPU=1 timeout 600 python3 bench.py --gpus 2 --p 200000 --steps 2 --warmup 1 --cpu-cols 8192 > $O/bench_shared2.log 2> $O/bench_shared2.err; echo shared2 rc=$?; tail -1 $O/bench_shared2.log > $O/${RND}_bench_selflaunch_shared_gpu_world2_line.json
+  timeout 600 python3 bench.py --dist --p 250000 --steps 5 --warmup 3 --cpu-cols 0 --e2e-cols 0 > $O/bench_dist1.log 2>&1; echo dist1 rc=$?; tail -1 $O/bench_dist1.log > $O/${RND}_bench_dist_rccl_world1_line.json
+  timeout 300 python3 tools/host_timeline.py --rccl --n 4096 --p 125000 --K 10 --fits 12 --fresh --show last > $O/${RND}_host_timeline_p125k_rccl.txt 2>&1
+fi
+if has configs; then
+  rm -f $O/${RND}_other_configs_lines.jsonl
+  for c in c3 c4 simpls nipals_q10 unipals_q10 nipals_mb; do timeout 600 python3 tools/bench_configs.py $c 2>/dev/null | tail -1 >> $O/${RND}_other_configs_lines.jsonl; done
+fi
+if has shapes; then
+  ( timeout 900 python3 tools/time_shapes.py 8 NIPALS 1 2>/dev/null | grep '^n='; timeout 600 python3 tools/time_shapes.py 8 UNIPALS 1 1200,2500,3000,5000,6000,7000,8192,12000,16384 2>/dev/null | grep '^n=' ) > $O/${RND}_shapes.txt
+fi
+if has cv; then timeout 900 python3 tools/time_cv.py > $O/${RND}_time_cv.txt 2>&1; fi
+if has paper; then
+  ( timeout 900 python3 tools/paper_protocol.py a --data both 2>/dev/null; timeout 1500 python3 tools/paper_protocol.py b --data both 2>/dev/null ) | grep '^{' > $O/${RND}_paper_protocol.jsonl
+fi
+if has sparse; then timeout 600 python3 tools/time_sparse.py 1000000 0.05 > $O/${RND}_sparse_n4096_p1m.txt 2>&1; fi
+if has long; then
+  ( for s in "16384 100000" "1000000 2000" "20000 20000" "20000 1000" "65536 30000"; do timeout 400 python3 tools/time_long.py $s 2>&1 | grep -v "host phases"; done ) > $O/${RND}_long_columns.txt
+fi
+cd /tmp && export TMPDIR=/tmp
+if has prof; then
+  rm -rf $O/stats $O/pmc
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 6 --cpu-cols 0 --e2e-cols 0 --no-extras > $O/bench_under_rocprof.log 2>&1; echo stats rc=$?
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc/FETCH_SIZE -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-cols 0 --e2e-cols 0 --no-extras > $O/pmc_fetch.log 2>&1; echo fetch rc=$?
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc/WRITE_SIZE -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-cols 0 --e2e-cols 0 --no-extras > $O/pmc_write.log 2>&1; echo write rc=$?
+  ( cd $R && python3 tools/pmc_to_json.py $O/pmc 4096 1000000 $RND > $O/pmc_c2_summary.txt 2>&1; cp profiles/${RND}_pmc_traffic_c2.json profiles/${RND}_pmc_*_bench_c2_counter_collection.csv $O/ 2>/dev/null )
+fi
+if has gaps; then
+  rm -rf $O/trace125k
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace125k -- python3 $R/tools/gap_fit.py 125000 rccl > $O/gap125k.log 2>&1; echo trace rc=$?
+  ( cd $R && python3 tools/trace_gaps.py $O/trace125k --list > $O/${RND}_gaps_p125k.txt 2>&1 )
+fi
+ls $O | head -60
