@@ -1,11 +1,11 @@
 #!/bin/bash
 # Evidence of one round (everything named profiles/<round>_*): run on the GPU box from the repo root,
-#   gpurun --timeout 3400 -- 'bash tools/gpu_evidence.sh r05 [part ...]'      parts: bench dist configs shapes cv paper sparse prof long gaps (default: all)
+#   gpurun --timeout 3400 -- 'bash tools/gpu_evidence.sh r05 [part ...]'      parts: bench dist configs shapes cv paper sparse fuzz prof long gaps (default: all)
 # then, back on the build machine:  python tools/collect_evidence.py r05 [--table]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 RND=${1:-r05}
 shift
-PARTS=${*:-bench dist configs shapes cv paper sparse prof long gaps}
+PARTS=${*:-bench dist configs shapes cv paper sparse fuzz prof long gaps}
 O=$R/gpurun_out/${RND}ev
 mkdir -p $O
 cd $R
@@ -30,6 +30,11 @@ if has paper; then
   ( timeout 900 python3 tools/paper_protocol.py a --data both 2>/dev/null; timeout 1500 python3 tools/paper_protocol.py b --data both 2>/dev/null ) | grep '^{' > $O/${RND}_paper_protocol.jsonl
 fi
 if has sparse; then timeout 600 python3 tools/time_sparse.py 1000000 0.05 > $O/${RND}_sparse_n4096_p1m.txt 2>&1; fi
+if has fuzz; then
+  ( echo "tests/fuzz.py on the code of $RND (random shapes / block splits / methods / settings incl. column offsets and missing values; HIP path vs the oracles, worst relative error over all fitted attributes and predictions):"
+    for sd in 505 606; do echo -n "small seed $sd: "; timeout 900 python3 tools/fuzz_parity.py 200 $sd 2>&1 | tail -1; done
+    for sd in 707; do echo -n "register-resident columns (1024 < n <= 8192) seed $sd: "; timeout 900 python3 tools/fuzz_parity.py 60 $sd big 2>&1 | tail -1; done ) > $O/${RND}_fuzz.txt
+fi
 if has long; then
   ( for s in "16384 100000" "1000000 2000" "20000 20000" "20000 1000" "65536 30000"; do timeout 400 python3 tools/time_long.py $s 2>&1 | grep -v "host phases"; done ) > $O/${RND}_long_columns.txt
 fi
