@@ -656,7 +656,7 @@ def time_allreduce(ctx, comm, count, reps=200):
     us = (time.perf_counter() - t0) / reps * 1e6
     if hasattr(buf, "free"):
         buf.free()
-    return {"doubles": int(count), "mean_us": round(us, 1), "per_fit": "one per pass (21 per fit)"}
+    return {"doubles": int(count), "mean_us": round(us, 1), "per_fit": "one per pass over X (K + 1 per fit on the default route, 2K + 1 with two passes per component)"}
 
 
 def strong_scaling(ctx, mbpls_amd, dT, Y, r, rank, world, n, p_total, K, method, barrier_sync, max_over_ranks):

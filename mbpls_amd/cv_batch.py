@@ -98,8 +98,11 @@ def predict_folds(estimator, Xdev, ctx, comm, y, splits, batch=None):
         batch = max(1, _folds_per_batch(ctx, p, K + (q if q > 1 else 0), len(splits)))
     std = bool(estimator.standardize)
     out = np.full((n, q), np.nan)
-    # one response, a method without iteration (or NIPALS, whose second iteration only confirms the first): one sweep
-    one_pass = q == 1 and estimator.method != "NIPALS"
+    # one response: ONE sweep per component -- a method without iteration, or NIPALS, whose second iteration only confirms
+    # the first (the default route of a single fit as well; MBPLS_NIPALS_Q1_FIXED_POINT=0 makes the folds iterate like
+    # the reference)
+    from .plan import FitOptions
+    one_pass = q == 1 and (estimator.method != "NIPALS" or FitOptions.from_env().q1_fixed_point)
     method = estimator.method if q > 1 else "NIPALS"
     eng = HipEngine(ctx=ctx, comm=comm)
     eng.load_device(Xdev, copy=False)

@@ -505,8 +505,9 @@ def test_row_subset_fit_and_cross_val_predict(gpu_required, q):
 
 
 @pytest.mark.parametrize("blocks,std,cv", [(1, True, "loo"), (2, True, 7), (3, False, 5), (2, True, "thirds")])
-def test_cross_val_predict_batched_folds(gpu_required, blocks, std, cv):
-    """One-response NIPALS: up to 256 folds per pass over X (cv_batch) == the fold-by-fold loop == a loop of oracle fits,
+def test_cross_val_predict_batched_folds(gpu_required, q1_route, blocks, std, cv):
+    """One-response NIPALS (one sweep per component and fold, or the reference's two: q1_route): up to 256 folds per pass
+    over X (cv_batch) == the fold-by-fold loop == a loop of oracle fits,
     for leave-one-out, k-fold and an explicit split list, one and several blocks, with and without standardisation; a
     constant column and a column that is constant on one fold's training rows only included."""
     from mbpls_amd import MBPLS, cv_batch
