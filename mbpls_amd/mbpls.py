@@ -86,7 +86,7 @@ def _require_finite(out):
 
 def _global_block_sizes(eng):
     """block widths of the whole problem (summed over column shards)"""
-    return eng.comm.allreduce_host(np.asarray(eng.block_sizes, dtype=np.float64))
+    return solvers._global_sizes(eng)
 
 
 def _is_block_list(X):

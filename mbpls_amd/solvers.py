@@ -276,8 +276,14 @@ class _StreamedColumns:
 
 def _global_sizes(eng):
     """Block sizes of the WHOLE problem (summed over shards) for the BIP correction."""
-    s = np.asarray(eng.block_sizes, dtype=np.float64)
-    return eng.comm.allreduce_host(s)
+    # (once per fit: under column shards this is a collective -- every rank asks the same number of times, in the same
+    # places, so remembering the answer on the engine of THIS fit keeps the ranks in step)
+    cached = getattr(eng, "_global_sizes_of_fit", None)
+    if cached is not None and cached[0] == tuple(eng.block_sizes):
+        return cached[1].copy()
+    s = eng.comm.allreduce_host(np.asarray(eng.block_sizes, dtype=np.float64))
+    eng._global_sizes_of_fit = (tuple(eng.block_sizes), np.array(s, dtype=np.float64))
+    return s
 
 
 def _finalise_device(eng, res, wslot, K, col_norm, blk_norm, V, pslot="P", W_host=None, P_host=None, fetch=True, C=None):
