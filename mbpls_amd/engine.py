@@ -779,8 +779,9 @@ class HipEngine(EngineBase):
         pass (loadings + lazy deflation + the products X^T y, X_b (X^T y)_b of the next component, see
         solvers.fit_unipals); the step kernel forms ts = X (X^T y) / ||.||, v, u, the scalar c with w = c X^T y, the block
         norms and scores between the passes.  No iteration, so nothing is speculative; the offset check of the first
-        step is the same as for NIPALS."""
-        first_pass()
+        step is the same as for NIPALS.  ``first_pass``: None when the caller has already queued it."""
+        if first_pass is not None:
+            first_pass()
         with _ResidentQueue(self, Y, K, 0, 0.0, mode=1) as rq:
             S, Wc, Pm = self.slots[gslot], self.slots[wslot], self.slots[self._lazy_pslot]
             p8 = 8 * self.p

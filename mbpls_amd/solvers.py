@@ -637,12 +637,12 @@ def fit_nipals(eng, Y, K, standardize, max_tol=1e-14, norm=2, calc_all=True, max
     if _nipals_on_grams(eng, q):
         _plan(eng, solver="nipals: inner loop on per-block association matrices")
         return _fit_nipals_grams(eng, Y, K, standardize, max_tol, norm, calc_all, max_iter)
-    sizes = _global_sizes(eng)
     resp = _Responses(Y)
     Y = resp.Y                                              # missing responses (sparse_data=True) as zeros + masks
     if q == 1 and eng.opts.q1_fixed_point and not eng.sparse and not resp.sparse and max_iter >= 1:
         _check_norm_order(norm)                       # raises for invalid orders exactly as the reference (:887)
         return _fit_nipals_q1_fixed_point(eng, Y, K, standardize, calc_all)
+    sizes = _global_sizes(eng)
     u0 = resp.start()
     alpha0 = 1.0 / u0.T.dot(u0).item()
     eng.slot("Wn", K)
@@ -912,25 +912,35 @@ def fit_unipals(eng, Y, K, standardize, keep_raw_weights=False):
     host as well and returned as ``_W_raw_host`` (the NIPALS fixed-point route hands them out as W_non_normal_)."""
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
-    p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
     # One response: w = tlsv(X^T y) and ts = X w / ||X w|| of the n >= p branch (:396-417) are the X^T y / ||.|| and
     # X (X^T y) / ||.|| of the p > n branch (:489-503) -- the same component up to the sign convention of the SVD --
     # so tall data takes the one-pass-per-component path as well (device-resident queue, X never written).
+    # (the total width is a collective under column shards: only asked where the branch depends on it)
+    p_total = eng.p if q == 1 else int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
     wide = p_total > n or q == 1
     if wide and q > 1 and not eng.sparse and eng.opts.unipals_nodeflate:
         _plan(eng, solver="unipals: several responses, one pass per component (maintained products)")
         return _fit_unipals_wide_multi(eng, Y, K, standardize)
-    sizes = _global_sizes(eng)
-    eng.slot("Wc", K)
-    eng.slot("P", K)
-    eng.slot("S", max(q, 1))
     y0 = Y[:, 0:1]
+    eng.slot("S", max(q, 1))
     if wide:
         # one response: every pass is a sweep / deflate_sweep, lazy deflation applies.  Several responses: X (X^T Y)
         # goes through the many-right-hand-side products, which need the deflated matrix itself -> explicit.
         # (the n >= p branch mixes in xt_v / x_w on the deflated X as well: explicit)
         eng.use_lazy_deflation(K, "P", prefer="lazy" if q == 1 else "explicit")
     fuse = wide and q == 1
+    # One response: a component is ONE pass and everything between two passes is n x B algebra -- the whole fit is queued
+    # on the device (engine.unipals_resident), the host reads the results once.  Its first pass (statistics + first
+    # sweep) needs nothing but the matrix, the start vector and the S slot: launched NOW, so the GPU is at work while
+    # the host allocates the other slots and the host copies of the attributes (0.1 ms of every fit)
+    go_resident = fuse and eng.resident_supported(q, K, 0)
+    first = None
+    if go_resident:
+        first = eng.deferred_first_pass(standardize, y0, 1.0, ("S", 0))
+        first()
+    sizes = _global_sizes(eng)
+    eng.slot("Wc", K)
+    eng.slot("P", K)
     # n >= p: the stored matrix is only read (deflation applied to the small operands, below) once a rewrite of it costs
     # more than the n x q projections on the host: from about half a gigabyte (a 160 MB matrix -- the paper's shape (a)
     # -- is deflated in 50 us, the projections cost 0.2 ms)
@@ -943,17 +953,15 @@ def fit_unipals(eng, Y, K, standardize, keep_raw_weights=False):
     # p > n: W_ and P_ are streamed to the host column by column while the deflation passes run (as in NIPALS)
     W_h = _host_array(eng, (eng.p, K)) if wide else None
     P_h = _host_array(eng, (eng.p, K)) if wide else None
-    if fuse and eng.resident_supported(q, K, 0):
-        # one response: a component is ONE pass and everything between two passes is n x B algebra -- the whole fit
-        # is queued on the device (engine.unipals_resident), the host reads the results once
-        first = eng.deferred_first_pass(standardize, y0, 1.0, ("S", 0))
+    if go_resident:
         eng.host_array((eng.p, K), reserve="R")
         eng.host_array((eng.p, q), reserve="beta")
         Wraw_h = _host_array(eng, (eng.p, K)) if keep_raw_weights else None
         for attempt in range(2):
-            out = eng.unipals_resident(Y, K, "Wc", "S", W_h, P_h, first, Wraw_h)
+            # (first pass already queued; offset data: queued again, first pass included, with centring passes)
+            out = eng.unipals_resident(Y, K, "Wc", "S", W_h, P_h, first if attempt else None, Wraw_h)
             if out.get("reason") != "offset":
-                break                                       # (offset data: queued again with centring passes)
+                break
         resident = out.get("reason") != "barrier"
     else:
         resident = False
