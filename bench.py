@@ -888,7 +888,7 @@ def parse_pmc_csv(path, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 
-def run_pmc_children(a, timeout_s=240):
+def run_pmc_children(a, timeout_s=120):
     """Two child runs of ONE fit of this workload under `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace` (separate
     passes; no other trace domain), from /tmp with TMPDIR=/tmp as the profiler wants.  Unit and correction exactly as
     MI355X_MICROARCH.md section HBM prescribes: the derived counters are in KiB; on gfx950 FETCH_SIZE tallies the
