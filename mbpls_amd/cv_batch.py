@@ -62,11 +62,25 @@ def _folds_per_batch(ctx, p, K, n_folds):
 MAX_RESPONSES = 16
 
 
-def eligible(estimator, q, n, p, n_folds, ctx=None):
+def _agree_min(comm, value):
+    """the smallest ``value`` over the ranks of a column-sharded run (every rank must take the same route and the same
+    batch size, or their collectives no longer pair up); the value itself on one GPU"""
+    if not getattr(comm, "is_distributed", False):
+        return value
+    world, rank = int(comm.world_size), int(comm.rank)
+    mine = np.zeros(world)
+    mine[rank] = float(value)
+    return type(value)(comm.allreduce_host(mine).min())
+
+
+def eligible(estimator, q, n, p, n_folds, ctx=None, comm=None):
     """One response: EVERY method -- with a single response NIPALS, UNIPALS, KERNEL and SIMPLS fit the same model
     (ordinary PLS1 on the concatenated blocks: identical ``beta_`` and predictions to 1e-14), so
     their folds take the batched NIPALS passes, without the confirming second iteration.  Several responses: NIPALS
-    (the inner loop of every fold advances together, a fold leaves it when its own stop rule is met)."""
+    (the inner loop of every fold advances together, a fold leaves it when its own stop rule is met).
+    ``p``: this rank's columns; under column shards (``comm``) the branch conditions use the total width and the
+    memory test is agreed between the ranks."""
+    p_total = p if not getattr(comm, "is_distributed", False) else int(comm.allreduce_host(np.array([float(p)]))[0])
     K = int(estimator.n_components)
     if estimator.sparse_data is True or n_folds < 2 or K > 32:
         return False
@@ -81,9 +95,9 @@ def eligible(estimator, q, n, p, n_folds, ctx=None):
         # singular vector of the same n x q matrix G the NIPALS loop iterates on (times a q x q factor of Y^T Y), so a
         # component is the same q sweeps per batch plus F thin SVDs; the n >= p branches are a different model (an
         # eigenvector of a non-symmetric matrix is not its singular vector) and stay with the fold-by-fold loop
-        ok = estimator.method in ("UNIPALS", "KERNEL") and q <= MAX_RESPONSES and p > n
+        ok = estimator.method in ("UNIPALS", "KERNEL") and q <= MAX_RESPONSES and p_total > n
     if ok and ctx is not None:
-        ok = _folds_per_batch(ctx, p, K + (q if q > 1 else 0), n_folds) >= min(MIN_FOLDS, n_folds)
+        ok = _agree_min(comm, _folds_per_batch(ctx, p, K + (q if q > 1 else 0), n_folds)) >= min(MIN_FOLDS, n_folds)
     return ok
 
 
@@ -95,7 +109,7 @@ def predict_folds(estimator, Xdev, ctx, comm, y, splits, batch=None):
     y = np.asarray(y, dtype=np.float64).reshape(n, -1)
     q = y.shape[1]
     if batch is None:
-        batch = max(1, _folds_per_batch(ctx, p, K + (q if q > 1 else 0), len(splits)))
+        batch = max(1, _agree_min(comm, _folds_per_batch(ctx, p, K + (q if q > 1 else 0), len(splits))))
     std = bool(estimator.standardize)
     out = np.full((n, q), np.nan)
     # one response: ONE sweep per component -- a method without iteration, or NIPALS, whose second iteration only confirms
@@ -285,7 +299,7 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol, one_pass=False, method="NIP
             """block sums of squares of g = alpha X_k^T u (left on the device) and t~_b = X_k,b g_b -- for every fold"""
             weights(deflate(U, k), alpha)
             XC = eng.x_w_slot("cvC", 0, F, per_block=True)                   # per block: X_b C_b (n x F)
-            sums = dsums.get().reshape(B, F, 2)
+            sums = eng.comm.allreduce_host(dsums.get()).reshape(B, F, 2)   # (block sums: over the column shards too)
             t = np.empty((B, n, F))
             for b in range(B):
                 t[b] = deflate((XC[b] - sums[b, :, 1]) * M, k)
@@ -397,7 +411,7 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol, one_pass=False, method="NIP
         for f in range(F):
             _capi.check(lib.mbpls_hip_cross_product_dev(ctx.handle, p, Pst.ptr + 8 * p * f, p * F, K, Wst.ptr + 8 * p * f,
                                                         p * F, K, dC.ptr + 8 * K * K * f))
-        Cm = dC.get().reshape(F, K, K)
+        Cm = eng.comm.allreduce_host(dC.get()).reshape(F, K, K)           # P_f^T W_f: summed over the column shards
         D = 1.0 / np.sqrt((nu_all ** 2).sum(axis=0))                         # F x K: 1 / ||W~[:, k]||
         Mv = np.matmul(D[:, :, None] * np.linalg.pinv(Cm * D[:, None, :]), V.transpose(0, 2, 1))     # F x K x q
         dMv = ctx.from_host(np.ascontiguousarray(Mv).ravel())                # per fold a K x q row-major matrix
@@ -410,7 +424,7 @@ def _one_batch(eng, Xdev, y, part, out, K, std, tol, one_pass=False, method="NIP
             _capi.check(lib.mbpls_hip_cv_weights(Xdev.handle, F, 1, Bq.ptr + 8 * p * F * j, dmu.ptr, drs.ptr, None, None,
                                                  dg.ptr, Cs.ptr, dsums.ptr))
             XC = eng.x_w_slot("cvC", 0, F, per_block=True)
-            sums = dsums.get().reshape(B, F, 2)
+            sums = eng.comm.allreduce_host(dsums.get()).reshape(B, F, 2)   # (block sums: over the column shards too)
             yhat = sum(XC[b] - sums[b, :, 1] for b in range(B)) * ysig[:, j] + ymu[:, j]          # n x F
             for f, (tr, te) in enumerate(part):
                 te = np.asarray(te)

@@ -7,8 +7,9 @@ slice of X.  Here X is uploaded once and only ever read:
 * batched folds (``cv_batch``): up to 256 folds are fitted per pass over X -- every read of the raw matrix serves all
   of them through many-right-hand-side products, the folds' column statistics and deflations are applied
   algebraically.  Covers one response with every method (they fit the same model then) and several responses with
-  NIPALS and with the p > n branches of UNIPALS / KERNEL;
-* fold by fold (everything else: several-response SIMPLS, the n >= p branches, missing values, column shards): a fold is a
+  NIPALS and with the p > n branches of UNIPALS / KERNEL -- also under column shards (every rank holds its columns of
+  every block; the n x F products and the small sums are all-reduced, every rank returns all predictions);
+* fold by fold (everything else: several-response SIMPLS, the n >= p branches, missing values): a fold is a
   *row mask* handed to the standardise pass, which writes zero rows for the held-out samples into the working copy and
   takes the column statistics over the training samples only; predictions for the held-out rows come from one ``x_w``
   pass over the same resident matrix.  No re-upload, no host slicing.
@@ -61,8 +62,8 @@ def cross_val_predict(estimator, X, y, cv=5, groups=None, batch_folds=True):
         if Xdev.n != n:
             raise ValueError(f"Found input variables with inconsistent numbers of samples: [{Xdev.n}, {n}]")
         from . import cv_batch
-        if (batch_folds and not runtime.get_comm().is_distributed
-                and cv_batch.eligible(estimator, y2.shape[1], n, Xdev.p, len(splits), runtime.get_context())):
+        if batch_folds and cv_batch.eligible(estimator, y2.shape[1], n, Xdev.p, len(splits), runtime.get_context(),
+                                             runtime.get_comm()):
             try:
                 return cv_batch.predict_folds(estimator, Xdev, runtime.get_context(), runtime.get_comm(), y2, splits)
             except cv_batch.DegenerateFold:

@@ -126,6 +126,33 @@ def main():
             ref = orc.fit(full2, Y2, n_components=3, method=method, full_svd=True)
             mdl = MBPLS(n_components=3, method=method).fit(local2, Y2)
             check(mdl, ref, ranges2, full_new2, local_new2, Yn2, method + " n>=p", orc.predict, orc.transform)
+        # cross-validation under column shards: folds batched per pass over X (one response with two methods, three
+        # responses with NIPALS) and the fold-by-fold loop, every rank against a loop of oracle fits on the full columns
+        from mbpls_amd import cv_batch
+        from mbpls_amd.model_selection import cross_val_predict
+        nc, sizes_c = 48, [301, 400]
+        Xc, Yc = orc.make_latent(nc, sum(sizes_c), 3, r=6, seed=9)
+        cuts_c = np.cumsum(sizes_c)[:-1]
+        full_c = list(np.split(Xc, cuts_c, axis=1))
+        local_c = [np.ascontiguousarray(b[:, lo:hi]) for b, (lo, hi) in zip(full_c, shard_columns(sizes_c, rank, world))]
+        calls, real = [], cv_batch.predict_folds
+        cv_batch.predict_folds = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        for method, qc, cv in (("NIPALS", 1, nc), ("KERNEL", 1, 6), ("NIPALS", 3, 8)):
+            Yq = Yc[:, :qc]
+            est = MBPLS(n_components=3, method=method)
+            from sklearn.model_selection import KFold
+            splits = list(KFold(cv).split(Xc))
+            want = np.empty_like(Yq)
+            for tr, te in splits:
+                r = orc.fit([b[tr] for b in full_c], Yq[tr], n_components=3, method=method)
+                want[te] = orc.predict(r, [b[te] for b in full_c])
+            calls.clear()
+            got = cross_val_predict(est, local_c, Yq, cv=cv)
+            assert calls == [1], (method, qc, calls)                 # the batched path ran, on every rank
+            loop = cross_val_predict(est, local_c, Yq, cv=cv, batch_folds=False)
+            assert util.relerr(got, want) < 1e-8, (method, qc, util.relerr(got, want))
+            assert util.relerr(loop, want) < 1e-8, (method, qc, util.relerr(loop, want))
+        cv_batch.predict_folds = real
     print(f"rank {rank}/{world}: sharded fit on a shared GPU == oracle", flush=True)
     dist.barrier()
     dist.destroy_process_group()
