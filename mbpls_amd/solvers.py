@@ -938,7 +938,8 @@ def fit_unipals(eng, Y, K, standardize, keep_raw_weights=False):
     if go_resident:
         first = eng.deferred_first_pass(standardize, y0, 1.0, ("S", 0))
         first()
-    sizes = _global_sizes(eng)
+    else:
+        sizes = _global_sizes(eng)
     eng.slot("Wc", K)
     eng.slot("P", K)
     # n >= p: the stored matrix is only read (deflation applied to the small operands, below) once a rewrite of it costs
@@ -963,6 +964,10 @@ def fit_unipals(eng, Y, K, standardize, keep_raw_weights=False):
             if out.get("reason") != "offset":
                 break
         resident = out.get("reason") != "barrier"
+        # (the block sizes of the whole problem are a collective under column shards, and its read-back waits for the
+        # stream: asked only now, with the queue drained -- behind the first pass it kept the host from building the
+        # queue for the length of that pass)
+        sizes = _global_sizes(eng)
     else:
         resident = False
     _plan(eng, solver=("unipals: device-resident queue, one pass per component" if resident else
