@@ -75,7 +75,6 @@ int mbpls_hip_device_info(mbpls_ctx* ctx, char* name, size_t name_len, int* comp
 /* Tunables (all optional): "chunks_per_cu", "rows_per_thread", "prefetch", "xw_chunks_per_cu",
  * "xw_mfma_from" (x_w with more right-hand sides than this uses the matrix-core kernel, default 8),
  * "gram_slice_features" (features per split-K slice of the Gram kernel for long feature ranges, 0 = off),
- * "gram_interleave" (default 1: the Gram kernel issues its operand loads between the MFMAs of a k-step; 0: in front),
  * "long_columns_from" (0..65536, default 8192: matrices with more samples than this use the two-phase long-column
  * passes instead of the register-resident ones, which spill above 8192 and have no lazy / implicit flavour there),
  * "sub_columns" (default 1: matrices with n <= 1024 samples run the column passes with several columns per wave;

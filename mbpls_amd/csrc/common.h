@@ -94,7 +94,6 @@ struct mbpls_ctx {
   int xw_chunks_per_cu = 1;
   int xw_mfma_from = 8;      // x_w with more right-hand sides than this runs on the matrix cores
   int64_t gram_slice_features = 131072;   // Gram: features per split-K slice for long feature ranges (0 = off)
-  int gram_interleave = 1;   // Gram: operand loads issued between the MFMAs of a step (0: in a block in front of them; A/B)
   int sub_columns = 1;       // n <= 256: several columns per wave (colpass_sub.hip); 0 = the one-column-per-workgroup kernels
   int64_t long_columns_from = 8192;    // n above this: streamed-column kernels (colpass_long.hip)
   // ... and among those, the never-writes-X passes run on CLUSTERS of workgroups that share a column and read X once

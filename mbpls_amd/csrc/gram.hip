@@ -40,10 +40,7 @@ struct GramArgs {
 // SCALE 1: z = (x - mean) * rscale (two operations per value, safe for any column offset); SCALE 2: z = fma(x, rscale,
 // -mean * rscale) (one operation; its rounding is amplified by |mean_j|/scale_j, so callers use it when the
 // statistics pass reported a small offset measure).
-// IL (SCALE == 0 only): the four loads of the group three steps ahead are issued BETWEEN the MFMAs of the current step
-// (after the 4th, 8th, 12th and 16th) instead of in a block in front of them, so a wave never stops feeding the matrix
-// pipe to issue loads.
-template <int SCALE, bool IL = false>
+template <int SCALE>
 __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
   // XCD-aware remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous run of work items
   const int nwg = gridDim.x;
@@ -156,43 +153,13 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a) {
       __builtin_amdgcn_sched_barrier(0);                                                                    \
     }                                                                                                       \
   }
-  /* interleaved form: groups S, S+1, S+2 are in flight (12 loads) when the step starts; vmcnt(8) retires group S */  \
-#define MB_GRAM_STEP_IL(S, SL)                                                                              \
-  {                                                                                                         \
-    int64_t nx = it + (S) + PD - 1;                                                                         \
-    nx = nx < nmain ? nx : nmain - 1;                                                                       \
-    const char* g = xb + nx * gstride;                                                                      \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                      \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                      \
-      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                      \
-          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[S][mi >> 1][mi & 1], bv[S][ni >> 1][ni & 1], \
-                                                             acc[mi][ni], 0, 0, 0);                         \
-      __builtin_amdgcn_sched_barrier(0);                                                                    \
-      if (mi == 0) MB_GLD(av[SL][0], oa[0], g);                                                             \
-      if (mi == 1) MB_GLD(bv[SL][0], ob[0], g);                                                             \
-      if (mi == 2) MB_GLD(av[SL][1], oa[1], g);                                                             \
-      if (mi == 3) MB_GLD(bv[SL][1], ob[1], g);                                                             \
-      __builtin_amdgcn_sched_barrier(0);                                                                    \
-    }                                                                                                       \
-  }
-    if constexpr (IL && SCALE == 0) {
-      for (int64_t it = 0; it < nmain; it += PD) {
-        MB_GRAM_STEP_IL(0, 3)
-        MB_GRAM_STEP_IL(1, 0)
-        MB_GRAM_STEP_IL(2, 1)
-        MB_GRAM_STEP_IL(3, 2)
-      }
-    } else {
-      for (int64_t it = 0; it < nmain; it += PD) {
-        MB_GRAM_STEP(0, 3)
-        MB_GRAM_STEP(1, 0)
-        MB_GRAM_STEP(2, 1)
-        MB_GRAM_STEP(3, 2)
-      }
+    for (int64_t it = 0; it < nmain; it += PD) {
+      MB_GRAM_STEP(0, 3)
+      MB_GRAM_STEP(1, 0)
+      MB_GRAM_STEP(2, 1)
+      MB_GRAM_STEP(3, 2)
     }
 #undef MB_GRAM_STEP
-#undef MB_GRAM_STEP_IL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -337,7 +304,6 @@ extern "C" int mbpls_hip_gram_scaled(const mbpls_mat* m, const double* d_mean, c
     ProfScope prof(ctx, MBPLS_K_GRAM, 8.0 * (double)n * (double)p);
     if (ms && centre_first) hipLaunchKernelGGL(k_gram<1>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
     else if (ms) hipLaunchKernelGGL(k_gram<2>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
-    else if (ctx->gram_interleave) hipLaunchKernelGGL((k_gram<0, true>), dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(k_gram<0>, dim3((unsigned)(ntiles * nslices)), dim3(256), 0, ctx->stream, a);
   }
   MB_HIP(hipGetLastError());
