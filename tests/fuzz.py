@@ -9,7 +9,11 @@ from oracle import mbpls_oracle_sparse as ors
 from tests import util
 
 
-def run(cases, seed, verbose=True, big=False):
+def run(cases, seed, verbose=True, big=False, long=False):
+    """``big``: register-resident columns (1024 < n <= 8192); ``long``: long columns (8192 < n <= 40000: clusters of
+    workgroups / two-phase passes, the multi-workgroup step from 32768 on) on narrow matrices.  One-response NIPALS takes
+    the default route (one pass per component) or the reference's two passes, at random."""
+    import os
     from mbpls_amd import MBPLS
     warnings.filterwarnings("ignore")
     rng = np.random.RandomState(seed)
@@ -19,7 +23,11 @@ def run(cases, seed, verbose=True, big=False):
         n = int(rng.choice([rng.randint(3, 40), rng.randint(40, 700), rng.choice([64, 128, 256, 512, 1024])]))
         if big:      # register-resident columns (1024 < n <= 8192), ragged and odd sample counts included
             n = int(rng.choice([rng.randint(1025, 4096), rng.randint(4097, 8192), rng.choice([2048, 4096, 4097, 8191, 8192])]))
+        if long:
+            n = int(rng.choice([rng.randint(8193, 20000), rng.randint(20000, 40000), rng.choice([8194, 16384, 32768, 32769])]))
         p = int(rng.choice([rng.randint(1, 30), rng.randint(30, 3000)]))
+        if long:
+            p = int(rng.choice([rng.randint(1, 30), rng.randint(30, 400)]))
         q = int(rng.choice([1, 1, 2, 3, 5])) if big else int(rng.choice([1, 1, 2, 3]))
         K = int(min(rng.randint(1, 5), max(1, min(n - 1, p))))
         method = str(rng.choice(["NIPALS", "NIPALS", "UNIPALS", "KERNEL", "SIMPLS"]))
@@ -32,7 +40,8 @@ def run(cases, seed, verbose=True, big=False):
         sparse = method == "NIPALS" and n >= 20 and p >= 20 and rng.rand() < 0.4
         if sparse:
             X[rng.rand(n, p) < rng.choice([0.01, 0.05])] = np.nan
-        tag = f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} blocks={nb} sparse={sparse}"
+        two_pass = method == "NIPALS" and q == 1 and not sparse and rng.rand() < 0.5
+        tag = f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} blocks={nb} sparse={sparse} two_pass={two_pass}"
         try:
             if sparse:
                 ref = ors.fit(sp(X), Y, n_components=K, standardize=std)
@@ -41,6 +50,7 @@ def run(cases, seed, verbose=True, big=False):
         except Exception as e:
             print_(tag, "oracle failed:", type(e).__name__); continue
         try:
+            os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0" if two_pass else "1"
             m = MBPLS(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse).fit(sp(X), Y)
             w = util.compare(util.model_to_flat(m), util.model_to_flat(ref), 1e-6, what=tag)
             w = max(w, util.relerr(m.predict(sp(X)), (ors if sparse else orc).predict(ref, sp(X))))
@@ -50,4 +60,6 @@ def run(cases, seed, verbose=True, big=False):
         except Exception as e:
             bad += 1
             print_(tag, "FAILED:", type(e).__name__, str(e)[:200])
+        finally:
+            os.environ.pop("MBPLS_NIPALS_Q1_FIXED_POINT", None)
     return bad, worst

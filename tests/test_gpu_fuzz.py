@@ -18,3 +18,11 @@ def test_random_problems_register_resident_columns(gpu_required):
     bad, worst = fuzz.run(25, seed=5, verbose=False, big=True)
     assert bad == 0
     assert worst < 1e-8, worst
+
+
+def test_random_problems_long_columns(gpu_required):
+    """... and on long columns (8192 < n <= 40000, narrow matrices): cluster passes, the storing two-phase passes, the
+    multi-workgroup step kernel"""
+    bad, worst = fuzz.run(16, seed=7, verbose=False, long=True)
+    assert bad == 0
+    assert worst < 1e-8, worst

@@ -1,5 +1,5 @@
-"""Randomised parity sweep on the GPU (see tests/fuzz.py):  python tools/fuzz_parity.py [cases] [seed] [big]
-(big: 1024 < n <= 8192 instead of the few-samples shapes)"""
+"""Randomised parity sweep on the GPU (see tests/fuzz.py):  python tools/fuzz_parity.py [cases] [seed] [big|long]
+(big: 1024 < n <= 8192 instead of the few-samples shapes; long: 8192 < n <= 40000, narrow matrices)"""
 import os
 import sys
 
@@ -7,5 +7,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import fuzz
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-bad, worst = fuzz.run(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0, big=len(sys.argv) > 3 and sys.argv[3] == "big")
+mode = sys.argv[3] if len(sys.argv) > 3 else ""
+bad, worst = fuzz.run(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0, big=mode == "big", long=mode == "long")
 print(f"{cases} cases, {bad} failures, worst relerr {worst:.2e}")
