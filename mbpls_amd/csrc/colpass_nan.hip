@@ -116,10 +116,14 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
           xc[k] = real ? xc[k] : 0.0;
         }
       }
-      unsigned pm = 0u;
+      // one bit per row of the thread: 64 rows per thread (32768 < n <= 65536) need a 64-bit mask -- with 32 bits the
+      // rows 32..63 of every thread took the flags of rows 0..31 and a missing value there poisoned the sums (found
+      // by the long-column fuzz sweep of round 5; n <= 32768 was never affected)
+      using pm_t = typename std::conditional<(R > 32), unsigned long long, unsigned>::type;
+      pm_t pm = 0;
 #pragma unroll
-      for (int k = 0; k < R; ++k) pm |= ((xc[k] == xc[k]) ? 1u : 0u) << k;
-      auto present = [&](int k) -> bool { return (pm >> k) & 1u; };
+      for (int k = 0; k < R; ++k) pm |= (pm_t)((xc[k] == xc[k]) ? 1u : 0u) << k;
+      auto present = [&](int k) -> bool { return (pm >> k) & (pm_t)1; };
 
       if constexpr (STD) {
         if (a.mode != MBPLS_SCALE_FIT && a.count) {      // present samples per column (FIT counts them anyway)

@@ -9,7 +9,7 @@ from oracle import mbpls_oracle_sparse as ors
 from tests import util
 
 
-def run(cases, seed, verbose=True, big=False, long=False):
+def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_errors=False):
     """``big``: register-resident columns (1024 < n <= 8192); ``long``: long columns (8192 < n <= 40000: clusters of
     workgroups / two-phase passes, the multi-workgroup step from 32768 on) on narrow matrices.  One-response NIPALS takes
     the default route (one pass per component) or the reference's two passes, at random."""
@@ -42,6 +42,8 @@ def run(cases, seed, verbose=True, big=False, long=False):
             X[rng.rand(n, p) < rng.choice([0.01, 0.05])] = np.nan
         two_pass = method == "NIPALS" and q == 1 and not sparse and rng.rand() < 0.5
         tag = f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} blocks={nb} sparse={sparse} two_pass={two_pass}"
+        if only is not None and c != only:                 # (same random sequence, one case fitted: reproducing a failure)
+            continue
         try:
             if sparse:
                 ref = ors.fit(sp(X), Y, n_components=K, standardize=std)
@@ -60,6 +62,8 @@ def run(cases, seed, verbose=True, big=False, long=False):
         except Exception as e:
             bad += 1
             print_(tag, "FAILED:", type(e).__name__, str(e)[:200])
+            if raise_errors:
+                raise
         finally:
             os.environ.pop("MBPLS_NIPALS_Q1_FIXED_POINT", None)
     return bad, worst

@@ -238,3 +238,24 @@ def test_row_subset_fit_and_cross_validation_with_missing_values(gpu_required):
     assert util.relerr(got, want) < 1e-8
     assert np.isnan(Xd.download(0, 600)).sum() == np.isnan(Xs[0]).sum()      # the resident matrix is untouched
     Xd.close()
+
+
+@pytest.mark.parametrize("n,q", [(32768, 1), (32770, 1), (40000, 3), (65536, 1)])
+def test_missing_values_on_very_long_columns(gpu_required, n, q):
+    """32768 < n <= 65536: the missing-value passes hold 64 rows per thread; the per-row presence flags need a 64-bit
+    mask there (a 32-bit one gave rows 32..63 the flags of rows 0..31 -- NaN sums; found by the long-column fuzz sweep of
+    round 5).  n = 32768 is the last shape of the 32-rows-per-thread configuration."""
+    from mbpls_amd import MBPLS
+    p = 22
+    X, Y = orc.make_latent(n, p, q, r=4, seed=n)
+    rng = np.random.RandomState(1)
+    X[rng.rand(n, p) < 0.05] = np.nan
+    blocks = [X[:, :10], X[:, 10:]]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = ors.fit(blocks, Y, n_components=3)
+        mdl = MBPLS(n_components=3, sparse_data=True).fit(blocks, Y)
+    w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"sparse n={n} q={q}")
+    assert w < 1e-8, w
+    util.check_nipals_iterations(mdl, ref, two=False)
+    assert util.relerr(mdl.predict(blocks), ors.predict(ref, blocks)) < 1e-8
