@@ -24,12 +24,13 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         if big:      # register-resident columns (1024 < n <= 8192), ragged and odd sample counts included
             n = int(rng.choice([rng.randint(1025, 4096), rng.randint(4097, 8192), rng.choice([2048, 4096, 4097, 8191, 8192])]))
         if long:
-            n = int(rng.choice([rng.randint(8193, 20000), rng.randint(20000, 40000), rng.choice([8194, 16384, 32768, 32769])]))
+            n = int(rng.choice([rng.randint(8193, 20000), rng.randint(20000, 40000), rng.randint(40000, 66000),
+                                rng.choice([8194, 16384, 32768, 32769, 65536, 65537, 131072])]))
         p = int(rng.choice([rng.randint(1, 30), rng.randint(30, 3000)]))
         if long:
             p = int(rng.choice([rng.randint(1, 30), rng.randint(30, 400)]))
         q = int(rng.choice([1, 1, 2, 3, 5])) if big else int(rng.choice([1, 1, 2, 3]))
-        K = int(min(rng.randint(1, 5), max(1, min(n - 1, p))))
+        K = int(min(rng.choice([rng.randint(1, 5), rng.randint(5, 10)]), max(1, min(n - 1, p))))
         method = str(rng.choice(["NIPALS", "NIPALS", "UNIPALS", "KERNEL", "SIMPLS"]))
         std = bool(rng.rand() < 0.7)
         nb = int(min(p, rng.randint(1, 4)))
@@ -37,25 +38,46 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         X, Y = orc.make_latent(n, p, q, r=min(4, p), seed=1000 + c)
         X = X + rng.uniform(-3, 3, size=p) * (rng.rand() < 0.5)          # column offsets (implicit standardisation)
         sp = (lambda A: A) if nb == 1 else (lambda A: [np.ascontiguousarray(b) for b in np.split(A, cuts, axis=1)])
-        sparse = method == "NIPALS" and n >= 20 and p >= 20 and rng.rand() < 0.4
+        sparse = method == "NIPALS" and n >= 20 and p >= 20 and n <= 65536 and rng.rand() < 0.4   # (NaN passes: n <= 65536)
         if sparse:
             X[rng.rand(n, p) < rng.choice([0.01, 0.05])] = np.nan
         two_pass = method == "NIPALS" and q == 1 and not sparse and rng.rand() < 0.5
-        tag = f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} blocks={nb} sparse={sparse} two_pass={two_pass}"
+        calc_all = bool(rng.rand() < 0.8)
+        norm = [2, 2, 1, np.inf, "fro"][int(rng.randint(0, 5))] if (method == "NIPALS" and not sparse) else 2
+        nn = int(rng.randint(1, 12))                                       # new samples for predict / transform
+        Xn, Yn = orc.make_latent(nn, p, q, r=min(4, p), seed=5000 + c)
+        if sparse:
+            Xn[rng.rand(nn, p) < 0.05] = np.nan
+        tag = (f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} blocks={nb} sparse={sparse} two_pass={two_pass} "
+               f"calc_all={calc_all} norm={norm}")
         if only is not None and c != only:                 # (same random sequence, one case fitted: reproducing a failure)
             continue
         try:
             if sparse:
                 ref = ors.fit(sp(X), Y, n_components=K, standardize=std)
             else:
-                ref = orc.fit(sp(X), Y, n_components=K, method=method, standardize=std, full_svd=True)
+                ref = orc.fit(sp(X), Y, n_components=K, method=method, standardize=std, full_svd=True, calc_all=calc_all,
+                              nipals_convergence_norm=norm, max_iter=3000)
         except Exception as e:
             print_(tag, "oracle failed:", type(e).__name__); continue
         try:
             os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0" if two_pass else "1"
-            m = MBPLS(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse).fit(sp(X), Y)
+            m = MBPLS(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse,
+                      calc_all=(calc_all or sparse), nipals_convergence_norm=norm).fit(sp(X), Y)
             w = util.compare(util.model_to_flat(m), util.model_to_flat(ref), 1e-6, what=tag)
-            w = max(w, util.relerr(m.predict(sp(X)), (ors if sparse else orc).predict(ref, sp(X))))
+            o = ors if sparse else orc
+            w = max(w, util.relerr(m.predict(sp(X)), o.predict(ref, sp(X))))
+            # new data: predict, and transform with block scores (the reference has none for SIMPLS, nor -- a bug of its
+            # own, SURVEY 8c' G5 -- without standardisation and 2-D Y)
+            w = max(w, util.relerr(m.predict(sp(Xn)), o.predict(ref, sp(Xn))))
+            blocks_ok = method != "SIMPLS"
+            got = m.transform(sp(Xn), Yn, return_block_scores=blocks_ok)
+            want = o.transform(ref, sp(Xn), Yn, return_block_scores=blocks_ok)
+            sgn = np.sign(np.sum(ref.Ts_ * m.Ts_, axis=0)); sgn[sgn == 0] = 1.0
+            if nn > 1:                                     # (one new sample: U of the transform is +-1 per column, sign only)
+                w = max(w, util.relerr(got[0] * sgn, want[0]), util.relerr(got[-1] * sgn, want[-1]))
+                if blocks_ok:
+                    w = max(w, max(util.relerr(a * sgn, b) for a, b in zip(got[1], want[1])))
             worst = max(worst, w)
             if w > 1e-9:
                 print_(tag, f"relerr {w:.2e}")
