@@ -389,7 +389,11 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             Ts = eng._xw(dR, K, False, mean, scale, mat=mat, nan=nan)               # :1117 / :1250, :1106-1115
             _require_finite(Ts)
             T = None
-            if self.method != 'SIMPLS' and (return_block_scores):
+            if self.method != 'SIMPLS' and (return_block_scores) and np.vstack(self.W_).shape[1] == 0:
+                # KERNEL fitted with calc_all=False has no block weights (:740 is skipped): the reference's loop
+                # (:1129-1155) then stacks K products with empty slices -- block scores without columns
+                T = [np.empty((Ts.shape[0], 0)) for _ in range(self.num_blocks_)]
+            elif self.method != 'SIMPLS' and (return_block_scores):
                 W = np.vstack(self.W_)
                 dW = eng.ctx.from_host(W)
                 XW = eng._xw(dW, K, True, mean, scale, mat=mat, nan=nan)
