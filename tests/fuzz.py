@@ -82,7 +82,10 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
             if nn > 1:                                     # (one new sample: U of the transform is +-1 per column, sign only)
                 w = max(w, util.relerr(got[0] * sgn, want[0]), util.relerr(got[-1] * sgn, want[-1]))
                 if blocks_ok:
-                    w = max(w, max(util.relerr(a * sgn, b) for a, b in zip(got[1], want[1])))
+                    for a, b in zip(got[1], want[1]):
+                        assert a.shape == b.shape, (a.shape, b.shape)      # (KERNEL, calc_all=False: no columns, both)
+                        if a.shape[1]:
+                            w = max(w, util.relerr(a * sgn, b))
             worst = max(worst, w)
             if w > 1e-9:
                 print_(tag, f"relerr {w:.2e}")
