@@ -86,6 +86,17 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                         assert a.shape == b.shape, (a.shape, b.shape)      # (KERNEL, calc_all=False: no columns, both)
                         if a.shape[1]:
                             w = max(w, util.relerr(a * sgn, b))
+            # now and then: cross-validation, folds batched per pass over X against the fold-by-fold loop (small shapes)
+            if not (big or long) and not sparse and n >= 12 and rng.rand() < 0.2:
+                from mbpls_amd.model_selection import cross_val_predict
+                folds = int(rng.choice([3, 5, min(n, 40)]))
+                est = MBPLS(n_components=min(K, 3), method=method, standardize=std, full_svd=True)
+                a_ = cross_val_predict(est, sp(X), Y, cv=folds)
+                b_ = cross_val_predict(est, sp(X), Y, cv=folds, batch_folds=False)
+                wcv = util.relerr(a_, b_)
+                if wcv > 1e-7:
+                    print_(tag, f"cross_val_predict batched vs loop {wcv:.2e} (cv={folds})")
+                w = max(w, wcv)
             worst = max(worst, w)
             if w > 1e-9:
                 print_(tag, f"relerr {w:.2e}")
