@@ -88,6 +88,10 @@ def eligible(estimator, q, n, p, n_folds, ctx=None, comm=None):
         ok = estimator.method in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS")
         if estimator.method == "NIPALS":
             ok = estimator.nipals_convergence_norm in (2, -2, "fro", "nuc")
+        if estimator.method == "SIMPLS" and not estimator.standardize:
+            # SIMPLS centres its scores (:1007-1009) whatever the data; on data that is NOT centred it is therefore a
+            # different model from the other three (found by the randomised sweep of round 5): fold by fold
+            ok = False
     elif estimator.method == "NIPALS":
         ok = q <= MAX_RESPONSES and estimator.nipals_convergence_norm in (2, -2, "fro", "nuc")
     else:

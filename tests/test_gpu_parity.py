@@ -1185,3 +1185,31 @@ def test_ragged_sample_counts_above_4096(gpu_required, monkeypatch, n):
     mu = MBPLS(n_components=3, method="UNIPALS").fit(blocks, Y)
     ru = orc.fit(blocks, Y, n_components=3, method="UNIPALS", full_svd=True)
     assert util.compare(util.model_to_flat(mu), util.model_to_flat(ru), TOL, what=f"ragged n={n}, UNIPALS") < 1e-9
+
+
+def test_simpls_folds_without_standardisation_are_not_batched(gpu_required):
+    """With one response the four methods fit the same model -- on CENTRED data.  SIMPLS centres its scores itself
+    (mbpls.py:1007-1009), so with standardize=False it is a different model from the others and its folds must not take
+    the batched NIPALS passes (they did: found by the randomised sweep of round 5)."""
+    from mbpls_amd import MBPLS, cv_batch
+    from mbpls_amd.model_selection import cross_val_predict
+    n, p, K = 60, 40, 3
+    X, Y = orc.make_latent(n, p, 1, r=4, seed=3)
+    X = X + 2.0                                        # not centred
+    est = MBPLS(n_components=K, method="SIMPLS", standardize=False, full_svd=True)
+    assert not cv_batch.eligible(est, 1, n, p, 5)
+    assert cv_batch.eligible(MBPLS(n_components=K, method="SIMPLS", full_svd=True), 1, n, p, 5)
+    assert cv_batch.eligible(MBPLS(n_components=K, method="KERNEL", standardize=False), 1, n, p, 5)
+    from sklearn.model_selection import KFold
+    want = np.empty_like(Y)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = cross_val_predict(est, X, Y, cv=5)
+        for tr, te in KFold(5).split(X):
+            r = orc.fit(X[tr], Y[tr], n_components=K, method="SIMPLS", standardize=False, full_svd=True)
+            want[te] = orc.predict(r, X[te])
+        # the other three methods DO coincide on such data, batched
+        k_b = cross_val_predict(MBPLS(n_components=K, method="KERNEL", standardize=False), X, Y, cv=5)
+        k_l = cross_val_predict(MBPLS(n_components=K, method="KERNEL", standardize=False), X, Y, cv=5, batch_folds=False)
+    assert util.relerr(got, want) < 1e-8
+    assert util.relerr(k_b, k_l) < 1e-9
