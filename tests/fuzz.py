@@ -67,8 +67,28 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
             print_(tag, "oracle failed:", type(e).__name__); continue
         try:
             os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0" if two_pass else "1"
-            m = MBPLS(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse,
-                      calc_all=(calc_all or sparse), nipals_convergence_norm=norm).fit(sp(X), Y)
+            est = MBPLS(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse,
+                        calc_all=(calc_all or sparse), nipals_convergence_norm=norm)
+            form = int(rng.randint(0, 8))
+            Yin = Y[:, 0] if (q == 1 and form % 2) else Y                  # 1-D responses now and then
+            if form == 0 and not sparse:
+                # a matrix already resident in HBM: fitted with copy=True, it must come back bit for bit
+                import mbpls_amd
+                from mbpls_amd import DeviceMatrix
+                offs = np.concatenate(([0], cuts, [p])).astype(np.int64)
+                dX = DeviceMatrix(mbpls_amd.get_context(), n, p, offs)
+                dX.upload(X, 0)
+                m = est.fit(dX, Yin)
+                assert np.array_equal(dX.download(), X), "copy=True: the caller's resident matrix was modified"
+                dX.close()
+            elif form == 1:
+                m = est.fit(sp(np.asfortranarray(X)) if nb == 1 else [np.asfortranarray(b) for b in sp(X)], Yin)
+            elif form == 2 and not sparse:
+                Xw = np.empty((n, 2 * p)); Xw[:, ::2] = X                    # non-contiguous views of a wider array
+                m = est.fit(sp(Xw[:, ::2]) if nb == 1 else [Xw[:, ::2][:, a:b] for a, b in
+                                                             zip(np.concatenate(([0], cuts)), np.concatenate((cuts, [p])))], Yin)
+            else:
+                m = est.fit(sp(X), Yin)
             w = util.compare(util.model_to_flat(m), util.model_to_flat(ref), 1e-6, what=tag)
             o = ors if sparse else orc
             w = max(w, util.relerr(m.predict(sp(X)), o.predict(ref, sp(X))))
