@@ -57,8 +57,11 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         Xn, Yn = orc.make_latent(nn, p, q, r=min(4, p), seed=5000 + c)
         if sparse:
             Xn[rng.rand(nn, p) < 0.05] = np.nan
+        # (every random decision of a case is drawn HERE, whatever happens to its fit: ``only`` replays the same case)
+        form = int(rng.randint(0, 8))
+        do_cv, cv_pick = bool(rng.rand() < 0.2), int(rng.randint(0, 3))
         tag = (f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} blocks={nb} sparse={sparse} two_pass={two_pass} "
-               f"calc_all={calc_all} norm={norm}")
+               f"calc_all={calc_all} norm={norm} form={form}")
         if only is not None and c != only:                 # (same random sequence, one case fitted: reproducing a failure)
             continue
         try:
@@ -73,7 +76,6 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
             os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0" if two_pass else "1"
             est = MBPLS(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse,
                         calc_all=(calc_all or sparse), nipals_convergence_norm=norm)
-            form = int(rng.randint(0, 8))
             Yin = Y[:, 0] if (q == 1 and form % 2) else Y                  # 1-D responses now and then
             if form == 0 and not sparse:
                 # a matrix already resident in HBM: fitted with copy=True, it must come back bit for bit
@@ -111,9 +113,9 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                         if a.shape[1]:
                             w = max(w, util.relerr(a * sgn, b))
             # now and then: cross-validation, folds batched per pass over X against the fold-by-fold loop (small shapes)
-            if not (big or long) and not sparse and n >= 12 and rng.rand() < 0.2:
+            if not (big or long) and not sparse and n >= 12 and do_cv:
                 from mbpls_amd.model_selection import cross_val_predict
-                folds = int(rng.choice([3, 5, min(n, 40)]))
+                folds = [3, 5, min(n, 40)][cv_pick]
                 est = MBPLS(n_components=min(K, 3), method=method, standardize=std, full_svd=True)
                 a_ = cross_val_predict(est, sp(X), Y, cv=folds)
                 b_ = cross_val_predict(est, sp(X), Y, cv=folds, batch_folds=False)
