@@ -9,7 +9,25 @@ from oracle import mbpls_oracle_sparse as ors
 from tests import util
 
 
-def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_errors=False):
+def _local_view(ref, ranges, offs):
+    """the oracle's attributes as ONE RANK of a column-sharded fit holds them: n-side attributes whole, p-side attributes
+    restricted to the rank's columns of every block"""
+    flat = util.model_to_flat(ref)
+    rows = np.concatenate([np.arange(offs[b] + lo, offs[b] + hi) for b, (lo, hi) in enumerate(ranges)])
+    out = {}
+    for k, v in flat.items():
+        base = k.split("/")[0]
+        if base in ("W_", "P_", "W_non_normal_") and "/" in k:
+            lo, hi = ranges[int(k.split("/")[1])]
+            out[k] = np.asarray(v)[lo:hi]
+        elif base in ("R_", "beta_", "W_concat_") or (base == "W_" and "/" not in k):
+            out[k] = np.asarray(v)[rows] if np.asarray(v).shape[0] == offs[-1] else v
+        else:
+            out[k] = v
+    return out
+
+
+def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_errors=False, shard=None):
     """``big``: register-resident columns (1024 < n <= 8192); ``long``: long columns (8192 < n <= 40000: clusters of
     workgroups / two-phase passes, the multi-workgroup step from 32768 on) on narrow matrices.  One-response NIPALS takes
     the default route (one pass per component) or the reference's two passes, at random."""
@@ -41,7 +59,13 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
             K = int(min(K, max(1, n // 4)))
         std = bool(rng.rand() < 0.7)
         nb = int(min(p, rng.randint(1, 4)))
+        if shard is not None:
+            nb = int(min(nb, max(1, p // (2 * shard[2]))))     # every rank holds at least two columns of every block
         cuts = np.sort(rng.choice(np.arange(1, p), nb - 1, replace=False)) if nb > 1 else np.array([], dtype=int)
+        if shard is not None and nb > 1:                       # (blocks of at least 2 x world columns)
+            w2 = 2 * shard[2]
+            cuts = np.sort(rng.choice(np.arange(1, p // w2), nb - 1, replace=False)) * w2 if p // w2 > nb else np.array([], dtype=int)
+            nb = len(cuts) + 1
         X, Y = orc.make_latent(n, p, q, r=min(4, p), seed=1000 + c)
         X = X + rng.uniform(-3, 3, size=p) * (rng.rand() < 0.5)          # column offsets (implicit standardisation)
         sp = (lambda A: A) if nb == 1 else (lambda A: [np.ascontiguousarray(b) for b in np.split(A, cuts, axis=1)])
@@ -81,6 +105,28 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
             est = MBPLS(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse,
                         calc_all=(calc_all or sparse), nipals_convergence_norm=norm)
             Yin = Y[:, 0] if (q == 1 and form % 2) else Y                  # 1-D responses now and then
+            if shard is not None:
+                # column shards: this rank fits ITS columns of every block; compared with the oracle's attributes as the
+                # rank holds them (n-side whole, p-side sliced); predictions and scores of new data are global
+                import mbpls_amd
+                from mbpls_amd.comm import shard_columns
+                comm, rank, world = shard
+                offs = np.concatenate(([0], cuts, [p])).astype(np.int64)
+                sizes = [int(offs[b + 1] - offs[b]) for b in range(nb)]
+                ranges = shard_columns(sizes, rank, world)
+                loc = lambda A: [np.ascontiguousarray(A[:, offs[b] + lo:offs[b] + hi]) for b, (lo, hi) in enumerate(ranges)]
+                with mbpls_amd.column_sharded(comm):
+                    m = est.fit(loc(X), Yin)
+                    w = util.compare(util.model_to_flat(m), _local_view(ref, ranges, offs), 1e-6, what=tag)
+                    o = ors if sparse else orc
+                    w = max(w, util.relerr(m.predict(loc(Xn)), o.predict(ref, sp(Xn))))
+                    if nn > 1:
+                        sgn = np.sign(np.sum(ref.Ts_ * m.Ts_, axis=0)); sgn[sgn == 0] = 1.0
+                        w = max(w, util.relerr(m.transform(loc(Xn)) * sgn, o.transform(ref, sp(Xn))))
+                worst = max(worst, w)
+                if w > 1e-9:
+                    print_(tag, f"relerr {w:.2e} (rank {rank} of {world})")
+                continue
             if form == 0 and not sparse:
                 # a matrix already resident in HBM: fitted with copy=True, it must come back bit for bit
                 import mbpls_amd

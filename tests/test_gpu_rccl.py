@@ -42,6 +42,19 @@ def test_two_ranks_share_one_gpu(gpu_required):
     assert r.stdout.count("sharded fit on a shared GPU == oracle") == 2, r.stdout
 
 
+def test_two_ranks_random_problems(gpu_required):
+    """the randomised sweep (tests/fuzz.py) with every problem column-sharded over two ranks that share the GPU"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MBPLS_FUZZ_CASES="40", MBPLS_FUZZ_SEED="3")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_shared_gpu_fuzz_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("random sharded problems == oracle") == 2, r.stdout
+
+
 def _run_rank_equality(world, shared):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
