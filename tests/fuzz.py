@@ -47,6 +47,8 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         p = int(rng.choice([rng.randint(1, 30), rng.randint(30, 3000)]))
         if long:
             p = int(rng.choice([rng.randint(1, 30), rng.randint(30, 400)]))
+        if shard is not None:
+            p = max(p, 2 * shard[2])           # (a rank without a single column is not a configuration anyone runs)
         q = int(rng.choice([1, 1, 2, 3, 5])) if big else int(rng.choice([1, 1, 2, 3]))
         kmax = int(rng.choice([rng.randint(1, 5), rng.randint(5, 10)]))
         if big or long:
