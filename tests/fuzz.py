@@ -56,9 +56,10 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         K = int(min(kmax, max(1, min(n - 1, p))))
         method = str(rng.choice(["NIPALS", "NIPALS", "UNIPALS", "KERNEL", "SIMPLS"]))
         if method == "SIMPLS":
-            # (the reference's SIMPLS loses orthogonality -- |Ts^T Ts - I| up to 1e-2 -- once K approaches the number of
-            # samples, on uncentred data most of all: no implementation can follow it there)
-            K = int(min(K, max(1, n // 4)))
+            # (the reference's SIMPLS loses orthogonality -- |Ts^T Ts - I| from 1e-8 at eight or nine components up to 1e-2
+            # once K approaches the number of samples, on uncentred data most of all: no implementation can follow it
+            # to 1e-6 there)
+            K = int(min(K, 5, max(1, n // 4)))
         std = bool(rng.rand() < 0.7)
         nb = int(min(p, rng.randint(1, 4)))
         if shard is not None:
