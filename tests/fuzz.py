@@ -27,7 +27,7 @@ def _local_view(ref, ranges, offs):
     return out
 
 
-def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_errors=False, shard=None):
+def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_errors=False, shard=None, wide=False):
     """``big``: register-resident columns (1024 < n <= 8192); ``long``: long columns (8192 < n <= 40000: clusters of
     workgroups / two-phase passes, the multi-workgroup step from 32768 on) on narrow matrices.  One-response NIPALS takes
     the default route (one pass per component) or the reference's two passes, at random."""
@@ -37,6 +37,7 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
     rng = np.random.RandomState(seed)
     print_ = print if verbose else (lambda *a, **k: None)
     worst, bad = 0.0, 0
+    reused = None                      # one estimator object refitted with new parameters now and then (stale state)
     for c in range(cases):
         n = int(rng.choice([rng.randint(3, 40), rng.randint(40, 700), rng.choice([64, 128, 256, 512, 1024])]))
         if big:      # register-resident columns (1024 < n <= 8192), ragged and odd sample counts included
@@ -47,11 +48,14 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         p = int(rng.choice([rng.randint(1, 30), rng.randint(30, 3000)]))
         if long:
             p = int(rng.choice([rng.randint(1, 30), rng.randint(30, 400)]))
+        if wide:                               # few samples x very many features: the everyday multiblock-PLS shape
+            n = int(rng.choice([rng.randint(3, 40), rng.randint(40, 300), rng.choice([16, 64, 128, 256])]))
+            p = int(rng.choice([rng.randint(3000, 30000), rng.randint(30000, 200000)]))
         if shard is not None:
             p = max(p, 2 * shard[2])           # (a rank without a single column is not a configuration anyone runs)
-        q = int(rng.choice([1, 1, 2, 3, 5])) if big else int(rng.choice([1, 1, 2, 3]))
+        q = int(rng.choice([1, 1, 2, 3, 5])) if big else int(rng.choice([1, 1, 2, 3, int(rng.randint(4, 13))]))
         kmax = int(rng.choice([rng.randint(1, 5), rng.randint(5, 10)]))
-        if big or long:
+        if big or long or wide:
             kmax = min(kmax, 4)                # (the CPU oracle iterates hundreds of times per component for q > 1)
         K = int(min(kmax, max(1, min(n - 1, p))))
         method = str(rng.choice(["NIPALS", "NIPALS", "UNIPALS", "KERNEL", "SIMPLS"]))
@@ -78,7 +82,7 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         two_pass = method == "NIPALS" and q == 1 and not sparse and rng.rand() < 0.5
         calc_all = bool(rng.rand() < 0.8)
         norm = [2, 2, 1, np.inf, "fro"][int(rng.randint(0, 5))] if (method == "NIPALS" and not sparse) else 2
-        if big or long:
+        if big or long or wide:
             norm = 2
         nn = int(rng.randint(1, 12))                                       # new samples for predict / transform
         Xn, Yn = orc.make_latent(nn, p, q, r=min(4, p), seed=5000 + c)
@@ -87,6 +91,7 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         # (every random decision of a case is drawn HERE, whatever happens to its fit: ``only`` replays the same case)
         form = int(rng.randint(0, 8))
         do_cv, cv_pick = bool(rng.rand() < 0.2), int(rng.randint(0, 3))
+        reuse = bool(rng.rand() < 0.3)
         tag = (f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} blocks={nb} sparse={sparse} two_pass={two_pass} "
                f"calc_all={calc_all} norm={norm} form={form}")
         if only is not None and c != only:                 # (same random sequence, one case fitted: reproducing a failure)
@@ -105,8 +110,13 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
             print_(tag, "skipped: the reference's NIPALS loop does not converge (iteration cap of the oracle)"); continue
         try:
             os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0" if two_pass else "1"
-            est = MBPLS(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse,
-                        calc_all=(calc_all or sparse), nipals_convergence_norm=norm)
+            params = dict(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse,
+                          calc_all=(calc_all or sparse), nipals_convergence_norm=norm)
+            if reuse and reused is not None:
+                est = reused.set_params(**params)          # the SAME object, fitted before with other data and settings
+            else:
+                est = MBPLS(**params)
+            reused = est
             Yin = Y[:, 0] if (q == 1 and form % 2) else Y                  # 1-D responses now and then
             if shard is not None:
                 # column shards: this rank fits ITS columns of every block; compared with the oracle's attributes as the
@@ -166,7 +176,7 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                         if a.shape[1]:
                             w = max(w, util.relerr(a * sgn, b))
             # now and then: cross-validation, folds batched per pass over X against the fold-by-fold loop (small shapes)
-            if not (big or long) and not sparse and n >= 12 and do_cv:
+            if not (big or long or wide) and not sparse and n >= 12 and do_cv:
                 from mbpls_amd.model_selection import cross_val_predict
                 folds = [3, 5, min(n, 40)][cv_pick]
                 est = MBPLS(n_components=min(K, 3), method=method, standardize=std, full_svd=True)

@@ -1,5 +1,5 @@
-"""Randomised parity sweep on the GPU (see tests/fuzz.py):  python tools/fuzz_parity.py [cases] [seed] [big|long]
-(big: 1024 < n <= 8192 instead of the few-samples shapes; long: 8192 < n <= 40000, narrow matrices)"""
+"""Randomised parity sweep on the GPU (see tests/fuzz.py):  python tools/fuzz_parity.py [cases] [seed] [big|long|wide]
+(big: 1024 < n <= 8192 instead of the few-samples shapes; long: 8192 < n <= 131072, narrow matrices; wide: n <= 300, p up to 200000)"""
 import os
 import sys
 
@@ -8,5 +8,6 @@ from tests import fuzz
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 mode = sys.argv[3] if len(sys.argv) > 3 else ""
-bad, worst = fuzz.run(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0, big=mode == "big", long=mode == "long")
+bad, worst = fuzz.run(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0, big=mode == "big", long=mode == "long",
+                      wide=mode == "wide")
 print(f"{cases} cases, {bad} failures, worst relerr {worst:.2e}")
