@@ -28,3 +28,10 @@ def test_random_problems_long_columns(gpu_required):
     bad, worst = fuzz.run(16, seed=7, verbose=False, long=True)
     assert bad == 0
     assert worst < 1e-8, worst
+
+
+def test_random_problems_wide(gpu_required):
+    """... and on few samples x very many features (n <= 300, p up to 200 000): the column-group kernels at width"""
+    bad, worst = fuzz.run(12, seed=9, verbose=False, wide=True)
+    assert bad == 0
+    assert worst < 1e-8, worst
