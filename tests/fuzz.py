@@ -92,8 +92,14 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         form = int(rng.randint(0, 8))
         do_cv, cv_pick = bool(rng.rand() < 0.2), int(rng.randint(0, 3))
         reuse = bool(rng.rand() < 0.3)
+        # a non-default route now and then (the switches of mbpls_amd/plan.py): same numbers on every route
+        routes = [{}, {}, {}, {"MBPLS_DEFLATION": "explicit"}, {"MBPLS_IMPLICIT_STD": "0"}, {"MBPLS_RESIDENT": "0"},
+                  {"MBPLS_NIPALS_SUBSPACE": "0"}, {"MBPLS_NIPALS_SUBSPACE": "0", "MBPLS_NIPALS_GRAM": "0"},
+                  {"MBPLS_UNIPALS_NODEFLATE": "0"}, {"MBPLS_R_INCREMENTAL": "0"}, {"MBPLS_STREAM_STATS": "0"},
+                  {"MBPLS_KERNEL_IMPLICIT": "1"}, {"MBPLS_KERNEL_IMPLICIT": "0"}, {"MBPLS_NIPALS_QSPACE": "0"}]
+        route = routes[int(rng.randint(0, len(routes)))]
         tag = (f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} blocks={nb} sparse={sparse} two_pass={two_pass} "
-               f"calc_all={calc_all} norm={norm} form={form}")
+               f"calc_all={calc_all} norm={norm} form={form}" + (f" route={route}" if route else ""))
         if only is not None and c != only:                 # (same random sequence, one case fitted: reproducing a failure)
             continue
         try:
@@ -110,6 +116,7 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
             print_(tag, "skipped: the reference's NIPALS loop does not converge (iteration cap of the oracle)"); continue
         try:
             os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0" if two_pass else "1"
+            os.environ.update(route)
             params = dict(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse,
                           calc_all=(calc_all or sparse), nipals_convergence_norm=norm)
             if reuse and reused is not None:
@@ -196,4 +203,6 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                 raise
         finally:
             os.environ.pop("MBPLS_NIPALS_Q1_FIXED_POINT", None)
+            for key in route:
+                os.environ.pop(key, None)
     return bad, worst
