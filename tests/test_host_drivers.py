@@ -221,3 +221,32 @@ def test_host_thread_limits_are_set_and_put_back():
     finally:
         runtime._state["tp_limit"] = old
     assert [lc.num_threads for lc in tp.lib_controllers] == before
+
+
+def test_random_problems_through_the_host_drivers(monkeypatch):
+    """A randomised sweep of the host drivers (solvers.py on the numpy engine -- no GPU here): shapes, block splits, the
+    four methods, both routes of one-response NIPALS, calc_all, +- standardisation -- against the oracle.  (The GPU suite
+    runs the same kind of sweep on the HIP engine, tests/fuzz.py.)"""
+    from oracle import mbpls_oracle as orc
+    rng = np.random.RandomState(12)
+    worst = 0.0
+    for c in range(60):
+        n = int(rng.choice([rng.randint(6, 40), rng.randint(40, 200)]))
+        p = int(rng.choice([rng.randint(2, 30), rng.randint(30, 400)]))
+        q = int(rng.choice([1, 1, 2, 3]))
+        method = str(rng.choice(["NIPALS", "NIPALS", "UNIPALS", "KERNEL", "SIMPLS"]))
+        K = int(min(rng.randint(1, 5), max(1, min(n // 4, p))))
+        std, calc_all = bool(rng.rand() < 0.7), bool(rng.rand() < 0.8)
+        nb = int(min(p, rng.randint(1, 4)))
+        cuts = np.sort(rng.choice(np.arange(1, p), nb - 1, replace=False)) if nb > 1 else np.array([], dtype=int)
+        X, Y = orc.make_latent(n, p, q, r=min(4, p), seed=3000 + c)
+        X = X + rng.uniform(-3, 3, size=p) * (rng.rand() < 0.5)
+        Xin = X if nb == 1 else [np.ascontiguousarray(b) for b in np.split(X, cuts, axis=1)]
+        monkeypatch.setenv("MBPLS_NIPALS_Q1_FIXED_POINT", "0" if rng.rand() < 0.5 else "1")
+        ref = orc.fit(Xin, Y, n_components=K, method=method, standardize=std, full_svd=True, calc_all=calc_all, max_iter=3000)
+        if method == "NIPALS" and max(ref.nipals_iterations_) >= 3000:
+            continue                                       # (the reference's own loop does not converge: nothing to compare)
+        res = run_driver(Xin, Y, method, K, std, calc_all)
+        what = f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} calc_all={calc_all} blocks={nb}"
+        worst = max(worst, util.compare(util.model_to_flat(res), util.model_to_flat(ref), 1e-6, what=what))
+    assert worst < 1e-7, worst
