@@ -29,10 +29,54 @@ def main():
     # vector from a p x q matrix whose ROWS are split over the ranks, and X^T X w needs every rank's columns
     for fixture in ("matrix_pgtn", "matrix_ngtp"):
         worst = max(worst, one_fixture(util.load(fixture), rank, world, comm))
+    worst = max(worst, random_sweep(rank, world, comm))
     # all ranks must have taken identical decisions (iteration counts) and agree on the global scores
     print(f"rank {rank}: sharded == unsharded reference, worst rel err {worst:.2e}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def random_sweep(rank, world, comm, cases=30):
+    """random shapes / block splits / methods / routes, every problem column-sharded over the ranks: each rank's result
+    against the oracle's attributes as that rank holds them (tests/fuzz._local_view)"""
+    from oracle import mbpls_oracle as orc
+    from tests import fuzz
+    rng = np.random.RandomState(21)                       # (the same problems on every rank)
+    worst = 0.0
+    for c in range(cases):
+        n = int(rng.choice([rng.randint(8, 40), rng.randint(40, 160)]))
+        nb = int(rng.randint(1, 4))
+        sizes = [int(rng.randint(2 * world, 2 * world + 60)) for _ in range(nb)]
+        p = sum(sizes)
+        q = int(rng.choice([1, 1, 2, 3]))
+        method = str(rng.choice(["NIPALS", "NIPALS", "UNIPALS", "KERNEL", "SIMPLS"]))
+        K = int(min(rng.randint(1, 5), max(1, min(n // 4, p))))
+        std, ca = bool(rng.rand() < 0.7), bool(rng.rand() < 0.8)
+        os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0" if rng.rand() < 0.5 else "1"
+        X, Y = orc.make_latent(n, p, q, r=4, seed=4000 + c)
+        X = X + rng.uniform(-3, 3, size=p) * (rng.rand() < 0.5)
+        offs = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+        full = [X[:, offs[b]:offs[b + 1]] for b in range(nb)]
+        ref = orc.fit(full, Y, n_components=K, method=method, standardize=std, full_svd=True, calc_all=ca, max_iter=3000)
+        if method == "NIPALS" and max(ref.nipals_iterations_) >= 3000:
+            continue
+        ranges = shard_columns(sizes, rank, world)
+        local = [np.ascontiguousarray(b[:, lo:hi]) for b, (lo, hi) in zip(full, ranges)]
+        Ys = ColumnScaler().fit(Y).transform(Y) if std else Y
+        eng = NumpyEngine(comm).load_host_blocks(local)
+        if method == "NIPALS":
+            res = solvers.fit_nipals(eng, Ys, K, std, calc_all=ca)
+        elif method == "UNIPALS":
+            res = solvers.fit_unipals(eng, Ys, K, std)
+        elif method == "KERNEL":
+            res = solvers.fit_kernel(eng, Ys, K, std, ca)
+        else:
+            res = solvers.fit_simpls(eng, Ys, K, std)
+        what = f"rank{rank} case {c}: n={n} sizes={sizes} q={q} K={K} {method} std={std} ca={ca}"
+        worst = max(worst, util.compare(util.model_to_flat(res), fuzz._local_view(ref, ranges, offs), 1e-6, what=what))
+    os.environ.pop("MBPLS_NIPALS_Q1_FIXED_POINT", None)
+    assert worst < 1e-7, worst
+    return worst
 
 
 def one_fixture(g, rank, world, comm):
