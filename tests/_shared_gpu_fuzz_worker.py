@@ -21,7 +21,7 @@ def main():
     mbpls_amd.set_device(0)
     comm = mbpls_amd.TorchDistComm(device="cuda:0")
     cases, seed = int(os.environ.get("MBPLS_FUZZ_CASES", "40")), int(os.environ.get("MBPLS_FUZZ_SEED", "3"))
-    bad, worst = fuzz.run(cases, seed, verbose=(rank == 0), shard=(comm, rank, world))
+    bad, worst = fuzz.run(cases, seed, verbose=(rank == 0 or bool(os.environ.get("MBPLS_FUZZ_TRACE"))), shard=(comm, rank, world))
     everyone = [None] * world
     dist.all_gather_object(everyone, (bad, worst))
     assert all(b == 0 for b, _ in everyone), everyone

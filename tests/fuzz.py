@@ -102,6 +102,8 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                f"calc_all={calc_all} norm={norm} form={form}" + (f" route={route}" if route else ""))
         if only is not None and c != only:                 # (same random sequence, one case fitted: reproducing a failure)
             continue
+        if os.environ.get("MBPLS_FUZZ_TRACE"):             # every case announced before its fit (which rank stopped where)
+            print(f"[trace pid {os.getpid()}] {tag}", flush=True)
         try:
             if sparse:
                 ref = ors.fit(sp(X), Y, n_components=K, standardize=std, max_iter=3000)
