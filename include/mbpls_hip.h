@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 7   /* 7: mbpls_hip_cluster_columns (cluster passes launched cooperatively, capacity from the occupancy query, time-outs flagged in host-mapped memory); 6: mbpls_hip_mat_transpose; mbpls_nipals_step.C / ldc / host_seq, mbpls_hip_queue_r_update, mbpls_hip_flush_r_update (R_ / beta_ column by column during the fit), mbpls_hip_copier_submit / _wait (native copier thread; replaces mbpls_hip_event_record / _memcpy_d2h_after / _event_destroy); 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
+#define MBPLS_HIP_ABI_VERSION 8   /* 8: mbpls_hip_fence (overlapped copies ordered behind what was queued before the pass they run beside); 7: mbpls_hip_cluster_columns (cluster passes launched cooperatively, capacity from the occupancy query, time-outs flagged in host-mapped memory); 6: mbpls_hip_mat_transpose; mbpls_nipals_step.C / ldc / host_seq, mbpls_hip_queue_r_update, mbpls_hip_flush_r_update (R_ / beta_ column by column during the fit), mbpls_hip_copier_submit / _wait (native copier thread; replaces mbpls_hip_event_record / _memcpy_d2h_after / _event_destroy); 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
 
 enum {
   MBPLS_OK = 0,
@@ -104,9 +104,12 @@ int mbpls_hip_malloc(mbpls_ctx* ctx, size_t bytes, void** d_ptr);
 int mbpls_hip_free(mbpls_ctx* ctx, void* d_ptr);
 int mbpls_hip_memcpy_h2d(mbpls_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int mbpls_hip_memcpy_d2h(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);  /* synchronous */
-/* D2H on a separate non-blocking stream: does NOT wait for kernels queued on the context's stream, so
- * results that are already final (e.g. loadings column k-1) reach the host while the next pass runs.
- * The caller guarantees that d_src is complete; synchronous w.r.t. the host on return. */
+/* D2H on a separate non-blocking stream: does NOT wait for the kernels queued on the context's stream behind the last
+ * mbpls_hip_fence, so results that are already final (e.g. loadings column k-1) reach the host while the next pass
+ * runs.  It DOES wait for what was queued before that fence: call mbpls_hip_fence right before launching the pass
+ * the copy is to run beside -- the small kernels that produced the column (a scaling, an upload) are then through.
+ * Synchronous w.r.t. the host on return. */
+int mbpls_hip_fence(mbpls_ctx* ctx);
 int mbpls_hip_memcpy_d2h_overlap(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int mbpls_hip_memcpy_d2d(mbpls_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 int mbpls_hip_memset(mbpls_ctx* ctx, void* d_ptr, int value, size_t bytes);

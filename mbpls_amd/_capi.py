@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmbpls_hip.so")
 ROW_MAJOR, COL_MAJOR = 0, 1
 COMM_ID_BYTES = 128
 SCALE_FIT, SCALE_APPLY, SCALE_NONE = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp, _i64, _dbl, _int, _sz = C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
@@ -57,6 +57,7 @@ SIGNATURES = {
     "mbpls_hip_sync": (_int, [_vp]),
     "mbpls_hip_device_info": (_int, [_vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_sz), C.POINTER(_sz)]),
     "mbpls_hip_set_tunable": (_int, [_vp, C.c_char_p, _int]),
+    "mbpls_hip_fence": (_int, [_vp]),
     "mbpls_hip_cluster_status": (_int, [_vp, C.POINTER(_int)]),
     "mbpls_hip_cluster_columns": (_int, [_vp, _i64, C.POINTER(_int)]),
     "mbpls_hip_malloc": (_int, [_vp, _sz, _pp]),
@@ -336,6 +337,10 @@ class Context:
             self.long_columns_from = max(0, min(int(value), 65536))
         if key == "cluster_passes":
             self.cluster_passes = 1 if value else 0
+
+    def fence(self):
+        """overlapped copies issued from now on wait for everything queued on the compute stream so far"""
+        check(self.lib.mbpls_hip_fence(self.handle))
 
     def cluster_columns(self, n):
         """the never-writes-X passes of a matrix with n samples run on clusters of workgroups (one read of X)"""

@@ -115,6 +115,7 @@ struct mbpls_ctx {
   size_t stage_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t copy_stream = nullptr;   // non-blocking: D2H of finished results while kernels run
+  hipEvent_t fence_ev = nullptr;       // mbpls_hip_fence: what was queued before it is finished before the next overlapped copy reads
   // ring of small K x K matrices for right_multiply
   void* small_m = nullptr;
   unsigned small_m_slot = 0;

@@ -266,6 +266,7 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
   for (hipEvent_t e : ctx->pin_ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->fence_ev) (void)hipEventDestroy(ctx->fence_ev);
   if (ctx->pin_d2h) (void)hipHostFree(ctx->pin_d2h);
   if (ctx->pin_small) {
     for (hipEvent_t e : ctx->pin_small_ev)
@@ -471,11 +472,21 @@ int mbpls_hip_memcpy_d2h(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t 
   return MBPLS_OK;
 }
 
+int mbpls_hip_fence(mbpls_ctx* ctx) {
+  MB_ARG(ctx, "ctx is NULL");
+  if (!ctx->fence_ev) MB_HIP(hipEventCreateWithFlags(&ctx->fence_ev, hipEventDisableTiming));
+  MB_HIP(hipEventRecord(ctx->fence_ev, ctx->stream));
+  return MBPLS_OK;
+}
+
 int mbpls_hip_memcpy_d2h_overlap(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   MB_ARG(ctx && (bytes == 0 || (h_dst && d_src)), "NULL argument");
   if (bytes == 0) return MBPLS_OK;
   MB_HIP(hipSetDevice(ctx->device));   // may be called from a helper thread (the current device is per thread)
   if (!ctx->copy_stream) MB_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  // not ordered behind the pass that is running -- but behind the last fence: the small kernels that produced a finished
+  // column (a scaling, an upload) were queued BEFORE the pass and must be through before the copy reads their output
+  if (ctx->fence_ev) MB_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->fence_ev, 0));
   MB_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
   MB_HIP(hipStreamSynchronize(ctx->copy_stream));
   return MBPLS_OK;

@@ -581,6 +581,8 @@ class HipEngine(EngineBase):
         """a2+a3: g = alpha X^T v (into the slot column), t~_b = X_b g_b, ||g_b||^2.  One read of X.
         ``overlap``: host work to do while the kernel runs (e.g. fetching finished columns)."""
         n, B = self.n, self.nblocks
+        if overlap is not None:
+            self.ctx.fence()    # (its copies wait for what was queued before this pass, not for the pass)
         if self._istd:
             v = self._centre(v)
         if self._lazy_pslot:
@@ -613,6 +615,8 @@ class HipEngine(EngineBase):
 
     def deflate_sweep(self, ts, inv_tt, deflate, p_slot, v=None, alpha=1.0, g_slot=None, overlap=None):
         """a5+a7 (+ next component's first sweep): p = inv_tt X^T ts, X -= ts p^T.  One read + one write."""
+        if overlap is not None:
+            self.ctx.fence()    # (its copies wait for what was queued before this pass, not for the pass)
         n, B = self.n, self.nblocks
         if self._istd:       # raw-space pass: zero-sum vectors
             ts = self._centre(ts)
@@ -875,6 +879,8 @@ class HipEngine(EngineBase):
     def _xw(self, Wdev, c, per_block, mean=None, scale=None, mat=None, nan=None, overlap=None):
         """nan: None dense; "skip" missing entries contribute nothing; "indicator" sums of W over the present
         columns of every row (csrc/gemv.hip k_xw NANM).  ``overlap``: host work to do while the kernel runs."""
+        if overlap is not None:
+            self.ctx.fence()    # (its copies wait for what was queued before this product, not for the product)
         if mat is None and self._kscale and mean is None:
             mean, scale = self.mean, self.scale          # raw working matrix: standardise on the fly
         mat = mat if mat is not None else self.X

@@ -1028,6 +1028,9 @@ def fit_unipals(eng, Y, K, standardize, keep_raw_weights=False):
                 # produced for M = X (X^T y) -- the same products, not taken twice
                 c = u.T.dot(y0).item() / yy
                 eng.right_mul(("S", 0, 1), np.array([[c]]), ("Wc", k))
+                # (stream_out below copies this column on the COPY stream while the deflation pass runs: ordered behind
+                # this small kernel by the fence deflate_sweep records -- without one the copy could overtake it, seen
+                # with two ranks sharing one GPU in the randomised sharded sweep of round 5)
                 t_raw, ssq = c * m_raw, c * c * g_ssq
             else:
                 t_raw, ssq = eng.sweep(u, 1.0, ("Wc", k))   # w_raw = X^T u (:503), t~_b = X_b w_raw_b
