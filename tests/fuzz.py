@@ -145,6 +145,18 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                     if nn > 1:
                         sgn = np.sign(np.sum(ref.Ts_ * m.Ts_, axis=0)); sgn[sgn == 0] = 1.0
                         w = max(w, util.relerr(m.transform(loc(Xn)) * sgn, o.transform(ref, sp(Xn))))
+                    if not sparse and n >= 12 and do_cv:
+                        # cross-validation under column shards: folds batched per pass (products and small sums
+                        # all-reduced) against the fold-by-fold loop, every rank holding all predictions
+                        from mbpls_amd.model_selection import cross_val_predict
+                        folds = [3, 5, min(n, 40)][cv_pick]
+                        est = MBPLS(n_components=min(K, 3), method=method, standardize=std, full_svd=True)
+                        a_ = cross_val_predict(est, loc(X), Y, cv=folds)
+                        b_ = cross_val_predict(est, loc(X), Y, cv=folds, batch_folds=False)
+                        wcv = util.relerr(a_, b_)
+                        if wcv > 1e-7:
+                            print_(tag, f"cross_val_predict batched vs loop {wcv:.2e} (cv={folds}, rank {rank} of {world})")
+                        w = max(w, wcv)
                 worst = max(worst, w)
                 if w > 1e-9:
                     print_(tag, f"relerr {w:.2e} (rank {rank} of {world})")
