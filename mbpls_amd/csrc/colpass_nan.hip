@@ -292,6 +292,191 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   }
 }
 
+// Columns too long for the registers of one workgroup (n > ctx->nan_long_from, default 65536: the R = 64 shape above
+// ends there).  Same ownership -- one workgroup per chunk of columns, same sums in the same places -- but a column is
+// STREAMED: thread t owns rows t, t + T, t + 2T, ... of every column and of the chunk's partial vectors A / D (which
+// live in their [nchunks][n] slots of the workspace instead of registers), and a column is visited once per
+// dependent reduction (statistics: count+sum, centred squares, store; sweep: dot products, then the update of A / D).
+// The re-visits hit L2 (a column of 10^6 samples is 8 MB; shorter ones stay in the XCD's 4 MB), HBM sees the column
+// once or twice.  A correctness path: the reference's own loop over rows and columns with missing entries
+// (mbpls.py:846-873) is Python, nobody waits for it at this size.
+template <bool STD, bool DEFL, bool SWEEP>
+__global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
+  __shared__ double red[2 * 128];
+  int buf = 0;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int64_t n = a.n, ld = a.ld;
+  const int chunk = blockIdx.x;
+  const int64_t j0 = uniform64(a.c0[chunk]), j1 = uniform64(a.c1[chunk]);
+  double* __restrict__ acc = SWEEP ? a.part_t + (int64_t)chunk * n : nullptr;
+  double* __restrict__ dac = SWEEP ? a.part_d + (int64_t)chunk * n : nullptr;
+  if constexpr (SWEEP)
+    for (int64_t i = tid; i < n; i += T) acc[i] = dac[i] = 0.0;
+  const double* __restrict__ rowmask = STD ? a.rowmask : nullptr;
+  // a sample excluded from the fit (cross-validation fold) loads as 0: present, and without weight in any sum
+  auto excluded = [&](int64_t i) -> bool { return rowmask && rowmask[i] == 0.0; };
+  double ssq_g = 0.0, ssq_p = 0.0, ssq_x = 0.0;
+
+  for (int64_t jj = j0; jj < j1; ++jj) {
+    const double* __restrict__ col = a.src + jj * ld;
+    double gj = 0.0;
+    if constexpr (STD) {
+      double* __restrict__ out = a.dst + jj * ld;
+      if (a.mode != MBPLS_SCALE_FIT && a.count) {
+        double c1[1] = {0.0};
+        for (int64_t i = tid; i < n; i += T) {
+          const double x = col[i];
+          c1[0] += (x == x && !excluded(i)) ? 1.0 : 0.0;
+        }
+        block_sum8<1>(c1, red, buf);
+        if (tid == 0) a.count[jj] = c1[0];
+      }
+      double mean = 0.0, scale = 1.0;
+      if (a.mode == MBPLS_SCALE_FIT) {
+        double sc[2] = {0.0, 0.0};
+        for (int64_t i = tid; i < n; i += T) {
+          const double x = col[i];
+          const bool use = x == x && !excluded(i);
+          sc[0] += use ? x : 0.0;
+          sc[1] += use ? 1.0 : 0.0;
+        }
+        block_sum8<2>(sc, red, buf);
+        const double cnt = sc[1];
+        mean = sc[0] / cnt;
+        double cq[2] = {0.0, 0.0};
+        for (int64_t i = tid; i < n; i += T) {
+          const double x = col[i];
+          const double dlt = (x == x && !excluded(i)) ? x - mean : 0.0;
+          cq[0] += dlt;
+          cq[1] = fma(dlt, dlt, cq[1]);
+        }
+        block_sum8<2>(cq, red, buf);
+        const double var = (cq[1] - cq[0] * cq[0] / cnt) / cnt;
+        const double eps = 2.220446049250313e-16;
+        const double nme = cnt * mean * eps;
+        const double bound = cnt * eps * var + nme * nme;
+        scale = (var <= bound) ? 1.0 : sqrt(var);
+        if (tid == 0) {
+          a.mean[jj] = mean;
+          a.scale[jj] = scale;
+          if (a.count) a.count[jj] = cnt;
+          if (a.var_out) a.var_out[jj] = (var <= bound) ? 0.0 : var;
+        }
+      } else if (a.mode == MBPLS_SCALE_APPLY) {
+        mean = a.mean[jj];
+        scale = a.scale[jj];
+      }
+      double r2[2] = {0.0, 0.0};
+      for (int64_t i = tid; i < ld; i += T) {
+        double z = 0.0;
+        if (i < n && !excluded(i)) {
+          z = col[i];
+          if (a.mode != MBPLS_SCALE_NONE) z = z - mean;          // NaN stays NaN
+        }
+        if (a.mode != MBPLS_SCALE_NONE) z = z / scale;
+        out[i] = z;
+        const bool pr = z == z;
+        ssq_x = fma(pr ? z : 0.0, pr ? z : 0.0, ssq_x);          // nansum(X^2), mbpls.py:826
+        if constexpr (SWEEP) {
+          if (i < n) {
+            const double vk = a.v[i];
+            r2[0] = fma(pr ? z : 0.0, vk, r2[0]);
+            r2[1] = fma(pr ? vk : 0.0, vk, r2[1]);
+          }
+        }
+      }
+      if constexpr (SWEEP) {
+        block_sum8<2>(r2, red, buf);
+        gj = (r2[1] != 0.0) ? r2[0] / r2[1] : 0.0;
+        const double g2 = gj * gj;
+        for (int64_t i = tid; i < n; i += T) {                   // (this thread's own stores of the loop above)
+          const double z = out[i];
+          const bool pr = z == z;
+          acc[i] = fma(gj, pr ? z : 0.0, acc[i]);
+          dac[i] += pr ? g2 : 0.0;
+        }
+      }
+    } else if constexpr (DEFL) {
+      // one reduction: <x,ts>_present, <ts,ts>_present and, for the fused sweep, <x,u>, <u,u>, <ts,u>
+      double* __restrict__ out = a.dst + jj * ld;
+      double r5[SWEEP ? 5 : 2];
+#pragma unroll
+      for (int q = 0; q < (SWEEP ? 5 : 2); ++q) r5[q] = 0.0;
+      for (int64_t i = tid; i < n; i += T) {
+        const double x = col[i], tk = a.ts[i];
+        const bool pr = x == x;
+        const double xz = pr ? x : 0.0, tz = pr ? tk : 0.0;
+        r5[0] = fma(xz, tk, r5[0]);
+        r5[1] = fma(tz, tk, r5[1]);
+        if constexpr (SWEEP) {
+          const double vk = a.v[i];
+          const double vz = pr ? vk : 0.0;
+          r5[2] = fma(xz, vk, r5[2]);
+          r5[3] = fma(vz, vk, r5[3]);
+          r5[4] = fma(tz, vk, r5[4]);
+        }
+      }
+      block_sum8<(SWEEP ? 5 : 2)>(r5, red, buf);
+      const double pj = (r5[1] != 0.0) ? r5[0] / r5[1] : 0.0;
+      ssq_p = fma(pj, pj, ssq_p);
+      if (tid == 0 && a.pvec) a.pvec[jj] = pj;
+      if constexpr (SWEEP) {
+        if (a.deflate) gj = (r5[3] != 0.0) ? fma(-pj, r5[4], r5[2]) / r5[3] : 0.0;
+        else gj = (r5[3] != 0.0) ? r5[2] / r5[3] : 0.0;
+      }
+      if (a.deflate || SWEEP) {
+        const double g2 = gj * gj;
+        for (int64_t i = tid; i < n; i += T) {
+          double x = col[i];
+          const bool pr = x == x;
+          if (a.deflate) {
+            x = fma(-pj, a.ts[i], x);                             // NaN stays NaN (:969)
+            out[i] = x;
+          }
+          if constexpr (SWEEP) {
+            acc[i] = fma(gj, pr ? x : 0.0, acc[i]);
+            dac[i] += pr ? g2 : 0.0;
+          }
+        }
+      }
+    } else if constexpr (SWEEP) {
+      double r2[2] = {0.0, 0.0};
+      for (int64_t i = tid; i < n; i += T) {
+        const double x = col[i], vk = a.v[i];
+        const bool pr = x == x;
+        r2[0] = fma(pr ? x : 0.0, vk, r2[0]);
+        r2[1] = fma(pr ? vk : 0.0, vk, r2[1]);
+      }
+      block_sum8<2>(r2, red, buf);
+      gj = (r2[1] != 0.0) ? r2[0] / r2[1] : 0.0;
+      const double g2 = gj * gj;
+      for (int64_t i = tid; i < n; i += T) {
+        const double x = col[i];
+        const bool pr = x == x;
+        acc[i] = fma(gj, pr ? x : 0.0, acc[i]);
+        dac[i] += pr ? g2 : 0.0;
+      }
+    }
+    if constexpr (SWEEP) {
+      ssq_g = fma(gj, gj, ssq_g);
+      if (tid == 0 && a.g) a.g[jj] = gj;
+    }
+  }
+
+  if constexpr (STD) {
+    double s[1] = {ssq_x};
+    block_sum8<1>(s, red, buf);
+    ssq_x = s[0];
+  }
+  if (tid == 0) {
+    double* ps = a.part_s + (int64_t)chunk * 4;
+    ps[0] = ssq_g;
+    ps[1] = ssq_p;
+    ps[2] = ssq_x;
+    ps[3] = 0.0;
+  }
+}
+
 template <bool STD, bool DEFL, bool SWEEP>
 static int launch_nan(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, int64_t p) {
   const bool writes = STD || (DEFL && a.deflate);
@@ -301,9 +486,13 @@ static int launch_nan(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, in
   if (a.n <= SUB_MAX_N && ctx->sub_columns) return launch_nan_sub(ctx, ct, a, STD, DEFL, SWEEP);
   Cfg cfg;
   int T = 0;
-  if (!pick_cfg(ctx, a.n, &cfg, &T, false)) {
-    set_error("the missing-value column passes support n <= 65536 (got n=%lld)", (long long)a.n);
-    return MBPLS_ERR_UNSUPPORTED;
+  if (a.n > ctx->nan_long_from || !pick_cfg(ctx, a.n, &cfg, &T, false)) {
+    // streamed columns: as many threads as there are rows, up to 1024
+    const int TL = (int)std::min<int64_t>(1024, (a.n + 63) / 64 * 64);
+    hipLaunchKernelGGL((k_colpass_nan_long<STD, DEFL, SWEEP>), dim3((unsigned)ct.nchunks), dim3((unsigned)TL), 0,
+                       ctx->stream, a);
+    MB_HIP(hipGetLastError());
+    return MBPLS_OK;
   }
   if (cfg.R == 8 && cfg.TMAX == 512 && T < 256 && (STD || DEFL)) {
     // the fused R=8 variants stage u / ts in LDS arrays sized for 512 threads: small workgroups would be capped at two

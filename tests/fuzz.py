@@ -76,7 +76,7 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         X, Y = orc.make_latent(n, p, q, r=min(4, p), seed=1000 + c)
         X = X + rng.uniform(-3, 3, size=p) * (rng.rand() < 0.5)          # column offsets (implicit standardisation)
         sp = (lambda A: A) if nb == 1 else (lambda A: [np.ascontiguousarray(b) for b in np.split(A, cuts, axis=1)])
-        sparse = method == "NIPALS" and n >= 20 and p >= 20 and n <= 65536 and rng.rand() < 0.4   # (NaN passes: n <= 65536)
+        sparse = method == "NIPALS" and n >= 20 and p >= 20 and rng.rand() < 0.4
         if sparse:
             X[rng.rand(n, p) < rng.choice([0.01, 0.05])] = np.nan
         two_pass = method == "NIPALS" and q == 1 and not sparse and rng.rand() < 0.5
@@ -98,8 +98,11 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                   {"MBPLS_UNIPALS_NODEFLATE": "0"}, {"MBPLS_R_INCREMENTAL": "0"}, {"MBPLS_STREAM_STATS": "0"},
                   {"MBPLS_KERNEL_IMPLICIT": "1"}, {"MBPLS_KERNEL_IMPLICIT": "0"}, {"MBPLS_NIPALS_QSPACE": "0"}]
         route = routes[int(rng.randint(0, len(routes)))]
+        # missing values: every third input form through the streamed-column kernel that n > 65536 takes (any n runs on it)
+        stream_nan = sparse and form % 3 == 0
         tag = (f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} blocks={nb} sparse={sparse} two_pass={two_pass} "
-               f"calc_all={calc_all} norm={norm} form={form}" + (f" route={route}" if route else ""))
+               f"calc_all={calc_all} norm={norm} form={form}" + (f" route={route}" if route else "")
+               + (" streamed" if stream_nan else ""))
         if only is not None and c != only:                 # (same random sequence, one case fitted: reproducing a failure)
             continue
         if os.environ.get("MBPLS_FUZZ_TRACE"):             # every case announced before its fit (which rank stopped where)
@@ -119,6 +122,9 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         try:
             os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0" if two_pass else "1"
             os.environ.update(route)
+            if stream_nan:
+                import mbpls_amd
+                mbpls_amd.get_context().set_tunable("nan_long_from", 0)
             params = dict(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse,
                           calc_all=(calc_all or sparse), nipals_convergence_norm=norm)
             if reuse and reused is not None:
@@ -216,6 +222,8 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
             if raise_errors:
                 raise
         finally:
+            if stream_nan:
+                mbpls_amd.get_context().set_tunable("nan_long_from", 65536)
             os.environ.pop("MBPLS_NIPALS_Q1_FIXED_POINT", None)
             for key in route:
                 os.environ.pop(key, None)

@@ -259,3 +259,57 @@ def test_missing_values_on_very_long_columns(gpu_required, n, q):
     assert w < 1e-8, w
     util.check_nipals_iterations(mdl, ref, two=False)
     assert util.relerr(mdl.predict(blocks), ors.predict(ref, blocks)) < 1e-8
+
+
+@pytest.mark.parametrize("n,q,std", [(65538, 1, True), (70001, 2, True), (131072, 1, False)])
+def test_missing_values_beyond_the_register_shapes(gpu_required, n, q, std):
+    """n > 65536: no workgroup holds a column any more -- the missing-value passes stream it (k_colpass_nan_long), any n;
+    same sums in the same places (:846-873, :919-926, :969)."""
+    from mbpls_amd import MBPLS
+    p = 22
+    X, Y = orc.make_latent(n, p, q, r=4, seed=n)
+    rng = np.random.RandomState(2)
+    X[rng.rand(n, p) < 0.04] = np.nan
+    blocks = [X[:, :9], X[:, 9:]]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = ors.fit(blocks, Y, n_components=3, standardize=std)
+        mdl = MBPLS(n_components=3, sparse_data=True, standardize=std).fit(blocks, Y)
+    w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"sparse n={n} q={q}")
+    assert w < 1e-8, w
+    util.check_nipals_iterations(mdl, ref, two=False)
+    Xn = [b[:50] for b in blocks]
+    assert util.relerr(mdl.predict(Xn), ors.predict(ref, Xn)) < 1e-8
+    assert util.relerr(mdl.transform(Xn), ors.transform(ref, Xn)) < 1e-8
+
+
+@pytest.mark.parametrize("n,p,q,std", [(300, 40, 1, True), (1031, 64, 3, True), (4096, 30, 1, False), (5000, 200, 2, True)])
+def test_streamed_missing_value_passes_at_every_n(gpu_required, n, p, q, std):
+    """the same kernel at sizes the register shapes cover ("nan_long_from" = 0): equal to the oracle, and to the
+    register-resident passes to rounding; cross-validation folds (row masks) included"""
+    from mbpls_amd import MBPLS, get_context
+    from mbpls_amd.model_selection import cross_val_predict
+    X, Y = orc.make_latent(n, p, q, r=4, seed=n + p)
+    rng = np.random.RandomState(3)
+    X[rng.rand(n, p) < 0.05] = np.nan
+    X[:, 3] += 7.0
+    blocks = [X[:, :p // 3], X[:, p // 3:]]
+    ctx = get_context()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = ors.fit(blocks, Y, n_components=3, standardize=std)
+        est = MBPLS(n_components=3, sparse_data=True, standardize=std)
+        reg = MBPLS(n_components=3, sparse_data=True, standardize=std).fit(blocks, Y)
+        cv_reg = cross_val_predict(est, blocks, Y, cv=3) if n <= 1100 else None
+        ctx.set_tunable("nan_long_from", 0)
+        try:
+            mdl = MBPLS(n_components=3, sparse_data=True, standardize=std).fit(blocks, Y)
+            cv_str = cross_val_predict(est, blocks, Y, cv=3) if n <= 1100 else None
+        finally:
+            ctx.set_tunable("nan_long_from", 65536)
+    w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"streamed sparse n={n}")
+    assert w < 1e-8, w
+    assert util.compare(util.model_to_flat(mdl), util.model_to_flat(reg), TOL, what="streamed vs register") < 1e-9
+    util.check_nipals_iterations(mdl, ref, two=False)
+    if cv_reg is not None:
+        assert util.relerr(cv_str, cv_reg) < 1e-9
