@@ -77,8 +77,9 @@ int mbpls_hip_device_info(mbpls_ctx* ctx, char* name, size_t name_len, int* comp
  * "gram_slice_features" (features per split-K slice of the Gram kernel for long feature ranges, 0 = off),
  * "long_columns_from" (0..65536, default 8192: matrices with more samples than this use the two-phase long-column
  * passes instead of the register-resident ones, which spill above 8192 and have no lazy / implicit flavour there),
- * "nan_long_from" (0..65536, default 65536: the missing-value passes stream columns with more samples than this
- * instead of holding them in registers -- any n; 0 = every n above the several-columns-per-wave range),
+ * "nan_long_from" (0..65536, default 8192: the missing-value passes stream columns with more samples than this
+ * instead of holding them in registers -- any n; 0 = every n above the several-columns-per-wave range; 65536 = the
+ * register shapes wherever they exist, which spill above 8192),
  * "sub_columns" (default 1: matrices with n <= 1024 samples run the column passes with several columns per wave;
  * 0 = one column per workgroup at every n -- same results, kept for A/B tests),
  * "cluster_passes" (default 1: the never-writes-X passes of long columns -- statistics + sweep, sweep, loadings + sweep

@@ -292,8 +292,8 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   }
 }
 
-// Columns too long for the registers of one workgroup (n > ctx->nan_long_from, default 65536: the R = 64 shape above
-// ends there).  Same ownership -- one workgroup per chunk of columns, same sums in the same places -- but a column is
+// Columns too long for the registers of one workgroup (n > ctx->nan_long_from, default 8192: the R = 32 / 64 shapes
+// above cover up to 65536 rows but spill -- measured 2x slower than this kernel at every n above 8192, round 5).  Same ownership -- one workgroup per chunk of columns, same sums in the same places -- but a column is
 // STREAMED: thread t owns rows t, t + T, t + 2T, ... of every column and of the chunk's partial vectors A / D (which
 // live in their [nchunks][n] slots of the workspace instead of registers), and a column is visited once per
 // dependent reduction (statistics: count+sum, centred squares, store; sweep: dot products, then the update of A / D).
@@ -318,13 +318,14 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
   double ssq_g = 0.0, ssq_p = 0.0, ssq_x = 0.0;
 
   for (int64_t jj = j0; jj < j1; ++jj) {
-    const double* __restrict__ col = a.src + jj * ld;
+    const double* col = a.src + jj * ld;
     double gj = 0.0;
     if constexpr (STD) {
-      double* __restrict__ out = a.dst + jj * ld;
+      double* out = a.dst + jj * ld;
       if (a.mode != MBPLS_SCALE_FIT && a.count) {
         double c1[1] = {0.0};
-        for (int64_t i = tid; i < n; i += T) {
+  #pragma unroll 4
+      for (int64_t i = tid; i < n; i += T) {
           const double x = col[i];
           c1[0] += (x == x && !excluded(i)) ? 1.0 : 0.0;
         }
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
       double mean = 0.0, scale = 1.0;
       if (a.mode == MBPLS_SCALE_FIT) {
         double sc[2] = {0.0, 0.0};
-        for (int64_t i = tid; i < n; i += T) {
+  #pragma unroll 4
+      for (int64_t i = tid; i < n; i += T) {
           const double x = col[i];
           const bool use = x == x && !excluded(i);
           sc[0] += use ? x : 0.0;
@@ -344,7 +346,8 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
         const double cnt = sc[1];
         mean = sc[0] / cnt;
         double cq[2] = {0.0, 0.0};
-        for (int64_t i = tid; i < n; i += T) {
+  #pragma unroll 4
+      for (int64_t i = tid; i < n; i += T) {
           const double x = col[i];
           const double dlt = (x == x && !excluded(i)) ? x - mean : 0.0;
           cq[0] += dlt;
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
         scale = a.scale[jj];
       }
       double r2[2] = {0.0, 0.0};
+#pragma unroll 4
       for (int64_t i = tid; i < ld; i += T) {
         double z = 0.0;
         if (i < n && !excluded(i)) {
@@ -389,7 +393,8 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
         block_sum8<2>(r2, red, buf);
         gj = (r2[1] != 0.0) ? r2[0] / r2[1] : 0.0;
         const double g2 = gj * gj;
-        for (int64_t i = tid; i < n; i += T) {                   // (this thread's own stores of the loop above)
+  #pragma unroll 4
+      for (int64_t i = tid; i < n; i += T) {                   // (this thread's own stores of the loop above)
           const double z = out[i];
           const bool pr = z == z;
           acc[i] = fma(gj, pr ? z : 0.0, acc[i]);
@@ -398,10 +403,11 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
       }
     } else if constexpr (DEFL) {
       // one reduction: <x,ts>_present, <ts,ts>_present and, for the fused sweep, <x,u>, <u,u>, <ts,u>
-      double* __restrict__ out = a.dst + jj * ld;
+      double* out = a.dst + jj * ld;
       double r5[SWEEP ? 5 : 2];
 #pragma unroll
       for (int q = 0; q < (SWEEP ? 5 : 2); ++q) r5[q] = 0.0;
+#pragma unroll 4
       for (int64_t i = tid; i < n; i += T) {
         const double x = col[i], tk = a.ts[i];
         const bool pr = x == x;
@@ -426,7 +432,8 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
       }
       if (a.deflate || SWEEP) {
         const double g2 = gj * gj;
-        for (int64_t i = tid; i < n; i += T) {
+  #pragma unroll 4
+      for (int64_t i = tid; i < n; i += T) {
           double x = col[i];
           const bool pr = x == x;
           if (a.deflate) {
@@ -441,6 +448,7 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
       }
     } else if constexpr (SWEEP) {
       double r2[2] = {0.0, 0.0};
+#pragma unroll 4
       for (int64_t i = tid; i < n; i += T) {
         const double x = col[i], vk = a.v[i];
         const bool pr = x == x;
@@ -450,6 +458,7 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
       block_sum8<2>(r2, red, buf);
       gj = (r2[1] != 0.0) ? r2[0] / r2[1] : 0.0;
       const double g2 = gj * gj;
+#pragma unroll 4
       for (int64_t i = tid; i < n; i += T) {
         const double x = col[i];
         const bool pr = x == x;

@@ -100,6 +100,7 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         route = routes[int(rng.randint(0, len(routes)))]
         # missing values: every third input form through the streamed-column kernel that n > 65536 takes (any n runs on it)
         stream_nan = sparse and form % 3 == 0
+        nan_from = 0 if stream_nan else (65536 if (sparse and form % 3 == 1) else None)   # ... and the register shapes to 65536
         tag = (f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} blocks={nb} sparse={sparse} two_pass={two_pass} "
                f"calc_all={calc_all} norm={norm} form={form}" + (f" route={route}" if route else "")
                + (" streamed" if stream_nan else ""))
@@ -122,9 +123,9 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         try:
             os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0" if two_pass else "1"
             os.environ.update(route)
-            if stream_nan:
+            if nan_from is not None:
                 import mbpls_amd
-                mbpls_amd.get_context().set_tunable("nan_long_from", 0)
+                mbpls_amd.get_context().set_tunable("nan_long_from", nan_from)
             params = dict(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse,
                           calc_all=(calc_all or sparse), nipals_convergence_norm=norm)
             if reuse and reused is not None:
@@ -222,8 +223,8 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
             if raise_errors:
                 raise
         finally:
-            if stream_nan:
-                mbpls_amd.get_context().set_tunable("nan_long_from", 65536)
+            if nan_from is not None:
+                mbpls_amd.get_context().set_tunable("nan_long_from", 8192)
             os.environ.pop("MBPLS_NIPALS_Q1_FIXED_POINT", None)
             for key in route:
                 os.environ.pop(key, None)
