@@ -324,8 +324,7 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
       double* out = a.dst + jj * ld;
       if (a.mode != MBPLS_SCALE_FIT && a.count) {
         double c1[1] = {0.0};
-  #pragma unroll 4
-      for (int64_t i = tid; i < n; i += T) {
+        for (int64_t i = tid; i < n; i += T) {
           const double x = col[i];
           c1[0] += (x == x && !excluded(i)) ? 1.0 : 0.0;
         }
@@ -335,8 +334,7 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
       double mean = 0.0, scale = 1.0;
       if (a.mode == MBPLS_SCALE_FIT) {
         double sc[2] = {0.0, 0.0};
-  #pragma unroll 4
-      for (int64_t i = tid; i < n; i += T) {
+        for (int64_t i = tid; i < n; i += T) {
           const double x = col[i];
           const bool use = x == x && !excluded(i);
           sc[0] += use ? x : 0.0;
@@ -346,8 +344,7 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
         const double cnt = sc[1];
         mean = sc[0] / cnt;
         double cq[2] = {0.0, 0.0};
-  #pragma unroll 4
-      for (int64_t i = tid; i < n; i += T) {
+        for (int64_t i = tid; i < n; i += T) {
           const double x = col[i];
           const double dlt = (x == x && !excluded(i)) ? x - mean : 0.0;
           cq[0] += dlt;
@@ -370,7 +367,6 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
         scale = a.scale[jj];
       }
       double r2[2] = {0.0, 0.0};
-#pragma unroll 4
       for (int64_t i = tid; i < ld; i += T) {
         double z = 0.0;
         if (i < n && !excluded(i)) {
@@ -393,8 +389,7 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
         block_sum8<2>(r2, red, buf);
         gj = (r2[1] != 0.0) ? r2[0] / r2[1] : 0.0;
         const double g2 = gj * gj;
-  #pragma unroll 4
-      for (int64_t i = tid; i < n; i += T) {                   // (this thread's own stores of the loop above)
+        for (int64_t i = tid; i < n; i += T) {                   // (this thread's own stores of the loop above)
           const double z = out[i];
           const bool pr = z == z;
           acc[i] = fma(gj, pr ? z : 0.0, acc[i]);
@@ -407,7 +402,6 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
       double r5[SWEEP ? 5 : 2];
 #pragma unroll
       for (int q = 0; q < (SWEEP ? 5 : 2); ++q) r5[q] = 0.0;
-#pragma unroll 4
       for (int64_t i = tid; i < n; i += T) {
         const double x = col[i], tk = a.ts[i];
         const bool pr = x == x;
@@ -432,8 +426,7 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
       }
       if (a.deflate || SWEEP) {
         const double g2 = gj * gj;
-  #pragma unroll 4
-      for (int64_t i = tid; i < n; i += T) {
+        for (int64_t i = tid; i < n; i += T) {
           double x = col[i];
           const bool pr = x == x;
           if (a.deflate) {
@@ -448,7 +441,6 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
       }
     } else if constexpr (SWEEP) {
       double r2[2] = {0.0, 0.0};
-#pragma unroll 4
       for (int64_t i = tid; i < n; i += T) {
         const double x = col[i], vk = a.v[i];
         const bool pr = x == x;
@@ -458,7 +450,6 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
       block_sum8<2>(r2, red, buf);
       gj = (r2[1] != 0.0) ? r2[0] / r2[1] : 0.0;
       const double g2 = gj * gj;
-#pragma unroll 4
       for (int64_t i = tid; i < n; i += T) {
         const double x = col[i];
         const bool pr = x == x;
