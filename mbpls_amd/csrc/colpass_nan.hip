@@ -293,13 +293,18 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
 }
 
 // Columns too long for the registers of one workgroup (n > ctx->nan_long_from, default 8192: the R = 32 / 64 shapes
-// above cover up to 65536 rows but spill -- measured 2x slower than this kernel at every n above 8192, round 5).  Same ownership -- one workgroup per chunk of columns, same sums in the same places -- but a column is
-// STREAMED: thread t owns rows t, t + T, t + 2T, ... of every column and of the chunk's partial vectors A / D (which
-// live in their [nchunks][n] slots of the workspace instead of registers), and a column is visited once per
-// dependent reduction (statistics: count+sum, centred squares, store; sweep: dot products, then the update of A / D).
-// The re-visits hit L2 (a column of 10^6 samples is 8 MB; shorter ones stay in the XCD's 4 MB), HBM sees the column
-// once or twice.  A correctness path: the reference's own loop over rows and columns with missing entries
-// (mbpls.py:846-873) is Python, nobody waits for it at this size.
+// above cover up to 65536 rows but spill -- measured 2x slower than this kernel at every n above 8192, round 5).
+// Same ownership -- one workgroup per chunk of columns, same sums in the same places -- but a column is STREAMED:
+// thread t owns rows t, t + T, t + 2T, ... of every column and of the chunk's partial vectors A / D (which live in
+// their [nchunks][n] slots of the workspace instead of registers), and a column is visited once per dependent
+// reduction (statistics: count + sum, centred squares, store; sweep: dot products, then the update of A / D).  The
+// re-visits hit L2; HBM sees the column once or twice.  Columns go in groups of NL_CB: the row loops that read the
+// n-vectors u / ts and the one that updates A / D (and rewrites X when it deflates) run once per group, which cuts the
+// vector traffic per column to a quarter; the sums are formed column by column in the same order as without groups.
+// The reference's own loop over rows and columns with missing entries (mbpls.py:846-873) is Python -- nobody waits for
+// it at this size.
+constexpr int NL_CB = 4;
+
 template <bool STD, bool DEFL, bool SWEEP>
 __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
   __shared__ double red[2 * 128];
@@ -317,149 +322,185 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
   auto excluded = [&](int64_t i) -> bool { return rowmask && rowmask[i] == 0.0; };
   double ssq_g = 0.0, ssq_p = 0.0, ssq_x = 0.0;
 
-  for (int64_t jj = j0; jj < j1; ++jj) {
-    const double* col = a.src + jj * ld;
-    double gj = 0.0;
-    if constexpr (STD) {
-      double* out = a.dst + jj * ld;
-      if (a.mode != MBPLS_SCALE_FIT && a.count) {
-        double c1[1] = {0.0};
-        for (int64_t i = tid; i < n; i += T) {
-          const double x = col[i];
-          c1[0] += (x == x && !excluded(i)) ? 1.0 : 0.0;
-        }
-        block_sum8<1>(c1, red, buf);
-        if (tid == 0) a.count[jj] = c1[0];
-      }
-      double mean = 0.0, scale = 1.0;
-      if (a.mode == MBPLS_SCALE_FIT) {
-        double sc[2] = {0.0, 0.0};
-        for (int64_t i = tid; i < n; i += T) {
-          const double x = col[i];
-          const bool use = x == x && !excluded(i);
-          sc[0] += use ? x : 0.0;
-          sc[1] += use ? 1.0 : 0.0;
-        }
-        block_sum8<2>(sc, red, buf);
-        const double cnt = sc[1];
-        mean = sc[0] / cnt;
-        double cq[2] = {0.0, 0.0};
-        for (int64_t i = tid; i < n; i += T) {
-          const double x = col[i];
-          const double dlt = (x == x && !excluded(i)) ? x - mean : 0.0;
-          cq[0] += dlt;
-          cq[1] = fma(dlt, dlt, cq[1]);
-        }
-        block_sum8<2>(cq, red, buf);
-        const double var = (cq[1] - cq[0] * cq[0] / cnt) / cnt;
-        const double eps = 2.220446049250313e-16;
-        const double nme = cnt * mean * eps;
-        const double bound = cnt * eps * var + nme * nme;
-        scale = (var <= bound) ? 1.0 : sqrt(var);
-        if (tid == 0) {
-          a.mean[jj] = mean;
-          a.scale[jj] = scale;
-          if (a.count) a.count[jj] = cnt;
-          if (a.var_out) a.var_out[jj] = (var <= bound) ? 0.0 : var;
-        }
-      } else if (a.mode == MBPLS_SCALE_APPLY) {
-        mean = a.mean[jj];
-        scale = a.scale[jj];
-      }
-      double r2[2] = {0.0, 0.0};
-      for (int64_t i = tid; i < ld; i += T) {
-        double z = 0.0;
-        if (i < n && !excluded(i)) {
-          z = col[i];
-          if (a.mode != MBPLS_SCALE_NONE) z = z - mean;          // NaN stays NaN
-        }
-        if (a.mode != MBPLS_SCALE_NONE) z = z / scale;
-        out[i] = z;
-        const bool pr = z == z;
-        ssq_x = fma(pr ? z : 0.0, pr ? z : 0.0, ssq_x);          // nansum(X^2), mbpls.py:826
-        if constexpr (SWEEP) {
-          if (i < n) {
-            const double vk = a.v[i];
-            r2[0] = fma(pr ? z : 0.0, vk, r2[0]);
-            r2[1] = fma(pr ? vk : 0.0, vk, r2[1]);
-          }
-        }
-      }
-      if constexpr (SWEEP) {
-        block_sum8<2>(r2, red, buf);
-        gj = (r2[1] != 0.0) ? r2[0] / r2[1] : 0.0;
-        const double g2 = gj * gj;
-        for (int64_t i = tid; i < n; i += T) {                   // (this thread's own stores of the loop above)
-          const double z = out[i];
-          const bool pr = z == z;
-          acc[i] = fma(gj, pr ? z : 0.0, acc[i]);
-          dac[i] += pr ? g2 : 0.0;
-        }
-      }
-    } else if constexpr (DEFL) {
-      // one reduction: <x,ts>_present, <ts,ts>_present and, for the fused sweep, <x,u>, <u,u>, <ts,u>
-      double* out = a.dst + jj * ld;
-      double r5[SWEEP ? 5 : 2];
+  for (int64_t jg = j0; jg < j1; jg += NL_CB) {
+    const int cnt = (int)((j1 - jg) < NL_CB ? (j1 - jg) : NL_CB);   // workgroup-uniform
+    double gj[NL_CB], pj[NL_CB];
 #pragma unroll
-      for (int q = 0; q < (SWEEP ? 5 : 2); ++q) r5[q] = 0.0;
-      for (int64_t i = tid; i < n; i += T) {
-        const double x = col[i], tk = a.ts[i];
-        const bool pr = x == x;
-        const double xz = pr ? x : 0.0, tz = pr ? tk : 0.0;
-        r5[0] = fma(xz, tk, r5[0]);
-        r5[1] = fma(tz, tk, r5[1]);
-        if constexpr (SWEEP) {
-          const double vk = a.v[i];
-          const double vz = pr ? vk : 0.0;
-          r5[2] = fma(xz, vk, r5[2]);
-          r5[3] = fma(vz, vk, r5[3]);
-          r5[4] = fma(tz, vk, r5[4]);
-        }
-      }
-      block_sum8<(SWEEP ? 5 : 2)>(r5, red, buf);
-      const double pj = (r5[1] != 0.0) ? r5[0] / r5[1] : 0.0;
-      ssq_p = fma(pj, pj, ssq_p);
-      if (tid == 0 && a.pvec) a.pvec[jj] = pj;
-      if constexpr (SWEEP) {
-        if (a.deflate) gj = (r5[3] != 0.0) ? fma(-pj, r5[4], r5[2]) / r5[3] : 0.0;
-        else gj = (r5[3] != 0.0) ? r5[2] / r5[3] : 0.0;
-      }
-      if (a.deflate || SWEEP) {
-        const double g2 = gj * gj;
-        for (int64_t i = tid; i < n; i += T) {
-          double x = col[i];
-          const bool pr = x == x;
-          if (a.deflate) {
-            x = fma(-pj, a.ts[i], x);                             // NaN stays NaN (:969)
-            out[i] = x;
+    for (int c = 0; c < NL_CB; ++c) gj[c] = pj[c] = 0.0;
+
+    if constexpr (STD) {
+      // statistics and the stored standardised column, column by column (every step depends on the one before)
+      for (int c = 0; c < cnt; ++c) {
+        const int64_t jj = jg + c;
+        const double* col = a.src + jj * ld;     // (src may be dst: no restrict)
+        double* out = a.dst + jj * ld;
+        if (a.mode != MBPLS_SCALE_FIT && a.count) {
+          double c1[1] = {0.0};
+          for (int64_t i = tid; i < n; i += T) {
+            const double x = col[i];
+            c1[0] += (x == x && !excluded(i)) ? 1.0 : 0.0;
           }
+          block_sum8<1>(c1, red, buf);
+          if (tid == 0) a.count[jj] = c1[0];
+        }
+        double mean = 0.0, scale = 1.0;
+        if (a.mode == MBPLS_SCALE_FIT) {
+          // sklearn StandardScaler on data with NaN (_incremental_mean_and_var with per-column counts)
+          double sc[2] = {0.0, 0.0};
+          for (int64_t i = tid; i < n; i += T) {
+            const double x = col[i];
+            const bool use = x == x && !excluded(i);
+            sc[0] += use ? x : 0.0;
+            sc[1] += use ? 1.0 : 0.0;
+          }
+          block_sum8<2>(sc, red, buf);
+          const double cntp = sc[1];
+          mean = sc[0] / cntp;
+          double cq[2] = {0.0, 0.0};
+          for (int64_t i = tid; i < n; i += T) {
+            const double x = col[i];
+            const double dlt = (x == x && !excluded(i)) ? x - mean : 0.0;
+            cq[0] += dlt;
+            cq[1] = fma(dlt, dlt, cq[1]);
+          }
+          block_sum8<2>(cq, red, buf);
+          const double var = (cq[1] - cq[0] * cq[0] / cntp) / cntp;
+          const double eps = 2.220446049250313e-16;
+          const double nme = cntp * mean * eps;
+          const double bound = cntp * eps * var + nme * nme;
+          scale = (var <= bound) ? 1.0 : sqrt(var);
+          if (tid == 0) {
+            a.mean[jj] = mean;
+            a.scale[jj] = scale;
+            if (a.count) a.count[jj] = cntp;
+            if (a.var_out) a.var_out[jj] = (var <= bound) ? 0.0 : var;
+          }
+        } else if (a.mode == MBPLS_SCALE_APPLY) {
+          mean = a.mean[jj];
+          scale = a.scale[jj];
+        }
+        double r2[2] = {0.0, 0.0};
+        for (int64_t i = tid; i < ld; i += T) {
+          double z = 0.0;
+          if (i < n && !excluded(i)) {
+            z = col[i];
+            if (a.mode != MBPLS_SCALE_NONE) z = z - mean;          // NaN stays NaN
+          }
+          if (a.mode != MBPLS_SCALE_NONE) z = z / scale;
+          out[i] = z;
+          const bool pr = z == z;
+          ssq_x = fma(pr ? z : 0.0, pr ? z : 0.0, ssq_x);          // nansum(X^2), mbpls.py:826
           if constexpr (SWEEP) {
-            acc[i] = fma(gj, pr ? x : 0.0, acc[i]);
-            dac[i] += pr ? g2 : 0.0;
+            if (i < n) {
+              const double vk = a.v[i];
+              r2[0] = fma(pr ? z : 0.0, vk, r2[0]);
+              r2[1] = fma(pr ? vk : 0.0, vk, r2[1]);
+            }
+          }
+        }
+        if constexpr (SWEEP) {
+          block_sum8<2>(r2, red, buf);
+          gj[c] = (r2[1] != 0.0) ? r2[0] / r2[1] : 0.0;
+        }
+      }
+    } else {
+      // one visit of the group for all its dot products: <x,ts>_present, <ts,ts>_present and, for the sweep,
+      // <x,u>, <u,u>, <ts,u> (DEFL + SWEEP: five per column; DEFL: the first two; SWEEP: <x,u>, <u,u>)
+      constexpr int NS = DEFL ? (SWEEP ? 5 : 2) : 2;
+      const double* base = a.src + jg * ld;
+      double r[NL_CB][NS];
+#pragma unroll
+      for (int c = 0; c < NL_CB; ++c)
+#pragma unroll
+        for (int q = 0; q < NS; ++q) r[c][q] = 0.0;
+      for (int64_t i = tid; i < n; i += T) {
+        double tk = 0.0, vk = 0.0;
+        if constexpr (DEFL) tk = a.ts[i];
+        if constexpr (SWEEP) vk = a.v[i];
+#pragma unroll
+        for (int c = 0; c < NL_CB; ++c) {
+          if (c < cnt) {
+            const double x = base[(int64_t)c * ld + i];
+            const bool pr = x == x;
+            const double xz = pr ? x : 0.0;
+            if constexpr (DEFL) {
+              const double tz = pr ? tk : 0.0;
+              r[c][0] = fma(xz, tk, r[c][0]);
+              r[c][1] = fma(tz, tk, r[c][1]);
+              if constexpr (SWEEP) {
+                const double vz = pr ? vk : 0.0;
+                r[c][2] = fma(xz, vk, r[c][2]);
+                r[c][3] = fma(vz, vk, r[c][3]);
+                r[c][4] = fma(tz, vk, r[c][4]);
+              }
+            } else {
+              r[c][0] = fma(xz, vk, r[c][0]);
+              r[c][1] = fma(pr ? vk : 0.0, vk, r[c][1]);
+            }
           }
         }
       }
-    } else if constexpr (SWEEP) {
-      double r2[2] = {0.0, 0.0};
-      for (int64_t i = tid; i < n; i += T) {
-        const double x = col[i], vk = a.v[i];
-        const bool pr = x == x;
-        r2[0] = fma(pr ? x : 0.0, vk, r2[0]);
-        r2[1] = fma(pr ? vk : 0.0, vk, r2[1]);
+#pragma unroll
+      for (int c = 0; c < NL_CB; ++c) {
+        if (c < cnt) {
+          block_sum8<NS>(r[c], red, buf);
+          if constexpr (DEFL) {
+            pj[c] = (r[c][1] != 0.0) ? r[c][0] / r[c][1] : 0.0;
+            ssq_p = fma(pj[c], pj[c], ssq_p);
+            if (tid == 0 && a.pvec) a.pvec[jg + c] = pj[c];
+            if constexpr (SWEEP) {
+              if (a.deflate) gj[c] = (r[c][3] != 0.0) ? fma(-pj[c], r[c][4], r[c][2]) / r[c][3] : 0.0;
+              else gj[c] = (r[c][3] != 0.0) ? r[c][2] / r[c][3] : 0.0;
+            }
+          } else {
+            gj[c] = (r[c][1] != 0.0) ? r[c][0] / r[c][1] : 0.0;
+          }
+        }
       }
-      block_sum8<2>(r2, red, buf);
-      gj = (r2[1] != 0.0) ? r2[0] / r2[1] : 0.0;
-      const double g2 = gj * gj;
+    }
+
+    // second visit of the group: rewrite X where it is deflated, add the group's columns to A / D (column by column,
+    // the order of the sums without groups)
+    const bool defl = DEFL && a.deflate;
+    if (SWEEP || defl) {
+      double* cols = (STD || DEFL) ? a.dst + jg * ld : nullptr;       // (STD: this thread's own stores above)
+      const double* rcols = (STD || DEFL) ? cols : a.src + jg * ld;
       for (int64_t i = tid; i < n; i += T) {
-        const double x = col[i];
-        const bool pr = x == x;
-        acc[i] = fma(gj, pr ? x : 0.0, acc[i]);
-        dac[i] += pr ? g2 : 0.0;
+        double a_ = 0.0, d_ = 0.0, tk = 0.0;
+        if constexpr (SWEEP) {
+          a_ = acc[i];
+          d_ = dac[i];
+        }
+        if (defl) tk = a.ts[i];
+#pragma unroll
+        for (int c = 0; c < NL_CB; ++c) {
+          if (c < cnt) {
+            double x = rcols[(int64_t)c * ld + i];
+            const bool pr = x == x;
+            if (defl) {
+              x = fma(-pj[c], tk, x);                               // NaN stays NaN (:969)
+              cols[(int64_t)c * ld + i] = x;
+            }
+            if constexpr (SWEEP) {
+              a_ = fma(gj[c], pr ? x : 0.0, a_);
+              d_ += pr ? gj[c] * gj[c] : 0.0;
+            }
+          }
+        }
+        if constexpr (SWEEP) {
+          acc[i] = a_;
+          dac[i] = d_;
+        }
       }
     }
     if constexpr (SWEEP) {
-      ssq_g = fma(gj, gj, ssq_g);
-      if (tid == 0 && a.g) a.g[jj] = gj;
+#pragma unroll
+      for (int c = 0; c < NL_CB; ++c) {
+        if (c < cnt) {
+          ssq_g = fma(gj[c], gj[c], ssq_g);
+          if (tid == 0 && a.g) a.g[jg + c] = gj[c];
+        }
+      }
     }
   }
 
