@@ -307,6 +307,9 @@ constexpr int NL_CB = 4;
 
 template <bool STD, bool DEFL, bool SWEEP>
 __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
+  // (the loadings-only pass has no A / D to update and reads ts twice per column either way: groups only cost it
+  // 4.3 -> 3.2 TB/s, measured)
+  constexpr int CB = (DEFL && !SWEEP) ? 1 : NL_CB;
   __shared__ double red[2 * 128];
   int buf = 0;
   const int tid = threadIdx.x, T = blockDim.x;
@@ -322,11 +325,11 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
   auto excluded = [&](int64_t i) -> bool { return rowmask && rowmask[i] == 0.0; };
   double ssq_g = 0.0, ssq_p = 0.0, ssq_x = 0.0;
 
-  for (int64_t jg = j0; jg < j1; jg += NL_CB) {
-    const int cnt = (int)((j1 - jg) < NL_CB ? (j1 - jg) : NL_CB);   // workgroup-uniform
-    double gj[NL_CB], pj[NL_CB];
+  for (int64_t jg = j0; jg < j1; jg += CB) {
+    const int cnt = (int)((j1 - jg) < CB ? (j1 - jg) : CB);   // workgroup-uniform
+    double gj[CB], pj[CB];
 #pragma unroll
-    for (int c = 0; c < NL_CB; ++c) gj[c] = pj[c] = 0.0;
+    for (int c = 0; c < CB; ++c) gj[c] = pj[c] = 0.0;
 
     if constexpr (STD) {
       // statistics and the stored standardised column, column by column (every step depends on the one before)
@@ -408,9 +411,9 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
       // <x,u>, <u,u>, <ts,u> (DEFL + SWEEP: five per column; DEFL: the first two; SWEEP: <x,u>, <u,u>)
       constexpr int NS = DEFL ? (SWEEP ? 5 : 2) : 2;
       const double* base = a.src + jg * ld;
-      double r[NL_CB][NS];
+      double r[CB][NS];
 #pragma unroll
-      for (int c = 0; c < NL_CB; ++c)
+      for (int c = 0; c < CB; ++c)
 #pragma unroll
         for (int q = 0; q < NS; ++q) r[c][q] = 0.0;
       for (int64_t i = tid; i < n; i += T) {
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
         if constexpr (DEFL) tk = a.ts[i];
         if constexpr (SWEEP) vk = a.v[i];
 #pragma unroll
-        for (int c = 0; c < NL_CB; ++c) {
+        for (int c = 0; c < CB; ++c) {
           if (c < cnt) {
             const double x = base[(int64_t)c * ld + i];
             const bool pr = x == x;
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
         }
       }
 #pragma unroll
-      for (int c = 0; c < NL_CB; ++c) {
+      for (int c = 0; c < CB; ++c) {
         if (c < cnt) {
           block_sum8<NS>(r[c], red, buf);
           if constexpr (DEFL) {
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
         }
         if (defl) tk = a.ts[i];
 #pragma unroll
-        for (int c = 0; c < NL_CB; ++c) {
+        for (int c = 0; c < CB; ++c) {
           if (c < cnt) {
             double x = rcols[(int64_t)c * ld + i];
             const bool pr = x == x;
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_colpass_nan_long(NanArgs a) {
     }
     if constexpr (SWEEP) {
 #pragma unroll
-      for (int c = 0; c < NL_CB; ++c) {
+      for (int c = 0; c < CB; ++c) {
         if (c < cnt) {
           ssq_g = fma(gj[c], gj[c], ssq_g);
           if (tid == 0 && a.g) a.g[jg + c] = gj[c];
