@@ -101,9 +101,22 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         # missing values: every third input form through the streamed-column kernel that n > 65536 takes (any n runs on it)
         stream_nan = sparse and form % 3 == 0
         nan_from = 0 if stream_nan else (65536 if (sparse and form % 3 == 1) else None)   # ... and the register shapes to 65536
+        # launch tunables of the C ABI (same numbers whatever they are): missing-value kernel choice; long columns on
+        # two-phase passes instead of clusters, on clusters of many small slabs, or (n <= 65536) in spilling registers
+        tun = {}
+        if nan_from is not None:
+            tun["nan_long_from"] = (nan_from, 8192)
+        if long and not sparse:
+            pick = (form + c) % 5
+            if pick == 1:
+                tun["cluster_passes"] = (0, 1)
+            elif pick == 2:
+                tun["cluster_slab_rows"] = (1024, 8192)
+            elif pick == 3 and n <= 65536:
+                tun["long_columns_from"] = (65536, 8192)
         tag = (f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} blocks={nb} sparse={sparse} two_pass={two_pass} "
                f"calc_all={calc_all} norm={norm} form={form}" + (f" route={route}" if route else "")
-               + (" streamed" if stream_nan else ""))
+               + (f" tunables={ {k: v[0] for k, v in tun.items()} }" if tun else ""))
         if only is not None and c != only:                 # (same random sequence, one case fitted: reproducing a failure)
             continue
         if os.environ.get("MBPLS_FUZZ_TRACE"):             # every case announced before its fit (which rank stopped where)
@@ -123,9 +136,10 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         try:
             os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0" if two_pass else "1"
             os.environ.update(route)
-            if nan_from is not None:
+            if tun:
                 import mbpls_amd
-                mbpls_amd.get_context().set_tunable("nan_long_from", nan_from)
+                for key, (val, _) in tun.items():
+                    mbpls_amd.get_context().set_tunable(key, val)
             params = dict(n_components=K, method=method, standardize=std, full_svd=True, sparse_data=sparse,
                           calc_all=(calc_all or sparse), nipals_convergence_norm=norm)
             if reuse and reused is not None:
@@ -223,8 +237,8 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
             if raise_errors:
                 raise
         finally:
-            if nan_from is not None:
-                mbpls_amd.get_context().set_tunable("nan_long_from", 8192)
+            for key, (_, default) in tun.items():
+                mbpls_amd.get_context().set_tunable(key, default)
             os.environ.pop("MBPLS_NIPALS_Q1_FIXED_POINT", None)
             for key in route:
                 os.environ.pop(key, None)
