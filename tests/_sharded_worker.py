@@ -30,6 +30,7 @@ def main():
     for fixture in ("matrix_pgtn", "matrix_ngtp"):
         worst = max(worst, one_fixture(util.load(fixture), rank, world, comm))
     worst = max(worst, random_sweep(rank, world, comm))
+    worst = max(worst, random_sweep_missing(rank, world, comm))
     # all ranks must have taken identical decisions (iteration counts) and agree on the global scores
     print(f"rank {rank}: sharded == unsharded reference, worst rel err {worst:.2e}", flush=True)
     dist.barrier()
@@ -73,6 +74,48 @@ def random_sweep(rank, world, comm, cases=30):
         else:
             res = solvers.fit_simpls(eng, Ys, K, std)
         what = f"rank{rank} case {c}: n={n} sizes={sizes} q={q} K={K} {method} std={std} ca={ca}"
+        worst = max(worst, util.compare(util.model_to_flat(res), fuzz._local_view(ref, ranges, offs), 1e-6, what=what))
+    os.environ.pop("MBPLS_NIPALS_Q1_FIXED_POINT", None)
+    assert worst < 1e-7, worst
+    return worst
+
+
+def random_sweep_missing(rank, world, comm, cases=14):
+    """the same with missing values (sparse_data=True): the masked sums A, D and the weight norms are what the ranks
+    exchange; one response on both routes, several responses"""
+    import warnings
+    from oracle import mbpls_oracle as orc
+    from oracle import mbpls_oracle_sparse as ors
+    from tests import fuzz
+    rng = np.random.RandomState(33)
+    worst = 0.0
+    for c in range(cases):
+        n = int(rng.randint(20, 100))
+        nb = int(rng.randint(1, 4))
+        sizes = [int(rng.randint(2 * world + 6, 2 * world + 60)) for _ in range(nb)]
+        p = sum(sizes)
+        q = int(rng.choice([1, 1, 2]))
+        K = int(min(rng.randint(1, 4), n // 4))
+        std = bool(rng.rand() < 0.7)
+        os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0" if rng.rand() < 0.5 else "1"
+        X, Y = orc.make_latent(n, p, q, r=4, seed=8000 + c)
+        X[rng.rand(n, p) < 0.04] = np.nan
+        offs = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+        full = [X[:, offs[b]:offs[b + 1]] for b in range(nb)]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = ors.fit(full, Y, n_components=K, standardize=std, max_iter=3000)
+        if max(ref.nipals_iterations_) >= 3000:
+            continue
+        ranges = shard_columns(sizes, rank, world)
+        local = [np.ascontiguousarray(b[:, lo:hi]) for b, (lo, hi) in zip(full, ranges)]
+        Ys = ColumnScaler().fit(Y).transform(Y) if std else Y
+        eng = NumpyEngine(comm).load_host_blocks(local)
+        eng.sparse = True
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = solvers.fit_nipals(eng, Ys, K, std, calc_all=True)
+        what = f"rank{rank} missing values, case {c}: n={n} sizes={sizes} q={q} K={K} std={std}"
         worst = max(worst, util.compare(util.model_to_flat(res), fuzz._local_view(ref, ranges, offs), 1e-6, what=what))
     os.environ.pop("MBPLS_NIPALS_Q1_FIXED_POINT", None)
     assert worst < 1e-7, worst

@@ -67,7 +67,49 @@ class NumpyEngine(EngineBase):
     def _ranges(self):
         return list(zip(self.block_offsets[:-1], self.block_offsets[1:]))
 
+    # ---- sparse_data=True: the masked sums of csrc/colpass_nan.hip (mbpls.py:846-854, :865-873, :919-926, :969)
+    def _nan_sweep_core(self, v, g_slot):
+        X = self.Xm
+        pres = ~np.isnan(X)
+        X0 = np.where(pres, X, 0.0)
+        v = np.asarray(v, dtype=np.float64).reshape(-1, 1)
+        num, den = X0.T.dot(v).ravel(), pres.T.astype(np.float64).dot(v ** 2).ravel()
+        g = np.where(den != 0.0, num / np.where(den == 0.0, 1.0, den), 0.0)
+        if g_slot is not None:
+            self.slots[g_slot[0]][:, g_slot[1]] = g
+        A = np.column_stack([X0[:, s:e].dot(g[s:e]) for s, e in self._ranges()])
+        D = np.column_stack([pres[:, s:e].astype(np.float64).dot(g[s:e] ** 2) for s, e in self._ranges()])
+        ssq = np.array([(g[s:e] ** 2).sum() for s, e in self._ranges()])
+        A, D, ssq = self.comm.allreduce_host(A), self.comm.allreduce_host(D), self.comm.allreduce_host(ssq)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = np.where(D > 0.0, A * (ssq[None, :] / D), 0.0)       # nu^2 A_i / D_i (engine._finish_pass)
+        return t, ssq
+
+    def _nan_prepare(self, standardize):
+        X = self.Xm
+        rm = getattr(self, "rowmask", None)
+        inc = np.ones(X.shape[0], dtype=bool) if rm is None else (np.asarray(rm).ravel() != 0)
+        X = np.where(inc[:, None], X, 0.0)                           # an excluded sample: present, and zero
+        use = ~np.isnan(X) & inc[:, None]
+        if standardize:
+            cnt = use.sum(axis=0).astype(np.float64)
+            mu = np.where(use, X, 0.0).sum(axis=0) / cnt
+            d = np.where(use, X - mu, 0.0)
+            var = ((d ** 2).sum(axis=0) - d.sum(axis=0) ** 2 / cnt) / cnt
+            sc = np.sqrt(var)
+            sc[var <= cnt * _EPS * var + (cnt * mu * _EPS) ** 2] = 1.0
+            X = np.where(inc[:, None], X - mu, 0.0) / sc             # NaN stays NaN
+
+            class _A:
+                def __init__(s, a): s.a = a
+                def get(s): return s.a
+            self.mean, self.scale, self.count = _A(mu), _A(sc), _A(cnt)
+        self.Xm = X
+        return self.comm.allreduce_host(np.array([np.nansum(X[:, s:e] ** 2) for s, e in self._ranges()]))
+
     def _sweep_core(self, v, alpha, g_slot):
+        if self.sparse:
+            return self._nan_sweep_core(v, g_slot)
         g = alpha * self.Xm.T.dot(v).ravel()
         if g_slot is not None:
             self.slots[g_slot[0]][:, g_slot[1]] = g
@@ -76,6 +118,12 @@ class NumpyEngine(EngineBase):
         return self.comm.allreduce_host(t), self.comm.allreduce_host(ssq)
 
     def prepare(self, standardize, v=None, alpha=1.0, g_slot=None, mean=None, scale=None):
+        if self.sparse:
+            ssq_x = self._nan_prepare(standardize)
+            if v is None:
+                return ssq_x, None, None
+            t, g = self._nan_sweep_core(v, g_slot)
+            return ssq_x, t, g
         X = self.Xm
         rm = getattr(self, "rowmask", None)
         inc = None if rm is None else (np.asarray(rm).ravel() != 0)
@@ -110,7 +158,13 @@ class NumpyEngine(EngineBase):
     def deflate_sweep(self, ts, inv_tt, deflate, p_slot, v=None, alpha=1.0, g_slot=None, overlap=None):
         if overlap is not None:
             overlap()
-        p = inv_tt * self.Xm.T.dot(ts).ravel()
+        if self.sparse:
+            pres = ~np.isnan(self.Xm)
+            tsc = np.asarray(ts, dtype=np.float64).reshape(-1, 1)
+            num, den = np.where(pres, self.Xm, 0.0).T.dot(tsc).ravel(), pres.T.astype(np.float64).dot(tsc ** 2).ravel()
+            p = np.where(den != 0.0, num / np.where(den == 0.0, 1.0, den), 0.0)
+        else:
+            p = inv_tt * self.Xm.T.dot(ts).ravel()
         if p_slot is not None:
             self.slots[p_slot[0]][:, p_slot[1]] = p
         ssq_p = self.comm.allreduce_host(np.array([(p[s:e] ** 2).sum() for s, e in self._ranges()]))

@@ -12,7 +12,7 @@ from tests.numpy_engine import NumpyEngine
 TOL = 1e-9
 
 
-def run_driver(X, Y, method, K, standardize=True, calc_all=True, norm=2, comm=None):
+def run_driver(X, Y, method, K, standardize=True, calc_all=True, norm=2, comm=None, sparse=False):
     blocks = X if isinstance(X, list) else [X]
     Y = np.asarray(Y, dtype=np.float64)
     if Y.ndim == 1:
@@ -20,6 +20,7 @@ def run_driver(X, Y, method, K, standardize=True, calc_all=True, norm=2, comm=No
     if standardize:
         Y = ColumnScaler().fit(Y).transform(Y)
     eng = NumpyEngine(comm).load_host_blocks(blocks)
+    eng.sparse = sparse
     if method == "NIPALS":
         return solvers.fit_nipals(eng, Y, K, standardize, 1e-14, norm, calc_all)
     if method == "UNIPALS":
@@ -250,3 +251,58 @@ def test_random_problems_through_the_host_drivers(monkeypatch):
         what = f"case {c}: n={n} p={p} q={q} K={K} {method} std={std} calc_all={calc_all} blocks={nb}"
         worst = max(worst, util.compare(util.model_to_flat(res), util.model_to_flat(ref), 1e-6, what=what))
     assert worst < 1e-7, worst
+
+
+def test_missing_values_reference_fixtures():
+    """sparse_data=True through the host drivers (masked passes of csrc/colpass_nan.hip restated in the numpy engine):
+    the attributes captured from the imported reference, missing values in X (sparse.npz) and in Y as well
+    (sparse_y.npz: start vector :832-836, masked Y loadings :891-897, masked Y scores :900-906)."""
+    worst = 0.0
+    for fixture, qs in (("sparse", (1, 2)), ("sparse_y", (2, 3))):
+        g = util.load(fixture)
+        for q in qs:
+            X, Y = g[f"in/q{q}/X"], g[f"in/q{q}/Y"]
+            for blocks in ("single", "multi"):
+                Xin = X if blocks == "single" else [np.ascontiguousarray(X[:, :40]), np.ascontiguousarray(X[:, 40:])]
+                for std in (True, False):
+                    pre = f"ref/q{q}/{blocks}/std{int(std)}"
+                    res = run_driver(Xin, Y, "NIPALS", 3, std, True, sparse=True)
+                    skip = FIT_ONLY_SKIP + ("y_mean", "y_scale")
+                    worst = max(worst, util.compare(util.model_to_flat(res), util.sub(g, pre), TOL, skip=skip,
+                                                    what=f"{fixture} {pre}"))
+    assert worst < 1e-9, worst
+
+
+def test_random_problems_with_missing_values_through_the_host_drivers(monkeypatch):
+    """... and a randomised sweep against the NaN-aware oracle: shapes, block splits, +- standardisation, one response
+    on both routes (at its fixed point after one pass, solvers.fit_nipals; or with the reference's confirming pass),
+    several responses"""
+    import warnings
+    from oracle import mbpls_oracle as orc
+    from oracle import mbpls_oracle_sparse as ors
+    rng = np.random.RandomState(21)
+    worst, done = 0.0, 0
+    for c in range(40):
+        n, p = int(rng.randint(20, 120)), int(rng.randint(20, 200))
+        q = int(rng.choice([1, 1, 2, 3]))
+        K = int(min(rng.randint(1, 4), n // 4))
+        std = bool(rng.rand() < 0.7)
+        nb = int(rng.randint(1, 4))
+        cuts = np.sort(rng.choice(np.arange(1, p), nb - 1, replace=False)) if nb > 1 else np.array([], dtype=int)
+        X, Y = orc.make_latent(n, p, q, r=4, seed=7000 + c)
+        X[rng.rand(n, p) < rng.choice([0.01, 0.05])] = np.nan
+        Xin = X if nb == 1 else [np.ascontiguousarray(b) for b in np.split(X, cuts, axis=1)]
+        one_pass = bool(rng.rand() < 0.5)
+        monkeypatch.setenv("MBPLS_NIPALS_Q1_FIXED_POINT", "1" if one_pass else "0")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = ors.fit(Xin, Y, n_components=K, standardize=std, max_iter=3000)
+            if max(ref.nipals_iterations_) >= 3000:
+                continue                                   # (the reference's own loop does not converge here)
+            res = run_driver(Xin, Y, "NIPALS", K, std, True, sparse=True)
+        what = f"case {c}: n={n} p={p} q={q} K={K} std={std} blocks={nb} one_pass={one_pass}"
+        worst = max(worst, util.compare(util.model_to_flat(res), util.model_to_flat(ref), 1e-6, what=what))
+        if q == 1:
+            assert list(res.nipals_iterations_) == ([1] * K if one_pass else list(ref.nipals_iterations_)), what
+        done += 1
+    assert done >= 30 and worst < 1e-7, (done, worst)
