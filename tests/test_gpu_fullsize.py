@@ -14,7 +14,8 @@ column passes that produced it:
 (d) lazy vs explicit deflation (MBPLS_DEFLATION) and implicit vs stored standardisation agree at full size.
 
 Sizes: C2 (n=4096, p=1e6, K=10 NIPALS), C3 (3 blocks 300k/300k/400k UNIPALS), C4 (n=8192, p=2e6, K=20 KERNEL,
-131 GB, fitted in place as the 288 GB of one MI355X cannot hold a second copy).  Tolerance 1e-6 relative
+131 GB, fitted in place as the 288 GB of one MI355X cannot hold a second copy), C5 (n=4096, 4 blocks, p=8e6, K=10
+NIPALS: 262 GB on one GPU, then the same matrix over two ranks sharing the GPU).  Tolerance 1e-6 relative
 (north_star), asserted at 1e-8.
 """
 import numpy as np
@@ -221,8 +222,9 @@ def test_c3_unipals_multiblock_full_size(gpu_required, monkeypatch):
 
 # ---------------------------------------------------------------------------------------------- C4
 def test_c4_kernel_full_size(gpu_required, monkeypatch):
-    """BASELINE config[3]: KERNEL method, n=8192, p=2,000,000, K=20 (131 GB; 1.34e14 flop Gram on the f64 matrix
-    cores).  First with the default copy=True: statistics-only preparation, every product standardises its operand in
+    """BASELINE config[3]: KERNEL method, n=8192, p=2,000,000, K=20 (131 GB).  First the default route of this shape
+    (maintained thin products: K + 1 read-only passes, no association matrix), then the 1.34e14-flop Gram on the f64
+    matrix cores (MBPLS_KERNEL_GRAM=1), the two compared at 1e-9.  The Gram route with the default copy=True: statistics-only preparation, every product standardises its operand in
     registers, the caller's matrix is untouched and no second 131 GB buffer exists.  Then with the stored path and
     copy=False (MBPLS_IMPLICIT_STD=0): X is standardised in place (the KERNEL branch never deflates X), so afterwards
     the resident matrix IS Z and the generic products can be applied to it directly."""
@@ -241,14 +243,29 @@ def test_c4_kernel_full_size(gpu_required, monkeypatch):
         from mbpls_amd.engine import HipEngine
         used, real = [], HipEngine.prepare_stats
         monkeypatch.setattr(HipEngine, "prepare_stats", lambda self, *a, **k: (used.append(True), real(self, *a, **k))[1])
+        # ---- the default route at this size: maintained thin products, one read-only pass per component, no Gram
+        # (n = 8192 >> 87 (K + 3): the cost model of solvers._kernel_on_products)
+        mp = MBPLS(n_components=K, method="KERNEL").fit(X, Y)
+        assert "maintained thin products" in mp.fit_plan_["solver"], mp.fit_plan_
+        assert "never written" in mp.fit_plan_["standardisation"], mp.fit_plan_
+        assert used == []
+        _, again = download_sample(X, ranges, width)
+        assert np.array_equal(again, raw)                                 # copy=True: the caller's matrix is intact
+        check_orthonormal(mp.Ts_)
+        check_generic_products(mp, X, Y, check_u=False)                   # transform / predict standardise on the fly
+        # ---- the association matrix on the f64 matrix cores (1.34e14 flop), forced
+        monkeypatch.setenv("MBPLS_KERNEL_GRAM", "1")
         monkeypatch.setenv("MBPLS_KERNEL_IMPLICIT", "1")  # (by itself only when a second 131 GB matrix does not fit)
         m0 = MBPLS(n_components=K, method="KERNEL").fit(X, Y)             # copy=True, nothing written, no working copy
         monkeypatch.delenv("MBPLS_KERNEL_IMPLICIT")
-        assert used == [True]
+        assert used == [True] and "association matrix" in m0.fit_plan_["solver"], m0.fit_plan_
         _, again = download_sample(X, ranges, width)
         assert np.array_equal(again, raw)
         check_orthonormal(m0.Ts_)
-        check_generic_products(m0, X, Y, check_u=False)                   # transform / predict standardise on the fly
+        check_generic_products(m0, X, Y, check_u=False)
+        w = util.compare(util.model_to_flat(mp), util.model_to_flat(m0), TOL, what="maintained products vs Gram")
+        assert w < 1e-9, w
+        del mp
         monkeypatch.setenv("MBPLS_IMPLICIT_STD", "0")
         mdl = MBPLS(n_components=K, method="KERNEL", copy=False).fit(X, Y)
         monkeypatch.delenv("MBPLS_IMPLICIT_STD")
@@ -301,6 +318,130 @@ def test_c4_kernel_full_size(gpu_required, monkeypatch):
     finally:
         X.close()
         ctx.trim_pool()
+
+
+# ---------------------------------------------------------------------------------------------- C5
+def _c5_one_gpu(ctx, n, sizes, K, out_dir):
+    """part (a): the whole multiblock problem on ONE GPU; leaves the fitted attributes in out_dir for part (b)"""
+    from mbpls_amd import MBPLS
+    offs = [0] + [int(v) for v in np.cumsum(sizes)]
+    p = offs[-1]
+    Tlat, Y = planted(n, 1, 32, 0)
+    X, _ = device_problem(ctx, n, p, offs)
+    try:
+        mdl = MBPLS(n_components=K, method="NIPALS").fit(X, Y)
+        assert mdl.nipals_iterations_ == [1] * K
+        # (a 262 GB matrix leaves no room for a working copy: this fit is only possible because nothing is stored)
+        assert "never written" in mdl.fit_plan_["standardisation"], mdl.fit_plan_
+        check_orthonormal(mdl.Ts_)
+        yhat = check_generic_products(mdl, X, Y)                          # Z R_ = Ts_, Z beta_ = Ts_ V_^T, block scores
+        assert 0.5 < 1.0 - np.sum((Y - yhat) ** 2) / np.sum((Y - Y.mean()) ** 2) < 1.0
+        # sampled columns: both ends, every block boundary, chunk boundaries, interior; the far end lies beyond
+        # 2^33 elements (n * p = 3.3e10 at the full size)
+        ranges, width = sample_ranges(X)
+        cols, data = download_sample(X, ranges, width)
+        assert cols.size >= 1500 and cols[-1] == p - 1
+        if p == 8_000_000:
+            assert (cols.astype(np.int64) * n > 2 ** 33).sum() > 500
+        Z = check_statistics(mdl, cols, data)
+        Wn, P = recurrence(Z, mdl.Ts_, mdl.U_)
+        Pfit, Wnfit, Wfit = np.vstack(mdl.P_), np.vstack(mdl.W_non_normal_), np.vstack(mdl.W_)
+        assert util.relerr(Pfit[cols], P) < TOL
+        assert util.relerr(Wnfit[cols], Wn) < TOL
+        # block weights: w_b = w~_b / ||w~_b|| per block (mbpls.py:860)
+        for b in range(len(sizes)):
+            nu = np.linalg.norm(mdl.W_non_normal_[b], axis=0)
+            assert util.relerr(mdl.W_[b], mdl.W_non_normal_[b] / nu) < 1e-12
+            sel = (cols >= offs[b]) & (cols < offs[b + 1])
+            assert sel.sum() >= 100
+        # block importances: columns of A_ sum to one (:889-890 super weights squared), A_corrected_ too (:950-964, equal
+        # block sizes: the correction is a renormalisation of the same numbers)
+        assert np.max(np.abs(mdl.A_.sum(axis=0) - 1.0)) < 1e-12
+        assert np.max(np.abs(mdl.A_corrected_.sum(axis=0) - 1.0)) < 1e-12
+        assert util.relerr(mdl.A_corrected_, mdl.A_) < 1e-12
+        # super level (:879-883) from the fitted block scores (which the generic products reproduced above):
+        # sw = T^T u / ||T^T u||, A_ = sw^2, ts = T sw / ||T sw||
+        for k in range(K):
+            Tk = np.column_stack([mdl.T_[b][:, k] for b in range(len(sizes))])
+            sw = Tk.T.dot(mdl.U_[:, k])
+            sw /= np.linalg.norm(sw)
+            assert util.relerr(sw ** 2, mdl.A_[:, k]) < TOL
+            ts = Tk.dot(sw)
+            assert util.relerr(ts / np.linalg.norm(ts), mdl.Ts_[:, k]) < TOL
+        # explained variance per block from the fitted loadings (analytic form of :933-947)
+        evb = np.array([(mdl.Ts_ ** 2).sum(axis=0) * (mdl.P_[b] ** 2).sum(axis=0) / (float(n) * sizes[b])
+                        for b in range(len(sizes))])        # (standardised block: ||Z_b||^2 = n p_b)
+        assert util.relerr(np.asarray(mdl.explained_var_xblocks_), evb) < TOL
+        assert util.relerr(np.asarray(mdl.explained_var_x_), evb.mean(axis=0)) < TOL     # (equal blocks)
+        # R_ = W (P^T W)^+ with W = the concatenated W_non_normal_, columns scaled to unit length (:985-988),
+        # recomputed on the host
+        Wc = Wnfit / np.linalg.norm(Wnfit, axis=0)
+        R = Wc.dot(np.linalg.pinv(Pfit.T.dot(Wc)))
+        assert util.relerr(mdl.R_, R) < TOL
+        assert util.relerr(mdl.beta_, R.dot(mdl.V_.T)) < TOL
+        del Wc, R, Wnfit, Wfit
+        cols2, data2 = download_sample(X, ranges[:3], width)
+        assert np.array_equal(data2, data[:, :cols2.size])                # copy=True: the caller's matrix is intact
+        import os
+        keep = {k: np.asarray(getattr(mdl, k)) for k in ("Ts_", "U_", "V_", "A_", "A_corrected_", "explained_var_x_",
+                                                         "explained_var_y_", "explained_var_xblocks_")}
+        keep.update({f"T_{b}": t for b, t in enumerate(mdl.T_)})
+        np.savez(os.path.join(out_dir, "problem.npz"), Tlat=Tlat, Y=Y, sizes=np.asarray(sizes), K=K, **keep)
+        for b in range(len(sizes)):
+            np.save(os.path.join(out_dir, f"P{b}.npy"), mdl.P_[b])
+            np.save(os.path.join(out_dir, f"W{b}.npy"), mdl.W_[b])
+        np.save(os.path.join(out_dir, "R.npy"), mdl.R_)
+        np.save(os.path.join(out_dir, "beta.npy"), mdl.beta_)
+    finally:
+        X.close()
+        ctx.trim_pool()
+
+
+def _c5_two_ranks(out_dir):
+    """part (b): tests/_c5_shard_worker.py on two ranks that share this GPU"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0", C5_DIR=str(out_dir))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "_c5_shard_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("== the one-GPU fit, replicated attributes bit-equal") == 2, r.stdout
+    print(r.stdout)
+
+
+def test_c5_multiblock_nipals_full_size(gpu_required, tmp_path):
+    """BASELINE config[4]: multiblock NIPALS, n=4096, FOUR equal blocks, p=8,000,000 in total, K=10, q=1.
+    (a) the whole problem (262 GB of X, 3.3e10 elements) on ONE GPU, through the property checks of the C2 test
+        (mbpls.py:809-993).  Lazy == explicit cannot be asserted at this size: an explicitly deflated working copy
+        would be a second 262 GB matrix; that identity is asserted at C2 / C3 size above.
+    (b) the same matrix split over TWO ranks sharing this GPU (each 4 x 1,000,000 columns, exchange over gloo): every
+        replicated attribute bit-equal across the ranks, and each rank's results equal to (a)'s.  Runs after (a)'s
+        matrix is released; when 2 x 131 GB + two contexts do not fit the device, (a) and (b) are repeated together at
+        4 x 1,500,000 columns (2 x 98 GB) and the test says so."""
+    import mbpls_amd
+    ctx = mbpls_amd.get_context()
+    ctx.trim_pool()
+    if ctx.info()["total_bytes"] < 270e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    n, K = 4096, 10
+    sizes = [2_000_000] * 4
+    d = tmp_path / "c5"
+    d.mkdir()
+    _c5_one_gpu(ctx, n, sizes, K, str(d))
+    free = ctx.info()["free_bytes"]
+    need = 8.0 * n * sum(sizes) + 2 * 4.0e9            # two shards + two contexts with their p x K slots
+    if free < need:
+        print(f"C5 (b): {free / 1e9:.1f} GB free < {need / 1e9:.1f} GB: two ranks at 4 x 1,500,000 columns instead")
+        sizes = [1_500_000] * 4
+        _c5_one_gpu(ctx, n, sizes, K, str(d))
+    _c5_two_ranks(d)
 
 
 # ------------------------------------------------------------------------------- several responses at C2 size
