@@ -176,6 +176,17 @@ def main():
             comm = mbpls_amd.TorchDistComm(device=f"cuda:{local_rank}")
             comm_info = {"backend": "torch.distributed/" + str(dist.get_backend()), "world_size": comm.world_size}
         mbpls_amd.set_comm(comm)
+        # which physical device every rank drives (hipDeviceGetPCIBusId) beside what RCCL reports for it: the record of
+        # an N-GPU run shows N DISTINCT devices -- and the run refuses to time anything otherwise
+        mine = {"rank": rank, "local_rank": local_rank, "pci_bus_id": ctx.pci_bus_id(),
+                "rccl_device": (comm_info or {}).get("rccl_device"), "rccl_user_rank": (comm_info or {}).get("rccl_user_rank")}
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
+        print(f"[bench] rank {rank}: device {mine['pci_bus_id']} (local rank {local_rank}, rccl_device {mine['rccl_device']})",
+              file=sys.stderr, flush=True)
+        comm_info = dict(comm_info, devices=devices)
+        if not shared_gpu and len({d["pci_bus_id"] for d in devices}) != world:
+            sys.exit(f"[bench] {world} ranks on {len({d['pci_bus_id'] for d in devices})} distinct device(s): {devices}")
     ctx = mbpls_amd.get_context()
 
     def barrier_sync():
@@ -279,10 +290,7 @@ def main():
     ref_units = sum(2 * i + 3 for i in ref_iters) + 1 + 3
     # X traffic the HIP path really generates per fit = sum of the kernels' algorithmic bytes (HIP-event
     # profile of the timed region); with lazy deflation every pass is read-only
-    fused_units = round(sum(v["bytes_per_launch"] * v["launches"] for v in prof.values()) / a.steps / (8.0 * n * p), 2)
-    unit_bytes = 8.0 * n * p * world
-    per_step = dt / a.steps
-    achieved = fused_units * unit_bytes / per_step / 1e9
+    fused_units, unit_bytes, per_step, achieved = job_throughput(prof, n, p, world, a.steps, dt)
 
     if rank == 0:
         dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"]) if prof else (None, None)
@@ -291,13 +299,7 @@ def main():
             k = dom[1]
             traffic, src = pmc_traffic(dom[0], n, p, live_pmc)
             ceiling = X.probe_read_bandwidth(3)      # best pure-read kernel on this box, same buffer (after the timed region)
-            roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(k["GBps"], 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(k["GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "measured_read_ceiling_GBps": round(ceiling, 1),
-                    "frac_of_measured_read_ceiling": round(k["GBps"] / ceiling, 4) if ceiling > 0 else None,
-                    "traffic_source": src, "bytes_per_launch": k["bytes_per_launch"], "avg_ms": round(k["avg_ms"], 4),
-                    "launches": k["launches"],
-                    "timing": "HIP events on the launch stream around every launch of the timed region"}
+            roof = roofline_of(dom[0], k, n, p, world, traffic, src, ceiling)
         out = {
             "metric": "mbpls_fit_achieved_hbm_GBps", "value": round(achieved, 1), "unit": "GB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(per_step * 1e3, 3),
@@ -558,6 +560,36 @@ def launch_ranks(world, argv, timeout=DEFAULT_LAUNCH_TIMEOUT_S, python=None):
         return 0
     bad = rcs[failed] if failed is not None else next((rc for rc in rcs if rc), 1)
     return bad if 0 < bad < 256 else 1
+
+
+def job_throughput(prof, n, p, world, steps, dt):
+    """``value`` of the line: the X bytes the kernels of one fit really move -- the sum of their algorithmic bytes from
+    the HIP-event profile of the timed region, in units of one traversal of THIS RANK's shard (8 n p bytes, p = columns
+    per GPU) -- times the number of ranks (weak scaling: every rank moves the same share; the timed region is bracketed by
+    barriers and ``dt`` is the maximum over ranks), divided by the time per fit.
+    Returns (units per fit, bytes of one traversal of the WHOLE matrix = 8 n (world p), seconds per fit, GB/s)."""
+    fused_units = round(sum(v["bytes_per_launch"] * v["launches"] for v in prof.values()) / steps / (8.0 * n * p), 2)
+    unit_bytes = 8.0 * n * p * world
+    per_step = dt / steps
+    return fused_units, unit_bytes, per_step, fused_units * unit_bytes / per_step / 1e9
+
+
+def roofline_of(name, k, n, p, world, traffic, src, ceiling):
+    """``roofline`` of the line for the dominant kernel ``k`` (profile entry of rank 0).  achieved / peak / frac are PER
+    GPU: one launch on one GPU moves ``bytes_per_launch`` = its algorithmic bytes over this rank's shard against that
+    GPU's 8 TB/s.  ``whole_job`` states the same launch over all ranks (world x the bytes, world x the peak; the
+    fraction is the same number), so that an N > 1 line can be read either way without guessing which p was meant."""
+    roof = {"bound": "hbm", "kernel": name, "achieved": round(k["GBps"], 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(k["GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "measured_read_ceiling_GBps": round(ceiling, 1),
+            "frac_of_measured_read_ceiling": round(k["GBps"] / ceiling, 4) if ceiling > 0 else None,
+            "traffic_source": src, "bytes_per_launch": k["bytes_per_launch"], "avg_ms": round(k["avg_ms"], 4),
+            "launches": k["launches"],
+            "timing": "HIP events on the launch stream around every launch of the timed region",
+            "scope": "per GPU (rank 0's launches over its own shard of p columns)",
+            "whole_job": {"n_gpus": world, "columns": p * world, "bytes_per_launch": k["bytes_per_launch"] * world,
+                          "achieved": round(k["GBps"] * world, 1), "peak": HBM_PEAK_GBPS * world}}
+    return roof
 
 
 def sharded_self_check(ctx, mbpls_amd, dT, Y, r, rank, world):

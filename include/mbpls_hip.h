@@ -33,14 +33,16 @@
 extern "C" {
 #endif
 
-#define MBPLS_HIP_ABI_VERSION 8   /* 8: mbpls_hip_fence (overlapped copies ordered behind what was queued before the pass they run beside); 7: mbpls_hip_cluster_columns (cluster passes launched cooperatively, capacity from the occupancy query, time-outs flagged in host-mapped memory); 6: mbpls_hip_mat_transpose; mbpls_nipals_step.C / ldc / host_seq, mbpls_hip_queue_r_update, mbpls_hip_flush_r_update (R_ / beta_ column by column during the fit), mbpls_hip_copier_submit / _wait (native copier thread; replaces mbpls_hip_event_record / _memcpy_d2h_after / _event_destroy); 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
+#define MBPLS_HIP_ABI_VERSION 9   /* 9: MBPLS_ERR_COMM, mbpls_hip_comm_set_timeout / _inject_fault (bounded waits under a communicator); 8: mbpls_hip_fence (overlapped copies ordered behind what was queued before the pass they run beside); 7: mbpls_hip_cluster_columns (cluster passes launched cooperatively, capacity from the occupancy query, time-outs flagged in host-mapped memory); 6: mbpls_hip_mat_transpose; mbpls_nipals_step.C / ldc / host_seq, mbpls_hip_queue_r_update, mbpls_hip_flush_r_update (R_ / beta_ column by column during the fit), mbpls_hip_copier_submit / _wait (native copier thread; replaces mbpls_hip_event_record / _memcpy_d2h_after / _event_destroy); 5: mbpls_hip_cluster_status (one-read passes for long columns), mbpls_hip_warmup, mbpls_hip_right_multiply_folds, mbpls_hip_cv_qloops; 2: device-resident step, RCCL communicator, scaled Gram / xt_v, masked NaN standardise; 3: mbpls_hip_loadings_sweep_raw; 4: mbpls_hip_comm_query, mbpls_hip_set_true_space_outputs, mbpls_hip_cross_product_dev, mbpls_hip_host_alloc, nu2_host, mbpls_hip_cv_weights / _cv_fold_stats / _xt_v_centred, mbpls_hip_finalise_small, mbpls_hip_right_multiply_dev, mbpls_hip_nipals_subspace_qloop */
 
 enum {
   MBPLS_OK = 0,
   MBPLS_ERR_ARG = -1,          /* bad argument / shape */
   MBPLS_ERR_HIP = -2,          /* a HIP runtime call failed */
   MBPLS_ERR_OOM = -3,          /* device allocation failed */
-  MBPLS_ERR_UNSUPPORTED = -4   /* shape outside what the kernels cover (e.g. n > 16384 fused) */
+  MBPLS_ERR_UNSUPPORTED = -4,  /* shape outside what the kernels cover (e.g. n > 16384 fused) */
+  MBPLS_ERR_COMM = -5          /* a peer of the RCCL communicator has gone (asynchronous error or missed deadline); the
+                                  communicator was aborted, the context's communicator is dead */
 };
 
 enum { MBPLS_ROW_MAJOR = 0,    /* host array is n x p C-order (numpy default), ld = row stride  */
@@ -72,6 +74,9 @@ int mbpls_hip_warmup(mbpls_ctx* ctx);
 int mbpls_hip_sync(mbpls_ctx* ctx);
 int mbpls_hip_device_info(mbpls_ctx* ctx, char* name, size_t name_len, int* compute_units,
                           size_t* total_bytes, size_t* free_bytes);
+/* PCI bus id of the context's device ("0000:c1:00.0"): a multi-GPU launcher proves with it that its N ranks sit on N
+ * distinct devices (bench.py prints it per rank beside what RCCL reports).                                            */
+int mbpls_hip_device_pci_bus_id(mbpls_ctx* ctx, char* out, size_t out_len);
 /* Tunables (all optional): "chunks_per_cu", "rows_per_thread", "prefetch", "xw_chunks_per_cu",
  * "xw_mfma_from" (x_w with more right-hand sides than this uses the matrix-core kernel, default 8),
  * "gram_slice_features" (features per split-K slice of the Gram kernel for long feature ranges, 0 = off),
@@ -96,6 +101,11 @@ int mbpls_hip_set_tunable(mbpls_ctx* ctx, const char* key, int value);
  * the fit again -- these passes never write X).  Without a time-out the call is a stream synchronisation and a read
  * of one host-mapped word. */
 int mbpls_hip_cluster_status(mbpls_ctx* ctx, int* timeouts);
+/* Column shards: this context's count of timed-out hand-offs so far as a double into *d_word (a word of the exchange
+ * buffer), on the stream -- queued in front of the all-reduce of that buffer, so that every rank reads the sum over the
+ * ranks behind the pass and all of them take the same decision (run the fit again on the two-phase passes, or not).
+ * Does not reset the count.                                                                                          */
+int mbpls_hip_cluster_status_into(mbpls_ctx* ctx, double* d_word);
 /* *yes = 1 when the never-writes-X passes of a matrix with n samples run on clusters of workgroups on this context:
  * "cluster_passes" is on, n is above "long_columns_from", and the device holds a whole pass at once (asked from the
  * runtime's occupancy query; the launches are cooperative, and a refused one switches the context to the two-phase
@@ -528,6 +538,18 @@ int mbpls_hip_comm_info(mbpls_ctx* ctx, int* world_size, int* rank, int* rccl_ve
 int mbpls_hip_comm_query(mbpls_ctx* ctx, int* rccl_ranks, int* rccl_user_rank, int* rccl_device);
 int mbpls_hip_comm_destroy(mbpls_ctx* ctx);
 int mbpls_hip_allreduce(mbpls_ctx* ctx, double* d_buf, size_t count);   /* sum, in place, asynchronous */
+/* A dead peer must not hang the caller inside a device queue.  With a communicator of more than one rank EVERY wait of
+ * this library for the compute stream (mbpls_hip_sync, the blocking copies, ...) polls the stream instead of blocking,
+ * queries ncclCommGetAsyncError about once a millisecond and enforces a deadline (default 600 s; the ranks of a fit may
+ * be skewed by a host-side upload, never by minutes of it).  On an asynchronous error or a missed deadline the
+ * communicator is aborted (ncclCommAbort: the stuck collective leaves the stream), the call returns MBPLS_ERR_COMM with a
+ * message naming the rank, and every later collective on the context fails at once -- the caller exits non-zero (it
+ * never re-executes itself) and the launcher tears the job down.                                                      */
+int mbpls_hip_comm_set_timeout(mbpls_ctx* ctx, int timeout_ms);
+/* Test hook (tests/test_gpu_rccl.py, world size 1): the next mbpls_hip_allreduce becomes a kernel that waits as a
+ * collective waits for a peer that has died; mode 1: the asynchronous error shows after `polls` queries, mode 2: never
+ * (the deadline has to catch it); mode 0: off.                                                                        */
+int mbpls_hip_comm_inject_fault(mbpls_ctx* ctx, int mode, int polls);
 
 /* ---- cross-validation folds batched per read of X (mbpls_amd/cv_batch.py; the reference's callers run
  * sklearn.model_selection.cross_val_predict(MBPLS(k), X, y, cv=n): n complete refits) ---------------------------------

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmbpls_hip.so")
 ROW_MAJOR, COL_MAJOR = 0, 1
 COMM_ID_BYTES = 128
 SCALE_FIT, SCALE_APPLY, SCALE_NONE = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _vp, _i64, _dbl, _int, _sz = C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
@@ -56,9 +56,11 @@ SIGNATURES = {
     "mbpls_hip_warmup": (_int, [_vp]),
     "mbpls_hip_sync": (_int, [_vp]),
     "mbpls_hip_device_info": (_int, [_vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_sz), C.POINTER(_sz)]),
+    "mbpls_hip_device_pci_bus_id": (_int, [_vp, C.c_char_p, _sz]),
     "mbpls_hip_set_tunable": (_int, [_vp, C.c_char_p, _int]),
     "mbpls_hip_fence": (_int, [_vp]),
     "mbpls_hip_cluster_status": (_int, [_vp, C.POINTER(_int)]),
+    "mbpls_hip_cluster_status_into": (_int, [_vp, _vp]),
     "mbpls_hip_cluster_columns": (_int, [_vp, _i64, C.POINTER(_int)]),
     "mbpls_hip_malloc": (_int, [_vp, _sz, _pp]),
     "mbpls_hip_free": (_int, [_vp, _vp]),
@@ -113,6 +115,8 @@ SIGNATURES = {
     "mbpls_hip_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
     "mbpls_hip_comm_query": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
     "mbpls_hip_comm_destroy": (_int, [_vp]),
+    "mbpls_hip_comm_set_timeout": (_int, [_vp, _int]),
+    "mbpls_hip_comm_inject_fault": (_int, [_vp, _int, _int]),
     "mbpls_hip_allreduce": (_int, [_vp, _vp, _sz]),
     "mbpls_hip_nipals_step": (_int, [_vp, C.POINTER(NipalsStep)]),
     "mbpls_hip_set_pass_params": (_int, [_vp, _vp]),
@@ -173,10 +177,20 @@ def load():
     return lib
 
 
+class CommLost(HipError):
+    """A peer of the RCCL communicator has gone (asynchronous error or missed deadline, csrc/rccl_comm.hip): the
+    communicator was aborted.  Nothing can be retried in this process group -- the caller lets the exception end the
+    process (non-zero exit) and the launcher tears the job down."""
+
+
+ERR_COMM = -5
+
+
 def check(rc):
     if rc != 0:
         msg = load().mbpls_hip_last_error()
-        raise HipError(f"mbpls_hip error {rc}: {msg.decode() if msg else '?'}")
+        text = f"mbpls_hip error {rc}: {msg.decode() if msg else '?'}"
+        raise (CommLost if rc == ERR_COMM else HipError)(text)
 
 
 def device_count():
@@ -327,6 +341,11 @@ class Context:
         cus, tot, free = _int(0), _sz(0), _sz(0)
         check(self.lib.mbpls_hip_device_info(self.handle, name, 256, C.byref(cus), C.byref(tot), C.byref(free)))
         return dict(name=name.value.decode(), compute_units=cus.value, total_bytes=tot.value, free_bytes=free.value)
+
+    def pci_bus_id(self):
+        buf = C.create_string_buffer(64)
+        check(self.lib.mbpls_hip_device_pci_bus_id(self.handle, buf, 64))
+        return buf.value.decode()
 
     long_columns_from = 8192     # mirrors the C default; n above it -> long-column passes
     cluster_passes = 0 if os.environ.get("MBPLS_HIP_CLUSTER_PASSES", "1") == "0" else 1   # ... on clusters of workgroups

@@ -164,6 +164,19 @@ class RcclComm:
             self.ctx.lib.mbpls_hip_comm_destroy(self.ctx.handle)
         self.ctx = None
 
+    def set_timeout(self, seconds):
+        """Deadline of one wait for the compute stream while collectives may be in flight (default 600 s).  A peer that
+        dies makes RCCL report an asynchronous error within milliseconds; the deadline is for the peer that is alive
+        but never arrives.  Either way the wait raises ``CommLost`` instead of hanging (csrc/rccl_comm.hip)."""
+        from . import _capi
+        _capi.check(self.ctx.lib.mbpls_hip_comm_set_timeout(self.ctx.handle, max(1, int(round(1e3 * seconds)))))
+
+    def inject_fault(self, mode, polls=0):
+        """test hook: the next all-reduce behaves like a collective whose peer has died (mode 1: RCCL's asynchronous
+        error turns up after ``polls`` queries; mode 2: it never does -- the deadline has to catch it; 0: off)"""
+        from . import _capi
+        _capi.check(self.ctx.lib.mbpls_hip_comm_inject_fault(self.ctx.handle, int(mode), int(polls)))
+
     def exchange_buffer(self, ctx, count):
         from ._capi import DeviceArray
         return DeviceArray(ctx, (int(count),), zero=True)

@@ -768,7 +768,7 @@ static int cl_chunks(mbpls_ctx* ctx, mbpls_mat* m, int G) {
   MB_HIP(hipMemcpyAsync(t->d_c0, t->h_c0.data(), sizeof(int64_t) * t->nchunks, hipMemcpyHostToDevice, ctx->stream));
   MB_HIP(hipMemcpyAsync(t->d_c1, t->h_c1.data(), sizeof(int64_t) * t->nchunks, hipMemcpyHostToDevice, ctx->stream));
   MB_HIP(hipMemcpyAsync(t->d_blk_start, t->h_blk_start.data(), sizeof(int) * (B + 1), hipMemcpyHostToDevice, ctx->stream));
-  MB_HIP(hipStreamSynchronize(ctx->stream));
+  MB_SYNC_STREAM(ctx);
   m->cluster_G = G;
   return MBPLS_OK;
 }
@@ -777,7 +777,7 @@ static int cl_exchange_buffer(mbpls_ctx* ctx, size_t doubles, double** xch, unsi
   const size_t need = 256 + sizeof(double) * doubles;
   if (ctx->cl_ws_bytes < need) {
     if (ctx->cl_ws) {
-      MB_HIP(hipStreamSynchronize(ctx->stream));
+      MB_SYNC_STREAM(ctx);
       (void)hipFree(ctx->cl_ws);
       ctx->cl_ws = nullptr;
       ctx->cl_ws_bytes = 0;
@@ -947,14 +947,31 @@ extern "C" int mbpls_hip_cluster_status(mbpls_ctx* ctx, int* timeouts) {
   MB_ARG(ctx && timeouts, "NULL argument");
   *timeouts = 0;
   if (!ctx->cl_ws || !ctx->cl_flag_h) return MBPLS_OK;
-  MB_HIP(hipStreamSynchronize(ctx->stream));
+  MB_SYNC_STREAM(ctx);
   if (__atomic_load_n(ctx->cl_flag_h, __ATOMIC_ACQUIRE) == 0u) return MBPLS_OK;   // the everyday answer: no copy at all
   unsigned v = 0;
   MB_HIP(hipMemcpyAsync(&v, ctx->cl_ws, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-  MB_HIP(hipStreamSynchronize(ctx->stream));
+  MB_SYNC_STREAM(ctx);
   MB_HIP(hipMemsetAsync(ctx->cl_ws, 0, sizeof(unsigned), ctx->stream));
   __atomic_store_n(ctx->cl_flag_h, 0u, __ATOMIC_RELEASE);
   *timeouts = (int)std::max(1u, v);
+  return MBPLS_OK;
+}
+
+namespace mbpls {
+__global__ void k_cl_status_into(const unsigned* __restrict__ err, double* __restrict__ out) {
+  *out = err ? (double)*err : 0.0;
+}
+}  // namespace mbpls
+
+// Column shards: whether a fit is run again after a hand-off time-out must be decided by ALL ranks alike (the re-run
+// issues collectives).  The count of this context's time-outs so far goes into a word of the exchange buffer on the
+// stream, in front of the all-reduce of that buffer: every rank then reads the SUM over the ranks behind the pass
+// and raises -- or does not -- together.  Does not reset the count (mbpls_hip_cluster_status does, on each rank).
+extern "C" int mbpls_hip_cluster_status_into(mbpls_ctx* ctx, double* d_word) {
+  MB_ARG(ctx && d_word, "NULL argument");
+  hipLaunchKernelGGL(k_cl_status_into, dim3(1), dim3(1), 0, ctx->stream, (const unsigned*)ctx->cl_ws, d_word);
+  MB_HIP(hipGetLastError());
   return MBPLS_OK;
 }
 

@@ -17,6 +17,10 @@
 namespace mbpls {
 
 void set_error(const char* fmt, ...);
+}  // namespace mbpls
+struct mbpls_ctx;
+namespace mbpls {
+int comm_guard_wait(mbpls_ctx* ctx);
 
 #define MB_HIP(call)                                                                      \
   do {                                                                                    \
@@ -52,6 +56,17 @@ void set_error(const char* fmt, ...);
   do {                        \
     int rc_ = (expr);         \
     if (rc_ != MBPLS_OK) return rc_; \
+  } while (0)
+
+// Every wait of the host for the compute stream goes through this: with a communicator of more than one rank on the
+// context a collective queued on the stream only completes when every peer takes part -- a dead peer would leave
+// hipStreamSynchronize waiting for ever.  comm_guard_wait (rccl_comm.hip) polls the stream instead, asks the
+// communicator for its asynchronous error state and enforces a deadline; on either it aborts the communicator (which
+// releases the stream) and the call returns MBPLS_ERR_COMM.  Without such a communicator it returns at once.
+#define MB_SYNC_STREAM(ctx_)                               \
+  do {                                                     \
+    if ((ctx_)->rccl) MB_TRY(::mbpls::comm_guard_wait(ctx_)); \
+    MB_HIP(hipStreamSynchronize((ctx_)->stream));          \
   } while (0)
 
 // One chunk table: contiguous column ranges that never straddle a block.

@@ -20,7 +20,7 @@ void set_error(const char* fmt, ...) {
 int ensure_ws(mbpls_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return MBPLS_OK;
   if (ctx->ws) {
-    MB_HIP(hipStreamSynchronize(ctx->stream));
+    MB_SYNC_STREAM(ctx);
     MB_HIP(hipFree(ctx->ws));
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
@@ -34,7 +34,7 @@ int ensure_ws(mbpls_ctx* ctx, size_t bytes) {
 int ensure_stage(mbpls_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->stage_bytes) return MBPLS_OK;
   if (ctx->stage) {
-    MB_HIP(hipStreamSynchronize(ctx->stream));
+    MB_SYNC_STREAM(ctx);
     MB_HIP(hipFree(ctx->stage));
     ctx->stage = nullptr;
     ctx->stage_bytes = 0;
@@ -70,7 +70,7 @@ ProfScope::~ProfScope() {
 
 static int drain_profile(mbpls_ctx* ctx) {
   if (ctx->pending.empty()) return MBPLS_OK;
-  MB_HIP(hipStreamSynchronize(ctx->stream));
+  MB_SYNC_STREAM(ctx);
   for (auto& pd : ctx->pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, pd.a, pd.b) == hipSuccess) {
@@ -123,7 +123,7 @@ int build_chunks(mbpls_ctx* ctx, const std::vector<int64_t>& offs, int target, C
   MB_HIP(hipMemcpyAsync(t->d_c0, t->h_c0.data(), sizeof(int64_t) * t->nchunks, hipMemcpyHostToDevice, ctx->stream));
   MB_HIP(hipMemcpyAsync(t->d_c1, t->h_c1.data(), sizeof(int64_t) * t->nchunks, hipMemcpyHostToDevice, ctx->stream));
   MB_HIP(hipMemcpyAsync(t->d_blk_start, t->h_blk_start.data(), sizeof(int) * (B + 1), hipMemcpyHostToDevice, ctx->stream));
-  MB_HIP(hipStreamSynchronize(ctx->stream));  // host vectors may be reused by the caller
+  MB_SYNC_STREAM(ctx);  // host vectors may be reused by the caller
   return MBPLS_OK;
 }
 
@@ -239,9 +239,14 @@ int mbpls_hip_create(int device, void* stream, mbpls_ctx** out) {
   if (const char* e = getenv("MBPLS_HIP_XW_CHUNKS_PER_CU")) ctx->xw_chunks_per_cu = std::max(1, atoi(e));
   if (const char* e = getenv("MBPLS_HIP_CLUSTER_PASSES")) ctx->cluster_passes = atoi(e) ? 1 : 0;
   hipError_t e0 = hipEventCreate(&ctx->ev0), e1 = hipEventCreate(&ctx->ev1);
-  if (e0 != hipSuccess || e1 != hipSuccess) {
+  // the copy stream and the fence event are used from helper threads (mbpls_hip_memcpy_d2h_overlap) beside
+  // mbpls_hip_fence on the fitting thread: created here, never lazily
+  hipError_t e2 = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+  hipError_t e3 = hipEventCreateWithFlags(&ctx->fence_ev, hipEventDisableTiming);
+  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     delete ctx;
-    set_error("hipEventCreate failed");
+    set_error("hipEventCreate / hipStreamCreate failed");
     return MBPLS_ERR_HIP;
   }
   *out = ctx;
@@ -287,7 +292,7 @@ int mbpls_hip_destroy(mbpls_ctx* ctx) {
 
 int mbpls_hip_sync(mbpls_ctx* ctx) {
   MB_ARG(ctx, "ctx is NULL");
-  MB_HIP(hipStreamSynchronize(ctx->stream));
+  MB_SYNC_STREAM(ctx);
   return MBPLS_OK;
 }
 
@@ -307,6 +312,12 @@ int mbpls_hip_device_info(mbpls_ctx* ctx, char* name, size_t name_len, int* comp
   MB_HIP(hipMemGetInfo(&f, &t));
   if (total_bytes) *total_bytes = t;
   if (free_bytes) *free_bytes = f;
+  return MBPLS_OK;
+}
+
+int mbpls_hip_device_pci_bus_id(mbpls_ctx* ctx, char* out, size_t out_len) {
+  MB_ARG(ctx && out && out_len >= 16, "need a buffer of at least 16 bytes");
+  MB_HIP(hipDeviceGetPCIBusId(out, (int)out_len, ctx->device));
   return MBPLS_OK;
 }
 
@@ -375,7 +386,7 @@ int mbpls_hip_malloc(mbpls_ctx* ctx, size_t bytes, void** d_ptr) {
 int mbpls_hip_free(mbpls_ctx* ctx, void* d_ptr) {
   MB_ARG(ctx, "ctx is NULL");
   if (!d_ptr) return MBPLS_OK;
-  MB_HIP(hipStreamSynchronize(ctx->stream));
+  MB_SYNC_STREAM(ctx);
   MB_HIP(hipFree(d_ptr));
   return MBPLS_OK;
 }
@@ -397,7 +408,7 @@ int mbpls_hip_host_alloc(mbpls_ctx* ctx, size_t bytes, void** h_ptr, void** d_pt
 int mbpls_hip_host_free(mbpls_ctx* ctx, void* h_ptr) {
   MB_ARG(ctx, "ctx is NULL");
   if (!h_ptr) return MBPLS_OK;
-  MB_HIP(hipStreamSynchronize(ctx->stream));
+  MB_SYNC_STREAM(ctx);
   {
     std::lock_guard<std::mutex> lock(ctx->pin_mutex);
     auto it = std::find(ctx->host_blocks.begin(), ctx->host_blocks.end(), h_ptr);
@@ -464,18 +475,17 @@ int mbpls_hip_memcpy_d2h(mbpls_ctx* ctx, void* h_dst, const void* d_src, size_t 
     std::lock_guard<std::mutex> lock(ctx->pin_mutex);
     if (!ctx->pin_d2h) MB_HIP(hipHostMalloc(&ctx->pin_d2h, BOUNCE, hipHostMallocDefault));
     MB_HIP(hipMemcpyAsync(ctx->pin_d2h, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    MB_HIP(hipStreamSynchronize(ctx->stream));
+    MB_SYNC_STREAM(ctx);
     memcpy(h_dst, ctx->pin_d2h, bytes);
     return MBPLS_OK;
   }
   MB_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  MB_HIP(hipStreamSynchronize(ctx->stream));
+  MB_SYNC_STREAM(ctx);
   return MBPLS_OK;
 }
 
 int mbpls_hip_fence(mbpls_ctx* ctx) {
   MB_ARG(ctx, "ctx is NULL");
-  if (!ctx->fence_ev) MB_HIP(hipEventCreateWithFlags(&ctx->fence_ev, hipEventDisableTiming));
   MB_HIP(hipEventRecord(ctx->fence_ev, ctx->stream));
   return MBPLS_OK;
 }
@@ -484,7 +494,6 @@ int mbpls_hip_memcpy_d2h_overlap(mbpls_ctx* ctx, void* h_dst, const void* d_src,
   MB_ARG(ctx && (bytes == 0 || (h_dst && d_src)), "NULL argument");
   if (bytes == 0) return MBPLS_OK;
   MB_HIP(hipSetDevice(ctx->device));   // may be called from a helper thread (the current device is per thread)
-  if (!ctx->copy_stream) MB_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   // not ordered behind the pass that is running -- but behind the last fence: the small kernels that produced a finished
   // column (a scaling, an upload) were queued BEFORE the pass and must be through before the copy reads their output
   if (ctx->fence_ev) MB_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->fence_ev, 0));
@@ -640,7 +649,7 @@ int mbpls_hip_mat_upload(mbpls_mat* m, const double* h_src, int64_t ld_host, int
                          n, col0, ncols);
       MB_HIP(hipGetLastError());
     }
-    MB_HIP(hipStreamSynchronize(ctx->stream));
+    MB_SYNC_STREAM(ctx);
     return MBPLS_OK;
   }
   MB_ARG(layout == MBPLS_ROW_MAJOR, "unknown layout %d", layout);
@@ -658,7 +667,7 @@ int mbpls_hip_mat_upload(mbpls_mat* m, const double* h_src, int64_t ld_host, int
     hipLaunchKernelGGL(k_transpose_in, grid, dim3(256), 0, ctx->stream, (const double*)ctx->stage, n, cw,
                        m->data + (col0 + c) * ld, ld);
     MB_HIP(hipGetLastError());
-    MB_HIP(hipStreamSynchronize(ctx->stream));  // staging is reused
+    MB_SYNC_STREAM(ctx);  // staging is reused
   }
   return MBPLS_OK;
 }
@@ -674,7 +683,7 @@ int mbpls_hip_mat_download(const mbpls_mat* m, double* h_dst, int64_t ld_host, i
     MB_ARG(ld_host >= n, "ld_host < n");
     MB_HIP(hipMemcpy2DAsync(h_dst, ld_host * sizeof(double), m->data + col0 * ld, ld * sizeof(double),
                             n * sizeof(double), ncols, hipMemcpyDeviceToHost, ctx->stream));
-    MB_HIP(hipStreamSynchronize(ctx->stream));
+    MB_SYNC_STREAM(ctx);
     return MBPLS_OK;
   }
   MB_ARG(layout == MBPLS_ROW_MAJOR, "unknown layout %d", layout);
@@ -691,7 +700,7 @@ int mbpls_hip_mat_download(const mbpls_mat* m, double* h_dst, int64_t ld_host, i
     MB_HIP(hipGetLastError());
     MB_HIP(hipMemcpy2DAsync(h_dst + c, ld_host * sizeof(double), ctx->stage, cw * sizeof(double),
                             cw * sizeof(double), n, hipMemcpyDeviceToHost, ctx->stream));
-    MB_HIP(hipStreamSynchronize(ctx->stream));
+    MB_SYNC_STREAM(ctx);
   }
   return MBPLS_OK;
 }

@@ -295,7 +295,7 @@ extern "C" int mbpls_hip_gram_scaled(const mbpls_mat* m, const double* d_mean, c
   }
   MB_HIP(hipMemcpyAsync(d_ti, ti.data(), sizeof(int) * ntiles, hipMemcpyHostToDevice, ctx->stream));
   MB_HIP(hipMemcpyAsync(d_tj, tj.data(), sizeof(int) * ntiles, hipMemcpyHostToDevice, ctx->stream));
-  MB_HIP(hipStreamSynchronize(ctx->stream));  // ti/tj are stack-owned
+  MB_SYNC_STREAM(ctx);  // ti/tj are stack-owned
   GramArgs a{};
   a.X = m->data; a.ld = m->ld; a.n = n; a.p = p; a.ms = ms;
   a.tile_i = d_ti; a.tile_j = d_tj; a.ntiles = ntiles; a.nslices = nslices; a.slice_len = slice_len;

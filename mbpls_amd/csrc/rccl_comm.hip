@@ -6,6 +6,9 @@
 // store).  librccl is loaded at run time (dlopen) -- a single-GPU user never touches it.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
+
+#include <chrono>
 
 #include "common.h"
 
@@ -22,12 +25,30 @@ struct RcclApi {
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 };
 
 struct RcclState {
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
+  bool dead = false;            // aborted after an asynchronous error or a missed deadline: every later call fails
+  int timeout_ms = 600000;      // deadline of one wait for the stream (mbpls_hip_comm_set_timeout)
+  // fault injection (mbpls_hip_comm_inject_fault; tests at world size 1): the next all-reduce is a kernel that waits for
+  // a word in host-mapped memory as a collective waits for a peer that has died; the communicator's asynchronous error
+  // turns up after `fault_polls` queries (mode 1) or never (mode 2: the deadline has to catch it); the abort releases it
+  int fault_mode = 0, fault_polls = 0, fault_seen = 0;
+  unsigned* hang_h = nullptr;   // host-mapped release word of the stand-in kernel
+  unsigned* hang_d = nullptr;
+  bool hanging = false;
 };
+
+// stand-in for a collective whose peer never arrives: spins until the host stores to the release word -- or, should
+// nobody abort it, for at most ~8 s of the 100 MHz real-time counter (it must never outlive a test)
+__global__ void k_wait_for_peer(volatile unsigned* release) {
+  const unsigned long long t0 = wall_clock64();
+  while (*release == 0u && wall_clock64() - t0 < 800000000ull) __builtin_amdgcn_s_sleep(64);
+}
 
 static RcclApi g_rccl;
 
@@ -61,6 +82,8 @@ static int load_rccl() {
   MB_SYM(CommCount, "ncclCommCount");
   MB_SYM(CommUserRank, "ncclCommUserRank");
   MB_SYM(CommCuDevice, "ncclCommCuDevice");
+  MB_SYM(CommGetAsyncError, "ncclCommGetAsyncError");
+  MB_SYM(CommAbort, "ncclCommAbort");
 #undef MB_SYM
   g_rccl.handle = h;
   return MBPLS_OK;
@@ -74,6 +97,60 @@ static int load_rccl() {
       return MBPLS_ERR_HIP;                                                                             \
     }                                                                                                   \
   } while (0)
+
+// Abort the communicator (ncclCommAbort frees the stream of a collective that can no longer complete) and mark it dead.
+static void comm_abort(mbpls_ctx* ctx, RcclState* st) {
+  if (st->dead) return;
+  st->dead = true;
+  if (st->hanging && st->hang_h) {          // (the injected stand-in: what the real abort does to a stuck kernel)
+    __atomic_store_n(st->hang_h, 1u, __ATOMIC_SEQ_CST);
+    st->hanging = false;
+  }
+  if (st->comm) (void)g_rccl.CommAbort(st->comm);
+  st->comm = nullptr;
+  (void)hipStreamSynchronize(ctx->stream);   // released now; what was queued behind the collective runs on garbage and ends
+}
+
+int comm_guard_wait(mbpls_ctx* ctx) {
+  RcclState* st = (RcclState*)ctx->rccl;
+  // (aborted earlier: the stream was drained then and no collective can be queued any more -- plain waits are safe, and
+  // the clean-up of the failed fit must be able to free its buffers)
+  if (!st || st->dead) return MBPLS_OK;
+  if (st->world <= 1 && !st->fault_mode) return MBPLS_OK;   // nothing on the stream depends on another process
+  using clock = std::chrono::steady_clock;
+  const auto t0 = clock::now();
+  auto next_check = t0 + std::chrono::microseconds(500);
+  for (unsigned spins = 0;; ++spins) {
+    const hipError_t q = hipStreamQuery(ctx->stream);
+    if (q == hipSuccess) return MBPLS_OK;
+    if (q != hipErrorNotReady) {
+      set_error("hipStreamQuery failed while waiting for the compute stream: %s", hipGetErrorString(q));
+      return MBPLS_ERR_HIP;
+    }
+    if (spins > 2000) usleep(50);             // ~ the first 200 us busy (a pass of a sharded fit is shorter than that)
+    const auto now = clock::now();
+    if (now < next_check) continue;
+    next_check = now + std::chrono::milliseconds(1);
+    ncclResult_t async = ncclSuccess;
+    if (st->fault_mode == 1 && st->hanging && ++st->fault_seen > st->fault_polls) async = ncclSystemError;
+    else if (st->comm && !st->fault_mode) (void)g_rccl.CommGetAsyncError(st->comm, &async);
+    const double waited_ms = std::chrono::duration<double, std::milli>(now - t0).count();
+    if (async != ncclSuccess && async != ncclInProgress) {
+      comm_abort(ctx, st);
+      set_error("RCCL reports an asynchronous error on rank %d of %d (%s) after %.0f ms of waiting for the compute "
+                "stream: a peer has gone; the communicator was aborted", st->rank, st->world,
+                g_rccl.GetErrorString(async), waited_ms);
+      return MBPLS_ERR_COMM;
+    }
+    if (waited_ms > (double)st->timeout_ms) {
+      comm_abort(ctx, st);
+      set_error("rank %d of %d waited %.0f ms for the compute stream (deadline %d ms, mbpls_hip_comm_set_timeout) with a "
+                "collective in flight: a peer is not taking part; the communicator was aborted", st->rank, st->world,
+                waited_ms, st->timeout_ms);
+      return MBPLS_ERR_COMM;
+    }
+  }
+}
 
 }  // namespace mbpls
 
@@ -149,9 +226,11 @@ int mbpls_hip_comm_destroy(mbpls_ctx* ctx) {
   MB_ARG(ctx, "ctx is NULL");
   RcclState* st = (RcclState*)ctx->rccl;
   if (!st) return MBPLS_OK;
+  if (st->hanging && st->hang_h) __atomic_store_n(st->hang_h, 1u, __ATOMIC_SEQ_CST);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->rccl = nullptr;
-  ncclResult_t r = g_rccl.CommDestroy(st->comm);
+  ncclResult_t r = st->comm ? g_rccl.CommDestroy(st->comm) : ncclSuccess;     // (aborted: nothing left to destroy)
+  if (st->hang_h) (void)hipHostFree(st->hang_h);
   delete st;
   if (r != ncclSuccess) {
     set_error("ncclCommDestroy failed: %s", g_rccl.GetErrorString(r));
@@ -165,9 +244,45 @@ int mbpls_hip_allreduce(mbpls_ctx* ctx, double* d_buf, size_t count) {
   RcclState* st = (RcclState*)ctx->rccl;
   MB_ARG(st != nullptr, "no communicator on this context (mbpls_hip_comm_init_rank)");
   if (count == 0) return MBPLS_OK;
+  if (st->dead) {
+    set_error("the communicator of this context was aborted earlier (dead peer or missed deadline); create a new context");
+    return MBPLS_ERR_COMM;
+  }
+  if (st->fault_mode && !st->hanging) {
+    // injected fault: this collective never completes by itself
+    if (!st->hang_h) {
+      MB_HIP(hipHostMalloc((void**)&st->hang_h, 64, hipHostMallocMapped | hipHostMallocCoherent));
+      MB_HIP(hipHostGetDevicePointer((void**)&st->hang_d, st->hang_h, 0));
+    }
+    __atomic_store_n(st->hang_h, 0u, __ATOMIC_SEQ_CST);
+    st->hanging = true;
+    st->fault_seen = 0;
+    hipLaunchKernelGGL(k_wait_for_peer, dim3(1), dim3(64), 0, ctx->stream, (volatile unsigned*)st->hang_d);
+    MB_HIP(hipGetLastError());
+    return MBPLS_OK;
+  }
   // in place, float64 sum, ordered on the context's stream: every rank receives bit-identical sums, so every rank
   // takes the same loop-exit decision (the step kernel's stop test, mbpls.py:841)
   MB_NCCL(g_rccl.AllReduce(d_buf, d_buf, count, ncclFloat64, ncclSum, st->comm, ctx->stream));
+  return MBPLS_OK;
+}
+
+int mbpls_hip_comm_set_timeout(mbpls_ctx* ctx, int timeout_ms) {
+  MB_ARG(ctx, "ctx is NULL");
+  RcclState* st = (RcclState*)ctx->rccl;
+  MB_ARG(st != nullptr, "no communicator on this context (mbpls_hip_comm_init_rank)");
+  MB_ARG(timeout_ms >= 1, "timeout must be >= 1 ms");
+  st->timeout_ms = timeout_ms;
+  return MBPLS_OK;
+}
+
+int mbpls_hip_comm_inject_fault(mbpls_ctx* ctx, int mode, int polls) {
+  MB_ARG(ctx, "ctx is NULL");
+  RcclState* st = (RcclState*)ctx->rccl;
+  MB_ARG(st != nullptr, "no communicator on this context (mbpls_hip_comm_init_rank)");
+  MB_ARG(mode >= 0 && mode <= 2 && polls >= 0, "mode 0 (off), 1 (asynchronous error after `polls` queries) or 2 (silent peer)");
+  st->fault_mode = mode;
+  st->fault_polls = polls;
   return MBPLS_OK;
 }
 

@@ -173,8 +173,7 @@ int mbpls_hip_cross_product(mbpls_ctx* ctx, int64_t p, const double* d_A, int64_
       hipLaunchKernelGGL(k_cross_final, dim3(cc), dim3(64), 0, ctx->stream, (const double*)partial, nwg, cc, d_out);
       MB_HIP(hipGetLastError());
       double* dst = (c1 <= CMAX && c2 <= CMAX) ? h_out : tile.data();
-      MB_HIP(hipMemcpyAsync(dst, d_out, sizeof(double) * cc, hipMemcpyDeviceToHost, ctx->stream));
-      MB_HIP(hipStreamSynchronize(ctx->stream));
+      MB_TRY(mbpls_hip_memcpy_d2h(ctx, dst, d_out, sizeof(double) * cc));     // (pinned bounce buffer; waits for the stream)
       if (dst != h_out)
         for (int i = 0; i < t1; ++i)
           for (int j = 0; j < t2; ++j) h_out[(size_t)(i0 + i) * c2 + (j0 + j)] = tile[(size_t)i * t2 + j];
@@ -208,12 +207,14 @@ int mbpls_hip_right_multiply(mbpls_ctx* ctx, int64_t p, const double* d_A, int64
         hM = tile.data();
       }
       double* dM = (double*)ctx->small_m + (size_t)(ctx->small_m_slot++ % RING) * CMAX * CMAX;
-      MB_HIP(hipMemcpyAsync(dM, hM, sizeof(double) * t1 * t2, hipMemcpyHostToDevice, ctx->stream));
+      // (through the context's ring of pinned slots: a pageable hipMemcpyAsync of a few hundred bytes is staged by the
+      // runtime and now and then EXECUTES tens of milliseconds late on an idle GPU -- ctx.hip, mbpls_hip_memcpy_h2d)
+      MB_TRY(mbpls_hip_memcpy_h2d(ctx, dM, hM, sizeof(double) * t1 * t2));
       hipLaunchKernelGGL(k_right_multiply, dim3(nwg), dim3(256), 0, ctx->stream, p, d_A + (int64_t)i0 * lda, lda, t1,
                          (const double*)dM, t2, d_C + (int64_t)j0 * ldc, ldc, i0 > 0 ? 1 : 0);
       MB_HIP(hipGetLastError());
     }
-  if (tiled) MB_HIP(hipStreamSynchronize(ctx->stream));
+  if (tiled) MB_SYNC_STREAM(ctx);
   return MBPLS_OK;
 }
 

@@ -89,7 +89,10 @@ class HipEngine(EngineBase):
         B, n = self.nblocks, self.n
         # exchange buffer: [t: n*B][ssq_g, ssq_p, ssq_x: 3*B][lazy-deflation sums: B*KD][sparse only, d: n*B]
         self._d_off = n * B + 3 * B + B * self.KD
-        self._xchg = self.comm.exchange_buffer(self.ctx, self._d_off + (n * B if self.sparse else 0))
+        # (the last word: under column shards the count of timed-out cluster hand-offs of every rank rides on the
+        # all-reduce of the buffer -- _stage_cluster_flag / check_cluster_passes)
+        self._flag_off = self._d_off + (n * B if self.sparse else 0)
+        self._xchg = self.comm.exchange_buffer(self.ctx, self._flag_off + 1)
         self._vec_n = [self.ctx.empty(n), self.ctx.empty(n)]
         self._coef = [self.ctx.empty(self.KD), self.ctx.empty(self.KD)]   # <ts_i, v>, <ts_i, ts>
         self._lazy_ts = []          # score vectors of the components deflated so far (lazy mode)
@@ -325,10 +328,11 @@ class HipEngine(EngineBase):
         self._last_d = None
         if self.comm.is_distributed:
             with self._timed("allreduce"):
+                staged = self._stage_cluster_flag()
                 self.comm.allreduce_device(self._xchg)
         with self._timed("wait_kernel+d2h_small"):
             h = self._xchg.get()
-        self.check_cluster_passes()
+        self.check_cluster_passes(shared=h[self._flag_off] if (self.comm.is_distributed and staged) else None)
         t = h[: n * B].reshape(B, n).T.copy() if want_t else None   # n x B
         o = n * B
         if self.sparse and want_t:
@@ -450,16 +454,37 @@ class HipEngine(EngineBase):
                 and bool(getattr(self.ctx, "cluster_passes", 0)) and hasattr(self.ctx, "cluster_status")
                 and self.ctx.cluster_columns(self.n))
 
-    def check_cluster_passes(self):
+    def _cluster_guarded(self):
+        return bool(getattr(self.ctx, "cluster_passes", 0) and not self.sparse
+                    and self.n > getattr(self.ctx, "long_columns_from", 8192) and hasattr(self.ctx, "cluster_status"))
+
+    def _stage_cluster_flag(self):
+        """column shards, in front of the all-reduce of the exchange buffer: this rank's count of timed-out hand-offs
+        into the buffer's last word (on the stream), so that every rank reads the sum behind the pass"""
+        if not self._cluster_guarded():
+            return False
+        _capi.check(self.ctx.lib.mbpls_hip_cluster_status_into(self.ctx.handle, self._xptr(self._flag_off)))
+        return True
+
+    def check_cluster_passes(self, shared=None):
         """Long columns: the workgroups of a cluster hand partial sums to each other inside a launch, every wait
         bounded; a wait that gave up leaves garbage behind -- never hand that to the caller, and never iterate on it:
         called behind every pass of a host-driven loop (the exchange buffer has just been read, so the check is a
-        read of one host-mapped word), when a device-resident queue returns, and at the end of the fit."""
-        if getattr(self.ctx, "cluster_passes", 0) and not self.sparse and self.n > getattr(self.ctx, "long_columns_from", 8192):
-            bad = self.ctx.cluster_status()
-            if bad:
-                raise _capi.ClusterTimeout(f"{bad} hand-off(s) between the workgroups of a column cluster timed out "
-                                           "(csrc/colpass_cluster.hip)")
+        read of one host-mapped word), when a device-resident queue returns, and at the end of the fit.
+        Column shards: the decision is COLLECTIVE -- a rank that raised alone would run its fit again (load,
+        collectives of the first pass) while its peers, several collectives ahead on its garbage sums, wait for other
+        ones.  Behind a pass the ranks' counts arrive summed in the exchange buffer (``shared``); elsewhere (end of a
+        queue, end of the fit) they are summed here.  Every rank then raises, or none does."""
+        if not self._cluster_guarded():
+            return
+        bad = self.ctx.cluster_status()                       # (also clears this rank's flag)
+        if self.comm.is_distributed:
+            if shared is None:
+                shared = self.comm.allreduce_host(np.array([float(bad)]))[0]
+            bad = max(bad, int(shared)) if np.isfinite(shared) else max(bad, 1)
+        if bad:
+            raise _capi.ClusterTimeout(f"{bad} hand-off(s) between the workgroups of a column cluster timed out "
+                                       "(csrc/colpass_cluster.hip)")
 
     def scaled_products(self):
         """after an implicit first pass (raw matrix, statistics known): the many-right-hand-side products X^T V / X W
@@ -1384,6 +1409,15 @@ class _ResidentQueue:
             self.state.free()
             return False
         par = self._view(h, "par")
+        if eng.comm.is_distributed and eng._cluster_guarded():
+            # column shards: a hand-off that gave up on ANY rank sends every rank up to MBPLS._fit (which runs the fit
+            # again on the two-phase passes) -- one small all-reduce per queue, long columns only
+            try:
+                eng.check_cluster_passes()
+            except _capi.ClusterTimeout:
+                wait_copies()
+                self.state.free()
+                raise
         if par[7] != 0.0:
             # a grid barrier of the multi-workgroup step gave up (cooperative launch: should never happen) -- nothing
             # was written to X, so the caller simply runs the fit with its host-driven loop.  (A hand-off of a cluster

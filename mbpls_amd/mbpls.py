@@ -93,6 +93,24 @@ def _is_block_list(X):
     return isinstance(X, list) and not isinstance(X[0], list)       # mbpls.py:301
 
 
+CLUSTER_REARM_FITS = 8
+
+
+def _rearm_cluster_passes(ctx):
+    """A hand-off time-out switches the (process-wide) context to the two-phase long-column passes; that is recorded on
+    the context with its reason and undone after CLUSTER_REARM_FITS further fits."""
+    down = getattr(ctx, "_cluster_downgrade", None)
+    if down is None:
+        return
+    if getattr(ctx, "cluster_passes", 0):          # (someone switched them on again by hand)
+        del ctx._cluster_downgrade
+        return
+    down["fits_left"] -= 1
+    if down["fits_left"] <= 0:
+        ctx.set_tunable("cluster_passes", 1)
+        del ctx._cluster_downgrade
+
+
 class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
     """(Multiblock) PLS regression, MI355X-native.  See the module docstring."""
 
@@ -185,6 +203,7 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         eng = self._engine()
         eng.sparse = sparse
         eng.rowmask = None if row_mask is None else row_mask.astype(np.float64)
+        _rearm_cluster_passes(eng.ctx)
         # A refit replaces the previous p x K attributes; releasing ~0.4 GB of numpy memory (page-table
         # teardown) costs ~15 ms of host time at p = 1e6 -- more than any single pass hides.  The engine drops
         # one stale object per column pass, right after the launch, while the host would only wait anyway.
@@ -234,6 +253,9 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
                     warnings.warn(f"{err}; this context now uses the two-phase long-column passes (two reads of X per "
                                   "pass) and the fit is run again", RuntimeWarning)
                     eng.ctx.set_tunable("cluster_passes", 0)
+                    # (not for good: the context takes the cluster passes again after CLUSTER_REARM_FITS fits -- a
+                    # co-tenant that stays costs one failed attempt in so many fits, one that has left costs nothing)
+                    eng.ctx._cluster_downgrade = dict(reason=str(err), fits_left=CLUSTER_REARM_FITS)
                     pending = eng.deferred_host_work
                     eng.close()
                     eng = self._engine()
@@ -264,6 +286,13 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
                    "few samples (column groups per wave)" if n_ <= 1024 else "register-resident columns")
             self.fit_plan_ = dict(method=self.method, **eng.plan, kernels=fam, centred_in_registers=bool(getattr(eng, "_cen", False)),
                                   column_shards=int(getattr(eng.comm, "world_size", 1)), sparse=bool(sparse))
+            if n_ > long_from and not sparse and not getattr(eng, "cluster_passes", False):
+                # why a long-column fit is on the two-read passes (half the throughput of the cluster passes)
+                down = getattr(eng.ctx, "_cluster_downgrade", None)
+                self.fit_plan_["cluster_passes_off"] = (
+                    f"a hand-off timed out earlier ({down['reason']}); re-armed in {down['fits_left']} fit(s)" if down
+                    else "switched off (tunable / MBPLS_HIP_CLUSTER_PASSES=0)" if not getattr(eng.ctx, "cluster_passes", 0)
+                    else "the device cannot hold a cluster of this shape at once (occupancy query / refused cooperative launch)")
         return self
 
     def check_sparsity_level(self, data):

@@ -1120,15 +1120,17 @@ def _kernel_extras(eng, res, Y, P, V, Ts, varxb, wslot, wnorm2):
                explained_var_y_=list(tt * (V ** 2).sum(axis=0) / vary))
 
 
-def _kernel_extras_device(eng, res, Y, V, Ts, varxb, wslot, wnorm2):
+def _kernel_extras_device(eng, res, Y, V, Ts, varxb, wslot, wnorm2, XW=None):
     """_kernel_extras with the p x K operands left on the device: slot "P" holds the loadings, slot "Wblk"
-    the per-block normalised weights (both produced by _finalise_device); K x K cross products per block."""
+    the per-block normalised weights (both produced by _finalise_device); K x K cross products per block.
+    ``XW``: the per-block products X_b wslot_b (n x K each) when the caller has them already."""
     B = eng.nblocks
     K = Ts.shape[1]
     sizes = _global_sizes(eng)
     offs = eng.block_offsets
     A = wnorm2 / wnorm2.sum(axis=0)                         # ||W_concat_[J_b, k]||^2 (:750)
-    XW = eng.x_w_slot(wslot, 0, K, per_block=True)
+    if XW is None:
+        XW = eng.x_w_slot(wslot, 0, K, per_block=True)
     T, pp_b = [], np.empty((B, K))
     for b in range(B):
         rows = (offs[b], offs[b + 1])
@@ -1145,6 +1147,76 @@ def _kernel_extras_device(eng, res, Y, V, Ts, varxb, wslot, wnorm2):
                explained_var_y_=list(tt * (V ** 2).sum(axis=0) / vary))
 
 
+# Sustained rates the route of KERNEL p > n is chosen with (one MI355X): the f64 matrix-core Gram
+# and a read-only column pass.  Only their ratio matters.
+_GRAM_FLOPS = 71.0e12
+_PASS_BYTES = 6.5e12
+
+
+def _kernel_on_products(eng, n, K, q):
+    """KERNEL p > n: the association matrix X X^T (n (n + 1) p flop on the f64 matrix cores, then O(n^2) per
+    component) or the maintained thin products of _kernel_scores_on_products (K + 1 passes over X, + 1 or 2 to set up
+    several responses)?  The Gram only wins while n(n+1)/71e12 < passes * 8n/6.5e12, i.e. n below ~ 87 (K + 3); at
+    BASELINE config[3] (n = 8192, K = 20) the passes are 4 x faster.  MBPLS_KERNEL_GRAM = 1 | 0 forces either; the
+    choice is the same on every rank of a column-sharded fit (n, K, q are)."""
+    if eng.sparse or getattr(eng, "rowmask", None) is not None:
+        return False
+    forced = eng.opts.kernel_gram
+    if forced is not None:
+        return forced == "0"
+    passes = K + 1 + (0 if q == 1 else (1 if q == 2 else 2))
+    return n * (n + 1.0) / _GRAM_FLOPS + 3 * 8.0 * n / _PASS_BYTES > passes * 8.0 * n / _PASS_BYTES
+
+
+def _kernel_scores_on_products(eng, Y, K, standardize):
+    """The component loop of KERNEL p > n (mbpls.py:704-728) WITHOUT the association matrix.  With orthonormal scores
+    the two-sided deflations :723-724 are AS_X,k = P X X^T P and AS_Y,k = P Y Y^T P, P = I - Ts Ts^T, so
+        S_k = AS_X,k AS_Y,k = [P X (X^T (P Y))] (P Y)^T                                   (:725)
+    has rank <= q and its first left singular vector (:712-715) is that of the n x q matrix M L with
+    M = P X (X^T (P Y)) and L L^T = (P Y)^T (P Y).  X^T (P Y) (p x q) and the per-block X_b (X^T (P Y))_b (n x q) are the
+    maintained products of _ResponseProducts -- the one pass a component costs is the fused sweep with v = ts, which
+    returns X^T ts (a column of :734 already) and X_b (X^T ts)_b.  The weights need no pass either:
+        u = AS_Y,k ts / ||.|| = (P Y) c / ||.||,  c = (P Y)^T ts  (:718-719)   =>   X^T u = [X^T (P Y)] c / ||.||   (:731)
+    and X_b (X^T u)_b = [X_b (X^T (P Y))_b] c / ||.|| are the block products of calc_all (:752).  X is never written.
+    Leaves the raw weights X^T U_ in slot "UT" and the loadings X^T Ts (Ts^T Ts)^+ (:734) in slot "P"; returns
+    (Ts, U, ||X_b||^2, per-block ||(X^T U_)_b||^2 (B x K), [X_b (X^T U_)_b] (n x K per block))."""
+    n, B = eng.n, eng.nblocks
+    q = Y.shape[1]
+    eng.slot("UT", K); eng.slot("Pl", K); eng.slot("S", q + 1)     # S = [X^T (P Y) | X^T ts of the component at hand]
+    eng.use_lazy_deflation(K, "Pl", prefer="lazy")        # (never deflates: the never-writes-X passes when they apply)
+    _plan(eng, solver="kernel p > n on maintained thin products X^T (P Y), X_b (X^T (P Y))_b: one pass over X per "
+                      "component, no association matrix")
+    for name, cols in (("R", K), ("beta", q), ("Wblk", K), ("P", K), ("Wc", K)):
+        eng.host_array((eng.p, cols), reserve=name)       # (pages mapped by the helper thread while the passes run)
+    prod = _ResponseProducts(eng, Y, standardize)
+    varxb = prod.varxb
+    Yd = Y.copy()
+    Ts = np.empty((n, K), order="F"); U = np.empty((n, K))
+    wnorm2 = np.empty((B, K)); tts = np.empty(K)
+    XW = [np.empty((n, K)) for _ in range(B)]
+    for k in range(K):
+        Tp = Ts[:, :k]
+        M = prod.total()
+        M = M - Tp.dot(Tp.T.dot(M))                         # P X X^T P Y (AS_X,k Y_d; :723)
+        ts = _tlsv(M.dot(_psd_factor(Yd.T.dot(Yd))))       # (:712-715): S = AS_X,k Y_d Y_d^T
+        if k:       # (an exhausted response leaves M at rounding level: keep the scores orthonormal all the same)
+            ts = ts - Tp.dot(Tp.T.dot(ts))
+            ts = ts / np.linalg.norm(ts)
+        c = Yd.T.dot(ts)
+        u = Yd.dot(c); un = np.linalg.norm(u); u = u / un   # (:718-719)
+        t_raw, wnorm2[:, k] = prod.combination(c / un, ("UT", k))    # X^T u (:731), X_b (X^T u)_b, ||(X^T u)_b||^2
+        tts[k] = ts.T.dot(ts).item()
+        prod.component(ts, 1.0 / tts[k], ("Pl", k))         # the pass: X^T ts / ts^T ts; X^T (P Y), X_b (..)_b without ts
+        Yd = Yd - ts.dot(ts.T.dot(Yd))                      # AS_Y = D AS_Y D (:724)
+        Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u
+        for b in range(B):
+            XW[b][:, k] = t_raw[:, b]
+    G = np.linalg.pinv(Ts.T.dot(Ts))
+    eng.slot("P", K)
+    eng.right_mul(("Pl", 0, K), tts[:, None] * G, ("P", 0))  # P = X^T Ts (Ts^T Ts)^+ (:734)
+    return Ts, U, varxb, wnorm2, XW
+
+
 def fit_kernel(eng, Y, K, standardize, calc_all=True):
     """mbpls.py:576-807.  p>n (:694-805): association matrix A = X X^T on the matrix cores, then the
     component loop runs on n x q thin factors: the reference's D A D (D = I - ts ts^T, :722-725) is
@@ -1152,7 +1224,10 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
-    if p_total > n and eng.stats_only_ok():
+    products = p_total > n and _kernel_on_products(eng, n, K, q)
+    if products:
+        pass                                                # (prepared by the route itself: statistics + first sweep)
+    elif p_total > n and eng.stats_only_ok():
         # p > n: every X-sized operation below is a matrix product (Gram, X^T [U Ts], X_b W_b) that can standardise
         # its operand in registers -- statistics only, X is neither copied nor written
         varxb = eng.prepare_stats(standardize)
@@ -1162,7 +1237,24 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
     empty_blocks = dict(W_=[np.empty((sz, 0)) for sz in eng.block_sizes], T_=[np.empty((n, 0)) for _ in range(B)],
                         A_=np.empty((B, 0)), A_corrected_=np.empty((B, 0)), explained_var_x_=[],
                         explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)))
+    if p_total > n and products:
+        Ts, U, varxb, wnorm2, XWraw = _kernel_scores_on_products(eng, Y, K, standardize)
+        G = np.linalg.pinv(Ts.T.dot(Ts))
+        V = Y.T.dot(Ts).dot(G)                          # (:735)
+        cn = np.sqrt(wnorm2.sum(axis=0))
+        eng.slot("Wc", K)
+        eng.right_mul(("UT", 0, K), np.diag(1.0 / cn), ("Wc", 0))     # column-normalised weights (:733)
+        res.update(Ts_=Ts, U_=U, V_=V)
+        fetch_all = _finalise_device(eng, res, "UT", K, cn, np.sqrt(wnorm2), V, fetch=False)   # (:737-738)
+        fetch_all()
+        res.W_concat_ = eng.fetch("Wc")
+        if calc_all:        # X_b W_b came with the maintained products: no further pass over X
+            _kernel_extras_device(eng, res, Y, V, Ts, varxb, "UT", wnorm2, XW=XWraw)
+        else:
+            res.update(empty_blocks)
+        return res
     if p_total > n:
+        _plan(eng, solver="kernel p > n: association matrix X X^T on the f64 matrix cores, O(n^2) rank updates")
         eng.gram()                                          # AS_X (:704)
         # the host is idle while the matrix cores build the association matrix: the p x K attributes' host arrays are
         # allocated now (their pages mapped by the helper thread: the copies at the end then run at PCIe speed instead of

@@ -46,3 +46,14 @@ def q1_route(request, monkeypatch):
     else:
         monkeypatch.delenv("MBPLS_NIPALS_Q1_FIXED_POINT", raising=False)
     return request.param
+
+
+KERNEL_ROUTES = {"gram": "1", "products": "0"}
+
+
+@pytest.fixture(params=list(KERNEL_ROUTES))
+def kernel_route(request, monkeypatch):
+    """both routes of KERNEL p > n: the association matrix X X^T on the matrix cores, and the maintained thin products
+    (one pass over X per component); without the variable a cost model picks one (solvers._kernel_on_products)"""
+    monkeypatch.setenv("MBPLS_KERNEL_GRAM", KERNEL_ROUTES[request.param])
+    return request.param

@@ -33,6 +33,7 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
     the default route (one pass per component) or the reference's two passes, at random."""
     import os
     from mbpls_amd import MBPLS
+    from mbpls_amd.plan import FitOptions
     warnings.filterwarnings("ignore")
     rng = np.random.RandomState(seed)
     print_ = print if verbose else (lambda *a, **k: None)
@@ -59,11 +60,6 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
             kmax = min(kmax, 4)                # (the CPU oracle iterates hundreds of times per component for q > 1)
         K = int(min(kmax, max(1, min(n - 1, p))))
         method = str(rng.choice(["NIPALS", "NIPALS", "UNIPALS", "KERNEL", "SIMPLS"]))
-        if method == "SIMPLS":
-            # (the reference's SIMPLS loses orthogonality -- |Ts^T Ts - I| from 1e-8 at eight or nine components up to 1e-2
-            # once K approaches the number of samples, on uncentred data most of all: no implementation can follow it
-            # to 1e-6 there)
-            K = int(min(K, 5, max(1, n // 4)))
         std = bool(rng.rand() < 0.7)
         nb = int(min(p, rng.randint(1, 4)))
         if shard is not None:
@@ -93,10 +89,13 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         do_cv, cv_pick = bool(rng.rand() < 0.2), int(rng.randint(0, 3))
         reuse = bool(rng.rand() < 0.3)
         # a non-default route now and then (the switches of mbpls_amd/plan.py): same numbers on every route
+        # (lower-case keys: fallback forms of mbpls_amd.plan.FALLBACK_FORMS, forced through FitOptions.forced)
         routes = [{}, {}, {}, {"MBPLS_DEFLATION": "explicit"}, {"MBPLS_IMPLICIT_STD": "0"}, {"MBPLS_RESIDENT": "0"},
-                  {"MBPLS_NIPALS_SUBSPACE": "0"}, {"MBPLS_NIPALS_SUBSPACE": "0", "MBPLS_NIPALS_GRAM": "0"},
-                  {"MBPLS_UNIPALS_NODEFLATE": "0"}, {"MBPLS_R_INCREMENTAL": "0"}, {"MBPLS_STREAM_STATS": "0"},
-                  {"MBPLS_KERNEL_IMPLICIT": "1"}, {"MBPLS_KERNEL_IMPLICIT": "0"}, {"MBPLS_NIPALS_QSPACE": "0"}]
+                  {"nipals_subspace": False}, {"nipals_subspace": False, "nipals_gram": False},
+                  {"unipals_nodeflate": False}, {"r_incremental": False}, {"stream_stats": False},
+                  {"MBPLS_KERNEL_IMPLICIT": "1"}, {"MBPLS_KERNEL_IMPLICIT": "0"}, {"nipals_qspace": False},
+                  {"MBPLS_KERNEL_GRAM": "1"}, {"MBPLS_KERNEL_GRAM": "0"},
+                  {"MBPLS_KERNEL_GRAM": "1", "MBPLS_KERNEL_IMPLICIT": "1"}]
         route = routes[int(rng.randint(0, len(routes)))]
         # missing values: every third input form through the streamed-column kernel that n > 65536 takes (any n runs on it)
         stream_nan = sparse and form % 3 == 0
@@ -129,13 +128,26 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                               nipals_convergence_norm=norm, max_iter=3000)
         except Exception as e:
             print_(tag, "oracle failed:", type(e).__name__); continue
+        # SIMPLS: the reference's Gram-Schmidt recurrence (mbpls.py:1015-1018) is classical and loses orthogonality
+        # itself -- |Ts^T Ts - I| from 1e-8 at eight or nine components up to 1e-2 once K approaches the number of
+        # samples, on uncentred data most of all.  A fit can follow it to about that defect, not to 1e-6: where 50 x
+        # the ORACLE's own defect exceeds 1e-8 that is the bound of the case (asserted; the case then stays out of
+        # ``worst``), everywhere else the usual 1e-6 (tests/test_gpu_parity.py::test_simpls_follows_the_reference_...)
+        bound = None
+        if method == "SIMPLS":
+            defect = float(np.max(np.abs(ref.Ts_.T.dot(ref.Ts_) - np.eye(K))))
+            if 50.0 * defect > 1e-8:
+                bound = 50.0 * defect
+        tol_case = max(1e-6, bound or 0.0)
         if method == "NIPALS" and max(ref.nipals_iterations_) >= 3000:
             # the REFERENCE's loop does not converge here (masked alternating regressions of some missing-value patterns,
             # structure-free deep components: it would run forever, :841): nothing to compare with
             print_(tag, "skipped: the reference's NIPALS loop does not converge (iteration cap of the oracle)"); continue
         try:
             os.environ["MBPLS_NIPALS_Q1_FIXED_POINT"] = "0" if two_pass else "1"
-            os.environ.update(route)
+            os.environ.update({k: v for k, v in route.items() if k.isupper()})
+            FitOptions.forced.clear()
+            FitOptions.forced.update({k: v for k, v in route.items() if not k.isupper()})
             if tun:
                 import mbpls_amd
                 for key, (val, _) in tun.items():
@@ -160,7 +172,7 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                 loc = lambda A: [np.ascontiguousarray(A[:, offs[b] + lo:offs[b] + hi]) for b, (lo, hi) in enumerate(ranges)]
                 with mbpls_amd.column_sharded(comm):
                     m = est.fit(loc(X), Yin)
-                    w = util.compare(util.model_to_flat(m), _local_view(ref, ranges, offs), 1e-6, what=tag)
+                    w = util.compare(util.model_to_flat(m), _local_view(ref, ranges, offs), tol_case, what=tag)
                     o = ors if sparse else orc
                     w = max(w, util.relerr(m.predict(loc(Xn)), o.predict(ref, sp(Xn))))
                     if nn > 1:
@@ -178,6 +190,10 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                         if wcv > 1e-7:
                             print_(tag, f"cross_val_predict batched vs loop {wcv:.2e} (cv={folds}, rank {rank} of {world})")
                         w = max(w, wcv)
+                if bound is not None:
+                    assert w <= bound, f"{tag}: SIMPLS {w:.2e} beyond 50 x the oracle's own orthogonality defect {bound:.2e}"
+                    print_(tag, f"relerr {w:.2e} within 50 x the oracle's own defect {bound:.2e} (rank {rank} of {world})")
+                    continue
                 worst = max(worst, w)
                 if w > 1e-9:
                     print_(tag, f"relerr {w:.2e} (rank {rank} of {world})")
@@ -200,7 +216,7 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                                                              zip(np.concatenate(([0], cuts)), np.concatenate((cuts, [p])))], Yin)
             else:
                 m = est.fit(sp(X), Yin)
-            w = util.compare(util.model_to_flat(m), util.model_to_flat(ref), 1e-6, what=tag)
+            w = util.compare(util.model_to_flat(m), util.model_to_flat(ref), tol_case, what=tag)
             o = ors if sparse else orc
             w = max(w, util.relerr(m.predict(sp(X)), o.predict(ref, sp(X))))
             # new data: predict, and transform with block scores (the reference has none for SIMPLS, nor -- a bug of its
@@ -228,9 +244,13 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                 if wcv > 1e-7:
                     print_(tag, f"cross_val_predict batched vs loop {wcv:.2e} (cv={folds})")
                 w = max(w, wcv)
-            worst = max(worst, w)
-            if w > 1e-9:
-                print_(tag, f"relerr {w:.2e}")
+            if bound is not None:
+                assert w <= bound, f"{tag}: SIMPLS {w:.2e} beyond 50 x the oracle's own orthogonality defect {bound:.2e}"
+                print_(tag, f"relerr {w:.2e} within 50 x the oracle's own defect {bound:.2e}")
+            else:
+                worst = max(worst, w)
+                if w > 1e-9:
+                    print_(tag, f"relerr {w:.2e}")
         except Exception as e:
             bad += 1
             print_(tag, "FAILED:", type(e).__name__, str(e)[:200])
@@ -242,4 +262,5 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
             os.environ.pop("MBPLS_NIPALS_Q1_FIXED_POINT", None)
             for key in route:
                 os.environ.pop(key, None)
+            FitOptions.forced.clear()
     return bad, worst

@@ -76,3 +76,31 @@ def test_pmc_counter_files_are_parsed_as_the_committed_summary_says():
     assert bench.pmc_traffic("sweep", 4096, 1_000_000, live)[0] == 1.0
     val, src = bench.pmc_traffic("sweep", 4096, 1_000_000, {"error": "x"})
     assert val == want["sweep"]["hbm_bytes_per_launch"] and "not measured in this run" in src
+
+
+def test_n_gpu_line_counts_the_whole_matrix():
+    """N > 1 (weak scaling, p columns PER GPU): ``value`` is the whole job -- the units the kernels of one fit move
+    times 8 n (world p) bytes over the time per fit -- while roofline.achieved / peak / bytes_per_launch are per GPU and
+    roofline.whole_job restates them over world x p columns.  bench.job_throughput / bench.roofline_of are the functions
+    the line is assembled from."""
+    import bench
+    n, p, steps, world = 4096, 1_000_000, 10, 8
+    unit = 8.0 * n * p                                   # one traversal of ONE rank's shard
+    ms = 5.0
+    prof = {"deflate_sweep": {"launches": 9 * steps, "bytes_per_launch": unit, "avg_ms": ms, "total_ms": 9 * steps * ms,
+                              "GBps": unit / (ms * 1e-3) / 1e9},
+            "standardize_sweep": {"launches": steps, "bytes_per_launch": unit, "avg_ms": ms, "total_ms": steps * ms,
+                                  "GBps": unit / (ms * 1e-3) / 1e9},
+            "loadings": {"launches": steps, "bytes_per_launch": unit, "avg_ms": ms, "total_ms": steps * ms,
+                         "GBps": unit / (ms * 1e-3) / 1e9}}
+    dt = steps * 0.056
+    for w in (1, world):
+        units, unit_bytes, per_step, value = bench.job_throughput(prof, n, p, w, steps, dt)
+        assert units == 11.0 and unit_bytes == 8.0 * n * (w * p) and abs(per_step - 0.056) < 1e-12
+        assert abs(value - 11.0 * 8.0 * n * p * w / 0.056 / 1e9) < 1e-6 * value      # the WHOLE job: w x the single-GPU figure
+        roof = bench.roofline_of("deflate_sweep", prof["deflate_sweep"], n, p, w, None, None, 6900.0)
+        assert roof["bytes_per_launch"] == unit and roof["peak"] == 8000.0            # per GPU
+        assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+        wj = roof["whole_job"]
+        assert wj["n_gpus"] == w and wj["columns"] == w * p and wj["bytes_per_launch"] == 8.0 * n * (w * p)
+        assert abs(wj["achieved"] / wj["peak"] - roof["frac"]) < 1e-3

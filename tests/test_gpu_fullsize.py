@@ -258,7 +258,7 @@ def test_c4_kernel_full_size(gpu_required, monkeypatch):
         monkeypatch.setenv("MBPLS_KERNEL_IMPLICIT", "1")  # (by itself only when a second 131 GB matrix does not fit)
         m0 = MBPLS(n_components=K, method="KERNEL").fit(X, Y)             # copy=True, nothing written, no working copy
         monkeypatch.delenv("MBPLS_KERNEL_IMPLICIT")
-        assert used == [True] and "association matrix" in m0.fit_plan_["solver"], m0.fit_plan_
+        assert used == [True] and "matrix cores" in m0.fit_plan_["solver"], m0.fit_plan_
         _, again = download_sample(X, ranges, width)
         assert np.array_equal(again, raw)
         check_orthonormal(m0.Ts_)
@@ -477,9 +477,8 @@ def test_c2_several_responses_full_size(gpu_required, monkeypatch):
         Wc = Wn / np.linalg.norm(Wn, axis=0)
         R = Wc.dot(np.linalg.pinv(np.vstack(mdl.P_).T.dot(Wc)))                     # (:988)
         assert util.relerr(mdl.R_, R) < TOL and util.relerr(mdl.beta_, R.dot(mdl.V_.T)) < TOL
-        monkeypatch.setenv("MBPLS_NIPALS_SUBSPACE", "0")                            # per-block association matrices
-        m2 = MBPLS(n_components=K, method="NIPALS").fit(X, Y)
-        monkeypatch.delenv("MBPLS_NIPALS_SUBSPACE")
+        with util.forced_routes(nipals_subspace=False):                             # per-block association matrices
+            m2 = MBPLS(n_components=K, method="NIPALS").fit(X, Y)
         assert m2.fit_plan_["solver"] != mdl.fit_plan_["solver"], m2.fit_plan_
         assert all(abs(a - b) <= 2 for a, b in zip(m2.nipals_iterations_, mdl.nipals_iterations_))
         assert util.compare(util.model_to_flat(m2), util.model_to_flat(mdl), 1e-7, what="Gram route vs maintained") < 1e-7
@@ -497,9 +496,8 @@ def test_c2_several_responses_full_size(gpu_required, monkeypatch):
             for k in range(K):
                 c = Wfit[cols[sel], k].dot(Wraw[sel, k]) / Wraw[sel, k].dot(Wraw[sel, k])
                 assert np.max(np.abs(Wfit[cols[sel], k] - c * Wraw[sel, k])) < TOL * np.max(np.abs(Wfit[cols[sel], k]))
-        monkeypatch.setenv("MBPLS_UNIPALS_NODEFLATE", "0")                          # explicitly deflated working copy
-        m2 = MBPLS(n_components=K, method="UNIPALS").fit(X, Y)
-        monkeypatch.delenv("MBPLS_UNIPALS_NODEFLATE")
+        with util.forced_routes(unipals_nodeflate=False):                           # explicitly deflated working copy
+            m2 = MBPLS(n_components=K, method="UNIPALS").fit(X, Y)
         assert util.compare(util.model_to_flat(m2), util.model_to_flat(mu), 1e-7, what="deflating vs maintained") < 1e-7
         del m2, mu
         # ---- SIMPLS (never deflates: P = Z^T Ts, Ts = Z R_, orthonormal scores, beta_ = R_ V_^T)

@@ -278,3 +278,22 @@ def test_refused_cooperative_launch_falls_through_to_two_phase_passes(gpu_requir
         ctx.set_tunable("cluster_cap", -1)
         ctx.set_tunable("long_columns_from", 8192)
         _long_mode(ctx, None)
+
+
+def test_cluster_timeout_under_column_shards_is_a_collective_decision(gpu_required):
+    """round-5 advisor (medium): a hand-off time-out on ONE rank must not send that rank alone into the re-run of the fit
+    -- see tests/_cluster_timeout_worker.py"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "_cluster_timeout_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("re-ran the fit on both, == oracle") == 2, r.stdout

@@ -79,3 +79,18 @@ def test_ranks_agree_bit_for_bit(gpu_required):
 
 def test_ranks_agree_bit_for_bit_on_a_shared_gpu(gpu_required):
     _run_rank_equality(2, shared=True)
+
+
+@pytest.mark.parametrize("mode", ["async", "deadline"])
+@pytest.mark.parametrize("route", ["queue", "host"])
+def test_a_dead_peer_is_an_error_not_a_hang(gpu_required, mode, route):
+    """mbpls_hip_allreduce queues a collective into a device queue; a peer that dies would leave every later wait for
+    the stream hanging for ever.  With a communicator on the context every such wait polls the stream, asks
+    ncclCommGetAsyncError and keeps a deadline; on either the communicator is aborted and the call returns
+    MBPLS_ERR_COMM (``CommLost``).  Fault-injected at world size 1 (tests/_comm_fault_worker.py): asynchronous error /
+    silent peer, device-resident queue / host-driven passes."""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_comm_fault_worker.py"), mode, route], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "dead peer" in r.stdout and "detected after" in r.stdout, r.stdout

@@ -1,4 +1,5 @@
 """Shared helpers for the parity tests: fixture loading and sign-aligned comparison."""
+import contextlib
 import os
 
 import numpy as np
@@ -97,3 +98,19 @@ def check_nipals_iterations(mdl, ref, K=None, two=True):
         assert got == want, (got, want)
     if K is not None:
         assert len(got) == K
+
+
+@contextlib.contextmanager
+def forced_routes(**forms):
+    """Force fallback forms of the solvers (mbpls_amd.plan.FALLBACK_FORMS: nipals_subspace, nipals_qspace, nipals_gram,
+    unipals_nodeflate, r_incremental, stream_stats) for the fits inside the block, e.g. ``nipals_subspace=False``.  These
+    are not switches of the product (no environment variable): a fit takes them when its shape needs them; the tests
+    compare each with the oracle."""
+    from mbpls_amd.plan import FitOptions
+    old = dict(FitOptions.forced)
+    FitOptions.forced.update(forms)
+    try:
+        yield
+    finally:
+        FitOptions.forced.clear()
+        FitOptions.forced.update(old)
