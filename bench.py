@@ -720,10 +720,14 @@ def other_solvers(ctx, X, n, K, r):
     warm-up and three timed fits each; passes = launches of X-sized kernels per fit (HIP-event profile)."""
     from mbpls_amd import MBPLS
     out = {}
-    for name, method, q in (("nipals_q10", "NIPALS", 10), ("unipals_q10", "UNIPALS", 10), ("simpls_q1", "SIMPLS", 1),
-                            ("unipals_q1", "UNIPALS", 1)):
+    # (KERNEL on both of its p > n routes: the default at this shape -- maintained thin products, one pass per
+    # component -- and the association matrix on the f64 matrix cores, forced; the Gram's TFLOP/s beside it)
+    for name, method, q, env in (("nipals_q10", "NIPALS", 10, {}), ("unipals_q10", "UNIPALS", 10, {}),
+                                 ("simpls_q1", "SIMPLS", 1, {}), ("unipals_q1", "UNIPALS", 1, {}),
+                                 ("kernel_q1", "KERNEL", 1, {}), ("kernel_q1_gram", "KERNEL", 1, {"MBPLS_KERNEL_GRAM": "1"})):
         note(f"  {name}")
         Yq = planted(n, q, r, 0)[1]                      # the same latent scores as X (seed 0), q response columns
+        os.environ.update(env)
         try:
             MBPLS(n_components=K, method=method).fit(X, Yq)
             ctx.profile(True); ctx.profile_reset()
@@ -743,10 +747,17 @@ def other_solvers(ctx, X, n, K, r):
                          "standardisation": getattr(m, "fit_plan_", {}).get("standardisation")}
             if hasattr(m, "nipals_iterations_"):
                 out[name]["nipals_iterations_total"] = int(sum(m.nipals_iterations_))
+            if "gram" in pr:
+                fl = float(n) * (n + 1) * X.p                # all Gram launches of one fit cover the p columns once
+                out[name]["gram_TFLOPs"] = round(fl / (pr["gram"]["total_ms"] / 3 * 1e-3) / 1e12, 2)
+                out[name]["gram_frac_of_f64_mfma_peak_78.6"] = round(out[name]["gram_TFLOPs"] / 78.6, 3)
             del keep, m
         except Exception as e:                           # noqa: BLE001 -- a side leg must not cost the line
             ctx.profile(False)
             out[name] = {"skipped": f"{type(e).__name__}: {e}"}
+        finally:
+            for key in env:
+                os.environ.pop(key, None)
     return out
 
 
@@ -966,12 +977,19 @@ def run_pmc_children(a, timeout_s=120):
                 k = out["kernels"].setdefault(nm, {})
                 k[counter + "_KiB_avg"] = avg
                 k["launches"] = cnt
+            if "arch" not in out:
+                out["arch"] = profiled_arch(d)
+        # the x 2 on FETCH_SIZE is a property of gfx950's counter (MI355X_MICROARCH.md): anywhere else the raw counter is
+        # reported and labelled as uncorrected
+        fetch_factor = 2.0 if out.get("arch") == "gfx950" else 1.0
+        if fetch_factor == 1.0:
+            out["method"] += f" -- UNCORRECTED here: the profiled device is {out.get('arch') or 'unknown'}, not gfx950"
         unit = 8.0 * a.n * a.p
         for nm, k in list(out["kernels"].items()):
             if "FETCH_SIZE_KiB_avg" not in k or "WRITE_SIZE_KiB_avg" not in k:
                 del out["kernels"][nm]
                 continue
-            k["hbm_read_bytes"] = 2.0 * k["FETCH_SIZE_KiB_avg"] * 1024.0
+            k["hbm_read_bytes"] = fetch_factor * k["FETCH_SIZE_KiB_avg"] * 1024.0
             k["hbm_write_bytes"] = k["WRITE_SIZE_KiB_avg"] * 1024.0
             k["hbm_bytes_per_launch"] = k["hbm_read_bytes"] + k["hbm_write_bytes"]
             k["over_algorithmic_8np"] = round(k["hbm_bytes_per_launch"] / unit, 4)
@@ -983,6 +1001,29 @@ def run_pmc_children(a, timeout_s=120):
         return {"error": f"{type(e).__name__}: {e}"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def profiled_arch(profile_dir):
+    """gcnArchName of the device a rocprofv3 run profiled: from the agent table the profiler writes beside its counter
+    files, else from rocm_agent_enumerator (a child process: this one has not touched the GPU yet)"""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    for f in glob.glob(os.path.join(profile_dir, "**", "*agent_info.csv"), recursive=True):
+        try:
+            m = re.search(r"gfx[0-9a-f]{3,4}", open(f).read())
+        except OSError:
+            m = None
+        if m:
+            return m.group(0)
+    exe = shutil.which("rocm_agent_enumerator") or "/opt/rocm/bin/rocm_agent_enumerator"
+    try:
+        txt = subprocess.run([exe], capture_output=True, text=True, timeout=30).stdout
+        archs = [ln.strip() for ln in txt.splitlines() if ln.strip().startswith("gfx") and ln.strip() != "gfx000"]
+        return archs[0] if archs else None
+    except Exception:                                     # noqa: BLE001
+        return None
 
 
 def pmc_traffic(kernel, n, p, live=None):
@@ -1114,6 +1155,26 @@ def run_first_fit_child(a):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def measured_full_width(n, p, K, method):
+    """The faithful oracle timed ONCE at the full width of this workload on a GPU box's host (tools/
+    cpu_baseline_full_width.py: 164-199 GB of host RAM, four minutes -- not part of the default run); the committed record,
+    labelled with its date and box, when it is for exactly this shape."""
+    for name in ("r06_cpu_baseline_full_width.json",):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.loads(f.read().strip().splitlines()[-1])
+        except (OSError, ValueError):
+            continue
+        if (d.get("n"), d.get("p"), d.get("K"), d.get("method")) == (n, p, K, method) and "measured_full_width_s" in d:
+            return {"measured_full_width_s": d["measured_full_width_s"], "lean_mode_s": d.get("lean_fit_s"),
+                    "blas_threads": d.get("blas_threads"), "peak_rss_GB": d.get("peak_rss_GB"),
+                    "gpu_vs_oracle_worst_relerr_all_attributes_at_full_width":
+                        d.get("gpu_vs_faithful_oracle_worst_relerr_all_attributes"),
+                    "source": f"profiles/{name} (tools/cpu_baseline_full_width.py, {d.get('date')}, host {d.get('host')}, "
+                              f"{d.get('cpus_visible')} CPUs visible) -- NOT measured in this run"}
+    return None
+
+
 def cpu_baseline(ctx, X, Y, n, p, cols, K, method, gpu_fit_s, gpu_check=True):
     """BASELINE.md section 3 protocol on the GPU box's host cores: the oracle in FAITHFUL mode (= the reference's numpy
     op sequence, n x p temporaries included) and in LEAN mode (the GPU's algorithm on the CPU) at three widths of the
@@ -1192,7 +1253,12 @@ def cpu_baseline(ctx, X, Y, n, p, cols, K, method, gpu_fit_s, gpu_check=True):
         err = float(max(np.max(np.abs(mdl.Ts_ * s - ref.Ts_)) / np.max(np.abs(ref.Ts_)),
                         np.max(np.abs(mdl.beta_ - ref.beta_)) / np.max(np.abs(ref.beta_)),
                         np.max(np.abs(mdl.P_[0] * s - ref.P_[0])) / np.max(np.abs(ref.P_[0]))))
-    return {"value": round(gbps, 3), "unit": "GB/s", "cores": thr, "kind": "port",
+    measured = measured_full_width(n, p, K, method)
+    if measured is not None:
+        ext = fit["faithful"]["extrapolated_full_size_fit_s"]
+        measured["extrapolation_of_this_run_s"] = ext
+        measured["extrapolation_over_measured"] = round(ext / measured["measured_full_width_s"], 4)
+    return {"value": round(gbps, 3), "unit": "GB/s", "cores": thr, "kind": "port", "measured_full_width": measured,
             "sample": f"oracle faithful mode (reference numpy op sequence) on the first {cols_timed} columns of the same "
                       f"matrix, n={n} K={K}: {t_cpu:.1f} s wall = {units} reference-algorithm units of 8np bytes / wall; "
                       f"BLAS threads = CPU quota = {thr} ({os.cpu_count()} logical CPUs visible); after one warm-up fit; "

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmbpls_hip.so")
-SOURCES = ["ctx.hip", "colpass.hip", "colpass_nan.hip", "colpass_long.hip", "colpass_cluster.hip", "colpass_sub.hip", "gemv.hip", "gram.hip", "gen.hip", "small.hip", "xtv_mfma.hip", "xw_mfma.hip", "nipals_step.hip", "axpy_cols.hip", "resident.hip", "step_reg.hip", "cv_batch.hip", "rccl_comm.hip", "copier.hip"]
+SOURCES = ["ctx.hip", "colpass.hip", "colpass_nan.hip", "colpass_nan_long.hip", "colpass_long.hip", "colpass_cluster.hip", "colpass_sub.hip", "gemv.hip", "gram.hip", "gen.hip", "small.hip", "xtv_mfma.hip", "xw_mfma.hip", "nipals_step.hip", "axpy_cols.hip", "resident.hip", "step_reg.hip", "cv_batch.hip", "rccl_comm.hip", "copier.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]

@@ -591,6 +591,11 @@ static int nan_reduce(mbpls_ctx* ctx, const mbpls_mat* m, const NanArgs& a, bool
   return reduce_chunks(ctx, m, a.part_d, a.part_s, d_d, nullptr, nullptr, nullptr);
 }
 
+// long columns (beyond the few-samples kernels and the register shapes): the two-phase passes of colpass_nan_long.hip
+static bool nan_two_phase(const mbpls_ctx* ctx, int64_t n) {
+  return ctx->nan_long_two_phase && n > ctx->nan_long_from && !(n <= SUB_MAX_N && ctx->sub_columns);
+}
+
 }  // namespace mbpls
 
 using namespace mbpls;
@@ -614,6 +619,9 @@ int mbpls_hip_nan_standardize_sweep_masked(const mbpls_mat* src, mbpls_mat* dst,
   MB_ARG(mode == MBPLS_SCALE_NONE || (d_mean && d_scale), "mean/scale buffers required");
   MB_ARG(!d_v || (d_t && d_d), "the fused sweep needs d_t and d_d");
   mbpls_ctx* ctx = dst->ctx;
+  if (nan_two_phase(ctx, dst->n))
+    return nan_long_standardize_sweep(src, dst, mode, d_rowmask, d_mean, d_scale, d_count, d_ssq_x, d_v, d_g, d_t, d_d,
+                                      d_ssq_g);
   NanArgs a{};
   MB_TRY(nan_buffers(ctx, dst, &a));
   a.src = src->data; a.dst = dst->data; a.ld = dst->ld; a.n = dst->n;
@@ -631,6 +639,7 @@ int mbpls_hip_nan_sweep(const mbpls_mat* m, const double* d_v, double* d_g, doub
                         double* d_ssq_g) {
   MB_ARG(m && d_v && d_t && d_d, "NULL argument");
   mbpls_ctx* ctx = m->ctx;
+  if (nan_two_phase(ctx, m->n)) return nan_long_sweep(m, d_v, d_g, d_t, d_d, d_ssq_g);
   NanArgs a{};
   MB_TRY(nan_buffers(ctx, m, &a));
   a.src = m->data; a.dst = nullptr; a.ld = m->ld; a.n = m->n;
@@ -645,6 +654,7 @@ int mbpls_hip_nan_deflate_sweep(mbpls_mat* m, const double* d_ts, int deflate, d
   MB_ARG(m && d_ts, "NULL argument");
   MB_ARG(!d_v || (d_t && d_d), "the fused sweep needs d_t and d_d");
   mbpls_ctx* ctx = m->ctx;
+  if (nan_two_phase(ctx, m->n)) return nan_long_deflate_sweep(m, d_ts, deflate, d_p, d_ssq_p, d_v, d_g, d_t, d_d, d_ssq_g);
   NanArgs a{};
   MB_TRY(nan_buffers(ctx, m, &a));
   a.src = m->data; a.dst = m->data; a.ld = m->ld; a.n = m->n;

@@ -258,6 +258,15 @@ struct NanArgs {
 };
 int launch_nan_sub(mbpls_ctx* ctx, const ChunkTable& ct, const NanArgs& a, bool STD, bool DEFL, bool SWEEP);
 
+// colpass_nan_long.hip: the missing-value passes for long columns as two streaming phases (same arguments as the
+// mbpls_hip_nan_* entry points)
+int nan_long_standardize_sweep(const mbpls_mat* src, mbpls_mat* dst, int mode, const double* d_rowmask, double* d_mean,
+                               double* d_scale, double* d_count, double* d_ssq_x, const double* d_v, double* d_g,
+                               double* d_t, double* d_d, double* d_ssq_g);
+int nan_long_sweep(const mbpls_mat* m, const double* d_v, double* d_g, double* d_t, double* d_d, double* d_ssq_g);
+int nan_long_deflate_sweep(mbpls_mat* m, const double* d_ts, int deflate, double* d_p, double* d_ssq_p,
+                           const double* d_v, double* d_g, double* d_t, double* d_d, double* d_ssq_g);
+
 // lazy deflation: at most KD - 1 previous components are corrected for inside a pass
 constexpr int KD = 40;
 

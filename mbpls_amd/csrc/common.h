@@ -112,6 +112,7 @@ struct mbpls_ctx {
   int sub_columns = 1;       // n <= 256: several columns per wave (colpass_sub.hip); 0 = the one-column-per-workgroup kernels
   int64_t long_columns_from = 8192;    // n above this: streamed-column kernels (colpass_long.hip)
   int64_t nan_long_from = 8192;        // missing-value passes: n above this streams the columns (colpass_nan.hip)
+  int nan_long_two_phase = 1;          // ... as two streaming phases with rows as a parallel dimension (colpass_nan_long.hip); 0: one workgroup per chunk re-visits its columns
   // ... and among those, the never-writes-X passes run on CLUSTERS of workgroups that share a column and read X once
   // (colpass_cluster.hip); 0 = the two-phase passes of colpass_long.hip for everything
   int cluster_passes = 1;

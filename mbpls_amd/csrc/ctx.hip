@@ -337,6 +337,7 @@ int mbpls_hip_set_tunable(mbpls_ctx* ctx, const char* key, int value) {
   else if (!strcmp(key, "step_spin_limit")) ctx->step_spin_limit = (unsigned)std::max(1, value);
   else if (!strcmp(key, "long_columns_from")) ctx->long_columns_from = std::max(0, std::min(value, 65536));
   else if (!strcmp(key, "nan_long_from")) ctx->nan_long_from = std::max(0, std::min(value, 65536));
+  else if (!strcmp(key, "nan_long_two_phase")) ctx->nan_long_two_phase = value ? 1 : 0;
   else if (!strcmp(key, "cluster_passes")) ctx->cluster_passes = value ? 1 : 0;
   else if (!strcmp(key, "cluster_cap")) ctx->cluster_cap = value;   // (tests: -1 = ask the runtime again)
   else if (!strcmp(key, "cluster_slab_rows")) ctx->cluster_slab_rows = std::max(128, std::min(value, 8192)) / 128 * 128;

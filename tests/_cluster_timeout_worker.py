@@ -29,13 +29,16 @@ def main():
     mbpls_amd.set_device(0)
     ctx = mbpls_amd.get_context()
     comm = mbpls_amd.TorchDistComm(device="cuda:0")
-    n, sizes = 2100, [500, 700]
+    n, sizes = 2100, [1300, 1500]               # (p > n: UNIPALS / KERNEL take their column-pass routes)
     cuts = np.cumsum(sizes)[:-1]
     ranges = shard_columns(sizes, rank, world)
     ctx.set_tunable("long_columns_from", 0)
     ctx.set_tunable("cluster_slab_rows", 128)
     ctx.set_tunable("cluster_exchange", 1)
-    for method, q in (("NIPALS", 1), ("NIPALS", 2), ("UNIPALS", 1), ("SIMPLS", 2)):
+    # (one response: a device-resident queue; several: host-driven sweeps; KERNEL: its maintained-products route.  SIMPLS
+    # on long columns runs on the many-right-hand-side products, which have no hand-offs)
+    os.environ["MBPLS_KERNEL_GRAM"] = "0"
+    for method, q in (("NIPALS", 1), ("NIPALS", 2), ("UNIPALS", 1), ("UNIPALS", 2), ("KERNEL", 1)):
         X, Y = orc.make_latent(n, sum(sizes), q, r=6, seed=30 + q)
         full = list(np.split(X, cuts, axis=1))
         local = [np.ascontiguousarray(b[:, lo:hi]) for b, (lo, hi) in zip(full, ranges)]
@@ -57,7 +60,8 @@ def main():
         assert util.relerr(mdl.Ts_ * s, ref.Ts_) < 1e-8, (method, q)
         for b, (lo, hi) in enumerate(ranges):
             assert util.relerr(mdl.P_[b] * s, ref.P_[b][lo:hi]) < 1e-8, (method, q, b)
-        assert util.relerr(mdl.predict(local), orc.predict(ref, full)) < 1e-8, (method, q)
+        with mbpls_amd.column_sharded(comm):
+            assert util.relerr(mdl.predict(local), orc.predict(ref, full)) < 1e-8, (method, q)
         assert ctx.cluster_status() == 0
     print(f"rank {rank}/{world}: a hand-off time-out on one rank re-ran the fit on both, == oracle", flush=True)
     dist.barrier()

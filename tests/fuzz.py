@@ -105,6 +105,8 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         tun = {}
         if nan_from is not None:
             tun["nan_long_from"] = (nan_from, 8192)
+            if stream_nan and form % 2:       # the one-workgroup-per-chunk streamed kernel instead of the two phases
+                tun["nan_long_two_phase"] = (0, 1)
         if long and not sparse:
             pick = (form + c) % 5
             if pick == 1:

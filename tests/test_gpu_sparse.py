@@ -255,16 +255,18 @@ def test_missing_values_on_very_long_columns(gpu_required, n, q):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         ref = ors.fit(blocks, Y, n_components=3)
-    # the register shapes ("nan_long_from" = 65536; since the streamed kernel exists they are no longer the default
-    # above 8192 samples: they spill and run at half its speed) and the default
-    for frm in (65536, 8192):
+    # the register shapes ("nan_long_from" = 65536; no longer the default above 8192 samples: they spill), the default
+    # (two streaming phases) and the one-workgroup-per-chunk streamed kernel
+    for frm, two_phase in ((65536, 1), (8192, 1), (8192, 0)):
         get_context().set_tunable("nan_long_from", frm)
+        get_context().set_tunable("nan_long_two_phase", two_phase)
         try:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 mdl = MBPLS(n_components=3, sparse_data=True).fit(blocks, Y)
         finally:
             get_context().set_tunable("nan_long_from", 8192)
+            get_context().set_tunable("nan_long_two_phase", 1)
         w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"sparse n={n} q={q}")
         assert w < 1e-8, w
         if q == 1:
@@ -297,10 +299,14 @@ def test_missing_values_beyond_the_register_shapes(gpu_required, n, q, std):
     assert util.relerr(mdl.transform(Xn), ors.transform(ref, Xn)) < 1e-8
 
 
-@pytest.mark.parametrize("n,p,q,std", [(300, 40, 1, True), (1031, 64, 3, True), (4096, 30, 1, False), (5000, 200, 2, True)])
-def test_streamed_missing_value_passes_at_every_n(gpu_required, n, p, q, std):
-    """the same kernel at sizes the register shapes cover ("nan_long_from" = 0): equal to the oracle, and to the
-    register-resident passes to rounding; cross-validation folds (row masks) included"""
+@pytest.mark.parametrize("two_phase", [1, 0])
+@pytest.mark.parametrize("n,p,q,std", [(300, 40, 1, True), (1031, 64, 3, True), (4096, 30, 1, False), (5000, 200, 2, True),
+                                       (2049, 3000, 1, True), (1500, 77, 2, False)])
+def test_streamed_missing_value_passes_at_every_n(gpu_required, n, p, q, std, two_phase):
+    """the long-column missing-value passes at sizes the register shapes cover ("nan_long_from" = 0) -- the two streaming
+    phases of colpass_nan_long.hip (default) and the one-workgroup-per-chunk kernel they replaced ("nan_long_two_phase"
+    = 0): equal to the oracle, and to the register-resident passes to rounding; cross-validation folds (row masks)
+    included"""
     from mbpls_amd import MBPLS, get_context
     from mbpls_amd.model_selection import cross_val_predict
     X, Y = orc.make_latent(n, p, q, r=4, seed=n + p)
@@ -316,11 +322,13 @@ def test_streamed_missing_value_passes_at_every_n(gpu_required, n, p, q, std):
         reg = MBPLS(n_components=3, sparse_data=True, standardize=std).fit(blocks, Y)
         cv_reg = cross_val_predict(est, blocks, Y, cv=3) if n <= 1100 else None
         ctx.set_tunable("nan_long_from", 0)
+        ctx.set_tunable("nan_long_two_phase", two_phase)
         try:
             mdl = MBPLS(n_components=3, sparse_data=True, standardize=std).fit(blocks, Y)
             cv_str = cross_val_predict(est, blocks, Y, cv=3) if n <= 1100 else None
         finally:
             ctx.set_tunable("nan_long_from", 8192)
+            ctx.set_tunable("nan_long_two_phase", 1)
     w = util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"streamed sparse n={n}")
     assert w < 1e-8, w
     assert util.compare(util.model_to_flat(mdl), util.model_to_flat(reg), TOL, what="streamed vs register") < 1e-9

@@ -62,7 +62,12 @@ if __name__ == "__main__":
     elif which == "c4":
         p = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
         # default copy=True: statistics-only preparation, the products standardise on the fly (no second 131 GB buffer)
-        run("C4 KERNEL Gram", 8192, p, 20, 1, "KERNEL", [0, p], os.environ.get("MBPLS_IMPLICIT_STD", "1") != "0")
+        # the default route at this shape (maintained thin products: K + 1 read-only passes), then the 1.34e14-flop Gram
+        run("C4 KERNEL (maintained products, default)", 8192, p, 20, 1, "KERNEL", [0, p], True)
+        os.environ["MBPLS_KERNEL_GRAM"] = "1"
+        run("C4 KERNEL (f64 MFMA Gram, MBPLS_KERNEL_GRAM=1)", 8192, p, 20, 1, "KERNEL", [0, p],
+            os.environ.get("MBPLS_IMPLICIT_STD", "1") != "0")
+        os.environ.pop("MBPLS_KERNEL_GRAM")
     elif which == "simpls":
         run("SIMPLS", 4096, 1_000_000, 10, 1, "SIMPLS", [0, 1_000_000], True)
     elif which == "nipals_q10":

@@ -25,7 +25,7 @@ from oracle import mbpls_oracle as orc
 from tests import util
 
 n, K = 4096, 10
-p = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+p = next((int(v) for v in sys.argv[1:] if v.isdigit()), 1_000_000)
 with open("/proc/meminfo") as f:
     avail = next(int(line.split()[1]) * 1024 for line in f if line.startswith("MemAvailable"))
 need = 6.5 * 8.0 * n * p

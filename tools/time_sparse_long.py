@@ -22,10 +22,11 @@ for n in ns:
     X[rng.rand(n, p) < 0.01] = np.nan
     D = DeviceMatrix(ctx, n, p)
     D.upload(X, 0)
-    for frm in (65536, 0):
+    for frm, two_phase in ((65536, 1), (0, 0), (0, 1)):
         if n > 65536 and frm:
             continue
         ctx.set_tunable("nan_long_from", frm)
+        ctx.set_tunable("nan_long_two_phase", two_phase)
         m = MBPLS(n_components=3, sparse_data=True)
         for rep in range(3):
             ctx.profile(rep == 2)
@@ -34,6 +35,7 @@ for n in ns:
         prof = ctx.profile_get()
         ctx.profile(False)
         line = "  ".join(f"{k}: {v['avg_ms']:.2f} ms {v['GBps']:.0f} GB/s x{v['launches']}" for k, v in prof.items())
-        print(f"n={n} p={p} {'streamed' if frm == 0 else 'registers'}: fit {1e3 * (t1 - t0):.1f} ms  iterations {m.nipals_iterations_}  {line}", flush=True)
+        print(f"n={n} p={p} {('two phases' if two_phase else 'one workgroup per chunk') if frm == 0 else 'registers'}: fit {1e3 * (t1 - t0):.1f} ms  iterations {m.nipals_iterations_}  {line}", flush=True)
     ctx.set_tunable("nan_long_from", 8192)
+    ctx.set_tunable("nan_long_two_phase", 1)
     D.close()
