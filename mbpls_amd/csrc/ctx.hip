@@ -26,7 +26,16 @@ int ensure_ws(mbpls_ctx* ctx, size_t bytes) {
     ctx->ws_bytes = 0;
   }
   size_t want = std::max(bytes, (size_t)1 << 20);
-  MB_HIP(hipMalloc(&ctx->ws, want));
+  hipError_t e = hipMalloc(&ctx->ws, want);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->ws = nullptr;
+    size_t f = 0, t = 0;
+    (void)hipMemGetInfo(&f, &t);
+    set_error("workspace of %.2f GB (chunk partials of a pass) does not fit the device: %.2f GB free of %.2f GB (%s)",
+              (double)want / 1e9, (double)f / 1e9, (double)t / 1e9, hipGetErrorString(e));
+    return MBPLS_ERR_OOM;
+  }
   ctx->ws_bytes = want;
   return MBPLS_OK;
 }
@@ -39,7 +48,16 @@ int ensure_stage(mbpls_ctx* ctx, size_t bytes) {
     ctx->stage = nullptr;
     ctx->stage_bytes = 0;
   }
-  MB_HIP(hipMalloc(&ctx->stage, bytes));
+  hipError_t e = hipMalloc(&ctx->stage, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->stage = nullptr;
+    size_t f = 0, t = 0;
+    (void)hipMemGetInfo(&f, &t);
+    set_error("scratch of %.2f GB (staging / per-slab partials of a pass) does not fit the device: %.2f GB free of %.2f GB (%s)",
+              (double)bytes / 1e9, (double)f / 1e9, (double)t / 1e9, hipGetErrorString(e));
+    return MBPLS_ERR_OOM;
+  }
   ctx->stage_bytes = bytes;
   return MBPLS_OK;
 }

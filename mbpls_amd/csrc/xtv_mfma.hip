@@ -269,10 +269,10 @@ int xtv_mfma(mbpls_ctx* ctx, const mbpls_mat* m, const double* d_V, int64_t ldv,
     MB_HIP(hipGetLastError());
   }
   if (d_ssq) {
-    int64_t* d_off = (int64_t*)((char*)ctx->ws + ((sizeof(double) * (size_t)total + 255) / 256) * 256);
-    MB_HIP(hipMemcpyAsync(d_off, m->block_offsets.data(), off_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // (the matrix keeps its block offsets on the device: no pageable host-to-device copy in the middle of a pass -- such
+    // copies are staged by the runtime and have been seen to execute tens of milliseconds late, small.hip)
     hipLaunchKernelGGL(k_block_colssq, dim3((unsigned)m->nblocks, (unsigned)c), dim3(256), 0, ctx->stream,
-                       (const double*)d_G, ldg, (const int64_t*)d_off, m->nblocks, d_ssq);
+                       (const double*)d_G, ldg, (const int64_t*)m->d_block_offsets, m->nblocks, d_ssq);
     MB_HIP(hipGetLastError());
   }
   return MBPLS_OK;

@@ -69,13 +69,87 @@ def cross_val_predict(estimator, X, y, cv=5, groups=None, batch_folds=True):
             except cv_batch.DegenerateFold:
                 pass                     # a fold broke down: the loop below treats every fold like a single fit
         out = np.full((n, y2.shape[1]), np.nan)
+        pending = _HeldOutPredictions(Xdev, out, sparse=estimator.sparse_data is True)
         for train, test in splits:
             est = MBPLS(**{**estimator.get_params(), "copy": True})
             mask = np.zeros(n, dtype=bool)
             mask[train] = True
             est._fit(Xdev, y2, mask)
-            out[test] = est.predict(Xdev)[test]
+            pending.add(est, test)
+        pending.flush()
         return out
     finally:
         if owned:
             Xdev.close()
+
+
+class _HeldOutPredictions:
+    """Predictions of the fold-by-fold loop without one full pass over X PER FOLD (``est.predict(Xdev)[test]`` computes
+    all n rows to keep a few).  predict is (X_std beta) sigma_y + mu_y (mbpls.py:1386) with the fold's own scalers:
+        X_std,f beta_f = X (beta_f / sigma_f) - mu_f^T (beta_f / sigma_f)
+    -- a product of the RAW resident matrix with p x q columns and a constant.  The folds' columns are collected and
+    multiplied together: one pass over X per up to 64 fold-responses instead of one per fold; every fold keeps its
+    held-out rows.  Missing values (``sparse_data=True``: an absent entry contributes nothing, :1376-1384): the constant
+    becomes a per-row sum over the PRESENT columns -- a second, indicator product with the columns mu_f o (beta_f /
+    sigma_f).  Under column shards the products and the constants are summed over the ranks."""
+
+    MAX_COLUMNS = 64
+
+    def __init__(self, Xdev, out, sparse):
+        self.X, self.out, self.sparse = Xdev, out, bool(sparse)
+        self.q = out.shape[1]
+        ctx = runtime.get_context()
+        budget = (ctx.info()["free_bytes"] + ctx._pool_bytes) // 8
+        self.cols = int(max(self.q, min(self.MAX_COLUMNS, budget // (8 * max(1, Xdev.p) * (2 if sparse else 1)))))
+        self.items = []
+        self.used = 0
+
+    def add(self, est, test):
+        if self.used + self.q > self.cols:
+            self.flush()
+        self.items.append((est, np.asarray(test)))
+        self.used += self.q
+
+    def flush(self):
+        if not self.items:
+            return
+        from .engine import HipEngine
+        X, q, p = self.X, self.q, self.X.p
+        eng = HipEngine(runtime.get_context(), runtime.get_comm())
+        ctx = eng.ctx
+        try:
+            nc = q * len(self.items)
+            W = np.empty((p, nc), order="F")
+            M = np.empty((p, nc), order="F") if self.sparse else None
+            const = np.zeros((1, nc))
+            for f, (est, _) in enumerate(self.items):
+                cols = slice(f * q, (f + 1) * q)
+                if est.standardize:
+                    mean = np.concatenate([sc.mean_ for sc in est.x_scalers_])
+                    scale = np.concatenate([sc.scale_ for sc in est.x_scalers_])
+                    W[:, cols] = est.beta_ / scale[:, None]
+                    if self.sparse:
+                        M[:, cols] = W[:, cols] * mean[:, None]
+                    else:
+                        const[0, cols] = mean.dot(W[:, cols])
+                else:
+                    W[:, cols] = est.beta_
+                    if self.sparse:
+                        M[:, cols] = 0.0
+            dW = ctx.from_host(W)
+            Yh = eng._xw(dW, nc, False, None, None, mat=X, nan="skip" if self.sparse else None)
+            dW.free()
+            if self.sparse and any(est.standardize for est, _ in self.items):
+                dM = ctx.from_host(M)
+                Yh = Yh - eng._xw(dM, nc, False, None, None, mat=X, nan="indicator")
+                dM.free()
+            elif not self.sparse:
+                Yh = Yh - eng.comm.allreduce_host(const)
+            for f, (est, test) in enumerate(self.items):
+                y = Yh[test, f * q:(f + 1) * q]
+                if not np.all(np.isfinite(y)):
+                    raise ValueError("Input X contains NaN, infinity or a value too large for dtype('float64').")
+                self.out[test] = est.y_scaler_.inverse_transform(y) if est.standardize else y
+        finally:
+            eng.close()
+            self.items, self.used = [], 0

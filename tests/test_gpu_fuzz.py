@@ -32,6 +32,6 @@ def test_random_problems_long_columns(gpu_required):
 
 def test_random_problems_wide(gpu_required):
     """... and on few samples x very many features (n <= 300, p up to 200 000): the column-group kernels at width"""
-    bad, worst = fuzz.run(12, seed=9, verbose=False, wide=True)
+    bad, worst = fuzz.run(6, seed=9, verbose=False, wide=True)     # (the CPU oracle is the slow side at these widths)
     assert bad == 0
     assert worst < 1e-8, worst
