@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
 
   // every row group walks the same number of rounds; a group past the end of the chunk re-reads the last column
   // and contributes nothing (no divergence inside the wave, the DPP rows stay whole)
-  double x[D][R], pp[D][SUB_LM], k0v[D], muv[D];
+  double x[D][R], pp[D][SUB_LM], k0v[D], muv[D], r2v[D];
   auto fetch = [&](int d, int64_t jr) {
     const int64_t j = (jr < j1) ? jr : j1 - 1;
     const double* col = a.src + j * ld;
@@ -157,6 +157,10 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
     for (int m = 0; m < SUB_LM; ++m) pp[d][m] = mine[m] ? prow[m][j] : 0.0;
     k0v[d] = (STD && ISTD) ? col[0] : 0.0;
     muv[d] = CEN ? a.mu[j] : 0.0;
+    // 1 / scale_j^2 of the raw-space passes travels WITH the column: a few dozen samples are reduced in ~50 cycles, far
+    // less than the latency of a load issued when the round begins -- every round then stalled on this one scalar
+    // (rocprofv3 --pmc, n = 40 / 128: SQ_WAIT_ANY 0.73-0.76 of the wave cycles, SQ_ACTIVE_INST_ANY 0.21-0.24)
+    r2v[d] = (ISTD && !STD) ? a.ir2[j] : 1.0;
   };
   const int64_t rounds = (j1 - j0 + NG - 1) / NG;
 #pragma unroll
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
 
       double r2c = 1.0;
       if constexpr (ISTD && !STD) {
-        r2c = a.ir2[valid ? jj : j1 - 1];
+        r2c = r2v[d];
         if constexpr (CEN) {
           const double muj = muv[d];
 #pragma unroll

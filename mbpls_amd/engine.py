@@ -1106,6 +1106,15 @@ class HipEngine(EngineBase):
         return np.asarray(self.G[1].get()).reshape(n, ldg).T[:n, :n]
 
 
+class _Keep:
+    """a flat float64 view over several adjacent host arrays, for one merged copy: keeps them alive, looks like an
+    array to ``Context.copier_submit``"""
+
+    def __init__(self, view, keeps):
+        self.view, self.keeps = view, keeps
+        self.ctypes, self.nbytes = view.ctypes, view.nbytes
+
+
 _PREFAULT = {}
 
 
@@ -1233,12 +1242,46 @@ class _ResidentQueue:
         # host image of [par .. Tb]: the n-vectors arrive per component through the copier, the scalars at the end
         self.h = np.empty(self.off["Tb"][0] + self.off["Tb"][1] - self.off["par"][0])
         self.result = None
+        # SMALL problems (the reference's own data sets: tens to hundreds of samples, thousands of features): a copy
+        # costs the copier ~30 us whatever its size, and a fit hands out six columns per component -- 36 copies made the
+        # fitting thread wait 1.1 ms for the copier behind a queue the GPU had finished in 0.45 ms (n = 150, p = 3000,
+        # K = 5: tools/host_timeline.py).  Below BULK_BYTES per attribute the columns are not streamed: ONE job behind
+        # the queue copies every array whole (adjacent columns merged into one copy) and the block normalisation of
+        # the weights is a few numpy divisions afterwards.
+        self.bulk = 8 * max(eng.p, n * max(B, 1)) * K <= self.BULK_BYTES
+        self._bulk_copies, self._bulk_posts = [], []
+
+    BULK_BYTES = 1 << 20
 
     @staticmethod
     def col(arr, k):
         c = arr[:, k]
         assert c.flags.c_contiguous
         return c
+
+    @staticmethod
+    def _merged(copies):
+        """adjacent (host view, device address) pairs -- columns k, k + 1 of the same arrays -- as one copy each"""
+        items = sorted(((int(src), dst.ctypes.data, dst.nbytes, dst) for dst, src in copies if dst.nbytes), key=lambda c: c[0])
+        out = []
+        for src, haddr, nb, keep in items:
+            if out and out[-1][0] + out[-1][2] == src and out[-1][1] + out[-1][2] == haddr:
+                out[-1][2] += nb
+                out[-1][3].append(keep)
+            else:
+                out.append([src, haddr, nb, [keep]])
+        merged = []
+        for src, haddr, nb, keeps in out:
+            view = np.ctypeslib.as_array((_capi.C.c_double * (nb // 8)).from_address(haddr))
+            view = view.view()
+            merged.append((_Keep(view, keeps), src))
+        return merged
+
+    def _submit_bulk(self):
+        """small problems: everything stream_out was asked for, as one job behind the whole queue"""
+        if self._bulk_copies:
+            self.ticket = self.scores_ticket = self.ctx.copier_submit(self._merged(self._bulk_copies))
+            self._bulk_copies = []
 
     def stream_out(self, copies, post=None, k=None, after_next_step=False):
         """copy finished device columns to the host (the context's copier thread, csrc/copier.hip) behind everything
@@ -1252,6 +1295,11 @@ class _ResidentQueue:
             for key, width in (("Ts", 1), ("U", 1), ("Tb", B)):
                 a = self.off[key][0] - o0 + n * width * k
                 copies = copies + [(self.h[a:a + n * width], self.ptr[key] + 8 * n * width * k)]
+        if self.bulk:
+            self._bulk_copies += copies
+            if post is not None:
+                self._bulk_posts.append(post)
+            return
         flag = (self.seq_h.ctypes.data, self.seq0 + self.nsteps + 1) if after_next_step else None
         self.ticket = self.ctx.copier_submit(copies, scale=post, flag=flag)
         if k is not None and k == self.K - 1:
@@ -1375,6 +1423,7 @@ class _ResidentQueue:
         h = None
         try:
             if et is None:
+                self._submit_bulk()
                 eng.run_deferred(all_of_it=True)          # host chores while the GPU works through the queue
                 with eng._timed("wait_kernel+d2h_small"):
                     # par .. V in ONE copy (waits for the queue); Ts, U, Tb have left column by column (stream_out)
@@ -1387,8 +1436,16 @@ class _ResidentQueue:
             ctx, ticket = self.ctx, self.ticket
             ctx._seq_base = self.seq0 + self.nsteps
 
+            posts, nu2_h, nB = self._bulk_posts, self.nu2_h, eng.nblocks
+
             def wait_copies():              # every column handed to the copier thread by this queue has landed
                 ctx.copier_wait(ticket)
+                while posts and ticket:     # (small problems: w_b = w~_b / ||w~_b|| here, not in the copier thread)
+                    src, dst, offs, addr = posts.pop()
+                    k = (int(addr) - nu2_h.ctypes.data) // (8 * nB)
+                    nu = np.sqrt(nu2_h[k * nB:(k + 1) * nB])
+                    for b in range(nB):
+                        np.divide(src[offs[b]:offs[b + 1]], nu[b], out=dst[offs[b]:offs[b + 1]])
 
             scores_ticket = self.scores_ticket or ticket
 

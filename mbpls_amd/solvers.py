@@ -248,7 +248,7 @@ class _StreamedColumns:
     runs -- the end of the fit then fetches R_ and beta_ only.  W_b[:, k] = w_b / ||w_b|| (:860, :510-512) is formed on
     the host from the fetched raw column."""
 
-    def __init__(self, eng, K, wslot, pslot="P", keep_raw=False, q=None):
+    def __init__(self, eng, K, wslot, pslot="P", keep_raw=False, q=None, concat=False):
         self.eng, self.wslot, self.pslot, self.pending = eng, wslot, pslot, None
         if q is not None:       # R_ / beta_ only exist at the very end: their pages are mapped while the GPU works
             eng.host_array((eng.p, K), reserve="R")
@@ -256,19 +256,31 @@ class _StreamedColumns:
         self.W = _host_array(eng, (eng.p, K))
         self.P = _host_array(eng, (eng.p, K))
         self.W_raw = _host_array(eng, (eng.p, K)) if keep_raw else None
+        # KERNEL: W_concat_ = raw column / its norm over ALL blocks (mbpls.py:733) beside the block weights
+        self.Wc = _host_array(eng, (eng.p, K)) if concat else None
 
     def component_done(self, k, blk_norm):
         self.flush()
         self.pending = (k, np.array(blk_norm, dtype=np.float64).ravel())
 
+    def finish(self):
+        """the last component's columns, behind the last pass: the small kernels that wrote them were queued AFTER the
+        last fence the overlapped copies wait for (engine.sweep records it in front of a pass), so the compute stream is
+        drained first"""
+        if self.pending is not None:
+            self.eng.sync()
+            self.flush()
+
     def flush(self):
-        """call with a pass over X in flight (or at the end of the fit)"""
+        """call with a pass over X in flight: the copies wait for what was queued before that pass (mbpls_hip_fence)"""
         if self.pending is None:
             return
         (k, nu), self.pending = self.pending, None
         eng, offs = self.eng, self.eng.block_offsets
         raw = self.W_raw if self.W_raw is not None else self.W
         eng.fetch_col(self.wslot, k, raw)
+        if self.Wc is not None:
+            np.divide(raw[:, k], np.sqrt(float(np.sum(nu * nu))), out=self.Wc[:, k])
         for b in range(eng.nblocks):
             np.divide(raw[offs[b]:offs[b + 1], k], nu[b], out=self.W[offs[b]:offs[b + 1], k])
         eng.fetch_col(self.pslot, k, self.P)
@@ -485,7 +497,7 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
     else:
         res.update(explained_var_x_=[], explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)),
                    A_corrected_=np.empty((B, 0)))
-    cols.flush()
+    cols.finish()
     _finalise_device(eng, res, "Wn", K, np.sqrt((nu_all ** 2).sum(axis=0)), nu_all, V, W_host=cols.W, P_host=cols.P)
     res.W_non_normal_ = _split(cols.W_raw, eng.block_offsets)
     return res
@@ -900,7 +912,7 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
         Acorr[:, k] = _bip_corrected(A[:, k], sizes)        # (:542-553)
     res = FitResult(Ts_=Ts, T_=T, U_=U, V_=V, A_=A, explained_var_x_=evx, explained_var_y_=evy,
                     explained_var_xblocks_=evxb, A_corrected_=Acorr)
-    cols.flush()
+    cols.finish()
     _finalise_device(eng, res, "Wc", K, tot_nrm, blk_nrm, V, W_host=cols.W, P_host=cols.P)    # (:569-572)
     return res
 
@@ -1179,15 +1191,17 @@ def _kernel_scores_on_products(eng, Y, K, standardize):
         u = AS_Y,k ts / ||.|| = (P Y) c / ||.||,  c = (P Y)^T ts  (:718-719)   =>   X^T u = [X^T (P Y)] c / ||.||   (:731)
     and X_b (X^T u)_b = [X_b (X^T (P Y))_b] c / ||.|| are the block products of calc_all (:752).  X is never written.
     Leaves the raw weights X^T U_ in slot "UT" and the loadings X^T Ts (Ts^T Ts)^+ (:734) in slot "P"; returns
-    (Ts, U, ||X_b||^2, per-block ||(X^T U_)_b||^2 (B x K), [X_b (X^T U_)_b] (n x K per block))."""
+    (Ts, U, ||X_b||^2, per-block ||(X^T U_)_b||^2 (B x K), [X_b (X^T U_)_b] (n x K per block), the columns streamed to
+    the host during the fit (block weights, W_concat_, loadings), the host loadings or None)."""
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     eng.slot("UT", K); eng.slot("Pl", K); eng.slot("S", q + 1)     # S = [X^T (P Y) | X^T ts of the component at hand]
     eng.use_lazy_deflation(K, "Pl", prefer="lazy")        # (never deflates: the never-writes-X passes when they apply)
     _plan(eng, solver="kernel p > n on maintained thin products X^T (P Y), X_b (X^T (P Y))_b: one pass over X per "
                       "component, no association matrix")
-    for name, cols in (("R", K), ("beta", q), ("Wblk", K), ("P", K), ("Wc", K)):
-        eng.host_array((eng.p, cols), reserve=name)       # (pages mapped by the helper thread while the passes run)
+    # finished columns leave beside the passes (copy stream; block / column normalisation on the idle host): X^T u and
+    # X^T ts / ts^T ts of component k while the pass of component k + 1 runs -- the end of the fit fetches R_, beta_ only
+    cols = _StreamedColumns(eng, K, "UT", pslot="Pl", q=q, concat=True)
     prod = _ResponseProducts(eng, Y, standardize)
     varxb = prod.varxb
     Yd = Y.copy()
@@ -1206,15 +1220,22 @@ def _kernel_scores_on_products(eng, Y, K, standardize):
         u = Yd.dot(c); un = np.linalg.norm(u); u = u / un   # (:718-719)
         t_raw, wnorm2[:, k] = prod.combination(c / un, ("UT", k))    # X^T u (:731), X_b (X^T u)_b, ||(X^T u)_b||^2
         tts[k] = ts.T.dot(ts).item()
-        prod.component(ts, 1.0 / tts[k], ("Pl", k))         # the pass: X^T ts / ts^T ts; X^T (P Y), X_b (..)_b without ts
+        # the pass: X^T ts / ts^T ts; X^T (P Y), X_b (..)_b without ts (the previous component's columns leave meanwhile)
+        prod.component(ts, 1.0 / tts[k], ("Pl", k), overlap=cols.flush)
+        cols.component_done(k, np.sqrt(wnorm2[:, k]))
         Yd = Yd - ts.dot(ts.T.dot(Yd))                      # AS_Y = D AS_Y D (:724)
         Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u
         for b in range(B):
             XW[b][:, k] = t_raw[:, b]
     G = np.linalg.pinv(Ts.T.dot(Ts))
     eng.slot("P", K)
-    eng.right_mul(("Pl", 0, K), tts[:, None] * G, ("P", 0))  # P = X^T Ts (Ts^T Ts)^+ (:734)
-    return Ts, U, varxb, wnorm2, XW
+    C = tts[:, None] * G
+    eng.right_mul(("Pl", 0, K), C, ("P", 0))                # P = X^T Ts (Ts^T Ts)^+ (:734), on the device for P^T W below
+    cols.finish()
+    # the streamed columns ARE the loadings when the scores are orthonormal (C = I to rounding: always, unless a
+    # response was exhausted): no second copy of a p x K array then
+    P_host = cols.P if float(np.max(np.abs(C - np.eye(K)))) <= 1e-13 else None
+    return Ts, U, varxb, wnorm2, XW, cols, P_host
 
 
 def fit_kernel(eng, Y, K, standardize, calc_all=True):
@@ -1238,19 +1259,22 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
                         A_=np.empty((B, 0)), A_corrected_=np.empty((B, 0)), explained_var_x_=[],
                         explained_var_y_=[], explained_var_xblocks_=np.empty((B, 0)))
     if p_total > n and products:
-        Ts, U, varxb, wnorm2, XWraw = _kernel_scores_on_products(eng, Y, K, standardize)
+        Ts, U, varxb, wnorm2, XWraw, cols, P_host = _kernel_scores_on_products(eng, Y, K, standardize)
         G = np.linalg.pinv(Ts.T.dot(Ts))
         V = Y.T.dot(Ts).dot(G)                          # (:735)
         cn = np.sqrt(wnorm2.sum(axis=0))
-        eng.slot("Wc", K)
-        eng.right_mul(("UT", 0, K), np.diag(1.0 / cn), ("Wc", 0))     # column-normalised weights (:733)
         res.update(Ts_=Ts, U_=U, V_=V)
-        fetch_all = _finalise_device(eng, res, "UT", K, cn, np.sqrt(wnorm2), V, fetch=False)   # (:737-738)
-        fetch_all()
-        res.W_concat_ = eng.fetch("Wc")
+        # R_, beta_ (:737-738) and the block weights on the device; of the p x K arrays only R_ and beta_ are fetched here
+        _finalise_device(eng, res, "UT", K, cn, np.sqrt(wnorm2), V, fetch=False)
+        wait_r, wait_b = eng.fetch_async("R")[1], eng.fetch_async("beta")[1]
         if calc_all:        # X_b W_b came with the maintained products: no further pass over X
             _kernel_extras_device(eng, res, Y, V, Ts, varxb, "UT", wnorm2, XW=XWraw)
-        else:
+        offs = eng.block_offsets
+        res.R_, res.beta_ = wait_r(), wait_b()
+        res.W_ = _split(cols.W, offs)
+        res.P_ = _split(P_host if P_host is not None else eng.fetch("P"), offs)
+        res.W_concat_ = cols.Wc
+        if not calc_all:
             res.update(empty_blocks)
         return res
     if p_total > n:

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Evidence of one round (everything named profiles/<round>_*): run on the GPU box from the repo root,
-#   gpurun --timeout 3400 -- 'bash tools/gpu_evidence.sh r05 [part ...]'      parts: bench dist configs shapes cv paper sparse fuzz prof long gaps (default: all)
+#   gpurun --timeout 3400 -- 'bash tools/gpu_evidence.sh r05 [part ...]'      parts: bench dist configs shapes cv paper sparse fuzz prof long gaps sparselong kroutes (default: all)
 # then, back on the build machine:  python tools/collect_evidence.py r05 [--table]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 RND=${1:-r05}
 shift
-PARTS=${*:-bench dist configs shapes cv paper sparse fuzz prof long gaps}
+PARTS=${*:-bench dist configs shapes cv paper sparse fuzz prof long gaps sparselong kroutes}
 O=$R/gpurun_out/${RND}ev
 mkdir -p $O
 cd $R
@@ -20,7 +20,7 @@ if has dist; then
 fi
 if has configs; then
   rm -f $O/${RND}_other_configs_lines.jsonl
-  for c in c3 c4 simpls nipals_q10 unipals_q10 nipals_mb; do timeout 600 python3 tools/bench_configs.py $c 2>/dev/null | tail -1 >> $O/${RND}_other_configs_lines.jsonl; done
+  for c in c3 c4 simpls nipals_q10 unipals_q10 nipals_mb; do timeout 600 python3 tools/bench_configs.py $c 2>/dev/null | grep "^{" >> $O/${RND}_other_configs_lines.jsonl; done
 fi
 if has shapes; then
   ( timeout 900 python3 tools/time_shapes.py 8 NIPALS 1 2>/dev/null | grep '^n='; timeout 600 python3 tools/time_shapes.py 8 UNIPALS 1 1200,2500,3000,5000,6000,7000,8192,12000,16384 2>/dev/null | grep '^n=' ) > $O/${RND}_shapes.txt
@@ -49,6 +49,20 @@ if has prof; then
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc/FETCH_SIZE -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-cols 0 --e2e-cols 0 --no-extras > $O/pmc_fetch.log 2>&1; echo fetch rc=$?
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc/WRITE_SIZE -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-cols 0 --e2e-cols 0 --no-extras > $O/pmc_write.log 2>&1; echo write rc=$?
   ( cd $R && python3 tools/pmc_to_json.py $O/pmc 4096 1000000 $RND > $O/pmc_c2_summary.txt 2>&1; cp profiles/${RND}_pmc_traffic_c2.json profiles/${RND}_pmc_*_bench_c2_counter_collection.csv $O/ 2>/dev/null )
+fi
+if has sparselong; then
+  # missing values on long columns (two streaming phases): timings, kernel stats, HBM traffic from the PMC counters
+  ( cd $R && timeout 900 python3 tools/time_sparse_long.py 16384 32768 65536 200000 2>/dev/null | grep '^n=' > $O/${RND}_sparse_long_columns.txt )
+  rm -rf $O/sl_stats $O/sl_pmc
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sl_stats -- python3 $R/tools/sparse_long_one.py 32768 61035 3 > $O/sl_stats.log 2>&1; echo sl stats rc=$?
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/sl_pmc/FETCH_SIZE -- python3 $R/tools/sparse_long_one.py 32768 61035 1 > $O/sl_fetch.log 2>&1; echo sl fetch rc=$?
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/sl_pmc/WRITE_SIZE -- python3 $R/tools/sparse_long_one.py 32768 61035 1 > $O/sl_write.log 2>&1; echo sl write rc=$?
+  ( cd $R && python3 tools/pmc_kernels_to_json.py $O/sl_pmc $O/${RND}_pmc_traffic_sparse_long.json $(python3 -c "print(8.0*32768*61035)") k_nl_ > $O/${RND}_pmc_traffic_sparse_long.txt 2>&1
+    cp $(find $O/sl_stats -name '*kernel_stats.csv' | head -1) $O/${RND}_sparse_long_rocprofv3_kernel_stats.csv 2>/dev/null
+    for c in FETCH_SIZE WRITE_SIZE; do cp $(find $O/sl_pmc/$c -name '*counter_collection.csv' | head -1) $O/${RND}_pmc_${c}_sparse_long_counter_collection.csv 2>/dev/null; done )
+fi
+if has kroutes; then
+  ( cd $R && ( timeout 600 python3 tools/time_kernel_routes.py small; timeout 900 python3 tools/time_kernel_routes.py big; timeout 600 python3 tools/time_kernel_routes.py c4 ) 2>/dev/null | grep '^{' > $O/${RND}_kernel_routes.jsonl )
 fi
 if has gaps; then
   rm -rf $O/trace125k
