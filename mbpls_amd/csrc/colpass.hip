@@ -45,23 +45,20 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   // column data; with the lazy-deflation state that no longer fits 128.  Its score vector ts therefore
   // lives in LDS (32 KB, each thread re-reads only its own row pairs: conflict-free ds_read_b128).
   constexpr bool TS_LDS = DEFL && SWEEP && R == 8 && TMAX == 512;
-  // 4096 < n <= 8192 (R = 16, 512 threads: one 8-wave workgroup per CU, 256 VGPRs per wave): the fused pass holds
-  // x[2], ts, v, acc = 160 VGPRs of column data and, with the lazy-deflation state, spilled 9-31 registers to scratch
-  // inside its column loop (.private_segment_fixed_size 36-124 bytes, round 6).  Its sweep vector lives in LDS (64 KB of
-  // the CU's 160): no spill.  (Two workgroups per CU -- one column in flight, v in LDS, 128 VGPRs -- spill 75.)
-#ifndef MB_R16_V_LDS
-#define MB_R16_V_LDS 1
-#endif
-  constexpr bool V_LDS = TS_LDS || (MB_R16_V_LDS && DEFL && SWEEP && R == 16 && TMAX == 512);
+  // (Round 6 tried two things here and kept neither, same-box A/B in profiles/r06_ab_colpass_v_lds_r2_prefetch.txt: the
+  // sweep vector in LDS for the R = 16 fused pass too -- its 9-31 spilled registers go away (.private_segment_fixed_size
+  // 36-124 -> 0) and the pass is 1.5-3.7 % SLOWER at n = 5000 ... 8192, unchanged at 4096; and 1/scale_j^2 requested
+  // with the column instead of at its start -- nothing for the fused pass, -13 % for the plain sweep at n = 4096, whose
+  // 128-VGPR budget it breaks.  Short columns do gain from the latter: colpass_sub.hip.)
   // dynamic LDS sized by the ACTUAL workgroup (2 x T x R/2 double2): a statically TMAX-sized array would cap small
   // workgroups (n < 4096) at two per CU
   extern __shared__ double2 s_dyn[];
   double2* s_ts = s_dyn;
   double2* s_v = s_dyn + (TS_LDS ? (int)blockDim.x * (R / 2) : 0);   // same treatment for the sweep vector there
-  double v[(SWEEP && !V_LDS) ? R : 1], ts[(DEFL && !TS_LDS) ? R : 1], acc[SWEEP ? R : 1];
+  double v[(SWEEP && !TS_LDS) ? R : 1], ts[(DEFL && !TS_LDS) ? R : 1], acc[SWEEP ? R : 1];
   double tsv = 0.0;
   if constexpr (SWEEP) {
-    if constexpr (V_LDS) {
+    if constexpr (TS_LDS) {
       double tmp[R];
       load_vec<R>(tmp, a.v, n, tid, T);
 #pragma unroll
@@ -73,7 +70,7 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
     for (int k = 0; k < R; ++k) acc[k] = 0.0;
   }
   auto v_pair = [&](int k) -> double2 {
-    if constexpr (V_LDS) return s_v[k * T + tid];
+    if constexpr (TS_LDS) return s_v[k * T + tid];
     else return make_double2(v[2 * k], v[2 * k + 1]);
   };
   if constexpr (DEFL && !TS_LDS) load_vec<R>(ts, a.ts, n, tid, T);
@@ -142,7 +139,6 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
   double pp[D];   // P[column, tid] of the column held in slot d (0 for threads >= kprev)
   double k0v[(STD && ISTD) ? D : 1];   // statistics-only pass: first sample of the column in slot d (the shift)
   double muv[CEN ? D : 1];  // raw-space passes on offset data: mean of the column in slot d, requested with the column
-  double r2v[(ISTD && !STD) ? D : 1];   // 1/scale_j^2 of the column in slot d (wave-uniform), requested with the column too
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     pp[d] = 0.0;
@@ -151,7 +147,6 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
       if (mine) pp[d] = prow[j0 + d];
       if constexpr (STD && ISTD) k0v[d] = a.src[(j0 + d) * ld];
       if constexpr (CEN) muv[d] = a.mu[j0 + d];
-      if constexpr (ISTD && !STD) r2v[d] = a.ir2[j0 + d];
     }
   }
 
@@ -299,11 +294,11 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
       }
 
       double gj = 0.0, pjk = 0.0;
-      // 1/scale_j^2 of the raw-space passes: requested with the column (short columns are reduced faster than a scalar
-      // load issued here comes back)
+      // 1/scale_j^2 of the raw-space passes: requested here, ahead of the dot products, so the scalar load is not
+      // waited for behind the reduction
       double r2c = 1.0;
       if constexpr (ISTD && !STD) {
-        r2c = r2v[d];
+        r2c = a.ir2[jj];
         if constexpr (CEN) {
           const double muj = muv[d];
 #pragma unroll
@@ -384,7 +379,6 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpa
         if (mine) pp[d] = prow[jj + D];
         if constexpr (STD && ISTD) k0v[d] = a.src[(jj + D) * ld];
         if constexpr (CEN) muv[d] = a.mu[jj + D];
-        if constexpr (ISTD && !STD) r2v[d] = a.ir2[jj + D];
       }
     }
   }
@@ -604,9 +598,7 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   const bool istd = STD ? (SWEEP && a.dst == nullptr) : (a.lazy && a.ir2 != nullptr);
   const bool cen = !STD && istd && a.mu != nullptr;   // offset data: subtract the column mean in registers
   // loadings+sweep at R=8 keeps ts and v in LDS (see TS_LDS in the kernel): T x R/2 double2 each
-  // ... and at R=16 the sweep vector alone (T x 8 double2)
-  const unsigned dyn_lds = (DEFL && SWEEP && cfg.R == 8 && cfg.TMAX == 512) ? 2u * (unsigned)T * 4u * 16u
-                           : (MB_R16_V_LDS && DEFL && SWEEP && cfg.R == 16 && cfg.TMAX == 512) ? (unsigned)T * 8u * 16u : 0u;
+  const unsigned dyn_lds = (DEFL && SWEEP && cfg.R == 8 && cfg.TMAX == 512) ? 2u * (unsigned)T * 4u * 16u : 0u;
 #define MB_LAUNCH(R_, TM_, D_)                                                                          \
   do {                                                                                                  \
     constexpr bool F_ = ((R_) >= 8);                                                                    \

@@ -50,11 +50,15 @@ __device__ __forceinline__ double group_sum(double v) {
 
 // LG lanes per column (8: eight columns per wave, n <= 16 KR; 16: four, n <= 32 KR; 32: two, n <= 64 KR; 64: one,
 // n <= 128 KR)
-template <int LG, int KR, int D, bool STD, bool DEFL, bool SWEEP, bool ISTD, bool CEN>
+// LM1: at most LG earlier components to correct for (or none: every pass that is not lazy) -- ONE correction slot per
+// lane instead of ceil(39 / LG).  The slots cost the 8-lane shapes ~80 VGPRs (pointers, coefficients, prefetched
+// loadings, accumulators for five of them): with them the fused pass sits at 194-218 VGPRs = two waves per SIMD, and
+// few-sample columns are short on bytes in flight, not on arithmetic (rocprofv3: waves parked 0.73-0.76 of their cycles).
+template <int LG, int KR, int D, bool STD, bool DEFL, bool SWEEP, bool ISTD, bool CEN, bool LM1 = false>
 __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
   constexpr int R = 2 * KR;
   constexpr int NG = 256 / LG;                       // column groups per workgroup
-  constexpr int SUB_LM = (KD - 1 + LG - 1) / LG;     // lazy corrections per lane: components s, s + LG, ...
+  constexpr int SUB_LM = LM1 ? 1 : (KD - 1 + LG - 1) / LG;     // lazy corrections per lane: components s, s + LG, ...
   __shared__ double s_t[SUB_MAX_N];
   __shared__ double s_s[NG][4];
   __shared__ double s_d[NG][SUB_LM * LG + 1];
@@ -451,9 +455,19 @@ static void launch_sub_kr(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& 
   const bool cen = !STD && istd && a.mu != nullptr;
   constexpr bool IS_ = !STD || SWEEP;
   constexpr bool CE_ = !STD;
-  if (cen) hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, IS_, CE_>), grid, block, 0, ctx->stream, a);
-  else if (istd) hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, IS_, false>), grid, block, 0, ctx->stream, a);
-  else hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, false, false>), grid, block, 0, ctx->stream, a);
+  // one correction slot per lane covers every pass that is not lazy and every lazy one with at most LG earlier components
+  const bool lm1 = STD || !a.lazy || a.kprev <= LG;
+  if (lm1) {
+    if (cen) hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, IS_, CE_, true>), grid, block, 0, ctx->stream, a);
+    else if (istd) hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, IS_, false, true>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, false, false, true>), grid, block, 0, ctx->stream, a);
+    return;
+  }
+  if constexpr (!STD) {
+    if (cen) hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, IS_, CE_>), grid, block, 0, ctx->stream, a);
+    else if (istd) hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, IS_, false>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_colpass_sub<LG, KR, D, STD, DEFL, SWEEP, false, false>), grid, block, 0, ctx->stream, a);
+  }
 }
 
 // (lanes per column, row pairs per lane) by n: the tightest cover of the column -- lanes past the end of a column

@@ -598,6 +598,11 @@ int mbpls_hip_mat_create(mbpls_ctx* ctx, int64_t n, int64_t p, int nblocks, cons
   // two resident per CU) the passes of a shard-sized fit run 3 % faster and the reduction 13 -> 9 us; at 10^6 columns
   // (976 per chunk) four stay 0.3-0.7 % ahead (rocprofv3, round 4).
   int cpc = ctx->chunks_per_cu;
+  // Few samples (n <= 128, colpass_sub.hip): the fused pass runs three 4-wave workgroups per CU (136-168 VGPRs), so FOUR
+  // chunks per CU are a round of three and a round of one; six are two full rounds -- loadings + deflation + sweep
+  // + 6 % (n = 40), + 8-12 % (n = 64), + 7 % (n = 128), - 3 % at n = 256 (profiles/r06_ab_sub_lm1.txt and the chunk sweep
+  // beside it): six up to 128 samples.
+  if (ctx->chunks_adaptive && cpc == 4 && n <= 128) cpc = 6;
   if (ctx->chunks_adaptive && cpc >= 4 && p / ((int64_t)ctx->cus * cpc) < 512) cpc /= 2;
   int rc = build_chunks(ctx, m->block_offsets, ctx->cus * cpc, &m->fine);
   if (rc == MBPLS_OK) {
