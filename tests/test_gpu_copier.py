@@ -143,3 +143,46 @@ def test_repeated_fits_are_bit_identical(n, p, blocks, K, method):
     first = digest(MBPLS(n_components=K, method=method).fit(X, Y))
     assert all(digest(MBPLS(n_components=K, method=method).fit(X, Y)) == first for _ in range(40))
     X.close()
+
+
+@pytest.mark.parametrize("method,blocks,K", [("NIPALS", 3, 5), ("UNIPALS", 1, 4), ("NIPALS", 2, 1)])
+def test_small_fits_copy_their_attributes_whole(monkeypatch, method, blocks, K):
+    """Small problems do not stream their columns out one by one (a copy costs the copier ~30 us whatever its size: 36
+    copies kept a 0.45 ms queue waiting 1.1 ms): engine._ResidentQueue collects them and submits ONE job of merged
+    copies behind the queue, the block normalisation of the weights follows on the host.  Same attributes, bit for
+    bit, as the streamed form (BULK_BYTES = 0), on both routes of one-response NIPALS."""
+    from mbpls_amd import MBPLS
+    from mbpls_amd import engine
+    from oracle import mbpls_oracle as orc
+    from tests import util
+    n, p = 150, 3000
+    X, Y = orc.make_latent(n, p, 1, r=6, seed=17 + K)
+    cuts = [p * (b + 1) // blocks for b in range(blocks - 1)]
+    Xs = [np.ascontiguousarray(b) for b in np.split(X, cuts, axis=1)] if blocks > 1 else X
+    submitted = []
+    real = _ctx().copier_submit.__func__
+
+    def spy(self, copies, **kw):
+        submitted.append(len(copies))
+        return real(self, copies, **kw)
+
+    monkeypatch.setattr(type(_ctx()), "copier_submit", spy)
+    for q1 in ("1", "0"):
+        monkeypatch.setenv("MBPLS_NIPALS_Q1_FIXED_POINT", q1)
+        submitted.clear()
+        bulk = MBPLS(n_components=K, method=method).fit(Xs, Y)
+        jobs_bulk = list(submitted)
+        monkeypatch.setattr(engine._ResidentQueue, "BULK_BYTES", 0)
+        submitted.clear()
+        streamed = MBPLS(n_components=K, method=method).fit(Xs, Y)
+        jobs_streamed = list(submitted)
+        monkeypatch.undo()
+        monkeypatch.setattr(type(_ctx()), "copier_submit", spy)
+        assert len(jobs_bulk) <= 3 < len(jobs_streamed) or K == 1, (jobs_bulk, jobs_streamed)
+        a, b = util.model_to_flat(bulk), util.model_to_flat(streamed)
+        assert set(a) == set(b)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+        ref = orc.fit(Xs, Y, n_components=K, method=method)
+        assert util.compare(a, util.model_to_flat(ref), 1e-6, what="bulk copies") < 1e-9
+

@@ -306,3 +306,18 @@ def test_random_problems_with_missing_values_through_the_host_drivers(monkeypatc
             assert list(res.nipals_iterations_) == ([1] * K if one_pass else list(ref.nipals_iterations_)), what
         done += 1
     assert done >= 30 and worst < 1e-7, (done, worst)
+
+
+def test_adjacent_copies_are_merged():
+    """_ResidentQueue._merged: columns k, k + 1 of the same device slot and the same F-ordered host array become one
+    copy; anything not adjacent on BOTH sides stays apart"""
+    from mbpls_amd.engine import _ResidentQueue
+    A = np.zeros((100, 4), order="F")
+    B = np.zeros((100, 2), order="F")
+    base = 1 << 20
+    copies = [(A[:, 1], base + 800), (A[:, 0], base), (A[:, 2], base + 1600), (B[:, 0], base + 2400), (A[:, 3], base + 9000),
+              (B[:, 1], base + 2400 + 800)]
+    merged = _ResidentQueue._merged(copies)
+    sizes = sorted((m[0].nbytes, m[1] - base) for m in merged)
+    assert sizes == [(800, 9000), (1600, 2400), (2400, 0)], sizes
+    assert merged[0][0].ctypes.data == A.ctypes.data
