@@ -266,6 +266,8 @@ class Context:
             self.trim_pool()
 
     def trim_pool(self):
+        for m in self.__dict__.pop("_mat_cache", {}).values():      # (small upload matrices kept between fits, engine.py)
+            m.close()
         for lst in self._pool.values():
             for ptr in lst:
                 self.lib.mbpls_hip_free(self.handle, ptr)

@@ -23,6 +23,7 @@ class HipEngine(EngineBase):
     has_association_matrices = True
     has_device_helpers = True
     KD = 40                     # == KD of csrc/colpass.hip (max lazily deflated components + 1)
+    MAT_CACHE_BYTES = 32 << 20  # uploaded matrices up to this size are kept (at most four shapes) for the next fit
     # Deflation strategy of the NIPALS / UNIPALS(p>n) drivers.  "lazy": X in HBM is never rewritten, the
     # rank-1 updates X <- X - ts p^T (mbpls.py:969) are applied algebraically inside the next passes
     # (one READ of X per loadings+deflation+sweep instead of read+write).  "explicit": in-place update.
@@ -58,10 +59,17 @@ class HipEngine(EngineBase):
         the caller's arrays are only ever read."""
         n = blocks[0].shape[0]
         offs = np.concatenate(([0], np.cumsum([b.shape[1] for b in blocks]))).astype(np.int64)
-        X = _capi.DeviceMatrix(self.ctx, n, int(offs[-1]), offs)
+        # small problems: the matrix object of the previous fit of this very shape, if there was one -- creating one
+        # costs seven allocations and uploads for the block offsets and chunk tables (70 us of a 0.6 ms fit at the
+        # README quick-start size); every column is overwritten by the uploads below
+        self._mat_key = (int(n), tuple(int(o) for o in offs))
+        X = self.ctx.__dict__.setdefault("_mat_cache", {}).pop(self._mat_key, None)
+        if X is None:
+            X = _capi.DeviceMatrix(self.ctx, n, int(offs[-1]), offs)
         for b, o in zip(blocks, offs[:-1]):
             X.upload(b, int(o))
         self._set_matrix(X, owns=True)
+        self._uploaded = X
         return self
 
     def load_device(self, dmat, copy=True):
@@ -112,8 +120,13 @@ class HipEngine(EngineBase):
             s.free()
         self.slots = {}
         if self.X is not None and self._owns_X:
-            self.X.close()
-        self.X = None
+            cache = self.ctx.__dict__.setdefault("_mat_cache", {}) if self.ctx.handle else None
+            if (cache is not None and self.X is getattr(self, "_uploaded", None) and self.X.nbytes <= self.MAT_CACHE_BYTES
+                    and len(cache) < 4 and self._mat_key not in cache):
+                cache[self._mat_key] = self.X           # (kept for the next fit of this shape; Context.trim_pool drops it)
+            else:
+                self.X.close()
+        self.X = self._uploaded = None
         if self.G is not None:
             self.G[0].close()
             if hasattr(self.G[1], "free"):

@@ -12,6 +12,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_BLAS_CAP = []
+
+
+def pytest_sessionstart(session):
+    """The BLAS pools of the test process (the oracle's numpy) are capped at the CPU quota of the box for the whole
+    session.  The GPU boxes show 256 CPUs under a 16-CPU cgroup quota: OpenBLAS sizes its pool from the first number
+    (128 threads), the pool spins for ~0.1 s after every call, uses up the quota of the 100 ms scheduler period within
+    12 ms and the whole process -- the thread that drives the GPU and the copier included -- stands still for the rest
+    of it.  A fit of 1.5 ms then takes 75 (profiles/r06_stall_throttled.txt; tools/stall_trace.py).  Inside a fit the
+    package limits the pools itself (runtime.host_threads); this is for the oracle fits and data generators around it."""
+    try:
+        import threadpoolctl
+        from mbpls_amd import runtime
+        _BLAS_CAP.append(threadpoolctl.threadpool_limits(limits=max(1, min(runtime.cpu_quota(), 32))))
+    except Exception:           # no threadpoolctl: the tests still run, wall-clock guards discount throttled periods
+        pass
+
+
 def _gpu_present():
     try:
         from mbpls_amd import _capi

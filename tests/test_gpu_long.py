@@ -257,7 +257,8 @@ def _two_phase_fits_do_not_stall(ctx):
     (the small matrices of the device helpers, the block offsets of the matrix-core X^T V) are staged by the runtime and
     now and then executed tens of milliseconds late.  They go through the context's pinned ring now (csrc/small.hip)
     or are not made at all (csrc/xtv_mfma.hip); the timeline of such a fit is profiles/r06_two_phase_*.  Here: eight
-    fits on the two-phase passes, none may take more than 20 ms, no pass more than 2 ms."""
+    fits on the two-phase passes, none may take more than 20 ms, no pass more than 2 ms -- fits during which the box's
+    cgroup ran out of CPU quota (util.cpu_throttled_periods) are not counted: those stand still wherever they are."""
     import time
     from mbpls_amd import MBPLS, DeviceMatrix
     from bench import planted
@@ -269,19 +270,29 @@ def _two_phase_fits_do_not_stall(ctx):
     ctx.sync()
     dT.free()
     try:
-        walls = []
-        for i in range(10):
+        walls, stalled = [], 0
+        for i in range(40):
+            thr0 = util.cpu_throttled_periods()
             ctx.profile(True); ctx.profile_reset()
             t0 = time.perf_counter()
             m = MBPLS(n_components=3).fit(X, Y)
             ctx.sync()
-            walls.append(time.perf_counter() - t0)
+            wall = time.perf_counter() - t0
             prof = ctx.profile_get(); ctx.profile(False)
-            if i >= 2:                                          # (the first fits of a shape build scratch and pools)
-                assert "two streaming phases" in m.fit_plan_["kernels"], m.fit_plan_
-                assert max(v["avg_ms"] for v in prof.values()) < 2.0, prof
-                assert m.fit_timings_["total"] < 0.020, m.fit_timings_
-        assert sorted(walls[2:])[len(walls[2:]) // 2] < 0.010, walls
+            assert "two streaming phases" in m.fit_plan_["kernels"], m.fit_plan_
+            if i < 2:                                               # (the first fits of a shape build scratch and pools)
+                continue
+            if thr0 >= 0 and util.cpu_throttled_periods() != thr0:  # the box took the CPU away during this fit
+                stalled += 1
+                continue
+            walls.append(wall)
+            worst = max(prof, key=lambda k: prof[k]["avg_ms"])
+            assert prof[worst]["avg_ms"] < 2.0, (i, worst, prof[worst], m.fit_timings_, walls)
+            assert m.fit_timings_["total"] < 0.020, (i, m.fit_timings_, walls)
+            if len(walls) == 8:
+                break
+        assert len(walls) >= 4, (walls, stalled)
+        assert sorted(walls)[len(walls) // 2] < 0.010, walls
     finally:
         X.close()
 

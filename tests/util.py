@@ -114,3 +114,18 @@ def forced_routes(**forms):
     finally:
         FitOptions.forced.clear()
         FitOptions.forced.update(old)
+
+
+def cpu_throttled_periods():
+    """Periods in which this process's cgroup ran out of CPU quota so far (cgroup v2 `cpu.stat`, else v1; -1 when the
+    file is not there).  The GPU boxes of the pool run under a 16-CPU quota shared with their neighbours and are
+    throttled in most 100 ms periods (profiles/r06_stall_throttled.txt): a wall-clock guard has to leave out the fits a
+    throttled period fell into -- the whole process, copier thread included, stands still for up to 75 ms there."""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            with open(path) as f:
+                d = dict(line.split() for line in f)
+            return int(d.get("nr_throttled", 0))
+        except (OSError, ValueError):
+            pass
+    return -1

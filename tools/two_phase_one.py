@@ -28,5 +28,7 @@ for i in range(fits):
     prof = ctx.profile_get(); ctx.profile(False)
     print(f"fit {i}: {1e3 * dt:.2f} ms  " + "  ".join(f"{k}: {v['avg_ms']:.3f} ms x{v['launches']}" for k, v in prof.items()),
           flush=True)
+    if dt > 0.010:
+        print("   slow:", {k: round(1e3 * v, 2) for k, v in m.fit_timings_.items() if v > 5e-4}, flush=True)
 print(m.fit_plan_)
 print({k: round(1e3 * v, 2) for k, v in m.fit_timings_.items()})
