@@ -35,6 +35,12 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
     from mbpls_amd import MBPLS
     from mbpls_amd.plan import FitOptions
     warnings.filterwarnings("ignore")
+    try:        # the oracle's BLAS pool at the CPU quota of the box (see tests/conftest.py), for runs outside pytest too
+        import threadpoolctl
+        from mbpls_amd import runtime
+        _cap = threadpoolctl.threadpool_limits(limits=max(1, min(runtime.cpu_quota(), 32)))    # noqa: F841
+    except Exception:
+        pass
     rng = np.random.RandomState(seed)
     print_ = print if verbose else (lambda *a, **k: None)
     worst, bad = 0.0, 0

@@ -32,12 +32,12 @@ fi
 if has sparse; then timeout 600 python3 tools/time_sparse.py 1000000 0.05 > $O/${RND}_sparse_n4096_p1m.txt 2>&1; fi
 if has fuzz; then
   ( echo "tests/fuzz.py on the code of $RND (random shapes / block splits / methods / settings incl. column offsets and missing values; HIP path vs the oracles, worst relative error over all fitted attributes and predictions):"
-    for sd in 505 606; do echo -n "small seed $sd: "; timeout 900 python3 tools/fuzz_parity.py 200 $sd 2>&1 | tail -1; done
-    for sd in 707; do echo -n "register-resident columns (1024 < n <= 8192) seed $sd: "; timeout 900 python3 tools/fuzz_parity.py 60 $sd big 2>&1 | tail -1; done
-    for sd in 808; do echo -n "long columns (8192 < n <= 131072) seed $sd: "; timeout 900 python3 tools/fuzz_parity.py 40 $sd long 2>&1 | tail -1; done
-    for sd in 909; do echo -n "wide (n <= 300, p up to 200000) seed $sd: "; timeout 900 python3 tools/fuzz_parity.py 40 $sd wide 2>&1 | tail -1; done
+    for sd in ${FUZZ_SMALL_SEEDS:-505 606}; do echo -n "small seed $sd: "; timeout 900 python3 tools/fuzz_parity.py 200 $sd 2>&1 | tail -1; done
+    for sd in ${FUZZ_BIG_SEEDS:-707}; do echo -n "register-resident columns (1024 < n <= 8192) seed $sd: "; timeout 900 python3 tools/fuzz_parity.py 60 $sd big 2>&1 | tail -1; done
+    for sd in ${FUZZ_LONG_SEEDS:-808}; do echo -n "long columns (8192 < n <= 131072) seed $sd: "; timeout 900 python3 tools/fuzz_parity.py 40 $sd long 2>&1 | tail -1; done
+    for sd in ${FUZZ_WIDE_SEEDS:-909}; do echo -n "wide (n <= 300, p up to 200000) seed $sd: "; timeout 900 python3 tools/fuzz_parity.py 40 $sd wide 2>&1 | tail -1; done
     echo "column shards, two ranks sharing the GPU (tests/_shared_gpu_fuzz_worker.py), 200 problems:"
-    PYTHONPATH=$R MBPLS_FUZZ_CASES=200 MBPLS_FUZZ_SEED=1001 timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29611 tests/_shared_gpu_fuzz_worker.py 2>&1 | grep "random sharded problems" ) > $O/${RND}_fuzz_suite_seeds.txt
+    PYTHONPATH=$R MBPLS_FUZZ_CASES=200 MBPLS_FUZZ_SEED=${FUZZ_SHARD_SEED:-1001} timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29611 tests/_shared_gpu_fuzz_worker.py 2>&1 | grep "random sharded problems" ) > $O/${RND}_fuzz_suite_seeds.txt
 fi
 if has long; then
   ( for s in "16384 100000" "1000000 2000" "20000 20000" "20000 1000" "65536 30000"; do timeout 400 python3 tools/time_long.py $s 2>&1 | grep -v "host phases"; done ) > $O/${RND}_long_columns.txt
