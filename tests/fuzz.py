@@ -141,9 +141,23 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         # samples, on uncentred data most of all.  A fit can follow it to about that defect, not to 1e-6: where 50 x
         # the ORACLE's own defect exceeds 1e-8 that is the bound of the case (asserted; the case then stays out of
         # ``worst``), everywhere else the usual 1e-6 (tests/test_gpu_parity.py::test_simpls_follows_the_reference_...)
+        # The defect is not the whole of it: with K next to the rank of the (centred) data the last score u - T (T^T u)
+        # (:1017-1019) is what cancellation leaves of a vector that lies in span(T) to six or seven digits.  Seed 1707,
+        # case 133 (n = 9, K = 8, standardised: rank 8): Ts orthonormal to 2e-10, yet ONE ULP on random elements of X
+        # moves the oracle's own U_[:, 7] by 7e-7 and V_[:, 7] by 2e-5.  The oracle refitted on inputs perturbed by one
+        # ulp measures that; the bound of a SIMPLS case is 50 x the larger of the two figures.
         bound = None
         if method == "SIMPLS":
             defect = float(np.max(np.abs(ref.Ts_.T.dot(ref.Ts_) - np.eye(K))))
+            prng = np.random.RandomState(77 + c)
+            Xp = X * (1.0 + 2.220446049250313e-16 * prng.choice([-1.0, 0.0, 1.0], size=X.shape))
+            try:
+                ref_p = orc.fit(sp(Xp), Y, n_components=K, method=method, standardize=std, full_svd=True,
+                                calc_all=calc_all, nipals_convergence_norm=norm, max_iter=3000)
+                sens = float(util.compare(util.model_to_flat(ref_p), util.model_to_flat(ref), np.inf, what=tag))
+            except Exception:
+                sens = 0.0
+            defect = max(defect, sens)
             if 50.0 * defect > 1e-8:
                 bound = 50.0 * defect
         tol_case = max(1e-6, bound or 0.0)
@@ -199,8 +213,8 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                             print_(tag, f"cross_val_predict batched vs loop {wcv:.2e} (cv={folds}, rank {rank} of {world})")
                         w = max(w, wcv)
                 if bound is not None:
-                    assert w <= bound, f"{tag}: SIMPLS {w:.2e} beyond 50 x the oracle's own orthogonality defect {bound:.2e}"
-                    print_(tag, f"relerr {w:.2e} within 50 x the oracle's own defect {bound:.2e} (rank {rank} of {world})")
+                    assert w <= bound, f"{tag}: SIMPLS {w:.2e} beyond 50 x the oracle's own defect / one-ulp sensitivity {bound:.2e}"
+                    print_(tag, f"relerr {w:.2e} within 50 x the oracle's own defect / one-ulp sensitivity {bound:.2e} (rank {rank} of {world})")
                     continue
                 worst = max(worst, w)
                 if w > 1e-9:
@@ -253,8 +267,8 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                     print_(tag, f"cross_val_predict batched vs loop {wcv:.2e} (cv={folds})")
                 w = max(w, wcv)
             if bound is not None:
-                assert w <= bound, f"{tag}: SIMPLS {w:.2e} beyond 50 x the oracle's own orthogonality defect {bound:.2e}"
-                print_(tag, f"relerr {w:.2e} within 50 x the oracle's own defect {bound:.2e}")
+                assert w <= bound, f"{tag}: SIMPLS {w:.2e} beyond 50 x the oracle's own defect / one-ulp sensitivity {bound:.2e}"
+                print_(tag, f"relerr {w:.2e} within 50 x the oracle's own defect / one-ulp sensitivity {bound:.2e}")
             else:
                 worst = max(worst, w)
                 if w > 1e-9:
