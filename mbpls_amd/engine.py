@@ -23,7 +23,7 @@ class HipEngine(EngineBase):
     has_association_matrices = True
     has_device_helpers = True
     KD = 40                     # == KD of csrc/colpass.hip (max lazily deflated components + 1)
-    MAT_CACHE_BYTES = 32 << 20  # uploaded matrices up to this size are kept (at most four shapes) for the next fit
+    MAT_CACHE_BYTES = 32 << 20  # uploaded matrices up to this size are kept (the four latest shapes) for the next fit
     # Deflation strategy of the NIPALS / UNIPALS(p>n) drivers.  "lazy": X in HBM is never rewritten, the
     # rank-1 updates X <- X - ts p^T (mbpls.py:969) are applied algebraically inside the next passes
     # (one READ of X per loadings+deflation+sweep instead of read+write).  "explicit": in-place update.
@@ -122,7 +122,9 @@ class HipEngine(EngineBase):
         if self.X is not None and self._owns_X:
             cache = self.ctx.__dict__.setdefault("_mat_cache", {}) if self.ctx.handle else None
             if (cache is not None and self.X is getattr(self, "_uploaded", None) and self.X.nbytes <= self.MAT_CACHE_BYTES
-                    and len(cache) < 4 and self._mat_key not in cache):
+                    and self._mat_key not in cache):
+                while len(cache) >= 4:                  # four shapes at most: the oldest one goes
+                    cache.pop(next(iter(cache))).close()
                 cache[self._mat_key] = self.X           # (kept for the next fit of this shape; Context.trim_pool drops it)
             else:
                 self.X.close()

@@ -186,3 +186,52 @@ def test_small_fits_copy_their_attributes_whole(monkeypatch, method, blocks, K):
         ref = orc.fit(Xs, Y, n_components=K, method=method)
         assert util.compare(a, util.model_to_flat(ref), 1e-6, what="bulk copies") < 1e-9
 
+
+
+def test_upload_matrices_of_small_fits_are_kept_and_overwritten(monkeypatch):
+    """Fits from host arrays of a small shape reuse the device matrix of the previous fit of that shape
+    (engine.HipEngine.load_host_blocks / close: seven allocations and uploads less per fit).  What the previous fit
+    left in it -- another data set, standardised and deflated in place by a storing route -- must not show: same
+    attributes, bit for bit, as a fit into a fresh matrix; the four latest shapes are kept, `trim_pool` returns them."""
+    from mbpls_amd import MBPLS
+    from oracle import mbpls_oracle as orc
+    from tests import util
+    ctx = _ctx()
+    ctx.trim_pool()
+    shapes = [(40, 200, [100]), (60, 333, []), (25, 1000, [10, 500]), (150, 300, [7]), (33, 64, [])]
+
+    def data(i, seed):
+        n, p, cuts = shapes[i]
+        X, Y = orc.make_latent(n, p, 1, r=4, seed=seed)
+        return ([np.ascontiguousarray(b) for b in np.split(X, cuts, axis=1)] if cuts else X), Y
+
+    def flat(i, seed, method="NIPALS"):
+        X, Y = data(i, seed)
+        return util.model_to_flat(MBPLS(n_components=3, method=method).fit(X, Y))
+
+    fresh = flat(0, 1)                                   # into a new matrix (nothing kept yet)
+    cache = ctx.__dict__["_mat_cache"]
+    assert len(cache) == 1
+    kept = next(iter(cache.values()))
+    monkeypatch.setenv("MBPLS_DEFLATION", "explicit")
+    monkeypatch.setenv("MBPLS_IMPLICIT_STD", "0")
+    flat(0, 2)                                           # another data set, stored standardised, deflated in place
+    monkeypatch.undo()
+    assert next(iter(cache.values())) is kept            # (the same matrix object went out and came back)
+    again = flat(0, 1)
+    assert set(again) == set(fresh)
+    for k in fresh:
+        assert np.array_equal(again[k], fresh[k]), k
+    ref = orc.fit(*data(0, 1), n_components=3)
+    assert util.compare(again, util.model_to_flat(ref), 1e-6, what="kept upload matrix") < 1e-9
+    for i in range(1, 5):                                # five shapes: the oldest one is dropped
+        flat(i, 10 + i, method=["UNIPALS", "KERNEL", "SIMPLS", "NIPALS"][i - 1])
+    assert len(cache) == 4 and (40, (0, 100, 200)) not in cache, list(cache)
+    big = orc.make_latent(40, 200_000, 1, r=4, seed=3)   # 64 MB: beyond engine.MAT_CACHE_BYTES, not kept
+    MBPLS(n_components=2).fit(*big)
+    assert len(cache) == 4 and all(m.nbytes <= 32 << 20 for m in cache.values())
+    ctx.trim_pool()
+    assert "_mat_cache" not in ctx.__dict__
+    final = flat(0, 1)
+    for k in fresh:
+        assert np.array_equal(final[k], fresh[k]), k

@@ -118,9 +118,10 @@ def forced_routes(**forms):
 
 def cpu_throttled_periods():
     """Periods in which this process's cgroup ran out of CPU quota so far (cgroup v2 `cpu.stat`, else v1; -1 when the
-    file is not there).  The GPU boxes of the pool run under a 16-CPU quota shared with their neighbours and are
-    throttled in most 100 ms periods (profiles/r06_stall_throttled.txt): a wall-clock guard has to leave out the fits a
-    throttled period fell into -- the whole process, copier thread included, stands still for up to 75 ms there."""
+    file is not there).  The GPU boxes of the pool show 256 CPUs under a 16-CPU quota; a BLAS pool sized from the first
+    number spins the quota of a 100 ms period away within 12 ms (profiles/r06_stall_throttled.txt; tests/conftest.py caps
+    the pool): a wall-clock guard has to leave out the fits a throttled period fell into -- the whole process, copier
+    thread included, stands still for up to 75 ms there."""
     for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
         try:
             with open(path) as f:
