@@ -26,7 +26,7 @@ namespace mbpls {
 // workgroups per CU.  At 129+ VGPRs only ONE 8-wave workgroup fits a CU and the pass runs ~2x slower
 // (measured: the lazy loadings+sweep variant at 157 VGPRs took 9.3 ms instead of 4.8 ms).
 template <int R, int TMAX, int D, bool STD, bool DEFL, bool SWEEP, bool FULL, bool ISTD = false, bool CEN = false>
-__global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : 1) void k_colpass(PassArgs a) {
+__global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : ((R == 20) ? 2 : 1)) void k_colpass(PassArgs a) {
   __shared__ double red[2 * 64];
   int buf = 0;
   if (a.dpar) {
@@ -574,7 +574,8 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   ProfScope prof(ctx, kind, 8.0 * (double)a.n * (double)p * (writes ? 2.0 : 1.0));
   Cfg cfg;
   int T = 0;
-  if (!pick_cfg(ctx, a.n, &cfg, &T, STD || (DEFL && SWEEP), true)) {
+  const bool stats_only = STD && SWEEP && a.dst == nullptr;     // (the ISTD flavour of the standardise pass, see below)
+  if (!pick_cfg(ctx, a.n, &cfg, &T, STD || (DEFL && SWEEP), true, stats_only)) {
     set_error("column passes support n <= 65536 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;
   }
@@ -632,6 +633,15 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   else if (cfg.R == 8) MB_LAUNCH_D(8, 1024);
   else if (cfg.R == 16 && cfg.TMAX == 512) MB_LAUNCH_D(16, 512);
   else if (cfg.R == 10) MB_LAUNCH(10, 512, 2);      // 4096 < n <= 5120, single-reduction passes: eight full waves
+  else if (cfg.R == 20) {                           // ... the statistics pass: two workgroups of four waves per CU
+    if constexpr (STD && !DEFL && SWEEP) {
+      if (full) hipLaunchKernelGGL((k_colpass<20, 256, 2, true, false, true, true, true>), grid, block, dyn_lds, ctx->stream, an);
+      else hipLaunchKernelGGL((k_colpass<20, 256, 2, true, false, true, false, true>), grid, block, dyn_lds, ctx->stream, an);
+    } else {
+      set_error("twenty rows per thread: statistics pass only");
+      return MBPLS_ERR_UNSUPPORTED;
+    }
+  }
   else if (istd) {
     set_error("implicit standardisation / statistics-only passes need n <= 8192 (got n=%lld)", (long long)a.n);
     return MBPLS_ERR_UNSUPPORTED;

@@ -103,11 +103,12 @@ struct Cfg {
 };
 
 // Choose rows-per-thread R and the workgroup size T = roundup(ceil(n/R), 64) <= TMAX.
-static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std_pass = false, bool has_r10 = false) {
+static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std_pass = false, bool has_r10 = false,
+                     bool has_r20 = false) {
   // preference order: smallest register footprint that still covers n with <= TMAX threads
   // the last two are correctness fallbacks for very long columns (8192 < n <= 65536): the column no longer
   // fits the register budget of 1024 threads, the compiler spills to scratch -> slow but exact
-  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}, {10, 512}, {4, 1024}, {32, 1024}, {64, 1024}};
+  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}, {10, 512}, {20, 256}, {4, 1024}, {32, 1024}, {64, 1024}};
   auto fits = [&](const Cfg& c, int* t) {
     int64_t need = (n + c.R - 1) / c.R;
     need = (need + 63) / 64 * 64;
@@ -131,6 +132,16 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
     *cfg = Cfg{10, 512};
     return fits(*cfg, T);
   }
+  // ... and the statistics pass there with TWENTY rows per thread on four waves.  With sixteen rows the several-reduction
+  // kernels hold 206-254 VGPRs (tools/kernel_resources.py): two waves per SIMD, eight per CU -- two workgroups of four
+  // waves at n = 4096, but ONE of five at n = 5000 (one of six at 6000, one of eight at 8192), alone on its CU with
+  // nothing to run while it reduces a column: the statistics pass falls from 6.8 TB/s at n = 4096 to 3.9 at 5000.
+  // Twenty rows on 256 threads keep two workgroups per CU up to 5120 samples (241-254 VGPRs, no scratch; the fused
+  // loadings + sweep flavours would spill 230-340 bytes per lane at twenty rows and stay on sixteen).
+  if (has_r20 && ctx->rows_per_thread <= 0 && n > 4096 && n <= 5120) {
+    *cfg = Cfg{20, 256};
+    return fits(*cfg, T);
+  }
   if (ctx->rows_per_thread <= 0 && !tuned8) {
     static const Cfg fat[] = {{16, 512}, {8, 512}, {4, 512}, {2, 256}};
     for (const Cfg& c : fat)
@@ -141,13 +152,13 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
   }
   if (ctx->rows_per_thread > 0) {
     for (const Cfg& c : table)
-      if (c.R == ctx->rows_per_thread && (has_r10 || c.R != 10) && fits(c, T)) {
+      if (c.R == ctx->rows_per_thread && (has_r10 || c.R != 10) && (has_r20 || c.R != 20) && fits(c, T)) {
         *cfg = c;
         return true;
       }
   }
   for (const Cfg& c : table)
-    if ((has_r10 || c.R != 10) && fits(c, T)) {
+    if ((has_r10 || c.R != 10) && c.R != 20 && fits(c, T)) {
       *cfg = c;
       return true;
     }
