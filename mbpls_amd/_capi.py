@@ -221,6 +221,7 @@ class Context:
         # reuse the 8np-byte working matrix instead of paying hipMalloc/hipFree of tens of GB
         self._pool = {}
         self._pool_bytes = 0
+        self._mat_cache = {}        # (n, block offsets) -> upload matrix of a small problem, kept for its next fit (engine.py)
         self._pool_cap = None
 
     # ---- pooled raw allocations
@@ -266,7 +267,8 @@ class Context:
             self.trim_pool()
 
     def trim_pool(self):
-        for m in self.__dict__.pop("_mat_cache", {}).values():      # (small upload matrices kept between fits, engine.py)
+        kept, self._mat_cache = self._mat_cache, {}
+        for m in kept.values():
             m.close()
         for lst in self._pool.values():
             for ptr in lst:

@@ -63,7 +63,7 @@ class HipEngine(EngineBase):
         # costs seven allocations and uploads for the block offsets and chunk tables (70 us of a 0.6 ms fit at the
         # README quick-start size); every column is overwritten by the uploads below
         self._mat_key = (int(n), tuple(int(o) for o in offs))
-        X = self.ctx.__dict__.setdefault("_mat_cache", {}).pop(self._mat_key, None)
+        X = self.ctx._mat_cache.pop(self._mat_key, None)
         if X is None:
             X = _capi.DeviceMatrix(self.ctx, n, int(offs[-1]), offs)
         for b, o in zip(blocks, offs[:-1]):
@@ -120,7 +120,7 @@ class HipEngine(EngineBase):
             s.free()
         self.slots = {}
         if self.X is not None and self._owns_X:
-            cache = self.ctx.__dict__.setdefault("_mat_cache", {}) if self.ctx.handle else None
+            cache = self.ctx._mat_cache if self.ctx.handle else None
             if (cache is not None and self.X is getattr(self, "_uploaded", None) and self.X.nbytes <= self.MAT_CACHE_BYTES
                     and self._mat_key not in cache):
                 while len(cache) >= 4:                  # four shapes at most: the oldest one goes

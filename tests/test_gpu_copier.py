@@ -210,7 +210,7 @@ def test_upload_matrices_of_small_fits_are_kept_and_overwritten(monkeypatch):
         return util.model_to_flat(MBPLS(n_components=3, method=method).fit(X, Y))
 
     fresh = flat(0, 1)                                   # into a new matrix (nothing kept yet)
-    cache = ctx.__dict__["_mat_cache"]
+    cache = ctx._mat_cache
     assert len(cache) == 1
     kept = next(iter(cache.values()))
     monkeypatch.setenv("MBPLS_DEFLATION", "explicit")
@@ -231,7 +231,7 @@ def test_upload_matrices_of_small_fits_are_kept_and_overwritten(monkeypatch):
     MBPLS(n_components=2).fit(*big)
     assert len(cache) == 4 and all(m.nbytes <= 32 << 20 for m in cache.values())
     ctx.trim_pool()
-    assert "_mat_cache" not in ctx.__dict__
+    assert not ctx._mat_cache and cache is not ctx._mat_cache
     final = flat(0, 1)
     for k in fresh:
         assert np.array_equal(final[k], fresh[k]), k
