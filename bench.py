@@ -162,6 +162,13 @@ def main():
                 comm_info = dict(comm.info(), backend="rccl (C ABI, mbpls_hip_allreduce on the kernels' stream)")
                 # what RCCL itself reports (ncclCommCount / ncclCommUserRank), not what was passed in
                 assert comm_info["rccl_ranks"] == world and comm_info["rccl_user_rank"] == rank, comm_info
+                # one small collective under a short deadline before anything is timed: a communicator that initialises
+                # but cannot move data (a transport the node does not offer, a peer that never arrives) is an error
+                # here -- CommLost after 90 s -- and every rank falls back together, instead of a hang in the first fit
+                comm.set_timeout(90.0)
+                got = float(comm.allreduce_host(np.array([rank + 1.0]))[0])
+                assert got == 0.5 * world * (world + 1), f"probe all-reduce returned {got}"
+                comm.set_timeout(600.0)
             except Exception as e:                      # noqa: BLE001 -- reported, then the fallback below
                 err = f"{type(e).__name__}: {e}"
             flags = [None] * world
