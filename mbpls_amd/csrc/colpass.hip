@@ -26,7 +26,7 @@ namespace mbpls {
 // workgroups per CU.  At 129+ VGPRs only ONE 8-wave workgroup fits a CU and the pass runs ~2x slower
 // (measured: the lazy loadings+sweep variant at 157 VGPRs took 9.3 ms instead of 4.8 ms).
 template <int R, int TMAX, int D, bool STD, bool DEFL, bool SWEEP, bool FULL, bool ISTD = false, bool CEN = false>
-__global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : ((R == 20) ? 2 : 1)) void k_colpass(PassArgs a) {
+__global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : ((TMAX == 256 && R >= 20) ? 2 : 1)) void k_colpass(PassArgs a) {
   __shared__ double red[2 * 64];
   int buf = 0;
   if (a.dpar) {
@@ -633,12 +633,18 @@ static int launch_pass(mbpls_ctx* ctx, const ChunkTable& ct, const PassArgs& a, 
   else if (cfg.R == 8) MB_LAUNCH_D(8, 1024);
   else if (cfg.R == 16 && cfg.TMAX == 512) MB_LAUNCH_D(16, 512);
   else if (cfg.R == 10) MB_LAUNCH(10, 512, 2);      // 4096 < n <= 5120, single-reduction passes: eight full waves
-  else if (cfg.R == 20) {                           // ... the statistics pass: two workgroups of four waves per CU
+  else if (cfg.TMAX == 256 && cfg.R >= 20) {         // 4096 < n <= 6144, statistics pass: two workgroups of four waves per CU
     if constexpr (STD && !DEFL && SWEEP) {
-      if (full) hipLaunchKernelGGL((k_colpass<20, 256, 2, true, false, true, true, true>), grid, block, dyn_lds, ctx->stream, an);
-      else hipLaunchKernelGGL((k_colpass<20, 256, 2, true, false, true, false, true>), grid, block, dyn_lds, ctx->stream, an);
+      if (!istd) {
+        set_error("twenty / twenty-four rows per thread: statistics pass only");
+        return MBPLS_ERR_UNSUPPORTED;
+      }
+      if (cfg.R == 20 && full) hipLaunchKernelGGL((k_colpass<20, 256, 2, true, false, true, true, true>), grid, block, dyn_lds, ctx->stream, an);
+      else if (cfg.R == 20) hipLaunchKernelGGL((k_colpass<20, 256, 2, true, false, true, false, true>), grid, block, dyn_lds, ctx->stream, an);
+      else if (full) hipLaunchKernelGGL((k_colpass<24, 256, 2, true, false, true, true, true>), grid, block, dyn_lds, ctx->stream, an);
+      else hipLaunchKernelGGL((k_colpass<24, 256, 2, true, false, true, false, true>), grid, block, dyn_lds, ctx->stream, an);
     } else {
-      set_error("twenty rows per thread: statistics pass only");
+      set_error("twenty / twenty-four rows per thread: statistics pass only");
       return MBPLS_ERR_UNSUPPORTED;
     }
   }

@@ -108,7 +108,7 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
   // preference order: smallest register footprint that still covers n with <= TMAX threads
   // the last two are correctness fallbacks for very long columns (8192 < n <= 65536): the column no longer
   // fits the register budget of 1024 threads, the compiler spills to scratch -> slow but exact
-  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}, {10, 512}, {20, 256}, {4, 1024}, {32, 1024}, {64, 1024}};
+  static const Cfg table[] = {{2, 256}, {4, 512}, {8, 512}, {8, 1024}, {16, 512}, {10, 512}, {20, 256}, {24, 256}, {4, 1024}, {32, 1024}, {64, 1024}};
   auto fits = [&](const Cfg& c, int* t) {
     int64_t need = (n + c.R - 1) / c.R;
     need = (need + 63) / 64 * 64;
@@ -132,14 +132,16 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
     *cfg = Cfg{10, 512};
     return fits(*cfg, T);
   }
-  // ... and the statistics pass there with TWENTY rows per thread on four waves.  With sixteen rows the several-reduction
-  // kernels hold 206-254 VGPRs (tools/kernel_resources.py): two waves per SIMD, eight per CU -- two workgroups of four
-  // waves at n = 4096, but ONE of five at n = 5000 (one of six at 6000, one of eight at 8192), alone on its CU with
-  // nothing to run while it reduces a column: the statistics pass falls from 6.8 TB/s at n = 4096 to 3.9 at 5000.
-  // Twenty rows on 256 threads keep two workgroups per CU up to 5120 samples (241-254 VGPRs, no scratch; the fused
-  // loadings + sweep flavours would spill 230-340 bytes per lane at twenty rows and stay on sixteen).
-  if (has_r20 && ctx->rows_per_thread <= 0 && n > 4096 && n <= 5120) {
-    *cfg = Cfg{20, 256};
+  // ... and the statistics pass up to n = 6144 with TWENTY (TWENTY-FOUR) rows per thread on four waves.  With sixteen rows
+  // the several-reduction kernels hold 206-254 VGPRs (tools/kernel_resources.py): two waves per SIMD, eight per CU -- two
+  // workgroups of four waves at n = 4096, but ONE of five at n = 5000 (one of six at 6000, one of eight at 8192), alone
+  // on its CU with nothing to run while it reduces a column: the statistics pass falls from 6.8 TB/s at n = 4096 to 3.9
+  // at 5000.  On 256 threads two workgroups share a CU: 20 rows (241-254 VGPRs, no scratch) 3.9 -> 6.3 TB/s at n = 5000,
+  // 24 rows (108 bytes of scratch per lane) 4.3 -> 6.0 at n = 6000; 28 / 32 rows spill 280 / 430 bytes and LOSE (3.5 / 2.7
+  // against 4.5 / 5.0 at n = 7000 / 8192), and so does the fused loadings + lazy deflation + sweep pass from twenty rows on
+  // (300 bytes of scratch: 2.7-3.0 against 4.7-5.2 TB/s) -- profiles/r06_stats_pass_r20.txt.
+  if (has_r20 && ctx->rows_per_thread <= 0 && n > 4096 && n <= 6144) {
+    *cfg = Cfg{n <= 5120 ? 20 : 24, 256};
     return fits(*cfg, T);
   }
   if (ctx->rows_per_thread <= 0 && !tuned8) {
@@ -152,13 +154,13 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
   }
   if (ctx->rows_per_thread > 0) {
     for (const Cfg& c : table)
-      if (c.R == ctx->rows_per_thread && (has_r10 || c.R != 10) && (has_r20 || c.R != 20) && fits(c, T)) {
+      if (c.R == ctx->rows_per_thread && (has_r10 || c.R != 10) && (has_r20 || c.TMAX != 256 || c.R < 20) && fits(c, T)) {
         *cfg = c;
         return true;
       }
   }
   for (const Cfg& c : table)
-    if ((has_r10 || c.R != 10) && c.R != 20 && fits(c, T)) {
+    if ((has_r10 || c.R != 10) && !(c.TMAX == 256 && c.R >= 20) && fits(c, T)) {
       *cfg = c;
       return true;
     }

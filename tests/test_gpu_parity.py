@@ -1218,11 +1218,11 @@ def test_large_host_to_device_copies_round_trip(gpu_required, mbytes):
     d1.free(); d2.free()
 
 
-@pytest.mark.parametrize("n", [4097, 4500, 5119, 5120, 5121, 6001, 8191])
+@pytest.mark.parametrize("n", [4097, 4500, 5119, 5120, 5121, 6001, 6144, 6145, 8191])
 def test_ragged_sample_counts_above_4096(gpu_required, monkeypatch, n):
     """4096 < n < 8192: columns that do not fill their workgroup (loads without selects, masked where a column becomes the
-    current one; up to n = 5120 ten rows per thread for the single-reduction passes and twenty on 256 threads for the
-    statistics pass -- n = 5120 fills those exactly --, sixteen otherwise), odd n (one padding
+    current one; up to n = 5120 ten rows per thread for the single-reduction passes; twenty / twenty-four rows on 256
+    threads for the statistics pass up to n = 5120 / 6144, which fill them exactly; sixteen otherwise), odd n (one padding
     element per column), never-writes-X and stored / explicitly deflating passes -- against the oracle."""
     from mbpls_amd import MBPLS
     X, Y = orc.make_latent(n, 1500, 1, seed=n)
