@@ -140,9 +140,32 @@ static bool pick_cfg(const mbpls_ctx* ctx, int64_t n, Cfg* cfg, int* T, bool std
   // 24 rows (108 bytes of scratch per lane) 4.3 -> 6.0 at n = 6000; 28 / 32 rows spill 280 / 430 bytes and LOSE (3.5 / 2.7
   // against 4.5 / 5.0 at n = 7000 / 8192), and so does the fused loadings + lazy deflation + sweep pass from twenty rows on
   // (300 bytes of scratch: 2.7-3.0 against 4.7-5.2 TB/s) -- profiles/r06_stats_pass_r20.txt.
-  if (has_r20 && ctx->rows_per_thread <= 0 && n > 4096 && n <= 6144) {
-    *cfg = Cfg{n <= 5120 ? 20 : 24, 256};
-    return fits(*cfg, T);
+  // Below 4096 the same kernels serve ragged n better than sixteen rows wherever they need fewer wave-instructions per
+  // column (waves per workgroup x rows per thread: the pass is issue bound) or a wave count that divides the eight slots
+  // of a CU: n = 1200 one wave of twenty rows instead of two of sixteen (5.0 -> 5.7 TB/s), n = 2500 two waves of twenty
+  // instead of three of sixteen (4.9 -> 6.4), n = 3000 two of twenty-four (5.7 -> 6.0).
+  if (has_r20 && ctx->rows_per_thread <= 0 && n > 1024 && n <= 6144) {
+    int best_r = 0;
+    double best = 0.0;
+    for (int r : {16, 20, 24}) {
+      const int64_t threads = ((n + r - 1) / r + 63) / 64 * 64;
+      if (threads > (r == 16 ? 512 : 256)) continue;
+      const int waves = (int)(threads / 64);
+      if (r == 16 && n == threads * 16 && waves <= 4) {      // sixteen rows fill their waves exactly: mask-free, 6.3 TB/s
+        best_r = 16;
+        break;
+      }
+      double cost = (double)waves * r;
+      if (waves != 1 && waves != 2 && waves != 4 && waves != 8) cost *= 1.15;   // does not divide the eight wave slots
+      if (best_r == 0 || cost < best - 1e-9) {
+        best_r = r;
+        best = cost;
+      }
+    }
+    if (best_r > 16) {
+      *cfg = Cfg{best_r, 256};
+      return fits(*cfg, T);
+    }
   }
   if (ctx->rows_per_thread <= 0 && !tuned8) {
     static const Cfg fat[] = {{16, 512}, {8, 512}, {4, 512}, {2, 256}};

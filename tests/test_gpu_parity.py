@@ -1218,6 +1218,26 @@ def test_large_host_to_device_copies_round_trip(gpu_required, mbytes):
     d1.free(); d2.free()
 
 
+@pytest.mark.parametrize("n", [1025, 1200, 1280, 1281, 1536, 2200, 2560, 2561, 3000, 3072, 3073])
+def test_ragged_sample_counts_below_4096(gpu_required, n):
+    """1024 < n < 4096: the statistics pass picks sixteen, twenty or twenty-four rows per thread by the wave-instructions
+    a column costs and by whether its waves divide the eight slots of a CU (colpass_util.h pick_cfg: one wave of twenty
+    rows at n = 1200, two of twenty at 2500, two of twenty-four at 3000; n = 1280 / 2560 / 3072 fill those exactly, one
+    more sample does not), the other passes stay on sixteen / eight -- offset data, two blocks, against the oracle."""
+    from mbpls_amd import MBPLS
+    X, Y = orc.make_latent(n, 900, 1, seed=n)
+    X = X + 2.0
+    blocks = [np.ascontiguousarray(X[:, :333]), np.ascontiguousarray(X[:, 333:])]
+    ref = orc.fit(blocks, Y, n_components=3, method="NIPALS")
+    mdl = MBPLS(n_components=3).fit(blocks, Y)
+    assert "never written" in str(mdl.fit_plan_.get("standardisation")), mdl.fit_plan_
+    assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what=f"ragged n={n}") < 1e-9
+    assert util.relerr(mdl.predict(blocks), orc.predict(ref, blocks)) < 1e-9
+    mu = MBPLS(n_components=3, method="UNIPALS").fit(blocks, Y)
+    ru = orc.fit(blocks, Y, n_components=3, method="UNIPALS", full_svd=True)
+    assert util.compare(util.model_to_flat(mu), util.model_to_flat(ru), TOL, what=f"ragged n={n}, UNIPALS") < 1e-9
+
+
 @pytest.mark.parametrize("n", [4097, 4500, 5119, 5120, 5121, 6001, 6144, 6145, 8191])
 def test_ragged_sample_counts_above_4096(gpu_required, monkeypatch, n):
     """4096 < n < 8192: columns that do not fill their workgroup (loads without selects, masked where a column becomes the
