@@ -18,9 +18,9 @@ blocks = re.split(r"remark: Function Name: ", txt)[1:]
 names = [b.split()[0] for b in blocks]
 dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
 for b, d in zip(blocks, dem):
-    m = re.search(kern + r"<(.*)>\(", d)
-    if not m or flt not in m.group(1):
+    m = re.search(kern + r"(?:<(.*)>)?\(", d)
+    if not m or flt not in (m.group(1) or ""):
         continue
     g = lambda k: (re.search(k + r": (\d+)", b) or [None, "?"])[1]
-    print(f"{m.group(1):58s} VGPR {g('    VGPRs'):>3s} AGPR {g('AGPRs'):>3s} scratch {g('ScratchSize .bytes/lane.'):>4s} "
+    print(f"{(m.group(1) or kern):58s} VGPR {g('    VGPRs'):>3s} AGPR {g('AGPRs'):>3s} scratch {g('ScratchSize .bytes/lane.'):>4s} "
           f"occupancy {g('Occupancy .waves/SIMD.')} LDS {g('LDS Size .bytes/block.')}")
