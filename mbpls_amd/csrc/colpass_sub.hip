@@ -54,6 +54,8 @@ __device__ __forceinline__ double group_sum(double v) {
 // lane instead of ceil(39 / LG).  The slots cost the 8-lane shapes ~80 VGPRs (pointers, coefficients, prefetched
 // loadings, accumulators for five of them): with them the fused pass sits at 194-218 VGPRs = two waves per SIMD, and
 // few-sample columns are short on bytes in flight, not on arithmetic (rocprofv3: waves parked 0.73-0.76 of their cycles).
+// (The column loop still waits with s_waitcnt vmcnt(0) -- four causes, all removable, and the loop with counted waits is
+// 5-13 % SLOWER below n = 128: what it saves in latency it spends in instructions, profiles/r06_sub_waitcnt_experiment.txt.)
 template <int LG, int KR, int D, bool STD, bool DEFL, bool SWEEP, bool ISTD, bool CEN, bool LM1 = false>
 __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
   constexpr int R = 2 * KR;
