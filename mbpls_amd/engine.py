@@ -1453,8 +1453,10 @@ class _ResidentQueue:
 
             posts, nu2_h, nB = self._bulk_posts, self.nu2_h, eng.nblocks
 
-            def wait_copies():              # every column handed to the copier thread by this queue has landed
+            def wait_copies(meaningful=True):   # every column handed to the copier thread by this queue has landed
                 ctx.copier_wait(ticket)
+                if not meaningful:          # a queue that gave up early copied zeros: nothing to normalise (0 / 0)
+                    posts.clear()
                 while posts and ticket:     # (small problems: w_b = w~_b / ||w~_b|| here, not in the copier thread)
                     src, dst, offs, addr = posts.pop()
                     k = (int(addr) - nu2_h.ctypes.data) // (8 * nB)
@@ -1474,7 +1476,7 @@ class _ResidentQueue:
             self.lib.mbpls_hip_sync(self.ctx.handle)
             self.seq_h[0] = np.inf          # (a job may be waiting for a step that was never launched)
             try:
-                wait_copies()
+                wait_copies(meaningful=False)
             except _capi.HipError:
                 pass                        # (the error that brought us here is the one to report)
             self.seq_h[0] = ctx._seq_base
@@ -1487,7 +1489,7 @@ class _ResidentQueue:
             try:
                 eng.check_cluster_passes()
             except _capi.ClusterTimeout:
-                wait_copies()
+                wait_copies(meaningful=False)
                 self.state.free()
                 raise
         if par[7] != 0.0:
@@ -1495,7 +1497,7 @@ class _ResidentQueue:
             # was written to X, so the caller simply runs the fit with its host-driven loop.  (A hand-off of a cluster
             # pass that gave up sets the same flag: that one goes up to MBPLS._fit, which runs the fit again on the
             # two-phase passes.)
-            wait_copies()
+            wait_copies(meaningful=False)
             self.state.free()
             eng.check_cluster_passes()
             self.result = dict(k_done=0, reason="barrier")
@@ -1503,7 +1505,7 @@ class _ResidentQueue:
         if par[2] != 0.0 and par[5] == 1.0:
             # offset data (max |mean|/scale = sqrt(par[6])): the caller queues again, now with centring passes
             eng._cen = True
-            wait_copies()
+            wait_copies(meaningful=False)
             self.state.free()
             self.result = dict(k_done=0, reason="offset", offset=float(np.sqrt(par[6])))
             return False

@@ -189,3 +189,40 @@ def test_sparse_oracle_with_missing_responses_vs_reference_fixture():
     Yb[dense_rows[0], 1] = np.nan
     with pytest.raises(ValueError):
         ors.fit(g["in/q2/X"], Yb, n_components=2)
+
+
+def _loo(fit, predict, X, y, K):
+    """leave-one-out predictions by a loop of fits (what sklearn's cross_val_predict(est, X, y, cv=len(y)) does)"""
+    n = len(y)
+    out = np.empty(n)
+    for i in range(n):
+        keep = np.arange(n) != i
+        Xtr = [b[keep] for b in X] if isinstance(X, list) else X[keep]
+        Xte = [b[i:i + 1] for b in X] if isinstance(X, list) else X[i:i + 1]
+        out[i] = np.ravel(predict(fit(Xtr, y[keep].reshape(-1, 1), K), Xte))[0]
+    return out
+
+
+@pytest.mark.parametrize("faithful", [False, True])
+def test_reference_real_data(faithful):
+    """The reference's bundled REAL data through the work flows of its example notebooks (fixture real_pectin,
+    tools/make_golden.py: FTIR spectra 37 x 148 + carbohydrate microarrays 37 x 30 -> pectin yield): the two-block fit,
+    single-block PLS of either block, and the leave-one-out curve over 1 .. 15 components of 36 samples each -- real
+    spectra are collinear, the deep components are the least well conditioned fits in the suite."""
+    g = util.load("real_pectin")
+    X1, X2, y = g["x1"], g["x2"], g["y"]
+    Y = y.reshape(-1, 1)
+    m = orc.fit([X1, X2], Y, n_components=3, faithful=faithful)
+    util.compare(_flat_with_new(m, [X1, X2], Y), util.sub(g, "ref/two_blocks"), TOL, what="real data, two blocks")
+    for name, X in (("ftir", X1), ("carb", X2)):
+        m = orc.fit(X, Y, n_components=5, faithful=faithful)
+        util.compare(_flat_with_new(m, X, Y), util.sub(g, f"ref/{name}"), 1e-8, what=f"real data, {name}")
+    fit = lambda X, Y, K: orc.fit(X, Y, n_components=K, faithful=faithful)
+    X12 = np.hstack((X1, X2))
+    for k in (1, 3, 6, 10, 15):
+        got = _loo(fit, orc.predict, X12, y, k)
+        assert util.relerr(got, g["loo/x1x2"][:, k - 1]) < 1e-7, (k, util.relerr(got, g["loo/x1x2"][:, k - 1]))
+    for name, X in (("ftir", X1), ("carb", X2)):
+        for c, k in enumerate((1, 3, 5)):
+            got = _loo(fit, orc.predict, X, y, k)
+            assert util.relerr(got, g[f"loo/{name}"][:, c]) < 1e-7, (name, k)

@@ -18,6 +18,9 @@ Fixture sets follow SURVEY.md 8(c'):
   G5 edges             constant column, 1-D Y, list-of-one, norm variants
   G6 sparse            sparse_data=True (NaN-aware NIPALS), dense Y
   G7 sparse_y          sparse_data=True with missing responses as well
+  G8 real_pectin       the reference's bundled real data (FTIR spectra 37 x 148, carbohydrate microarrays 37 x 30,
+                       pectin yield) through the work flows of its example notebooks: the two-block fit, the
+                       leave-one-out curves over 1 .. 15 components, single-block PLS of either block
 """
 import os
 import sys
@@ -275,6 +278,41 @@ def golden_sparse_y():
     np.savez_compressed(os.path.join(OUT, "sparse_y.npz"), **store)
 
 
+def golden_real_pectin():
+    """examples/real_world_applications/{PectinYield_MBPLS, FTIR_PLS, Carbohydrate_Microarray_PLS}.ipynb on
+    mbpls/data/MBPLS_intro/*.pkl (mbpls/data/get_data.py:31-49): x1 = FTIR, x2 = carbohydrate microarrays, y = the yield
+    (the index of the frames).  Captured: the data, MBPLS(3).fit([x1, x2], y) with every attribute and its scalers,
+    cross_val_predict(MBPLS(k), [x1 | x2], y, cv=37) for k = 1 .. 15 (the notebooks' "find the right number of LVs"),
+    the single-block fits MBPLS(5) of either block and their leave-one-out predictions."""
+    import pandas as pd
+    from sklearn.model_selection import cross_val_predict
+    d = os.path.join(REF, "mbpls", "data", "MBPLS_intro")
+    fr = {k: pd.read_pickle(os.path.join(d, k + ".pkl")) for k in
+          ("ftir1", "ftir2", "ftir3", "extraction1", "extraction2", "extraction3")}
+    x1 = pd.concat((fr["ftir1"], fr["ftir2"], fr["ftir3"]))
+    x2 = pd.concat((fr["extraction1"], fr["extraction2"], fr["extraction3"]))
+    y = np.array(x1.index, dtype=np.float64)
+    X1, X2 = np.asarray(x1, dtype=np.float64), np.asarray(x2, dtype=np.float64)
+    store = dict(x1=X1, x2=X2, y=y, wavenumbers=np.asarray(x1.columns, dtype=np.float64))
+    m = MBPLS(n_components=3)
+    m.fit([X1, X2], y)
+    capture(m, store, "ref/two_blocks", [X1, X2], y.reshape(-1, 1))
+    X12 = np.hstack((X1, X2))
+    store["loo/x1x2"] = np.column_stack([np.ravel(cross_val_predict(MBPLS(n_components=k), X12, y, cv=len(y)))
+                                         for k in range(1, 16)])
+    for name, X in (("ftir", X1), ("carb", X2)):
+        m = MBPLS(n_components=5)
+        m.fit(X, y)
+        capture(m, store, f"ref/{name}", X, y.reshape(-1, 1))
+        store[f"loo/{name}"] = np.column_stack([np.ravel(cross_val_predict(MBPLS(n_components=k), X, y, cv=len(y)))
+                                                for k in (1, 3, 5)])
+    # the frames go into the estimator as they are in the notebooks: the reference must give the same numbers for them
+    md = MBPLS(n_components=3)
+    md.fit([x1, x2], pd.DataFrame(y))
+    assert np.allclose(md.beta_, store["ref/two_blocks/beta_"])
+    np.savez_compressed(os.path.join(OUT, "real_pectin.npz"), **store)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rep = golden_ref_tests()
@@ -288,6 +326,7 @@ def main():
     golden_edges()
     golden_sparse()
     golden_sparse_y()
+    golden_real_pectin()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
