@@ -112,3 +112,40 @@ def test_leave_one_out_of_either_block(gpu_required, real, name, key):
     for c, k in enumerate((1, 3, 5)):
         got = np.ravel(cross_val_predict(MBPLS(n_components=k), X, y, cv=len(y)))
         assert util.relerr(got, real[f"loo/{name}"][:, c]) < 1e-7, (name, k)
+
+
+def _flat_model(m, Xnew, Ynew, block_scores):
+    flat = util.model_to_flat(m)
+    flat["predict"] = m.predict(Xnew)
+    if block_scores:
+        Ts, T, U = m.transform(Xnew, Ynew, return_block_scores=True)
+        for b, blk in enumerate(T):
+            flat[f"T_new/{b}"] = blk
+    else:
+        Ts, U = m.transform(Xnew, Ynew)
+    flat["Ts_new"], flat["U_new"] = Ts, U
+    return flat
+
+
+@pytest.mark.parametrize("layout", ["Xin2", "Xin4"])
+def test_mbdata_mat(gpu_required, layout, kernel_route):
+    """mbpls/data/MBdata.mat (fixture mbdata): ten samples x 100 variables in two or four blocks, three responses -- every
+    method, standardised and not -- and the same matrix with four missing values through sparse_data=True"""
+    from mbpls_amd import MBPLS
+    g = util.load("mbdata")
+    X, Y, Xmv = g["X"], g["Y"], g["Xmv"]
+    blocks = lambda A: [np.ascontiguousarray(A[:, lo - 1:hi]) for lo, hi in g[layout]]
+    worst = 0.0
+    for method, full in (("NIPALS", False), ("UNIPALS", True), ("KERNEL", True), ("SIMPLS", True)):
+        for std in (True, False):
+            ref = util.sub(g, f"ref/{layout}/{method}/std{int(std)}")
+            m = MBPLS(n_components=3, method=method, standardize=std, full_svd=full).fit(blocks(X), Y)
+            has_blocks = any(k.startswith("T_new") for k in ref)
+            worst = max(worst, util.compare(_flat_model(m, blocks(X), Y, has_blocks), ref, TOL,
+                                            what=f"mbdata {layout} {method} std{std}"))
+    assert worst < 1e-8, worst
+    for std in (True, False):
+        m = MBPLS(n_components=2, sparse_data=True, standardize=std).fit(blocks(Xmv), Y)
+        w = util.compare(_flat_model(m, blocks(Xmv), Y, True), util.sub(g, f"sparse/{layout}/std{int(std)}"), TOL,
+                         what=f"mbdata sparse {layout} std{std}")
+        assert w < 1e-8, w

@@ -226,3 +226,36 @@ def test_reference_real_data(faithful):
         for c, k in enumerate((1, 3, 5)):
             got = _loo(fit, orc.predict, X, y, k)
             assert util.relerr(got, g[f"loo/{name}"][:, c]) < 1e-7, (name, k)
+
+
+@pytest.mark.parametrize("faithful", [False, True])
+def test_reference_mbdata(faithful):
+    """mbpls/data/MBdata.mat (fixture mbdata, tools/make_golden.py): ten samples x 100 variables in two or four blocks,
+    three responses -- every method on both layouts, standardised and not -- and the same matrix with four missing
+    values through sparse_data=True."""
+    from oracle import mbpls_oracle_sparse as ors
+    g = util.load("mbdata")
+    X, Y, Xmv = g["X"], g["Y"], g["Xmv"]
+    cases = 0
+    for lay in ("Xin2", "Xin4"):
+        blocks = lambda A: [np.ascontiguousarray(A[:, lo - 1:hi]) for lo, hi in g[lay]]
+        for method, full in (("NIPALS", False), ("UNIPALS", True), ("KERNEL", True), ("SIMPLS", True)):
+            for std in (True, False):
+                m = orc.fit(blocks(X), Y, n_components=3, method=method, standardize=std, full_svd=full,
+                            faithful=faithful)
+                ref = util.sub(g, f"ref/{lay}/{method}/std{int(std)}")
+                has_blocks = any(k.startswith("T_new") for k in ref)
+                util.compare(_flat_with_new(m, blocks(X), Y, block_scores=has_blocks), ref, 1e-8,
+                             what=f"mbdata {lay} {method} std{std}")
+                cases += 1
+        for std in (True, False):
+            m = ors.fit(blocks(Xmv), Y, n_components=2, standardize=std)
+            flat = util.model_to_flat(m)
+            flat["predict"] = ors.predict(m, blocks(Xmv))
+            Ts, T, U = ors.transform(m, blocks(Xmv), Y, return_block_scores=True)
+            flat["Ts_new"], flat["U_new"] = Ts, U
+            for b, blk in enumerate(T):
+                flat[f"T_new/{b}"] = blk
+            util.compare(flat, util.sub(g, f"sparse/{lay}/std{int(std)}"), 1e-8, what=f"mbdata sparse {lay} std{std}")
+            cases += 1
+    assert cases == 20

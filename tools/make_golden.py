@@ -21,6 +21,8 @@ Fixture sets follow SURVEY.md 8(c'):
   G8 real_pectin       the reference's bundled real data (FTIR spectra 37 x 148, carbohydrate microarrays 37 x 30,
                        pectin yield) through the work flows of its example notebooks: the two-block fit, the
                        leave-one-out curves over 1 .. 15 components, single-block PLS of either block
+  G9 mbdata            mbpls/data/MBdata.mat (10 samples x 100 variables in 2 or 4 blocks, three responses, and the same
+                       matrix with four missing values): every method on both block layouts, sparse_data=True
 """
 import os
 import sys
@@ -313,6 +315,28 @@ def golden_real_pectin():
     np.savez_compressed(os.path.join(OUT, "real_pectin.npz"), **store)
 
 
+def golden_mbdata():
+    """mbpls/data/MBdata.mat -- a ten-sample multiblock set with its block layouts (Xin2: 2 x 50 variables, Xin4: 4 x 25),
+    three responses, and Xmv, the same matrix with four entries missing.  No code of the reference reads the file; fitted
+    here with the imported reference: four methods x two layouts x standardize, and sparse_data=True on Xmv."""
+    from scipy.io import loadmat
+    mat = loadmat(os.path.join(REF, "mbpls", "data", "MBdata.mat"))
+    X, Y, Xmv = (np.asarray(mat[k], dtype=np.float64) for k in ("X", "Y", "Xmv"))
+    store = dict(X=X, Y=Y, Xmv=Xmv, Xin2=np.asarray(mat["Xin2"], dtype=np.int64), Xin4=np.asarray(mat["Xin4"], dtype=np.int64))
+    for lay in ("Xin2", "Xin4"):
+        blocks = lambda A: [np.ascontiguousarray(A[:, lo - 1:hi]) for lo, hi in store[lay]]
+        for method, full in (("NIPALS", False), ("UNIPALS", True), ("KERNEL", True), ("SIMPLS", True)):
+            for std in (True, False):
+                m = MBPLS(n_components=3, method=method, standardize=std, full_svd=full)
+                m.fit(blocks(X), Y)
+                capture(m, store, f"ref/{lay}/{method}/std{int(std)}", blocks(X), Y)
+        for std in (True, False):
+            m = MBPLS(n_components=2, sparse_data=True, standardize=std)
+            m.fit(blocks(Xmv), Y)
+            capture(m, store, f"sparse/{lay}/std{int(std)}", blocks(Xmv), Y)
+    np.savez_compressed(os.path.join(OUT, "mbdata.npz"), **store)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rep = golden_ref_tests()
@@ -327,6 +351,7 @@ def main():
     golden_sparse()
     golden_sparse_y()
     golden_real_pectin()
+    golden_mbdata()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
