@@ -76,6 +76,14 @@ def test_single_block_pls_of_either_block(gpu_required, real, name, key):
     m = MBPLS(n_components=5).fit(X, Y)
     w = util.compare(_flat_with_new(m, X, Y), util.sub(real, f"ref/{name}"), TOL, what=f"pectin, {name}")
     assert w < 1e-7, w
+    # "mbpls.fit_transform(ftir, yield_all)" as the FTIR / microarray notebooks call it: a data frame and the yield
+    pd = pytest.importorskip("pandas")
+    m2 = MBPLS(n_components=5)
+    Ts, U = m2.fit_transform(pd.DataFrame(X, index=real["y"]), real["y"])
+    s = np.sign(np.sum(real[f"ref/{name}/Ts_"] * m2.Ts_, axis=0))
+    assert util.relerr(Ts * s, real[f"ref/{name}/Ts_new"]) < 1e-7
+    assert util.relerr(U * s, real[f"ref/{name}/U_new"]) < 1e-7
+    assert util.relerr(m2.beta_[:, 0], real[f"ref/{name}/beta_"][:, 0]) < 1e-7      # the notebooks' bar plot
 
 
 def test_leave_one_out_curve_over_the_number_of_components(gpu_required, real):
