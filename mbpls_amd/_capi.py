@@ -222,6 +222,7 @@ class Context:
         self._pool = {}
         self._pool_bytes = 0
         self._mat_cache = {}        # (n, block offsets) -> upload matrix of a small problem, kept for its next fit (engine.py)
+        self._offset_hints = {}     # (n, block offsets) of host data whose last fit needed centring passes (engine.py)
         self._pool_cap = None
 
     # ---- pooled raw allocations

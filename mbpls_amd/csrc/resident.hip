@@ -143,12 +143,15 @@ __global__ __launch_bounds__(WG1024) void k_nipals_step(mbpls_nipals_step s, Ste
   mptr r_to = s.ts_old;
   mptr r_tp = s.tspass;
 
-  if (s.run == 1 && kc == 0 && s.amp2_max > 0.0) {
+  if (s.run == 1 && kc == 0 && s.centre) {
     // the statistics pass left max_j (mean_j/scale_j)^2 per block where the lazy sums of later passes go: raw-space
     // dot products without centring are only good for modestly offset data -- hand back to the caller otherwise
+    // (the measure itself goes back with every fit: a caller that started with centring passes learns from it when the
+    // data no longer need them)
     double worst = 0.0;
     for (int b = 0; b < B; ++b) worst = fmax(worst, dd[b]);
-    if (!(worst <= s.amp2_max)) {
+    if (lead) par[6] = worst;
+    if (s.amp2_max > 0.0 && !(worst <= s.amp2_max)) {
       if (lead) {
         par[2] = 1.0;
         par[3] = 0.0;

@@ -99,11 +99,14 @@ __global__ __launch_bounds__(SR_T) void k_step_reg(mbpls_nipals_step s) {
   const double* dd = ssq_g + 3 * B;      // [B][nd] lazy-deflation sums
   const double dn = (double)n;
 
-  if (s.run == 1 && kc == 0 && s.amp2_max > 0.0) {
+  if (s.run == 1 && kc == 0 && s.centre) {
     // offset data: raw-space dot products without centring are only good for modestly offset columns (resident.hip)
+    // (the measure itself goes back with every fit: a caller that started with centring passes learns from it when the
+    // data no longer need them)
     double worst = 0.0;
     for (int b = 0; b < B; ++b) worst = fmax(worst, dd[b]);
-    if (!(worst <= s.amp2_max)) {
+    if (lead) par[6] = worst;
+    if (s.amp2_max > 0.0 && !(worst <= s.amp2_max)) {
       if (lead) {
         par[2] = 1.0;
         par[3] = 0.0;

@@ -70,6 +70,7 @@ class HipEngine(EngineBase):
             X.upload(b, int(o))
         self._set_matrix(X, owns=True)
         self._uploaded = X
+        self._hint_key = self._mat_key              # (offset hint of host data: by shape, see _offset_hint)
         return self
 
     def load_device(self, dmat, copy=True):
@@ -79,7 +80,42 @@ class HipEngine(EngineBase):
         # deflation and implicit standardisation it never does, and the caller's matrix is used as it is)
         self._src = dmat if copy else None
         self._set_matrix(dmat, owns=False)
+        self._hint_owner = dmat                     # (offset hint of a resident matrix: kept on the matrix object)
         return self
+
+    # Raw spectra, counts, intensities: the columns of real data sit many standard deviations away from zero, and the
+    # raw-space passes of a never-writes-X fit then have to centre in registers (CENTRE_FROM_OFFSET).  A device-resident
+    # queue only learns that from its own statistics pass: it stops, and the fit is queued again with centring passes --
+    # one statistics pass and a queue thrown away, 0.3 ms of a 0.55 ms fit on the reference's FTIR data, a whole pass
+    # over X at any size.  The measure of the last fit of a resident matrix (or of host data of this shape) is therefore
+    # remembered: the next fit starts with the flavour that one needed, and drops it again when the step kernel reports
+    # a measure that no longer asks for it.  Never under column shards: every rank must queue the same passes.
+    OFFSET_HINTS = 32
+
+    def _offset_hint(self):
+        if self.comm.is_distributed:
+            return False
+        owner = getattr(self, "_hint_owner", None)
+        if owner is not None:
+            return bool(getattr(owner, "_offset_hint", False))
+        return bool(self.ctx._offset_hints.get(getattr(self, "_hint_key", None), False))
+
+    def _set_offset_hint(self, needed):
+        if self.comm.is_distributed:
+            return
+        owner = getattr(self, "_hint_owner", None)
+        if owner is not None:
+            owner._offset_hint = bool(needed)
+            return
+        key = getattr(self, "_hint_key", None)
+        if key is None:
+            return
+        hints = self.ctx._offset_hints
+        hints.pop(key, None)
+        if needed:
+            while len(hints) >= self.OFFSET_HINTS:
+                hints.pop(next(iter(hints)))
+            hints[key] = True
 
     def _working_copy(self):
         """the matrix the standardise pass writes into: X itself when it is ours to overwrite, else a new one"""
@@ -1229,6 +1265,8 @@ class _ResidentQueue:
         self.ptr = ptr
         # raw-space passes without centring are only good for modestly offset data: the first step checks the measure
         # the statistics pass left behind and stops the queue when the centring flavour is needed
+        if self.istd and not eng._cen and eng._offset_hint():
+            eng._cen = True                         # (the last fit of this matrix / shape needed centring passes)
         amp2 = eng.CENTRE_FROM_OFFSET ** 2 if (self.istd and not eng._cen) else 0.0
         self.st = _capi.NipalsStep(n=n, nblocks=B, q=q, centre=int(self.istd), norm_kind=int(norm_kind), tol=float(tol),
                                    amp2_max=amp2, mode=int(mode), xchg=eng._xchg.ptr, Y=ptr["Y"], Ts=ptr["Ts"],
@@ -1505,11 +1543,14 @@ class _ResidentQueue:
         if par[2] != 0.0 and par[5] == 1.0:
             # offset data (max |mean|/scale = sqrt(par[6])): the caller queues again, now with centring passes
             eng._cen = True
+            eng._set_offset_hint(True)
             wait_copies(meaningful=False)
             self.state.free()
             self.result = dict(k_done=0, reason="offset", offset=float(np.sqrt(par[6])))
             return False
         k_done = K if par[2] == 0.0 else int(par[3])
+        if self.istd:                                # (what the statistics pass measured: the next fit's flavour)
+            eng._set_offset_hint(float(par[6]) > eng.CENTRE_FROM_OFFSET ** 2)
         scal = self._view(h, "scal").reshape(K, 4, B)
         if self.incr and k_done == K:
             # R_ / beta_ came column by column from R C = W~ with the triangular C the steps recorded: good as long as

@@ -844,16 +844,85 @@ def test_device_resident_unipals(gpu_required, monkeypatch, blocks, standardize,
         return out
 
     monkeypatch.setattr(HipEngine, "unipals_resident", spy)
+    import mbpls_amd
+    mbpls_amd.get_context()._offset_hints.clear()          # (what earlier fits of this shape found out: see below)
     mdl = MBPLS(n_components=K, method="UNIPALS", standardize=standardize).fit(Xs, Y)
     assert calls == (["offset", K] if offset and standardize else [K])
     tol = max(1e-9, 1e3 * offset * np.finfo(float).eps)
     assert util.compare(util.model_to_flat(mdl), util.model_to_flat(ref), TOL, what="resident unipals") < tol
+    # the next fit of host data of this shape starts with the flavour this one needed (engine.HipEngine._offset_hint):
+    # one queue, the same numbers bit for bit -- and goes back to plain passes once the data no longer ask for centring
+    calls.clear()
+    again = MBPLS(n_components=K, method="UNIPALS", standardize=standardize).fit(Xs, Y)
+    assert calls == [K]
+    a, b = util.model_to_flat(again), util.model_to_flat(mdl)
+    assert all(np.array_equal(a[k], b[k]) for k in b)
+    if offset and standardize:
+        Xc = X - X.mean(axis=0)
+        Xcs = [np.ascontiguousarray(c) for c in np.array_split(Xc, blocks, axis=1)] if blocks > 1 else Xc
+        refc = orc.fit(Xcs, Y, n_components=K, method="UNIPALS", standardize=standardize)
+        for expect_centring in (True, False):
+            calls.clear()
+            mc = MBPLS(n_components=K, method="UNIPALS", standardize=standardize).fit(Xcs, Y)
+            assert calls == [K] and mc.fit_plan_["centred_in_registers"] is expect_centring, (calls, mc.fit_plan_)
+            assert util.compare(util.model_to_flat(mc), util.model_to_flat(refc), TOL, what="hint, centred data") < 1e-9
+    calls.clear()
     monkeypatch.setenv("MBPLS_RESIDENT", "0")
     calls.clear()
     m0 = MBPLS(n_components=K, method="UNIPALS", standardize=standardize).fit(Xs, Y)
     assert calls == []
     assert util.compare(util.model_to_flat(mdl), util.model_to_flat(m0), TOL, what="resident vs host loop") < max(1e-11, tol)
     assert util.relerr(mdl.predict(Xs), orc.predict(ref, Xs)) < tol
+
+
+def test_offset_hint_of_a_resident_matrix(gpu_required, monkeypatch):
+    """Raw spectra sit many standard deviations from zero: a device-resident queue finds that out in its statistics pass,
+    stops, and the fit is queued again with centring passes.  The next fit of THAT matrix starts with them (the measure
+    is kept on the DeviceMatrix object); another matrix of the same shape learns it for itself; a one-pass-late return
+    to plain passes when the content no longer asks for centring.  Same numbers either way."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix
+    from mbpls_amd.engine import HipEngine
+    ctx = mbpls_amd.get_context()
+    n, p, K = 600, 5000, 3
+    X, Y = orc.make_latent(n, p, 1, seed=5)
+    Xo = X + 40.0
+    ref = orc.fit(Xo, Y, n_components=K)
+    calls = []
+
+    def spied(real):
+        def spy(self, *a, **k):
+            out = real(self, *a, **k)
+            calls.append(out.get("reason", out["k_done"]))
+            return out
+        return spy
+
+    for name in ("nipals_resident", "unipals_resident"):      # (one-response NIPALS queues its one-pass form by default)
+        monkeypatch.setattr(HipEngine, name, spied(getattr(HipEngine, name)))
+    D = DeviceMatrix(ctx, n, p)
+    D.upload(Xo, 0)
+    first = MBPLS(n_components=K).fit(D, Y)
+    assert calls == ["offset", K], calls
+    calls.clear()
+    second = MBPLS(n_components=K).fit(D, Y)
+    assert calls == [K] and second.fit_plan_["centred_in_registers"] is True
+    a, b = util.model_to_flat(first), util.model_to_flat(second)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert util.compare(b, util.model_to_flat(ref), TOL, what="offset hint") < 1e-9
+    E = DeviceMatrix(ctx, n, p)                      # another matrix of this shape: no hint of its own yet
+    E.upload(Xo, 0)
+    calls.clear()
+    MBPLS(n_components=K).fit(E, Y)
+    assert calls == ["offset", K], calls
+    E.close()
+    D.upload(X - X.mean(axis=0), 0)                  # new content, centred: one fit later the plain passes are back
+    refc = orc.fit(X - X.mean(axis=0), Y, n_components=K)
+    for expect in (True, False):
+        calls.clear()
+        m = MBPLS(n_components=K).fit(D, Y)
+        assert calls == [K] and m.fit_plan_["centred_in_registers"] is expect
+        assert util.compare(util.model_to_flat(m), util.model_to_flat(refc), TOL, what="offset hint, centred content") < 1e-9
+    D.close()
 
 
 @pytest.mark.parametrize("resume_at", [0, 3])
