@@ -425,7 +425,9 @@ typedef struct mbpls_nipals_step {
   double tol;              /* max_tol (:841)                                                                       */
   double amp2_max;         /* > 0, component 0 / run 1 only: the statistics pass left max_j (mean_j/scale_j)^2 per block
                               in the d area; above this value the step stops the queue with par[5] = 1 (the caller
-                              queues again with the centring flavour of the passes, d_mean given)                   */
+                              queues again with the centring flavour of the passes, d_mean given).  With `centre` the
+                              measure itself is reported in par[6] whatever amp2_max is: a caller that started with
+                              centring passes sees when the data no longer ask for them                             */
   const double* xchg;      /* exchange buffer of the pass that just finished                                       */
   const double* Y;         /* n x q standardised responses                                                         */
   double* Ts;              /* n x K  super scores (column kc written at convergence)                               */
