@@ -157,3 +157,35 @@ def test_mbdata_mat(gpu_required, layout, kernel_route):
         w = util.compare(_flat_model(m, blocks(Xmv), Y, True), util.sub(g, f"sparse/{layout}/std{int(std)}"), TOL,
                          what=f"mbdata sparse {layout} std{std}")
         assert w < 1e-8, w
+
+
+def test_everyday_sklearn_usage(gpu_required, real):
+    """What users do around the estimator, with the reference's numbers for the same calls (fixture keys usage/*): score /
+    r2_score / explained_variance_score, integer input, 1-D / list / Series responses, a Pipeline behind a StandardScaler,
+    GridSearchCV over n_components, transform without Y, a pickle round trip, one new sample."""
+    import pickle
+    pd = pytest.importorskip("pandas")
+    from sklearn.model_selection import GridSearchCV
+    from sklearn.pipeline import Pipeline
+    from sklearn.preprocessing import StandardScaler
+    from mbpls_amd import MBPLS
+    X1, X2, y = real["x1"], real["x2"], real["y"]
+    m = MBPLS(n_components=3).fit([X1, X2], y)
+    assert abs(m.score([X1, X2], y) - float(real["usage/score"])) < 1e-10
+    assert abs(m.r2_score([X1, X2], y) - float(real["usage/r2_score"])) < 1e-10
+    assert abs(m.explained_variance_score([X1, X2], y) - float(real["usage/explained_variance_score"])) < 1e-10
+    Ts = m.transform([X1, X2])                                      # without Y: the super scores alone
+    s = np.sign(np.sum(real["ref/two_blocks/Ts_"] * m.Ts_, axis=0))
+    assert util.relerr(np.asarray(Ts) * s, real["usage/transform_without_y"]) < 1e-9
+    assert m.predict([X1[:1], X2[:1]]).shape == (1, 1)
+    m2 = pickle.loads(pickle.dumps(m))
+    assert np.array_equal(m2.predict([X1, X2]), m.predict([X1, X2]))
+    mi = MBPLS(n_components=2).fit((X1 * 1000).astype(int), y)
+    assert mi.beta_.dtype == np.float64 and util.relerr(mi.beta_, real["usage/int_beta"]) < 1e-9
+    for yy in (list(y), pd.Series(y), y.reshape(-1, 1)):
+        assert MBPLS(n_components=2).fit(X1, yy).beta_.shape == (148, 1)
+    pipe = Pipeline([("sc", StandardScaler()), ("pls", MBPLS(n_components=2))]).fit(X1, y)
+    assert util.relerr(np.ravel(pipe.predict(X1)), real["usage/pipeline_predict"]) < 1e-9
+    gs = GridSearchCV(MBPLS(), {"n_components": [1, 2, 3, 4]}, cv=5, scoring="neg_mean_squared_error").fit(X1, y)
+    assert gs.best_params_["n_components"] == int(real["usage/grid_best_n_components"])
+    assert util.relerr(np.asarray(gs.cv_results_["mean_test_score"]), real["usage/grid_mean_test_score"]) < 1e-8

@@ -308,6 +308,23 @@ def golden_real_pectin():
         capture(m, store, f"ref/{name}", X, y.reshape(-1, 1))
         store[f"loo/{name}"] = np.column_stack([np.ravel(cross_val_predict(MBPLS(n_components=k), X, y, cv=len(y)))
                                                 for k in (1, 3, 5)])
+    # everyday sklearn usage around the estimator: score / r2_score / explained_variance_score, integer input, a
+    # Pipeline behind a StandardScaler, a GridSearchCV over n_components (5 folds), transform without Y
+    from sklearn.model_selection import GridSearchCV
+    from sklearn.pipeline import Pipeline
+    from sklearn.preprocessing import StandardScaler
+    m = MBPLS(n_components=3)
+    m.fit([X1, X2], y)
+    store["usage/score"] = np.float64(m.score([X1, X2], y))
+    store["usage/r2_score"] = np.float64(m.r2_score([X1, X2], y))
+    store["usage/explained_variance_score"] = np.float64(m.explained_variance_score([X1, X2], y))
+    store["usage/transform_without_y"] = np.asarray(m.transform([X1, X2]))
+    store["usage/int_beta"] = MBPLS(n_components=2).fit((X1 * 1000).astype(int), y).beta_
+    pipe = Pipeline([("sc", StandardScaler()), ("pls", MBPLS(n_components=2))])
+    store["usage/pipeline_predict"] = np.ravel(pipe.fit(X1, y).predict(X1))
+    gs = GridSearchCV(MBPLS(), {"n_components": [1, 2, 3, 4]}, cv=5, scoring="neg_mean_squared_error").fit(X1, y)
+    store["usage/grid_mean_test_score"] = np.asarray(gs.cv_results_["mean_test_score"])
+    store["usage/grid_best_n_components"] = np.int64(gs.best_params_["n_components"])
     # the frames go into the estimator as they are in the notebooks: the reference must give the same numbers for them
     md = MBPLS(n_components=3)
     md.fit([x1, x2], pd.DataFrame(y))
