@@ -91,14 +91,16 @@ class HipEngine(EngineBase):
     # remembered: the next fit starts with the flavour that one needed, and drops it again when the step kernel reports
     # a measure that no longer asks for it.  Never under column shards: every rank must queue the same passes.
     OFFSET_HINTS = 32
+    OFFSET_ASK_BYTES = 1 << 30      # matrices from this size on: an unknown matrix waits for its statistics pass instead
 
     def _offset_hint(self):
+        """True / False: what the last fit of this matrix (host data: of this shape) measured; None: nothing known"""
         if self.comm.is_distributed:
-            return False
+            return None
         owner = getattr(self, "_hint_owner", None)
         if owner is not None:
-            return bool(getattr(owner, "_offset_hint", False))
-        return bool(self.ctx._offset_hints.get(getattr(self, "_hint_key", None), False))
+            return getattr(owner, "_offset_hint", None)
+        return self.ctx._offset_hints.get(getattr(self, "_hint_key", None))
 
     def _set_offset_hint(self, needed):
         if self.comm.is_distributed:
@@ -112,10 +114,15 @@ class HipEngine(EngineBase):
             return
         hints = self.ctx._offset_hints
         hints.pop(key, None)
-        if needed:
-            while len(hints) >= self.OFFSET_HINTS:
-                hints.pop(next(iter(hints)))
-            hints[key] = True
+        while len(hints) >= self.OFFSET_HINTS:
+            hints.pop(next(iter(hints)))
+        hints[key] = bool(needed)
+
+    def _measured_offset(self):
+        """max_j (mean_j / scale_j)^2 as the statistics pass left it in the exchange buffer (waits for that pass)"""
+        n, B = self.n, self.nblocks
+        self.ctx.sync()
+        return float(np.max(_capi.DeviceArray(self.ctx, (B,), ptr=self._xptr(n * B + 3 * B)).get()))
 
     def _working_copy(self):
         """the matrix the standardise pass writes into: X itself when it is ours to overwrite, else a new one"""
@@ -1265,8 +1272,15 @@ class _ResidentQueue:
         self.ptr = ptr
         # raw-space passes without centring are only good for modestly offset data: the first step checks the measure
         # the statistics pass left behind and stops the queue when the centring flavour is needed
-        if self.istd and not eng._cen and eng._offset_hint():
-            eng._cen = True                         # (the last fit of this matrix / shape needed centring passes)
+        if self.istd and not eng._cen:
+            hint = eng._offset_hint()
+            if hint is None and not eng.comm.is_distributed and 8 * n * eng.p >= eng.OFFSET_ASK_BYTES:
+                # nothing known about this matrix and a pass takes longer than this queue takes to build: the first
+                # pass (already under way) is waited for and asked, instead of a queue that may have to be thrown away
+                hint = eng._measured_offset() > eng.CENTRE_FROM_OFFSET ** 2
+                eng._set_offset_hint(hint)
+            if hint:
+                eng._cen = True                     # (the last fit of this matrix / shape needed centring passes)
         amp2 = eng.CENTRE_FROM_OFFSET ** 2 if (self.istd and not eng._cen) else 0.0
         self.st = _capi.NipalsStep(n=n, nblocks=B, q=q, centre=int(self.istd), norm_kind=int(norm_kind), tol=float(tol),
                                    amp2_max=amp2, mode=int(mode), xchg=eng._xchg.ptr, Y=ptr["Y"], Ts=ptr["Ts"],

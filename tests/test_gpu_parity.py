@@ -925,6 +925,43 @@ def test_offset_hint_of_a_resident_matrix(gpu_required, monkeypatch):
     D.close()
 
 
+def test_unknown_big_matrix_asks_its_statistics_pass(gpu_required, monkeypatch):
+    """From 1 GiB on a pass takes longer than the queue takes to build: a matrix nothing is known about waits for its
+    statistics pass and queues the right flavour at once -- no queue thrown away, also on the first fit."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix
+    from mbpls_amd.engine import HipEngine
+    ctx = mbpls_amd.get_context()
+    n, p, K = 4096, 36000, 2                          # 1.18 GB
+    X, Y = orc.make_latent(n, p, 1, seed=9)
+    X += 25.0
+    ref = orc.fit(X, Y, n_components=K)
+    calls = []
+
+    def spied(real):
+        def spy(self, *a, **k):
+            out = real(self, *a, **k)
+            calls.append(out.get("reason", out["k_done"]))
+            return out
+        return spy
+
+    for name in ("nipals_resident", "unipals_resident"):
+        monkeypatch.setattr(HipEngine, name, spied(getattr(HipEngine, name)))
+    D = DeviceMatrix(ctx, n, p)
+    D.upload(X, 0)
+    m = MBPLS(n_components=K).fit(D, Y)
+    assert calls == [K] and m.fit_plan_["centred_in_registers"] is True, (calls, m.fit_plan_)
+    assert util.compare(util.model_to_flat(m), util.model_to_flat(ref), TOL, what="asked its statistics pass") < 1e-9
+    monkeypatch.setattr(HipEngine, "OFFSET_ASK_BYTES", 1 << 40)
+    D._offset_hint = None                             # (nothing known again, and too small to ask: the speculative queue)
+    calls.clear()
+    m2 = MBPLS(n_components=K).fit(D, Y)
+    assert calls == ["offset", K], calls
+    a, b = util.model_to_flat(m), util.model_to_flat(m2)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    D.close()
+
+
 @pytest.mark.parametrize("resume_at", [0, 3])
 def test_device_resident_nipals_resumes_on_the_host(gpu_required, two_pass_nipals, monkeypatch, resume_at):
     """The device queue is speculative (two iterations per component).  When a component does not meet the stop rule
