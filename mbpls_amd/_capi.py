@@ -223,6 +223,7 @@ class Context:
         self._pool_bytes = 0
         self._mat_cache = {}        # (n, block offsets) -> upload matrix of a small problem, kept for its next fit (engine.py)
         self._offset_hints = {}     # (n, block offsets) of host data whose last fit needed centring passes (engine.py)
+        self._host_pool = []        # owners of large host buffers handed out as attribute arrays (engine._pooled_host_array)
         self._pool_cap = None
 
     # ---- pooled raw allocations
@@ -268,6 +269,7 @@ class Context:
             self.trim_pool()
 
     def trim_pool(self):
+        self._host_pool = []                         # (large host buffers kept for the next fit's attributes, engine.py)
         kept, self._mat_cache = self._mat_cache, {}
         for m in kept.values():
             m.close()

@@ -231,8 +231,10 @@ class HipEngine(EngineBase):
         ready = getattr(self, "_host_ready", None)
         if ready is None:
             ready = self._host_ready = {}
-        out = np.empty(shape, order="F")
-        if prefault:
+        out, mapped = _pooled_host_array(self.ctx, shape)
+        if mapped:                                  # a buffer an earlier model has let go of: its pages are there
+            pass
+        elif prefault:
             # (the LAST column first: it is the one that arrives behind the last pass, when nothing hides a page fault)
             _prefault(out, tail_bytes=8 * int(shape[0]) if len(shape) == 2 else 0)
         elif prefault_tail_only and len(shape) == 2:
@@ -1162,6 +1164,37 @@ class HipEngine(EngineBase):
         n = self.n
         ldg = n + (n & 1)
         return np.asarray(self.G[1].get()).reshape(n, ldg).T[:n, :n]
+
+
+# The p x K attributes of a fit at BASELINE size are four or five arrays of 80 MB.  A caller that fits in a loop lets the
+# previous model go with every new one: 20-26 ms of munmap for 55 ms of fit (and as many page faults again for the next
+# fit's arrays, which the helper thread of host_array has to hide).  Large host buffers are therefore handed out as views
+# of owners the context keeps: an owner nobody else refers to any more -- every attribute, slice and view of it gone,
+# numpy collapses the base chain onto the owner -- is handed out again, pages mapped.  Bounded (HOST_POOL_BYTES), released
+# by Context.trim_pool().
+HOST_POOL_MIN = 4 << 20
+HOST_POOL_BYTES = 2 << 30
+
+
+def _pooled_host_array(ctx, shape):
+    """(F-ordered float64 array of ``shape``, True when its pages are mapped already)"""
+    import sys
+    size = int(np.prod(shape)) if len(shape) else 1
+    nbytes = 8 * size
+    if nbytes < HOST_POOL_MIN:
+        return np.empty(shape, order="F"), False
+    pool = ctx.__dict__.setdefault("_host_pool", [])     # (a Context has the attribute; the tests pass a bare object)
+    raw, mapped = None, False
+    for cand in pool:
+        # references to an owner at rest: the list, `cand`, the argument of getrefcount
+        if nbytes <= cand.nbytes <= nbytes + (nbytes >> 2) and sys.getrefcount(cand) == 3:
+            raw, mapped = cand, True
+            break
+    if raw is None:
+        raw = np.empty(nbytes, dtype=np.uint8)
+        if sum(r.nbytes for r in pool) + nbytes <= HOST_POOL_BYTES:
+            pool.append(raw)
+    return raw[:nbytes].view(np.float64).reshape(shape, order="F"), mapped
 
 
 class _Keep:

@@ -235,3 +235,34 @@ def test_upload_matrices_of_small_fits_are_kept_and_overwritten(monkeypatch):
     final = flat(0, 1)
     for k in fresh:
         assert np.array_equal(final[k], fresh[k]), k
+
+
+def test_attributes_of_a_model_that_was_let_go_are_reused_and_kept_ones_are_not():
+    """The p x K attributes are views of host buffers the context hands out again once nobody refers to them
+    (engine._pooled_host_array): a loop of fits at BASELINE size pays neither munmap nor page faults (20-26 ms of a 77 ms
+    iteration).  What the caller keeps of an old model -- a slice is enough -- stays untouched."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS, DeviceMatrix
+    from bench import planted
+    ctx = _ctx()
+    ctx.trim_pool()
+    n, p, K = 512, 300_000, 4                        # attributes of 9.6 MB
+    Ts, Y = planted(n, 1, 8, 0)
+    X = DeviceMatrix(ctx, n, p, [0, p // 2, p])
+    X.fill_latent(ctx.from_host(Ts), 8, 0.5, 7, 0)
+    m1 = MBPLS(n_components=K).fit(X, Y)
+    kept = m1.W_[1][:, 2]                            # a column of one block of an attribute
+    kept_copy, kept_addr = kept.copy(), kept.ctypes.data
+    addrs1 = {m1.R_.ctypes.data, m1.P_[0].ctypes.data}
+    ref_beta = m1.beta_.copy()
+    del m1
+    m2 = MBPLS(n_components=K).fit(X, Y)
+    addrs2 = {m2.R_.ctypes.data, m2.P_[0].ctypes.data, m2.W_[0].ctypes.data}
+    assert addrs1 & addrs2, (addrs1, addrs2)         # buffers of the model that was let go serve the new one
+    lo = m2.W_[0].ctypes.data
+    assert not (lo <= kept_addr < lo + 8 * p * K) or m2.W_[0].base is not kept.base
+    assert np.array_equal(kept, kept_copy)           # ... the kept column's buffer was not among them
+    assert np.array_equal(m2.beta_, ref_beta)
+    X.close()
+    ctx.trim_pool()
+    assert not ctx._host_pool

@@ -321,3 +321,39 @@ def test_adjacent_copies_are_merged():
     sizes = sorted((m[0].nbytes, m[1] - base) for m in merged)
     assert sizes == [(800, 9000), (1600, 2400), (2400, 0)], sizes
     assert merged[0][0].ctypes.data == A.ctypes.data
+
+
+def test_large_host_buffers_are_handed_out_again_only_when_nobody_refers_to_them():
+    """engine._pooled_host_array: the p x K attributes of a fit are views of owners the context keeps; an owner is handed
+    out again once every array, slice and view of it is gone (numpy collapses the base chain onto the owner) -- a caller
+    that fits in a loop then neither pays the munmap of the previous model nor the page faults of the next."""
+    from mbpls_amd import engine
+
+    class Ctx:
+        pass
+
+    ctx = Ctx()
+    small, mapped = engine._pooled_host_array(ctx, (1000, 3))
+    assert not mapped and small.flags.f_contiguous and not getattr(ctx, "_host_pool", [])       # below HOST_POOL_MIN
+    shape = (200_000, 4)                                                                         # 6.4 MB
+    a, mapped = engine._pooled_host_array(ctx, shape)
+    assert not mapped and a.shape == shape and a.flags.f_contiguous and a.dtype == np.float64
+    a[:] = 7.0
+    addr = a.ctypes.data
+    b, mapped = engine._pooled_host_array(ctx, shape)
+    assert not mapped and b.ctypes.data != addr                    # the first one is in use
+    col = a[:, 2]                                                  # what a caller keeps of a model it has let go
+    del a
+    c, mapped = engine._pooled_host_array(ctx, shape)
+    assert not mapped and c.ctypes.data != addr and np.all(col == 7.0)
+    del col
+    d, mapped = engine._pooled_host_array(ctx, shape)
+    assert mapped and d.ctypes.data == addr                        # nobody refers to it any more: handed out again
+    e, mapped = engine._pooled_host_array(ctx, (190_000, 4))       # a slightly smaller request takes a free owner too
+    assert not mapped or e.ctypes.data != addr
+    del b, c, d, e
+    f, mapped = engine._pooled_host_array(ctx, (190_000, 4))
+    assert mapped and f.shape == (190_000, 4) and f.flags.f_contiguous
+    g, mapped = engine._pooled_host_array(ctx, (20_000, 4))        # far smaller: a new owner, the big ones stay whole
+    assert not mapped
+    assert sum(r.nbytes for r in ctx._host_pool) <= engine.HOST_POOL_BYTES
