@@ -191,9 +191,20 @@ int mbpls_hip_right_multiply(mbpls_ctx* ctx, int64_t p, const double* d_A, int64
   constexpr int RING = 16;
   if (!ctx->small_m) MB_HIP(hipMalloc(&ctx->small_m, sizeof(double) * CMAX * CMAX * RING));
   const int nwg = (int)std::min<int64_t>((p + 255) / 256, (int64_t)ctx->cus * 8);
-  // any c1, c2: CMAX x CMAX tiles of M; the tiles along c1 accumulate into C (so with c1 > CMAX the output must not
-  // alias the input columns)
+  // any c1, c2: CMAX x CMAX tiles of M; the tiles along c1 accumulate into C.  A tiled product IN PLACE (C overlapping
+  // the columns of A: the update S <- S [I; -r] of the maintained products with more than 31 responses) would read
+  // columns an earlier tile has already overwritten: it is formed in the workspace and copied back.
   const bool tiled = c1 > CMAX || c2 > CMAX;
+  const double* a_end = d_A + (int64_t)(c1 - 1) * lda + p;
+  const double* c_end = d_C + (int64_t)(c2 - 1) * ldc + p;
+  const bool alias = tiled && d_A < c_end && d_C < a_end;
+  double* d_dst = d_C;
+  int64_t ld_dst = ldc;
+  if (alias) {
+    MB_TRY(ensure_ws(ctx, sizeof(double) * (size_t)p * (size_t)c2));
+    d_dst = (double*)ctx->ws;
+    ld_dst = p;
+  }
   std::vector<std::vector<double>> tiles;     // packed sub-blocks of M: alive until the copies have run (sync below)
   for (int j0 = 0; j0 < c2; j0 += CMAX)
     for (int i0 = 0; i0 < c1; i0 += CMAX) {
@@ -211,9 +222,12 @@ int mbpls_hip_right_multiply(mbpls_ctx* ctx, int64_t p, const double* d_A, int64
       // runtime and now and then EXECUTES tens of milliseconds late on an idle GPU -- ctx.hip, mbpls_hip_memcpy_h2d)
       MB_TRY(mbpls_hip_memcpy_h2d(ctx, dM, hM, sizeof(double) * t1 * t2));
       hipLaunchKernelGGL(k_right_multiply, dim3(nwg), dim3(256), 0, ctx->stream, p, d_A + (int64_t)i0 * lda, lda, t1,
-                         (const double*)dM, t2, d_C + (int64_t)j0 * ldc, ldc, i0 > 0 ? 1 : 0);
+                         (const double*)dM, t2, d_dst + (int64_t)j0 * ld_dst, ld_dst, i0 > 0 ? 1 : 0);
       MB_HIP(hipGetLastError());
     }
+  if (alias)
+    MB_HIP(hipMemcpy2DAsync(d_C, sizeof(double) * (size_t)ldc, d_dst, sizeof(double) * (size_t)p, sizeof(double) * (size_t)p,
+                            (size_t)c2, hipMemcpyDeviceToDevice, ctx->stream));
   if (tiled) MB_SYNC_STREAM(ctx);
   return MBPLS_OK;
 }

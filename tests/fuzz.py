@@ -61,6 +61,8 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         if shard is not None:
             p = max(p, 2 * shard[2])           # (a rank without a single column is not a configuration anyone runs)
         q = int(rng.choice([1, 1, 2, 3, 5])) if big else int(rng.choice([1, 1, 2, 3, int(rng.randint(4, 13))]))
+        if not (big or long or wide) and rng.rand() < 0.08:
+            q = int(rng.randint(30, 48))       # more responses than a 32 x 32 tile of the small device products holds
         kmax = int(rng.choice([rng.randint(1, 5), rng.randint(5, 10)]))
         if big or long or wide:
             kmax = min(kmax, 4)                # (the CPU oracle iterates hundreds of times per component for q > 1)

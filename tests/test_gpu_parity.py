@@ -423,6 +423,47 @@ def test_small_dense_helpers(ctx, p, c1, c2):
     eng.close()
 
 
+@pytest.mark.parametrize("p,c1,c2", [(5000, 33, 32), (5000, 34, 33), (70001, 41, 40), (3000, 101, 100), (900, 70, 33)])
+def test_right_multiply_in_place_beyond_one_tile(ctx, p, c1, c2):
+    """C = A M with more than 32 columns runs over 32 x 32 tiles of M, the tiles along c1 accumulating into C; IN PLACE
+    (C = the leading columns of A: the update S <- S [I; -r] of the maintained products) a later tile read columns an
+    earlier one had overwritten -- several-response UNIPALS with q >= 33 had components 2 ... K wrong by 2-25 % (found by
+    a probe with 40 and 100 responses; the randomised sweep stops at 12).  The aliased tiled product goes through the
+    workspace now."""
+    from mbpls_amd.engine import HipEngine
+    from mbpls_amd import DeviceMatrix
+    rng = np.random.RandomState(c1)
+    eng = HipEngine(ctx)
+    eng.load_device(DeviceMatrix(ctx, 8, p), copy=False)
+    A = rng.standard_normal((p, c1))
+    eng.put("A", A)
+    M = np.vstack([np.eye(c2), rng.standard_normal((c1 - c2, c2))]) if c1 > c2 else rng.standard_normal((c1, c2))
+    eng.right_mul(("A", 0, c1), M, ("A", 0))                       # in place over the leading c2 columns
+    got = eng.fetch("A")
+    assert util.relerr(got[:, :c2], A.dot(M)) < TIGHT
+    assert np.array_equal(got[:, c2:], A[:, c2:])                  # the other columns are untouched
+    G = rng.standard_normal((c1, c2))
+    eng.put("A", A)
+    eng.right_mul(("A", 0, c1), G, ("A", 0))                       # a general M, in place
+    assert util.relerr(eng.fetch("A")[:, :c2], A.dot(G)) < TIGHT
+    eng.close()
+
+
+@pytest.mark.parametrize("q", [33, 40, 100])
+def test_many_responses(gpu_required, q, kernel_route):
+    """more responses than one tile of the device helpers holds (32): every method against the oracle"""
+    from mbpls_amd import MBPLS
+    n, p, K = 200, 5000, 3
+    X, Y = orc.make_latent(n, p, q, r=6, seed=q)
+    blocks = [np.ascontiguousarray(X[:, :2200]), np.ascontiguousarray(X[:, 2200:])]
+    for method in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+        ref = orc.fit(blocks, Y, n_components=K, method=method, full_svd=True, max_iter=3000)
+        m = MBPLS(n_components=K, method=method, full_svd=True).fit(blocks, Y)
+        w = util.compare(util.model_to_flat(m), util.model_to_flat(ref), TOL, what=f"q={q} {method}")
+        assert w < 1e-9, (method, w)
+        assert util.relerr(m.predict(blocks), orc.predict(ref, blocks)) < 1e-9
+
+
 def test_q1_fixed_point_option(gpu_required, monkeypatch):
     """One pass per component for one-response NIPALS (the default; MBPLS_NIPALS_Q1_FIXED_POINT=1 says so explicitly):
     same attributes as the reference's two passes."""
