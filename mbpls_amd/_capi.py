@@ -219,6 +219,11 @@ class Context:
         self.device = int(device)
         # size-keyed cache of freed device buffers: repeated fits (bench steps, cross-validation)
         # reuse the 8np-byte working matrix instead of paying hipMalloc/hipFree of tens of GB
+        # one fit / predict / transform at a time per context: the passes of a fit share the context's parameter block,
+        # workspace, pinned rings and copier -- estimators driven from several threads (joblib's threading backend)
+        # take turns (mbpls.MBPLS, model_selection)
+        import threading
+        self.lock = threading.RLock()
         self._pool = {}
         self._pool_bytes = 0
         self._mat_cache = {}        # (n, block offsets) -> upload matrix of a small problem, kept for its next fit (engine.py)

@@ -111,6 +111,20 @@ def _rearm_cluster_passes(ctx):
         del ctx._cluster_downgrade
 
 
+
+def _one_at_a_time(method):
+    """fit / predict / transform of estimators that share a context take turns (Context.lock): the reference is plain
+    numpy and can be driven from several threads at once -- joblib's threading backend does --, the passes of a fit
+    share the context's parameter block, workspace and copier"""
+    import functools
+
+    @functools.wraps(method)
+    def locked(self, *args, **kwargs):
+        with runtime.get_context().lock:
+            return method(self, *args, **kwargs)
+    return locked
+
+
 class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
     """(Multiblock) PLS regression, MI355X-native.  See the module docstring."""
 
@@ -152,6 +166,7 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
         Y : 1-D or 2-D array"""
         return self._fit(X, Y, None)
 
+    @_one_at_a_time
     def _fit(self, X, Y, row_mask):
         """fit() on the samples where ``row_mask`` is True (None = all): the engine zeroes the excluded rows
         of its working copy, so the matrix never has to be re-uploaded or sliced for cross-validation folds
@@ -388,6 +403,7 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             scale = eng.ctx.from_host(np.concatenate([s.scale_ for s in self.x_scalers_]))
         return mat, mean, scale
 
+    @_one_at_a_time
     def predict(self, X, copy=True):
         """Predict y based on the fitted model (reference mbpls.py:1337): (X_std beta) sigma_y + mu_y."""
         self._check_fitted()
@@ -404,6 +420,7 @@ class MBPLS(TransformerMixin, RegressorMixin, MultiOutputMixin, BaseEstimator):
             y = self.y_scaler_.inverse_transform(y)
         return y
 
+    @_one_at_a_time
     def transform(self, X, Y=None, return_block_scores=False, copy=True):
         """Scores of new data (reference mbpls.py:1052): Ts = X_std R_; block scores by the
         deflation-free identity T_b = X_b W_b - Ts triu(P_b^T W_b, 1) (== the sequential deflation

@@ -39,6 +39,12 @@ def _resident(X):
 
 
 def cross_val_predict(estimator, X, y, cv=5, groups=None, batch_folds=True):
+    """Out-of-fold predictions of ``estimator`` (an ``MBPLS``), like sklearn's ``cross_val_predict``."""
+    with runtime.get_context().lock:          # (one caller at a time per context, as for fit / predict / transform)
+        return _cross_val_predict(estimator, X, y, cv, groups, batch_folds)
+
+
+def _cross_val_predict(estimator, X, y, cv, groups, batch_folds):
     """Out-of-fold predictions of ``estimator`` (an ``MBPLS``), like sklearn's ``cross_val_predict``.
 
     cv: int (KFold without shuffling, as sklearn does for regressors), a CV splitter, or an iterable of

@@ -14,14 +14,20 @@ def set_device(device):
     _state["device"] = int(device)
 
 
+_ctx_lock = __import__("threading").Lock()
+
+
 def get_context(device=None):
     """The shared ``Context`` of a device (created on first use; raises if no GPU / no library)."""
     d = _state["device"] if device is None else int(device)
     ctx = _contexts.get(d)
     if ctx is None or ctx.handle is None:
-        ctx = _capi.Context(d)
-        _contexts[d] = ctx
-        _warm_up(ctx)
+        with _ctx_lock:                       # (two threads asking first at the same time: one context, not two)
+            ctx = _contexts.get(d)
+            if ctx is None or ctx.handle is None:
+                ctx = _capi.Context(d)
+                _contexts[d] = ctx
+                _warm_up(ctx)
     return ctx
 
 

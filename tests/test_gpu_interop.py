@@ -117,3 +117,40 @@ def test_sklearn_check_estimator_at_least_as_the_reference(gpu_required):
     extra = {k: v for k, v in failed.items() if k not in REFERENCE_FAILS}
     assert len(res) >= 50
     assert not extra, extra
+
+
+def test_estimators_driven_from_several_threads(gpu_required):
+    """The reference is plain numpy: separate estimators can be fitted from several threads at once (joblib's threading
+    backend, a web service).  Here the passes of a fit share the context's parameter block, workspace, pinned rings and
+    copier: fit / predict / transform / cross_val_predict of one context take turns (Context.lock) -- found by a probe in
+    which four threads fitted at once and one of them ended in `SVD did not converge`."""
+    import threading
+    from mbpls_amd import MBPLS, cross_val_predict
+    from oracle import mbpls_oracle as orc
+    X, Y = orc.make_latent(60, 900, 2, r=4, seed=3)
+    blocks = [np.ascontiguousarray(X[:, :400]), np.ascontiguousarray(X[:, 400:])]
+    jobs = [(m, k) for m in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS") for k in (1, 2, 3)]
+    serial = {}
+    for m, k in jobs:
+        est = MBPLS(n_components=k, method=m).fit(blocks, Y)
+        serial[m, k] = (est.beta_.copy(), est.predict(blocks), cross_val_predict(MBPLS(n_components=k, method=m), blocks, Y, cv=6))
+    got, errors = {}, []
+
+    def work(m, k):
+        try:
+            for _ in range(3):
+                est = MBPLS(n_components=k, method=m).fit(blocks, Y)
+                got[m, k] = (est.beta_.copy(), est.predict(blocks),
+                             cross_val_predict(MBPLS(n_components=k, method=m), blocks, Y, cv=6))
+        except Exception as e:                      # noqa: BLE001 -- reported below
+            errors.append((m, k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for j in jobs:
+        for a, b in zip(got[j], serial[j]):
+            assert np.array_equal(a, b), j
