@@ -215,6 +215,9 @@ __global__ __launch_bounds__(TMAX, (R == 8 && TMAX == 512) ? 4 : ((TMAX == 256 &
               amp = fmax(amp, mean * mean * r2);   // SQUARED offset |mean|/scale: decides whether the later passes centre
               (void)m2;                            // (((K - mean)/scale)^2 <= n bounds the error of the shifted variance)
               ssq_x = fma(dn * var, r2, ssq_x);                   // sum z^2 of the column
+              // a NaN / inf / overflowing sample: fmax() above turned the NaN variance into 0 -- "a constant column" --
+              // and the fit went on without it; the sum of squares remembers (S2 - S2 is 0 for every finite S2)
+              ssq_x += s3[1] - s3[1];
               s_out[0][slot] = mean;
               s_out[1][slot] = var;
               s_out[2][slot] = r2;

@@ -484,6 +484,7 @@ __global__ __launch_bounds__(TMAX, TMAX / 256) void k_colpass_cl(ClArgs c) {
           ssq_g = fma(gt, cj, ssq_g);
           amp = fmax(amp, mean * mean * r2);
           ssq_x = fma(dn * var, r2, ssq_x);
+          ssq_x += S2 - S2;              // non-finite samples poison the sum (fmax() made their variance 0): colpass.hip
           if (writer) {
             if (lane == 0) {
               s_out[0][oslot] = mean;

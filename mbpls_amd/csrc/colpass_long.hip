@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_fin_std(FinStdArgs a) {
       scale = constant ? 1.0 : sqrt(var);
       r2 = constant ? 0.0 : 1.0 / var;
       rs = constant ? 0.0 : 1.0 / scale;
-      ssqx = constant ? 0.0 : dn * var * r2;
+      ssqx = (constant ? 0.0 : dn * var * r2) + (S2 - S2);   // (non-finite samples poison the sum: colpass.hip)
       dotc = constant ? 0.0 : Sv - m1 * svsum;          // <x - mean, v> over the kept rows
       a.mean[j] = mean;
       a.scale[j] = scale;

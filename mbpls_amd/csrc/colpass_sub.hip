@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void k_colpass_sub(PassArgs a) {
           if (valid) amp = fmax(amp, mean * mean * r2);
           if (writer) {
             ssq_x = fma(dn * var, r2, ssq_x);     // sum z^2 of the column, counted by one lane of the row
+            ssq_x += s2 - s2;                     // non-finite samples poison the sum (fmax() made their variance 0)
             a.mean[jj] = mean;
             a.scale[jj] = var;                    // k_finish_stats turns var into scale, g~ into g
             if (a.r2_out) a.r2_out[jj] = r2;

@@ -28,6 +28,9 @@ int comm_guard_wait(mbpls_ctx* ctx);
     if (e_ != hipSuccess) {                                                               \
       ::mbpls::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
                          __LINE__);                                                       \
+      /* the runtime remembers the error: left there, the hipGetLastError() behind the NEXT launch of a healthy call */ \
+      /* would report it again (an allocation that did not fit made the following fit fail with "out of memory") */     \
+      (void)hipGetLastError();                                                            \
       return e_ == hipErrorOutOfMemory ? MBPLS_ERR_OOM : MBPLS_ERR_HIP;                   \
     }                                                                                     \
   } while (0)

@@ -574,6 +574,7 @@ int mbpls_hip_mat_create(mbpls_ctx* ctx, int64_t n, int64_t p, int nblocks, cons
   } else {
     hipError_t e = hipMalloc((void**)&m->data, sizeof(double) * (size_t)m->ld * (size_t)p);
     if (e != hipSuccess) {
+      (void)hipGetLastError();
       set_error("hipMalloc of %.3f GB for a %lld x %lld matrix failed: %s",
                 (double)m->ld * p * 8 / 1e9, (long long)n, (long long)p, hipGetErrorString(e));
       delete m;
@@ -587,6 +588,7 @@ int mbpls_hip_mat_create(mbpls_ctx* ctx, int64_t n, int64_t p, int nblocks, cons
       e = hipMemcpyAsync(m->d_block_offsets, m->block_offsets.data(), sizeof(int64_t) * (size_t)(nblocks + 1),
                          hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) {
+      (void)hipGetLastError();
       set_error("block offsets: %s", hipGetErrorString(e));
       mbpls_hip_mat_destroy(m);
       return MBPLS_ERR_HIP;

@@ -154,3 +154,32 @@ def test_estimators_driven_from_several_threads(gpu_required):
     for j in jobs:
         for a, b in zip(got[j], serial[j]):
             assert np.array_equal(a, b), j
+
+
+@pytest.mark.parametrize("n,p", [(80, 600), (2000, 900), (9000, 300)])
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf, 1e308])
+def test_non_finite_input_is_a_value_error_on_every_route(gpu_required, n, p, bad):
+    """The reference's check_array raises ValueError for NaN, infinity or a value too large (its squares overflow); the
+    host scan it costs (1.7 s at BASELINE size) is left to the statistics pass here -- whose fmax(variance, 0) turned the
+    NaN variance of such a column into "constant column" for the routes that do not sweep in that pass: several-response
+    NIPALS ended in `SVD did not converge`, one-response SIMPLS returned a model.  The sum of squares is poisoned now
+    (few samples, register-resident, cluster and two-phase statistics alike); the next fit is unaffected."""
+    import mbpls_amd
+    from mbpls_amd import MBPLS
+    X, Y = orc.make_latent(n, p, 2, r=4, seed=n)
+    Xb = X.copy()
+    Xb[n // 3, p // 2] = bad
+    ctx = mbpls_amd.get_context()
+    for two_phase in ((False, True) if n > 8192 else (False,)):
+        ctx.set_tunable("cluster_passes", 0 if two_phase else 1)
+        try:
+            for q in (1, 2):
+                for method in ("NIPALS", "UNIPALS", "KERNEL", "SIMPLS"):
+                    for std in (True, False):
+                        with pytest.raises(ValueError, match="NaN, infinity or a value too large"):
+                            MBPLS(n_components=2, method=method, standardize=std).fit(Xb, Y[:, :q])
+        finally:
+            ctx.set_tunable("cluster_passes", 1)
+    ref = orc.fit(X, Y, n_components=2)
+    m = MBPLS(n_components=2).fit(X, Y)
+    assert util.compare(util.model_to_flat(m), util.model_to_flat(ref), 1e-6, what="after the errors") < 1e-9
