@@ -63,6 +63,10 @@ def _cross_val_predict(estimator, X, y, cv, groups, batch_folds):
         splits = list(check_cv(cv, y2, classifier=False).split(np.zeros((n, 1)), y2, groups))
     else:
         splits = [(np.asarray(tr), np.asarray(te)) for tr, te in cv]
+    # sklearn's cross_val_predict: every sample is predicted exactly once ("only works for partitions")
+    tested = np.concatenate([np.asarray(te).ravel() for _, te in splits]) if splits else np.empty(0, dtype=int)
+    if tested.size != n or not np.array_equal(np.sort(tested), np.arange(n)):
+        raise ValueError("cross_val_predict only works for partitions")
     Xdev, owned, host_blocks = _resident(X)
     try:
         if Xdev.n != n:

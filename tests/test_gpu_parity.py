@@ -650,6 +650,19 @@ def test_cross_val_predict_batched_folds_validate_like_fit(gpu_required):
     for std in (True, False):
         with pytest.raises(ValueError):
             cross_val_predict(MBPLS(n_components=2, standardize=std), X, Y, cv=8)
+    # ... and a splitter whose test sets are not a partition of the samples is refused as sklearn refuses it
+    from sklearn.model_selection import GroupKFold, KFold, ShuffleSplit
+    X, Y = orc.make_latent(40, 300, 1, r=4, seed=2)
+    with pytest.raises(ValueError, match="only works for partitions"):
+        cross_val_predict(MBPLS(n_components=2), X, Y, cv=ShuffleSplit(5, test_size=0.2, random_state=0))
+    with pytest.raises(ValueError, match="only works for partitions"):
+        cross_val_predict(MBPLS(n_components=2), X, Y, cv=list(KFold(4).split(X))[:3])
+    groups = np.repeat(np.arange(8), 5)
+    got = cross_val_predict(MBPLS(n_components=2), X, Y, cv=GroupKFold(4), groups=groups)
+    want = np.empty_like(Y)
+    for tr, te in GroupKFold(4).split(X, Y, groups):
+        want[te] = orc.predict(orc.fit(X[tr], Y[tr], n_components=2), X[te])
+    assert util.relerr(got, want) < 1e-9
 
 
 @pytest.mark.parametrize("n,p,q,K", [(5, 1, 1, 1), (3, 2, 1, 1), (7, 3, 2, 2), (64, 1, 1, 1), (2, 5, 1, 1), (6, 4, 1, 3),
