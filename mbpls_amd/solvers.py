@@ -1557,6 +1557,7 @@ def _fit_simpls_hostvec(eng, Y, K, standardize):
     device helpers)."""
     n = eng.n
     q = Y.shape[1]
+    _plan(eng, solver="simpls: two products per component, p-length vectors on the host (K + 1 + q > 32)")
     _prepare_products(eng, standardize)
     eng.slot("S", q); eng.slot("r", 1); eng.slot("p", 1)
     eng.xt_v(Y, 1.0, "S", 0)
