@@ -81,7 +81,8 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         # column offsets (implicit standardisation): mostly modest, now and then far beyond the eight standard deviations
         # from which the raw-space passes centre in registers -- raw spectra (a device queue that is stopped and queued
         # again, or starts with centring passes because the last fit of the shape needed them: engine._offset_hint)
-        X = X + rng.uniform(-3, 3, size=p) * (rng.rand() < 0.5) * float(rng.choice([1.0, 1.0, 1.0, 10.0, 300.0]))
+        offset_scale = float(rng.choice([1.0, 1.0, 1.0, 10.0, 300.0]))
+        X = X + rng.uniform(-3, 3, size=p) * (rng.rand() < 0.5) * offset_scale
         sp = (lambda A: A) if nb == 1 else (lambda A: [np.ascontiguousarray(b) for b in np.split(A, cuts, axis=1)])
         sparse = method == "NIPALS" and n >= 20 and p >= 20 and rng.rand() < 0.4
         if sparse:
@@ -151,8 +152,12 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         # case 133 (n = 9, K = 8, standardised: rank 8): Ts orthonormal to 2e-10, yet ONE ULP on random elements of X
         # moves the oracle's own U_[:, 7] by 7e-7 and V_[:, 7] by 2e-5.  The oracle refitted on inputs perturbed by one
         # ulp measures that; the bound of a SIMPLS case is 50 x the larger of the two figures.
+        # The same measure bounds fits of UNCENTRED data whose columns sit tens to hundreds of standard deviations from
+        # zero (standardize=False on raw spectra): X X^T is then one huge rank-one term plus the structure, and the
+        # reference's own later components move by 1e-7 under one ulp (seed 5707, case 198: KERNEL, offsets to 1400
+        # sigma, Ts orthonormal to 5e-9 only, W_concat_ of the fit 2.5e-6 off).
         bound = None
-        if method == "SIMPLS":
+        if method == "SIMPLS" or (not std and offset_scale >= 10.0 and not sparse):
             defect = float(np.max(np.abs(ref.Ts_.T.dot(ref.Ts_) - np.eye(K))))
             prng = np.random.RandomState(77 + c)
             Xp = X * (1.0 + 2.220446049250313e-16 * prng.choice([-1.0, 0.0, 1.0], size=X.shape))
@@ -218,7 +223,7 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                             print_(tag, f"cross_val_predict batched vs loop {wcv:.2e} (cv={folds}, rank {rank} of {world})")
                         w = max(w, wcv)
                 if bound is not None:
-                    assert w <= bound, f"{tag}: SIMPLS {w:.2e} beyond 50 x the oracle's own defect / one-ulp sensitivity {bound:.2e}"
+                    assert w <= bound, f"{tag}: {w:.2e} beyond 50 x the oracle's own defect / one-ulp sensitivity {bound:.2e}"
                     print_(tag, f"relerr {w:.2e} within 50 x the oracle's own defect / one-ulp sensitivity {bound:.2e} (rank {rank} of {world})")
                     continue
                 worst = max(worst, w)
@@ -272,7 +277,7 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
                     print_(tag, f"cross_val_predict batched vs loop {wcv:.2e} (cv={folds})")
                 w = max(w, wcv)
             if bound is not None:
-                assert w <= bound, f"{tag}: SIMPLS {w:.2e} beyond 50 x the oracle's own defect / one-ulp sensitivity {bound:.2e}"
+                assert w <= bound, f"{tag}: {w:.2e} beyond 50 x the oracle's own defect / one-ulp sensitivity {bound:.2e}"
                 print_(tag, f"relerr {w:.2e} within 50 x the oracle's own defect / one-ulp sensitivity {bound:.2e}")
             else:
                 worst = max(worst, w)
