@@ -1,6 +1,7 @@
 #!/bin/bash
 # Evidence of one round (everything named profiles/<round>_*): run on the GPU box from the repo root,
 #   gpurun --timeout 3400 -- 'bash tools/gpu_evidence.sh r05 [part ...]'      parts: bench dist configs shapes cv paper sparse fuzz prof long gaps sparselong kroutes (default: all)
+#   (fuzz part: FUZZ_SMALL_SEEDS / FUZZ_BIG_SEEDS / FUZZ_LONG_SEEDS / FUZZ_WIDE_SEEDS / FUZZ_SHARD_SEED choose the seeds of a campaign)
 # then, back on the build machine:  python tools/collect_evidence.py r05 [--table]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 RND=${1:-r05}
