@@ -274,15 +274,16 @@ class Context:
             self.trim_pool()
 
     def trim_pool(self):
-        self._host_pool = []                         # (large host buffers kept for the next fit's attributes, engine.py)
-        kept, self._mat_cache = self._mat_cache, {}
-        for m in kept.values():
-            m.close()
-        for lst in self._pool.values():
-            for ptr in lst:
-                self.lib.mbpls_hip_free(self.handle, ptr)
-        self._pool = {}
-        self._pool_bytes = 0
+        with self.lock:                                  # (not under a fit of another thread)
+            self._host_pool = []                         # (large host buffers kept for the next fit's attributes, engine.py)
+            kept, self._mat_cache = self._mat_cache, {}
+            for m in kept.values():
+                m.close()
+            for lst in self._pool.values():
+                for ptr in lst:
+                    self.lib.mbpls_hip_free(self.handle, ptr)
+            self._pool = {}
+            self._pool_bytes = 0
 
     def close(self):
         if getattr(self, "handle", None):
