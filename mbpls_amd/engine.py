@@ -10,6 +10,8 @@ the reference); p-length results stay in named device *slots* (p x K, column-maj
 from __future__ import annotations
 
 import contextlib
+import math
+import sys
 import time
 
 import numpy as np
@@ -1178,9 +1180,7 @@ HOST_POOL_BYTES = 2 << 30
 
 def _pooled_host_array(ctx, shape):
     """(F-ordered float64 array of ``shape``, True when its pages are mapped already)"""
-    import sys
-    size = int(np.prod(shape)) if len(shape) else 1
-    nbytes = 8 * size
+    nbytes = 8 * math.prod(shape)                       # (np.prod of a tuple costs 4 us, a small fit asks ten times)
     if nbytes < HOST_POOL_MIN:
         return np.empty(shape, order="F"), False
     pool = ctx.__dict__.setdefault("_host_pool", [])     # (a Context has the attribute; the tests pass a bare object)
