@@ -99,15 +99,21 @@ constexpr size_t COPIER_PIECE = (size_t)64 << 10;
 static void land_piece(const CopierState::Land& L, size_t a, size_t b) {
   if (L.dst) memcpy(L.dst + a, L.src + a, b - a);
   if (L.sdst) {
-    const double* __restrict__ src = (const double*)L.src;
-    double* __restrict__ out = L.sdst;
     int64_t j = (int64_t)(a / 8);
     const int64_t j1 = (int64_t)(b / 8);
+    const bool in_place = (const void*)L.src == (const void*)L.sdst;   // (a large column, normalised where it arrived)
     for (int blk = 0; blk < L.nblocks && j < j1; ++blk) {
       const int64_t e = L.offs[blk + 1] < j1 ? L.offs[blk + 1] : j1;
       if (e <= j) continue;
       const double d = sqrt(L.nu2[blk]);
-      for (; j < e; ++j) out[j] = src[j] / d;
+      if (in_place) {
+        double* out = L.sdst;
+        for (; j < e; ++j) out[j] = out[j] / d;
+      } else {
+        const double* __restrict__ src = (const double*)L.src;
+        double* __restrict__ out = L.sdst;
+        for (; j < e; ++j) out[j] = src[j] / d;
+      }
     }
   }
 }
@@ -208,6 +214,50 @@ static int copier_run(CopierState* cs, CopierJob& job) {
   double t_dma = 0.0, t_cpy = 0.0, t_scale = 0.0;
   int prev = -1, prev_slot = 0, nsmall = 0;
   bool scaled = !job.has_scale;      // the normalisation has been done with the copy that delivered its source
+  auto share_out = [&](CopierState::Land& L) {     // cs->land is filled in: its pieces go to this thread and the helpers
+    const int64_t npieces = (int64_t)((L.bytes + COPIER_PIECE - 1) / COPIER_PIECE);
+    cs->land_left.store(npieces, std::memory_order_relaxed);
+    const uint64_t epoch = ++cs->land_epoch;
+    cs->land_ticket.store(epoch << 32, std::memory_order_release);       // open: pieces 0 .. npieces - 1
+    land_work(cs, epoch, L);
+    while (cs->land_left.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+    cs->land_ticket.store((epoch << 32) | LAND_CLOSED, std::memory_order_seq_cst);
+  };
+  // The normalisation of a LARGE column, which arrived straight in the caller's pages: one thread divides 20 GB/s worth of
+  // column, 4.0 ms for the 80 MB of p = 10^7 -- as long as the DMA of the job's other two columns (55 GB/s), and with few
+  // samples the passes are shorter than the copies, so the fit waits for this thread (n = 100, p = 10^7, K = 4: 42 ms, 16
+  // of them this loop; MBPLS_COPIER_TRACE=1).  The column is therefore shared out in pieces like a landed small copy --
+  // and while the DMA of the job's NEXT large column is in flight (w~ is the first copy of its job, engine.nipals_resident).
+  // (A copy into pageable memory returns when it is complete, whatever its name says: the division is opened for the
+  // helpers BEFORE the call and this thread joins them after it.)
+  bool pending_scale = false;        // the source column of the normalisation has arrived, the division is still to do
+  uint64_t scale_epoch = 0;          // != 0: the division is open, the helpers are at it
+  auto scale_open = [&]() {
+    while (cs->land_readers.load(std::memory_order_seq_cst) > 0) __builtin_ia32_pause();
+    CopierState::Land& L = cs->land;
+    L = CopierState::Land{};
+    L.src = (const char*)job.s_src;
+    L.dst = nullptr;
+    L.bytes = (size_t)job.s_offs.back() * sizeof(double);
+    L.sdst = job.s_dst;
+    L.nu2 = job.s_nu2;
+    L.offs = job.s_offs.data();
+    L.nblocks = (int)job.s_offs.size() - 1;
+    cs->land_left.store((int64_t)((L.bytes + COPIER_PIECE - 1) / COPIER_PIECE), std::memory_order_relaxed);
+    scale_epoch = ++cs->land_epoch;
+    cs->land_ticket.store(scale_epoch << 32, std::memory_order_release);
+    cs->cv_help.notify_all();        // (a large DMA outlasts the helpers' polling)
+    pending_scale = false;
+  };
+  auto scale_finish = [&]() {
+    const double t0 = trace ? now_us() : 0.0;
+    land_work(cs, scale_epoch, cs->land);
+    while (cs->land_left.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+    cs->land_ticket.store((scale_epoch << 32) | LAND_CLOSED, std::memory_order_seq_cst);
+    scale_epoch = 0;
+    scaled = true;
+    if (trace) t_scale += now_us() - t0;
+  };
   auto land = [&]() -> int {         // the copy in flight in bounce[prev_slot] has arrived: move it to its destination
     if (prev < 0) return MBPLS_OK;
     const double a = trace ? now_us() : 0.0;
@@ -229,13 +279,7 @@ static int copier_run(CopierState* cs, CopierJob& job) {
       if ((const void*)job.s_dst == (const void*)c.h_dst) L.dst = nullptr;    // in place: the scaled values only
       scaled = true;
     }
-    const int64_t npieces = (int64_t)((L.bytes + COPIER_PIECE - 1) / COPIER_PIECE);
-    cs->land_left.store(npieces, std::memory_order_relaxed);
-    const uint64_t epoch = ++cs->land_epoch;
-    cs->land_ticket.store(epoch << 32, std::memory_order_release);       // open: pieces 0 .. npieces - 1
-    land_work(cs, epoch, L);
-    while (cs->land_left.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
-    cs->land_ticket.store((epoch << 32) | LAND_CLOSED, std::memory_order_seq_cst);
+    share_out(L);
     if (trace) {
       t_dma += b - a;
       t_cpy += now_us() - b;
@@ -258,8 +302,14 @@ static int copier_run(CopierState* cs, CopierJob& job) {
       // large columns (8 MB at BASELINE config[1]): straight into the caller's pages (mapped ahead by the host side)
       const int rc = land();
       if (rc != MBPLS_OK) return rc;
-      CP_HIP(hipMemcpyAsync(c.h_dst, c.d_src, c.bytes, hipMemcpyDeviceToHost, cs->stream));
-      CP_HIP(hipStreamSynchronize(cs->stream));
+      if (pending_scale) scale_open();             // (of an earlier column of this job, beside this column's DMA)
+      const hipError_t e_copy = hipMemcpyAsync(c.h_dst, c.d_src, c.bytes, hipMemcpyDeviceToHost, cs->stream);
+      const hipError_t e_sync = e_copy == hipSuccess ? hipStreamSynchronize(cs->stream) : e_copy;
+      if (scale_epoch) scale_finish();             // (also when the copy failed: the epoch must not stay open)
+      CP_HIP(e_sync);
+      if (job.has_scale && !scaled && (const void*)job.s_src == (const void*)c.h_dst &&
+          c.bytes == (size_t)job.s_offs.back() * sizeof(double))
+        pending_scale = true;
     }
   }
   {
@@ -271,6 +321,10 @@ static int copier_run(CopierState* cs, CopierJob& job) {
   // 16 KB left 2.2-3 KB of host memory behind (a fit with no column above 4 MB and no vector below 16 KB: 130 KB per fit,
   // found with an LD_PRELOAD allocation counter; smaller copies take a path of the runtime that synchronises by itself).
   if (nsmall > 0) CP_HIP(hipStreamSynchronize(cs->stream));
+  if (!scaled && (size_t)job.s_offs.back() * sizeof(double) > COPIER_BOUNCE_BYTES) {
+    scale_open();
+    scale_finish();
+  }
   const double t_s0 = trace ? now_us() : 0.0;
   if (!scaled) {                     // (its source did not come with one of this job's small copies)
     const int B = (int)job.s_offs.size() - 1;
@@ -288,7 +342,7 @@ static int copier_run(CopierState* cs, CopierJob& job) {
   if (trace) {
     size_t bytes = 0;
     for (auto& c : job.copies) bytes += c.bytes;
-    t_scale = now_us() - t_s0;
+    t_scale += now_us() - t_s0;
     fprintf(stderr, "[copier] job %llu: %d copies %.3f MB | waited for its event %.0f us | then: total %.0f us (waiting for DMA %.0f, memcpy %.0f, scaling %.0f)\n",
             (unsigned long long)job.id, (int)job.copies.size(), bytes / 1e6, t_ev - t_in, now_us() - t_ev, t_dma, t_cpy, t_scale);
   }

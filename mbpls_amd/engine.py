@@ -281,6 +281,19 @@ class HipEngine(EngineBase):
 
         return out, wait
 
+    def send_cols(self, cols):
+        """the copier thread carries the columns out behind everything queued on the compute stream so far"""
+        return self.ctx.copier_submit([(out[:, k], self.slots[name].ptr + 8 * self.p * k) for name, k, out in cols])
+
+    def send_slot(self, name, out):
+        S = self.slots[name]
+        assert out.shape == S.shape and out.flags.f_contiguous
+        return self.ctx.copier_submit([(out, S.ptr)])
+
+    def wait_sent(self, ticket):
+        with self._timed("wait_copies"):
+            self.ctx.copier_wait(ticket)
+
     def put(self, name, arr):
         arr = np.asarray(arr, dtype=np.float64)
         if arr.ndim == 1:
@@ -1192,7 +1205,18 @@ def _pooled_host_array(ctx, shape):
             break
     if raw is None:
         raw = np.empty(nbytes, dtype=np.uint8)
-        if sum(r.nbytes for r in pool) + nbytes <= HOST_POOL_BYTES:
+        held = sum(r.nbytes for r in pool)
+        i = 0
+        while held + nbytes > HOST_POOL_BYTES and i < len(pool):
+            # a full pool of other sizes (the caller has moved on to another problem): owners at rest go, oldest first
+            cand = pool[i]
+            if sys.getrefcount(cand) == 3:
+                held -= cand.nbytes
+                del pool[i]
+            else:
+                i += 1
+        cand = None
+        if held + nbytes <= HOST_POOL_BYTES:
             pool.append(raw)
     return raw[:nbytes].view(np.float64).reshape(shape, order="F"), mapped
 

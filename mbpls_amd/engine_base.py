@@ -36,6 +36,21 @@ class EngineBase:
         out = self.fetch(name)
         return out, (lambda: out)
 
+    # ---- finished columns on their way to the host while the fit goes on (HipEngine: the copier thread)
+    def send_cols(self, cols):
+        """cols = [(slot name, k, F-ordered host array)]: column k of each slot is final and goes to column k of its
+        host array; returns a ticket for ``wait_sent``"""
+        for name, k, out in cols:
+            self.fetch_col(name, k, out)
+        return 0
+
+    def send_slot(self, name, out):
+        out[...] = self.fetch(name)
+        return 0
+
+    def wait_sent(self, ticket):
+        pass
+
     # ---- routes an engine may offer
     def use_lazy_deflation(self, K, pslot, prefer=None):
         return False

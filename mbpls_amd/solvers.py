@@ -184,6 +184,33 @@ def _host_array(eng, shape):
     return eng.host_array(shape, prefault=False, prefault_tail_only=True)
 
 
+class _ColumnsOut:
+    """The columns of a finished SIMPLS component (w, r, p: :1005, :1010, :1011) and beta_ = R V^T (:1044) leave with the
+    context's copier thread, behind what is queued on the compute stream at that moment and beside everything that
+    follows -- instead of a synchronous copy in the fitting thread next to one pass (with few samples a pass is shorter
+    than the copy of its three columns: n = 100, p = 10^7, K = 4 spent 24 of 34 ms there), and instead of a p x K product
+    on the host for beta_ (7 ms of those 34)."""
+
+    def __init__(self, eng, K, q):
+        self.eng, self.ticket = eng, 0
+        self.W_h, self.R_h, self.P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
+        self.beta_h = eng.host_array((eng.p, q))
+
+    def send(self, c):
+        self.ticket = self.eng.send_cols([("W", c, self.W_h), ("R", c, self.R_h), ("P", c, self.P_h)])
+
+    def send_beta(self, V):
+        """V: q x K (the reference's V_); beta_ is formed in a slot from the R slot"""
+        eng = self.eng
+        eng.slot("beta", V.shape[0])
+        eng.right_mul(("R", 0, V.shape[1]), V.T, ("beta", 0))
+        self.ticket = eng.send_slot("beta", self.beta_h)
+
+    def wait(self):
+        ticket, self.ticket = self.ticket, 0
+        self.eng.wait_sent(ticket)
+
+
 class _ResponseProducts:
     """S = X^T (P Y) (p x q: columns 0..q-1 of a device slot, column q receives the loadings of the component at hand) and
     the per-block products X_b S_b (n x q each, host), kept up to date WITHOUT passes over X.  P = I - Ts Ts^T carries
@@ -1435,12 +1462,16 @@ def fit_simpls(eng, Y, K, standardize):
     rm = getattr(eng, "rowmask", None)
     inc = None if rm is None else (np.asarray(rm).ravel() != 0)
     Ts = np.empty((n, K), order="F"); U = np.empty((n, K)); Q = np.empty((q, K))   # (F: contiguous leading columns)
-    W_h, R_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
+    out = _ColumnsOut(eng, K, q)
+    try:
+        _simpls_fused_components(eng, Y, K, q, nz, cS, XS, XV, inc, Ts, U, Q, out)
+        out.send_beta(Q)                                    # (:1044)
+    finally:
+        out.wait()              # (on the error path too: the columns in flight land before the slots are released)
+    return FitResult(P_=_split(out.P_h, eng.block_offsets), Ts_=Ts, U_=U, R_=out.R_h, V_=Q, W_=out.W_h, beta_=out.beta_h)
 
-    def fetch_cols(c):          # columns of a finished component leave on the copy stream, beside a pass over X
-        for name, h in (("W", W_h), ("R", R_h), ("P", P_h)):
-            eng.fetch_col(name, c, h)
 
+def _simpls_fused_components(eng, Y, K, q, nz, cS, XS, XV, inc, Ts, U, Q, out):
     for comp in range(K):
         if q == 1:
             qv = np.array([[1.0]])                          # the 1 x 1 S^T S has the singular vector [1]
@@ -1454,9 +1485,10 @@ def fit_simpls(eng, Y, K, standardize):
         t = t / nt                                          # (:1008-1009)
         eng.right_mul(("W", comp, 1), np.array([[1.0 / nt]]), ("R", comp))   # r / ||t|| (:1010)
         # p = X^T t (:1011) into the scratch column of Z, and a = X p
-        tb, _ = eng.sweep(t, 1.0, ("Z", K), overlap=(lambda c=comp - 1: fetch_cols(c)) if comp > 0 else None)
+        tb, _ = eng.sweep(t, 1.0, ("Z", K))
         a = tb.sum(axis=1, keepdims=True)
         eng.right_mul(("Z", K, 1), np.array([[1.0]]), ("P", comp))
+        out.send(comp)                                      # w, r, p of this component are final
         qk = Y.T.dot(t)                                     # (:1012)
         u = Y.dot(qk)                                       # (:1013)
         coef = np.zeros((nz, 1))
@@ -1481,11 +1513,6 @@ def fit_simpls(eng, Y, K, standardize):
         XS -= xv.dot(vS)
         XV[:, comp:comp + 1] = xv
         Ts[:, comp:comp + 1] = t; U[:, comp:comp + 1] = u / np.linalg.norm(u); Q[:, comp:comp + 1] = qk
-    eng.sync()
-    fetch_cols(K - 1)
-    res = FitResult(P_=_split(P_h, eng.block_offsets), Ts_=Ts, U_=U, R_=R_h, V_=Q, W_=W_h)
-    res.beta_ = res.R_.dot(res.V_.T)                        # (:1044)
-    return res
 
 
 def _fit_simpls_products(eng, Y, K, standardize):
@@ -1505,12 +1532,16 @@ def _fit_simpls_products(eng, Y, K, standardize):
     rm = getattr(eng, "rowmask", None)
     inc = None if rm is None else (np.asarray(rm).ravel() != 0)
     Ts = np.empty((n, K), order="F"); U = np.empty((n, K)); Q = np.empty((q, K))   # (F: contiguous leading columns)
-    W_h, R_h, P_h = (_host_array(eng, (eng.p, K)) for _ in range(3))
+    out = _ColumnsOut(eng, K, q)
+    try:
+        _simpls_product_components(eng, Y, K, q, nz, cS, inc, Ts, U, Q, out)
+        out.send_beta(Q)                                    # (:1044)
+    finally:
+        out.wait()
+    return FitResult(P_=_split(out.P_h, eng.block_offsets), Ts_=Ts, U_=U, R_=out.R_h, V_=Q, W_=out.W_h, beta_=out.beta_h)
 
-    def fetch_cols(c):          # columns of a finished component leave on the copy stream, beside a pass over X
-        for name, h in (("W", W_h), ("R", R_h), ("P", P_h)):
-            eng.fetch_col(name, c, h)
 
+def _simpls_product_components(eng, Y, K, q, nz, cS, inc, Ts, U, Q, out):
     for comp in range(K):
         if q == 1:
             qv = np.array([[1.0]])                          # the 1 x 1 S^T S has the singular vector [1]
@@ -1524,9 +1555,8 @@ def _fit_simpls_products(eng, Y, K, standardize):
         t = t / nt                                          # (:1008-1009)
         eng.right_mul(("W", comp, 1), np.array([[1.0 / nt]]), ("R", comp))   # r / ||t|| (:1010)
         eng.xt_v(t, 1.0, "Z", K)                            # p = X^T t (:1011) into the scratch column
-        if comp > 0:
-            fetch_cols(comp - 1)
         eng.right_mul(("Z", K, 1), np.array([[1.0]]), ("P", comp))
+        out.send(comp)                                      # w, r, p of this component are final
         qk = Y.T.dot(t)                                     # (:1012)
         u = Y.dot(qk)                                       # (:1013)
         coef = np.zeros((nz, 1))
@@ -1545,11 +1575,6 @@ def _fit_simpls_products(eng, Y, K, standardize):
         M[comp, :] = -vS
         eng.right_mul(("Z", 0, nz), M, ("Z", cS))           # S <- S - v (v^T S) (:1019), in place
         Ts[:, comp:comp + 1] = t; U[:, comp:comp + 1] = u / np.linalg.norm(u); Q[:, comp:comp + 1] = qk
-    eng.sync()
-    fetch_cols(K - 1)
-    res = FitResult(P_=_split(P_h, eng.block_offsets), Ts_=Ts, U_=U, R_=R_h, V_=Q, W_=W_h)
-    res.beta_ = res.R_.dot(res.V_.T)                        # (:1044)
-    return res
 
 
 def _fit_simpls_hostvec(eng, Y, K, standardize):
