@@ -159,6 +159,12 @@ class HipEngine(EngineBase):
             self._src = None
 
     def close(self):
+        if self.ctx.handle and getattr(self, "_sent", 0):
+            # a fit that failed with columns on their way: they land before the slots they come from are released
+            try:
+                self.wait_sent(self._sent)
+            except Exception:       # noqa: BLE001 -- the failure that brought us here is the one to report
+                self._sent, self._sent_keep = 0, []
         if self.ctx.handle:
             self.ctx.lib.mbpls_hip_set_true_space_outputs(self.ctx.handle, None, None)
         for s in self.slots.values():
@@ -281,18 +287,33 @@ class HipEngine(EngineBase):
 
         return out, wait
 
-    def send_cols(self, cols):
-        """the copier thread carries the columns out behind everything queued on the compute stream so far"""
-        return self.ctx.copier_submit([(out[:, k], self.slots[name].ptr + 8 * self.p * k) for name, k, out in cols])
+    def send_cols(self, cols, unit=None):
+        """the copier thread carries the columns out behind everything queued on the compute stream so far, and forms
+        the block-normalised column from the one that has just arrived (csrc/copier.hip)"""
+        scale = None
+        if unit is not None:
+            src, dst, k, nu = unit
+            offs = getattr(self, "_offs64", None)
+            if offs is None:
+                offs = self._offs64 = np.ascontiguousarray(self.block_offsets, dtype=np.int64)
+            nu2 = np.ascontiguousarray(np.asarray(nu, dtype=np.float64).ravel() ** 2)     # (the thread divides by its root)
+            self._sent_keep = getattr(self, "_sent_keep", []) + [nu2]
+            scale = (src[:, k], dst[:, k], offs, nu2.ctypes.data)
+        self._sent = self.ctx.copier_submit([(out[:, k], self.slots[name].ptr + 8 * self.p * k) for name, k, out in cols],
+                                            scale=scale)
+        return self._sent
 
     def send_slot(self, name, out):
         S = self.slots[name]
         assert out.shape == S.shape and out.flags.f_contiguous
-        return self.ctx.copier_submit([(out, S.ptr)])
+        self._sent = self.ctx.copier_submit([(out, S.ptr)])
+        return self._sent
 
     def wait_sent(self, ticket):
         with self._timed("wait_copies"):
             self.ctx.copier_wait(ticket)
+        if ticket >= getattr(self, "_sent", 0):
+            self._sent, self._sent_keep = 0, []
 
     def put(self, name, arr):
         arr = np.asarray(arr, dtype=np.float64)

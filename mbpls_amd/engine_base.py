@@ -37,11 +37,18 @@ class EngineBase:
         return out, (lambda: out)
 
     # ---- finished columns on their way to the host while the fit goes on (HipEngine: the copier thread)
-    def send_cols(self, cols):
+    def send_cols(self, cols, unit=None):
         """cols = [(slot name, k, F-ordered host array)]: column k of each slot is final and goes to column k of its
-        host array; returns a ticket for ``wait_sent``"""
+        host array; ``unit`` = (src host array, dst host array, k, block norms): afterwards dst[:, k] = src[:, k]
+        block by block over its norm (w_b = w~_b / ||w~_b||, mbpls.py:860 / :510-512; src may be dst).  Returns a ticket
+        for ``wait_sent``"""
         for name, k, out in cols:
             self.fetch_col(name, k, out)
+        if unit is not None:
+            src, dst, k, nu = unit
+            offs = self.block_offsets
+            for b in range(self.nblocks):
+                np.divide(src[offs[b]:offs[b + 1], k], nu[b], out=dst[offs[b]:offs[b + 1], k])
         return 0
 
     def send_slot(self, name, out):

@@ -287,13 +287,25 @@ class _StreamedColumns:
         self.Wc = _host_array(eng, (eng.p, K)) if concat else None
 
     def component_done(self, k, blk_norm):
+        nu = np.array(blk_norm, dtype=np.float64).ravel()
+        if self.Wc is None:
+            # both columns are final and queued: they leave with the engine's copier behind what is queued now, beside
+            # everything that follows, and the block weights are formed from the raw column as it lands (with few
+            # samples a pass is shorter than these copies -- a synchronous copy beside ONE pass made the fitting thread
+            # wait: n = 100, p = 10^7, three responses 56 -> 33 ms, profiles/r06_wide_few_samples.txt)
+            raw = self.W_raw if self.W_raw is not None else self.W
+            self.ticket = self.eng.send_cols([(self.wslot, k, raw), (self.pslot, k, self.P)], unit=(raw, self.W, k, nu))
+            return
         self.flush()
-        self.pending = (k, np.array(blk_norm, dtype=np.float64).ravel())
+        self.pending = (k, nu)
 
     def finish(self):
         """the last component's columns, behind the last pass: the small kernels that wrote them were queued AFTER the
         last fence the overlapped copies wait for (engine.sweep records it in front of a pass), so the compute stream is
         drained first"""
+        if getattr(self, "ticket", 0):
+            ticket, self.ticket = self.ticket, 0
+            self.eng.wait_sent(ticket)
         if self.pending is not None:
             self.eng.sync()
             self.flush()
