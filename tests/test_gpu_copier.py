@@ -71,6 +71,65 @@ def test_large_copies_take_the_direct_path():
     assert np.array_equal(out, src) and np.array_equal(small, src[100:110])
 
 
+@pytest.mark.parametrize("in_place", [False, True])
+@pytest.mark.parametrize("position", [0, 1, 2])
+def test_block_normalisation_of_a_large_column(position, in_place):
+    """columns above the bounce size arrive straight in the caller's pages; their normalisation is shared out to the
+    helper threads -- beside the copy of the job's next large column when there is one (position 0, 1), after the last
+    copy otherwise (position 2) -- and must be the same IEEE division, with the other columns untouched"""
+    ctx = _ctx()
+    p, offs = 900_001, [0, 1, 300_000, 300_007, 900_001]                      # 7.2 MB columns, ragged blocks
+    rng = np.random.default_rng(position + 10 * in_place)
+    B = len(offs) - 1
+    src = np.asfortranarray(rng.standard_normal((p, 3)))
+    dev = ctx.from_host(src.ravel(order="F"))
+    nu2 = np.ascontiguousarray(rng.uniform(0.5, 4.0, B))                       # (plain host memory serves as well)
+    for rep in range(3):
+        out = np.full((p, 3), np.nan, order="F")
+        unit = out if in_place else np.full((p, 3), np.nan, order="F")
+        small = np.empty(7)
+        copies = [(out[:, k], dev.ptr + 8 * p * k) for k in range(3)]
+        copies.insert(1, (small, dev.ptr + 8 * 11))                            # a bounced copy between the large ones
+        t = ctx.copier_submit(copies, scale=(out[:, position], unit[:, position], np.asarray(offs, dtype=np.int64),
+                                             nu2.ctypes.data))
+        ctx.copier_wait(t)
+        want = src[:, position].copy()
+        for b in range(B):
+            want[offs[b]:offs[b + 1]] = src[offs[b]:offs[b + 1], position] / np.sqrt(nu2[b])
+        assert np.array_equal(unit[:, position], want)
+        assert np.array_equal(small, src[11:18, 0])
+        for k in range(3):
+            if k != position or not in_place:
+                assert np.array_equal(out[:, k], src[:, k])
+            if k != position and not in_place:
+                assert np.isnan(unit[:, k]).all()
+
+
+@pytest.mark.parametrize("method,q", [("NIPALS", 1), ("UNIPALS", 1), ("SIMPLS", 1), ("NIPALS", 2), ("UNIPALS", 3),
+                                      ("SIMPLS", 2), ("KERNEL", 1)])
+def test_few_samples_and_columns_above_the_bounce_size(method, q):
+    """n = 24, p = 600 000 in three ragged blocks: every attribute column is a large copy (4.8 MB), a pass is shorter
+    than the copies of its columns -- the resident queue's jobs, the several-response routes' send_cols with the block
+    normalisation, SIMPLS' columns and device-formed beta_ -- against the oracle"""
+    import warnings
+
+    from mbpls_amd import MBPLS
+    from oracle import mbpls_oracle as orc
+    from tests import util
+
+    rng = np.random.default_rng(77 + q)
+    n, sizes, K = 24, [1, 250_007, 349_992], 3
+    T = rng.standard_normal((n, 4))
+    blocks = [T.dot(rng.standard_normal((4, w))) + 0.5 * rng.standard_normal((n, w)) + 3.0 for w in sizes]
+    Y = T[:, :q] + 0.1 * rng.standard_normal((n, q))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = util.model_to_flat(orc.fit(blocks, Y, n_components=K, method=method))
+        for rep in range(2):                                  # (the second fit takes pooled host buffers)
+            m = MBPLS(n_components=K, method=method).fit(blocks, Y)
+            assert util.compare(util.model_to_flat(m), ref, 1e-8, what=f"{method} q={q} fit {rep}") < 1e-8
+
+
 def test_a_job_can_wait_for_a_value_in_host_mapped_memory_instead_of_an_event():
     """``flag``: no event on the stream; the job starts once the double at the address reaches the value (in a fit a
     step kernel queued behind the producers stores it, ``mbpls_nipals_step.host_seq``; here the host does)."""
