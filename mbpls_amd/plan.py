@@ -13,7 +13,7 @@ to compare every form with the oracle -- they have lost every A/B since round 3 
 | MBPLS_DEFLATION = lazy / explicit | lazy wherever it applies (one response, K < 39, no missing values, no row mask): X is never written | explicit: stored working copy, deflated in place (read + write) |
 | MBPLS_IMPLICIT_STD = 0 | standardisation implicit in the passes (X never written) | stored standardised copy |
 | MBPLS_KERNEL_IMPLICIT = 1 / 0 | KERNEL on the Gram: statistics-only preparation exactly when a working copy does not fit | force either |
-| MBPLS_KERNEL_GRAM = 1 / 0 | KERNEL p > n: cost model (solvers._kernel_on_products) -- maintained thin products unless n < ~87 (K + 3) | force the matrix-core Gram / the products |
+| MBPLS_KERNEL_GRAM = 1 / 0 | KERNEL p > n: cost model (solvers._kernel_on_products) -- maintained thin products unless n < ~87 (K + 3) on fewer than 2^18 columns | force the matrix-core Gram / the products |
 | MBPLS_RESIDENT = 0 | one response: the whole fit is one device queue | host-driven loop |
 | MBPLS_NIPALS_Q1_FIXED_POINT = 0 | one-response NIPALS: one pass per component | the reference's two passes per component |
 """

@@ -276,7 +276,7 @@ class _StreamedColumns:
     the host from the fetched raw column."""
 
     def __init__(self, eng, K, wslot, pslot="P", keep_raw=False, q=None, concat=False):
-        self.eng, self.wslot, self.pslot, self.pending = eng, wslot, pslot, None
+        self.eng, self.wslot, self.pslot = eng, wslot, pslot
         if q is not None:       # R_ / beta_ only exist at the very end: their pages are mapped while the GPU works
             eng.host_array((eng.p, K), reserve="R")
             eng.host_array((eng.p, q), reserve="beta")
@@ -285,44 +285,29 @@ class _StreamedColumns:
         self.W_raw = _host_array(eng, (eng.p, K)) if keep_raw else None
         # KERNEL: W_concat_ = raw column / its norm over ALL blocks (mbpls.py:733) beside the block weights
         self.Wc = _host_array(eng, (eng.p, K)) if concat else None
+        if concat:
+            eng.slot("Wcd", K)
 
     def component_done(self, k, blk_norm):
+        """the columns of component k are final and queued: they leave with the engine's copier behind what is queued
+        now, beside everything that follows, and the block weights are formed from the raw column as it lands.  (Until
+        round 6 they were copied synchronously beside ONE pass; with few samples a pass is shorter than these copies and
+        the fitting thread waited: n = 100, p = 10^7, three responses 56 -> 33 ms, profiles/r06_wide_few_samples.txt)"""
+        eng = self.eng
         nu = np.array(blk_norm, dtype=np.float64).ravel()
-        if self.Wc is None:
-            # both columns are final and queued: they leave with the engine's copier behind what is queued now, beside
-            # everything that follows, and the block weights are formed from the raw column as it lands (with few
-            # samples a pass is shorter than these copies -- a synchronous copy beside ONE pass made the fitting thread
-            # wait: n = 100, p = 10^7, three responses 56 -> 33 ms, profiles/r06_wide_few_samples.txt)
-            raw = self.W_raw if self.W_raw is not None else self.W
-            self.ticket = self.eng.send_cols([(self.wslot, k, raw), (self.pslot, k, self.P)], unit=(raw, self.W, k, nu))
-            return
-        self.flush()
-        self.pending = (k, nu)
+        raw = self.W_raw if self.W_raw is not None else self.W
+        cols = [(self.wslot, k, raw), (self.pslot, k, self.P)]
+        if self.Wc is not None:
+            # KERNEL: the same raw column over its norm across ALL blocks (:733) -- a second column on the device (a
+            # copier job carries one normalisation): 8p more bytes over PCIe for a p-length division on the host
+            eng.right_mul((self.wslot, k, 1), np.array([[1.0 / np.sqrt(float(np.sum(nu * nu)))]]), ("Wcd", k))
+            cols.insert(1, ("Wcd", k, self.Wc))
+        self.ticket = eng.send_cols(cols, unit=(raw, self.W, k, nu))
 
     def finish(self):
-        """the last component's columns, behind the last pass: the small kernels that wrote them were queued AFTER the
-        last fence the overlapped copies wait for (engine.sweep records it in front of a pass), so the compute stream is
-        drained first"""
-        if getattr(self, "ticket", 0):
-            ticket, self.ticket = self.ticket, 0
+        ticket, self.ticket = getattr(self, "ticket", 0), 0
+        if ticket:
             self.eng.wait_sent(ticket)
-        if self.pending is not None:
-            self.eng.sync()
-            self.flush()
-
-    def flush(self):
-        """call with a pass over X in flight: the copies wait for what was queued before that pass (mbpls_hip_fence)"""
-        if self.pending is None:
-            return
-        (k, nu), self.pending = self.pending, None
-        eng, offs = self.eng, self.eng.block_offsets
-        raw = self.W_raw if self.W_raw is not None else self.W
-        eng.fetch_col(self.wslot, k, raw)
-        if self.Wc is not None:
-            np.divide(raw[:, k], np.sqrt(float(np.sum(nu * nu))), out=self.Wc[:, k])
-        for b in range(eng.nblocks):
-            np.divide(raw[offs[b]:offs[b + 1], k], nu[b], out=self.W[offs[b]:offs[b + 1], k])
-        eng.fetch_col(self.pslot, k, self.P)
 
 
 def _global_sizes(eng):
@@ -515,7 +500,7 @@ def _fit_nipals_subspace(eng, Y, K, standardize, max_tol, norm, calc_all, max_it
         t_raw, ssq = prod.combination(c_used / uu, ("Wn", k))
         # the pass of the component: p = X^T ts (ts is orthogonal to the earlier scores), ||p_b||^2; the previous
         # component's attribute columns leave meanwhile
-        ssq_p = prod.component(ts, 1.0, ("P", k), overlap=cols.flush)
+        ssq_p = prod.component(ts, 1.0, ("P", k))
         nu = np.sqrt(ssq)
         Tm = (t_raw - Tp.dot(Tp.T.dot(t_raw))) / nu         # t_b = P X_b w_b (:875-877)
         sw = nu.reshape(-1, 1) / np.linalg.norm(nu)         # sw_b ~ t_b^T u = ||w~_b|| uu (:879-880)
@@ -935,7 +920,7 @@ def _fit_unipals_wide_multi(eng, Y, K, standardize):
         # w_raw = X_k^T u = X_0^T P Y v / ||Y v|| = S v / ||Y v|| (:503), X_0,b w_raw,b, ||w_raw,b||^2: maintained products
         t_raw, ssq = prod.combination(v / un, ("Wc", k))
         # the pass of the component: p = X_0^T ts / ts^T ts (:520); the previous component's columns leave meanwhile
-        ssq_p = prod.component(ts, 1.0 / tt, ("P", k), overlap=cols.flush)
+        ssq_p = prod.component(ts, 1.0 / tt, ("P", k))
         t_raw = t_raw - Tp.dot(Tp.T.dot(t_raw))             # X_k,b w_raw,b = P X_0,b w_raw,b (:515-517)
         tot = ssq.sum()
         blk_nrm[:, k] = np.sqrt(ssq); tot_nrm[k] = np.sqrt(tot)
@@ -1204,17 +1189,27 @@ _GRAM_FLOPS = 71.0e12
 _PASS_BYTES = 6.5e12
 
 
-def _kernel_on_products(eng, n, K, q):
+_KERNEL_STREAMED_COLUMNS = 1 << 18
+
+
+def _kernel_on_products(eng, n, K, q, p_total):
     """KERNEL p > n: the association matrix X X^T (n (n + 1) p flop on the f64 matrix cores, then O(n^2) per
     component) or the maintained thin products of _kernel_scores_on_products (K + 1 passes over X, + 1 or 2 to set up
     several responses)?  The Gram only wins while n(n+1)/71e12 < passes * 8n/6.5e12, i.e. n below ~ 87 (K + 3); at
-    BASELINE config[3] (n = 8192, K = 20) the passes are 4 x faster.  MBPLS_KERNEL_GRAM = 1 | 0 forces either; the
-    choice is the same on every rank of a column-sharded fit (n, K, q are)."""
+    BASELINE config[3] (n = 8192, K = 20) the passes are 4 x faster.  And it only wins on narrow matrices: with few
+    samples the fit is the PCIe time of its p x K attributes, which the products route sends out column by column
+    beside its passes while the Gram route has them all at the very end (n = 100, p = 10^7, K = 4: 56 against 33 ms;
+    n = 60, p = 10^6: 5.5 / 3.1; n = 200, p = 2 10^5: 2.8 / 2.6; n = 250, p = 10^5, K = 10: 2.9 / 3.5 --
+    profiles/r06_wide_few_samples.txt), so from 2^18 columns on the products are taken whatever n.
+    MBPLS_KERNEL_GRAM = 1 | 0 forces either; the choice is the same on every rank of a column-sharded fit (n, K, q and the
+    total width are)."""
     if eng.sparse or getattr(eng, "rowmask", None) is not None:
         return False
     forced = eng.opts.kernel_gram
     if forced is not None:
         return forced == "0"
+    if p_total >= _KERNEL_STREAMED_COLUMNS:
+        return True
     passes = K + 1 + (0 if q == 1 else (1 if q == 2 else 2))
     return n * (n + 1.0) / _GRAM_FLOPS + 3 * 8.0 * n / _PASS_BYTES > passes * 8.0 * n / _PASS_BYTES
 
@@ -1260,7 +1255,7 @@ def _kernel_scores_on_products(eng, Y, K, standardize):
         t_raw, wnorm2[:, k] = prod.combination(c / un, ("UT", k))    # X^T u (:731), X_b (X^T u)_b, ||(X^T u)_b||^2
         tts[k] = ts.T.dot(ts).item()
         # the pass: X^T ts / ts^T ts; X^T (P Y), X_b (..)_b without ts (the previous component's columns leave meanwhile)
-        prod.component(ts, 1.0 / tts[k], ("Pl", k), overlap=cols.flush)
+        prod.component(ts, 1.0 / tts[k], ("Pl", k))
         cols.component_done(k, np.sqrt(wnorm2[:, k]))
         Yd = Yd - ts.dot(ts.T.dot(Yd))                      # AS_Y = D AS_Y D (:724)
         Ts[:, k:k + 1] = ts; U[:, k:k + 1] = u
@@ -1284,7 +1279,7 @@ def fit_kernel(eng, Y, K, standardize, calc_all=True):
     n, B = eng.n, eng.nblocks
     q = Y.shape[1]
     p_total = int(eng.comm.allreduce_host(np.array([float(eng.p)]))[0])
-    products = p_total > n and _kernel_on_products(eng, n, K, q)
+    products = p_total > n and _kernel_on_products(eng, n, K, q, p_total)
     if products:
         pass                                                # (prepared by the route itself: statistics + first sweep)
     elif p_total > n and eng.stats_only_ok():

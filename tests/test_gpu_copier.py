@@ -128,6 +128,8 @@ def test_few_samples_and_columns_above_the_bounce_size(method, q):
         for rep in range(2):                                  # (the second fit takes pooled host buffers)
             m = MBPLS(n_components=K, method=method).fit(blocks, Y)
             assert util.compare(util.model_to_flat(m), ref, 1e-8, what=f"{method} q={q} fit {rep}") < 1e-8
+            if method == "KERNEL":      # (from 2^18 columns on whatever n: the route that streams its columns)
+                assert "maintained thin products" in m.fit_plan_["solver"], m.fit_plan_
 
 
 def test_a_job_can_wait_for_a_value_in_host_mapped_memory_instead_of_an_event():

@@ -46,7 +46,7 @@ def one(n, p, q, K, blocks=1, reps=3):
     class _E:           # what the cost model looks at
         sparse, rowmask = False, None
         opts = mbpls_amd.plan.FitOptions()
-    out["model_picks"] = "products" if solvers._kernel_on_products(_E, n, K, q) else "gram"
+    out["model_picks"] = "products" if solvers._kernel_on_products(_E, n, K, q, p) else "gram"
     out["faster"] = "products" if out["products_s"] < out["gram_s"] else "gram"
     print(json.dumps(out), flush=True)
     X.close()
