@@ -58,6 +58,10 @@ def run(cases, seed, verbose=True, big=False, long=False, only=None, raise_error
         if wide:                               # few samples x very many features: the everyday multiblock-PLS shape
             n = int(rng.choice([rng.randint(3, 40), rng.randint(40, 300), rng.choice([16, 64, 128, 256])]))
             p = int(rng.choice([rng.randint(3000, 30000), rng.randint(30000, 200000)]))
+            if os.environ.get("MBPLS_FUZZ_WIDE_P"):     # probes beyond the sweep: "lo,hi[,nmax]", e.g. columns above the
+                lo, hi, *nmax = (int(v) for v in os.environ["MBPLS_FUZZ_WIDE_P"].split(","))   # copier's bounce size
+                p = int(rng.randint(lo, hi))
+                n = min(n, nmax[0]) if nmax else n
         if shard is not None:
             p = max(p, 2 * shard[2])           # (a rank without a single column is not a configuration anyone runs)
         q = int(rng.choice([1, 1, 2, 3, 5])) if big else int(rng.choice([1, 1, 2, 3, int(rng.randint(4, 13))]))
