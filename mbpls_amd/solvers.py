@@ -255,11 +255,11 @@ class _ResponseProducts:
                         for b in range(eng.nblocks)])
         return np.column_stack([blk.dot(coef) for blk in self.XS]), ssq
 
-    def component(self, ts, inv_tt, pcol, overlap=None):
+    def component(self, ts, inv_tt, pcol):
         """the pass of a component: p = X^T ts / ts^T ts (stored as column ``pcol``), then S and X_b S_b without ts;
         returns ||p_b||^2 (B)"""
         eng, q = self.eng, self.q
-        tb, ssq_p = eng.sweep(ts, inv_tt, (self.sslot, q), overlap=overlap)
+        tb, ssq_p = eng.sweep(ts, inv_tt, (self.sslot, q))
         eng.right_mul((self.sslot, q, 1), np.array([[1.0]]), pcol)
         r = np.asarray(ts, dtype=np.float64).reshape(1, -1).dot(self.Y)          # ts^T Y (1 x q)
         M = np.vstack([np.eye(q), -r])
@@ -271,9 +271,9 @@ class _ResponseProducts:
 
 class _StreamedColumns:
     """The p x K attributes of a host-driven fit leaving the device one column at a time: the columns of component k
-    are final once its last pass has completed, and are copied (copy stream) while the first pass of component k + 1
-    runs -- the end of the fit then fetches R_ and beta_ only.  W_b[:, k] = w_b / ||w_b|| (:860, :510-512) is formed on
-    the host from the fetched raw column."""
+    are final once the small kernels behind its pass are queued, and leave with the engine's copier (engine.send_cols)
+    beside everything that follows -- the end of the fit then fetches R_ and beta_ only.  W_b[:, k] = w_b / ||w_b||
+    (:860, :510-512) is formed by the copier from the raw column as it lands."""
 
     def __init__(self, eng, K, wslot, pslot="P", keep_raw=False, q=None, concat=False):
         self.eng, self.wslot, self.pslot = eng, wslot, pslot
