@@ -387,3 +387,34 @@ def test_a_full_pool_of_other_sizes_makes_room(monkeypatch):
     # nothing at rest and no room: handed out unpooled, the pool stays as it is
     e, mapped = engine._pooled_host_array(ctx, big)
     assert not mapped and len(ctx._host_pool) == 2
+
+
+def test_send_cols_of_the_plain_engine_copies_and_normalises_like_the_copier():
+    """EngineBase.send_cols / send_slot / wait_sent: what the solvers call for the finished columns of a component -- on the
+    HIP engine a job of the copier thread (csrc/copier.hip), here plain copies; ``unit`` forms w_b = w~_b / ||w~_b||
+    (mbpls.py:860) block by block, in place or into a second array, and leaves every other column alone"""
+    from tests.numpy_engine import NumpyEngine
+
+    rng = np.random.RandomState(3)
+    eng = NumpyEngine().load_host_blocks([rng.randn(9, 4), rng.randn(9, 1), rng.randn(9, 6)])
+    K = 3
+    eng.slot("W", K)[...] = rng.randn(eng.p, K)
+    eng.slot("P", K)[...] = rng.randn(eng.p, K)
+    nu = np.array([2.0, 0.5, 3.0])
+    want = eng.slots["W"][:, 1].copy()
+    for b in range(3):
+        want[eng.block_offsets[b]:eng.block_offsets[b + 1]] /= nu[b]
+    for in_place in (False, True):
+        raw = np.full((eng.p, K), np.nan, order="F")
+        unit = raw if in_place else np.full((eng.p, K), np.nan, order="F")
+        P_h = np.full((eng.p, K), np.nan, order="F")
+        ticket = eng.send_cols([("W", 1, raw), ("P", 0, P_h)], unit=(raw, unit, 1, nu))
+        eng.wait_sent(ticket)
+        assert np.array_equal(unit[:, 1], want)
+        if not in_place:
+            assert np.array_equal(raw[:, 1], eng.slots["W"][:, 1])
+        assert np.array_equal(P_h[:, 0], eng.slots["P"][:, 0])
+        assert np.isnan(raw[:, [0, 2]]).all() and np.isnan(P_h[:, 1:]).all()
+    whole = np.empty((eng.p, K), order="F")
+    eng.wait_sent(eng.send_slot("P", whole))
+    assert np.array_equal(whole, eng.slots["P"])
